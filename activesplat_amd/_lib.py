@@ -1,0 +1,94 @@
+"""ctypes binding of the C ABI in include/gsplat_hip.h (libgsplat_hip.so, hipcc-built for gfx950).
+
+There is no CPU fallback: `get()` raises if the HIP library is missing.  `load_for_tests(path)` exists
+only so that tests/ can point the same binding at the host-emulated build of the kernel sources
+(tests/hipemu) while debugging kernel logic without a GPU; the product never calls it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
+
+_lib = None
+_emulated = False
+
+
+class GsCamera(C.Structure):
+    _fields_ = [("image_width", C.c_int32), ("image_height", C.c_int32), ("sh_degree", C.c_int32),
+                ("sh_coeffs", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("scale_modifier", C.c_float), ("reserved", C.c_int32), ("bg", C.c_void_p),
+                ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+
+
+class GsGeomLayout(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "geom", "rect", "tiles_touched", "offsets", "block_sums", "clamped")]
+
+
+class GsImageLayout(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "ranges", "final_T", "n_contrib")]
+
+
+class GsBinLayout(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "keys_unsorted", "vals_unsorted", "keys_sorted", "sort_temp")]
+
+
+# every symbol include/gsplat_hip.h declares (tests check the library exports all of them)
+SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
+           "gs_version", "gs_preprocess_forward", "gs_render_forward", "gs_render_backward", "gs_adam_step")
+
+
+def _bind(lib):
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.gs_geom_layout.argtypes = [i32, C.POINTER(GsGeomLayout)]
+    lib.gs_image_layout.argtypes = [i32, i32, C.POINTER(GsImageLayout)]
+    lib.gs_bin_layout.argtypes = [i64, i32, i32, C.POINTER(GsBinLayout)]
+    lib.gs_backward_scratch_bytes.argtypes = [i32]
+    lib.gs_backward_scratch_bytes.restype = C.c_uint64
+    lib.gs_last_error.restype = C.c_char_p
+    lib.gs_version.restype = C.c_char_p
+    lib.gs_preprocess_forward.argtypes = [C.POINTER(GsCamera), i32] + [vp] * 7 + [vp, vp, vp, vp, vp]
+    lib.gs_render_forward.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 7 + [vp]
+    lib.gs_render_backward.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 6 + [vp] * 5 + [vp] * 8 + [vp, vp]
+    lib.gs_adam_step.argtypes = [i64, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp]
+    for n in ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_preprocess_forward", "gs_render_forward",
+              "gs_render_backward", "gs_adam_step"):
+        getattr(lib, n).restype = C.c_int
+    return lib
+
+
+def get():
+    """The HIP library; raises loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). activesplat_amd has no CPU fallback.")
+        _lib = _bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def load_for_tests(path: str):
+    """TEST HOOK ONLY: bind an alternative build of the same C ABI (the host-emulated kernels)."""
+    global _lib, _emulated
+    _lib = _bind(C.CDLL(path))
+    _emulated = True
+    return _lib
+
+
+def unload_for_tests():
+    global _lib, _emulated
+    _lib = None
+    _emulated = False
+
+
+def emulated() -> bool:
+    return _emulated
+
+
+def check(rc: int):
+    if rc != 0:
+        raise Exception(get().gs_last_error().decode())

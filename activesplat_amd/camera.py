@@ -1,0 +1,34 @@
+"""Camera -> rasteriser settings.
+
+Mirror of the reference's `setup_camera` (src/mapper/splatam/utils/recon_helpers.py:4-28): same
+argument meaning, same matrix conventions (viewmatrix = w2c^T, projmatrix = (P w2c)^T as [1,4,4]
+tensors, OpenGL-style projection with off-centre principal point), plus an explicit `device`
+(the reference hard-codes .cuda()) and `bg`.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .rasterizer import GaussianRasterizationSettings
+
+
+def setup_camera(w, h, k, w2c, near=0.01, far=100, scale_modifier=1.0, bg=(0.0, 0.0, 0.0), device=None,
+                 sh_degree=0):
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    fx, fy, cx, cy = float(k[0][0]), float(k[1][1]), float(k[0][2]), float(k[1][2])
+    w2c_t = torch.as_tensor(np.asarray(w2c, dtype=np.float64) if not torch.is_tensor(w2c) else w2c).to(
+        device=device, dtype=torch.float32)
+    cam_center = torch.inverse(w2c_t)[:3, 3]
+    view = w2c_t.unsqueeze(0).transpose(1, 2)
+    opengl_proj = torch.tensor([[2 * fx / w, 0.0, -(w - 2 * cx) / w, 0.0],
+                                [0.0, 2 * fy / h, -(h - 2 * cy) / h, 0.0],
+                                [0.0, 0.0, far / (far - near), -(far * near) / (far - near)],
+                                [0.0, 0.0, 1.0, 0.0]], dtype=torch.float32, device=device).unsqueeze(0).transpose(1, 2)
+    full_proj = view.bmm(opengl_proj)
+    return GaussianRasterizationSettings(
+        image_height=int(h), image_width=int(w), tanfovx=w / (2 * fx), tanfovy=h / (2 * fy),
+        bg=torch.tensor(list(bg), dtype=torch.float32, device=device), scale_modifier=scale_modifier,
+        viewmatrix=view, projmatrix=full_proj, sh_degree=sh_degree, campos=cam_center,
+        prefiltered=False, debug=False)

@@ -1,0 +1,220 @@
+// api.hip -- the C ABI of libgsplat_hip.so (declared in include/gsplat_hip.h).
+// Plain pointers and sizes in, launches on the caller's stream out; no torch types, no hidden sync.
+#include <stdio.h>
+#include <string.h>
+
+#include "gs_common.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* a = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, a);
+    return code;
+}
+
+uint64_t align_up(uint64_t v, uint64_t a = 256) { return (v + a - 1) / a * a; }
+
+int tile_bits(int tiles)
+{
+    int b = 1;
+    while ((1 << b) < tiles) b++;
+    return b;
+}
+
+bool make_cam(const GsCamera* c, gs::Cam& k)
+{
+    if (!c || c->image_width <= 0 || c->image_height <= 0 || !c->bg || !c->viewmatrix || !c->projmatrix) return false;
+    if (!(c->tanfovx > 0.f) || !(c->tanfovy > 0.f)) return false;
+    k.W = c->image_width; k.H = c->image_height;
+    k.gx = (k.W + gs::kTile - 1) / gs::kTile; k.gy = (k.H + gs::kTile - 1) / gs::kTile;
+    if (k.gx >= 65536 || k.gy >= 65536) return false;
+    k.tanfovx = c->tanfovx; k.tanfovy = c->tanfovy;
+    k.fx = (float)k.W / (2.0f * c->tanfovx); k.fy = (float)k.H / (2.0f * c->tanfovy);
+    k.mod = c->scale_modifier;
+    k.sh_degree = c->sh_degree; k.sh_coeffs = c->sh_coeffs;
+    k.bg = c->bg; k.view = c->viewmatrix; k.proj = c->projmatrix; k.campos = c->campos;
+    return true;
+}
+
+gs::GeomPtrs carve_geom(void* base, int32_t P)
+{
+    GsGeomLayout L;
+    gs_geom_layout(P, &L);
+    char* b = (char*)base;
+    gs::GeomPtrs g;
+    g.geom = (float4*)(b + L.geom); g.rect = (uint2*)(b + L.rect); g.tiles = (uint32_t*)(b + L.tiles_touched);
+    g.offsets = (uint32_t*)(b + L.offsets); g.block_sums = (uint32_t*)(b + L.block_sums);
+    g.clamped = (uint32_t*)(b + L.clamped);
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gs_last_error(void) { return g_err; }
+const char* gs_version(void) { return "activesplat_amd gsplat_hip 0.1 (gfx950)"; }
+
+int gs_geom_layout(int32_t P, GsGeomLayout* out)
+{
+    if (!out || P < 0) return fail(GS_EINVAL, "gs_geom_layout: bad argument");
+    const uint64_t n = (uint64_t)(P > 0 ? P : 1);
+    const uint64_t nb = (n + gs::kBlock - 1) / gs::kBlock;
+    uint64_t o = 0;
+    out->geom = o; o = align_up(o + n * GS_GEOM_FLOATS * 4);
+    out->rect = o; o = align_up(o + n * 8);
+    out->tiles_touched = o; o = align_up(o + n * 4);
+    out->offsets = o; o = align_up(o + n * 4);
+    out->block_sums = o; o = align_up(o + (nb + 1) * 4);
+    out->clamped = o; o = align_up(o + n * 4);
+    out->total_bytes = o;
+    return GS_OK;
+}
+
+int gs_image_layout(int32_t width, int32_t height, GsImageLayout* out)
+{
+    if (!out || width <= 0 || height <= 0) return fail(GS_EINVAL, "gs_image_layout: bad argument");
+    const uint64_t tiles = (uint64_t)((width + gs::kTile - 1) / gs::kTile) * ((height + gs::kTile - 1) / gs::kTile);
+    const uint64_t hw = (uint64_t)width * height;
+    uint64_t o = 0;
+    out->ranges = o; o = align_up(o + tiles * 8);
+    out->final_T = o; o = align_up(o + hw * 4);
+    out->n_contrib = o; o = align_up(o + hw * 4);
+    out->total_bytes = o;
+    return GS_OK;
+}
+
+int gs_bin_layout(int64_t D, int32_t width, int32_t height, GsBinLayout* out)
+{
+    if (!out || D < 0 || width <= 0 || height <= 0) return fail(GS_EINVAL, "gs_bin_layout: bad argument");
+    const int tiles = ((width + gs::kTile - 1) / gs::kTile) * ((height + gs::kTile - 1) / gs::kTile);
+    const uint64_t n = (uint64_t)(D > 0 ? D : 1);
+    uint64_t o = 0;
+    out->keys_unsorted = o; o = align_up(o + n * 8);
+    out->vals_unsorted = o; o = align_up(o + n * 4);
+    out->keys_sorted = o; o = align_up(o + n * 8);
+    out->sort_temp = o; o = align_up(o + gs::sort_temp_bytes(D, 32 + tile_bits(tiles)));
+    out->total_bytes = o;
+    return GS_OK;
+}
+
+uint64_t gs_backward_scratch_bytes(int32_t P) { return align_up((uint64_t)(P > 0 ? P : 1) * gs::kGradStride * 4); }
+
+int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, const float* shs,
+                          const float* colors_precomp, const float* opacities, const float* scales,
+                          const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_state,
+                          uint32_t* d_num_rendered, uint32_t* h_num_rendered, gs_stream_t stream)
+{
+    gs::Cam k;
+    if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_preprocess_forward: invalid camera settings");
+    if (P < 0 || !geom_state || !d_num_rendered) return fail(GS_EINVAL, "gs_preprocess_forward: null state pointer");
+    if (P > 0 && (!means3D || !opacities || !radii)) return fail(GS_EINVAL, "gs_preprocess_forward: null input pointer");
+    if ((shs == nullptr) == (colors_precomp == nullptr) && P > 0)
+        return fail(GS_EINVAL, "Please provide excatly one of either SHs or precomputed colors!");
+    const bool have_sr = scales != nullptr && rotations != nullptr;
+    if (P > 0 && (have_sr == (cov3D_precomp != nullptr) || ((scales != nullptr) != (rotations != nullptr))))
+        return fail(GS_EINVAL, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (shs && (k.sh_degree < 0 || k.sh_degree > 3 || k.sh_coeffs < (k.sh_degree + 1) * (k.sh_degree + 1) || !k.campos))
+        return fail(GS_EINVAL, "gs_preprocess_forward: sh_degree / sh_coeffs / campos inconsistent");
+    hipStream_t st = (hipStream_t)stream;
+    gs::GeomPtrs gp = carve_geom(geom_state, P);
+    hipError_t e = gs::launch_preprocess_forward(k, P, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                                 cov3D_precomp, radii, gp, d_num_rendered, st);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: %s", hipGetErrorString(e));
+    if (h_num_rendered) {
+        e = hipMemcpyAsync(h_num_rendered, d_num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: D2H %s", hipGetErrorString(e));
+    }
+    return GS_OK;
+}
+
+int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, void* geom_state, void* bin_state,
+                      uint32_t* point_list, void* image_state, float* out_color, float* out_depth,
+                      float* out_opacity, gs_stream_t stream)
+{
+    gs::Cam k;
+    if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_render_forward: invalid camera settings");
+    if (P < 0 || D < 0 || !geom_state || !image_state || !out_color || !out_depth || !out_opacity)
+        return fail(GS_EINVAL, "gs_render_forward: null pointer");
+    if (D > 0 && (!bin_state || !point_list)) return fail(GS_EINVAL, "gs_render_forward: null binning workspace");
+    if (D >= (int64_t)1 << 32) return fail(GS_ECAPACITY, "gs_render_forward: more than 2^32 tile instances");
+    hipStream_t st = (hipStream_t)stream;
+    gs::GeomPtrs gp = carve_geom(geom_state, P);
+    GsImageLayout IL; gs_image_layout(k.W, k.H, &IL);
+    char* ib = (char*)image_state;
+    uint2* ranges = (uint2*)(ib + IL.ranges);
+    hipError_t e = hipMemsetAsync(ranges, 0, (size_t)k.gx * k.gy * 8, st);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: memset %s", hipGetErrorString(e));
+    if (D == 0) {   // nothing visible: the emitter still writes the (all-zero) scan offsets
+        e = gs::launch_emit(k, P, gp, nullptr, nullptr, st);
+        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: emit %s", hipGetErrorString(e));
+    } else {
+        GsBinLayout BL; gs_bin_layout(D, k.W, k.H, &BL);
+        char* bb = (char*)bin_state;
+        uint64_t* ku = (uint64_t*)(bb + BL.keys_unsorted); uint32_t* vu = (uint32_t*)(bb + BL.vals_unsorted);
+        uint64_t* ks = (uint64_t*)(bb + BL.keys_sorted);
+        e = gs::launch_emit(k, P, gp, ku, vu, st);
+        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: emit %s", hipGetErrorString(e));
+        const int end_bit = 32 + tile_bits(k.gx * k.gy);
+        e = gs::sort_pairs(bb + BL.sort_temp, (size_t)(BL.total_bytes - BL.sort_temp), ku, ks, vu, point_list, D, end_bit, st);
+        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: sort %s", hipGetErrorString(e));
+        e = gs::launch_ranges(D, ks, ranges, st);
+        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: ranges %s", hipGetErrorString(e));
+    }
+    e = gs::launch_blend_forward(k, ranges, point_list, gp.geom, out_color, out_depth, out_opacity,
+                                 (float*)(ib + IL.final_T), (uint32_t*)(ib + IL.n_contrib), st);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: blend %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* means3D, const float* shs,
+                       const float* colors_precomp, const float* scales, const float* rotations,
+                       const float* cov3D_precomp, const int32_t* radii, const void* geom_state,
+                       const uint32_t* point_list, const void* image_state, const float* dL_dcolor,
+                       float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities, float* dL_dcolors_precomp,
+                       float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* scratch,
+                       gs_stream_t stream)
+{
+    gs::Cam k;
+    if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_render_backward: invalid camera settings");
+    if (P < 0 || D < 0 || !geom_state || !image_state || !dL_dcolor || !scratch)
+        return fail(GS_EINVAL, "gs_render_backward: null pointer");
+    if (P == 0) return GS_OK;
+    if (!means3D || !radii || !dL_dmeans2D || !dL_dmeans3D || !dL_dopacities)
+        return fail(GS_EINVAL, "gs_render_backward: null input/output pointer");
+    if (shs ? !dL_dshs : !dL_dcolors_precomp) return fail(GS_EINVAL, "gs_render_backward: missing colour gradient output");
+    if (cov3D_precomp ? !dL_dcov3D : (!scales || !rotations || !dL_dscales || !dL_drotations))
+        return fail(GS_EINVAL, "gs_render_backward: missing covariance inputs/outputs");
+    hipStream_t st = (hipStream_t)stream;
+    gs::GeomPtrs gp = carve_geom(const_cast<void*>(geom_state), P);
+    GsImageLayout IL; gs_image_layout(k.W, k.H, &IL);
+    const char* ib = (const char*)image_state;
+    float* grad2d = (float*)scratch;
+    hipError_t e = hipMemsetAsync(grad2d, 0, (size_t)P * gs::kGradStride * 4, st);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_backward: memset %s", hipGetErrorString(e));
+    if (D > 0) {
+        e = gs::launch_blend_backward(k, (const uint2*)(ib + IL.ranges), point_list, gp.geom, (const float*)(ib + IL.final_T),
+                                      (const uint32_t*)(ib + IL.n_contrib), dL_dcolor, grad2d, st);
+        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_backward: blend %s", hipGetErrorString(e));
+    }
+    e = gs::launch_preprocess_backward(k, P, means3D, shs, scales, rotations, cov3D_precomp, radii, gp.clamped, grad2d,
+                                       dL_dmeans2D, dL_dmeans3D, dL_dopacities, dL_dcolors_precomp, dL_dshs, dL_dscales,
+                                       dL_drotations, dL_dcov3D, st);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_backward: preprocess %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                 float beta1, float beta2, float eps, int32_t step, gs_stream_t stream)
+{
+    if (n < 0 || step < 1) return fail(GS_EINVAL, "gs_adam_step: bad n/step");
+    if (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq)) return fail(GS_EINVAL, "gs_adam_step: null pointer");
+    hipError_t e = gs::launch_adam(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_adam_step: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+}  // extern "C"

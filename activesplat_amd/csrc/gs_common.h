@@ -1,0 +1,109 @@
+// gs_common.h -- shared declarations of the gfx950 rasteriser kernels (internal; the public
+// boundary is include/gsplat_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gsplat_hip.h"
+
+namespace gs {
+
+constexpr int kTile = GS_TILE;      // 16x16 pixel tile = one 256-thread workgroup = 4 wavefronts
+constexpr int kBlock = 256;
+constexpr int kWave = 64;           // CDNA wavefront
+constexpr int kQuad = 8;            // each wavefront owns one 8x8 pixel quadrant of the tile
+
+// By-value kernel argument; matrices stay in device memory exactly where the caller's settings
+// tensors put them (uniform loads -> scalar cache).
+struct Cam {
+    int W, H, gx, gy;
+    float tanfovx, tanfovy, fx, fy, mod;
+    int sh_degree, sh_coeffs;
+    const float* bg;
+    const float* view;
+    const float* proj;
+    const float* campos;
+};
+
+// Per-Gaussian screen-space record, 3 x float4 = 48 B, one gather per tile instance in the blend.
+//   q0 = (x, y, conic_a, conic_b)   q1 = (conic_c, opacity, r, g)   q2 = (b, depth, ext_x, ext_y)
+// ext_x/ext_y: half-extent (pixels) of the axis-aligned box outside of which alpha < 1/255 is
+// guaranteed; negative when the Gaussian can never reach 1/255.  Used only to skip work.
+struct GeomPtrs {
+    float4* geom;
+    uint2* rect;
+    uint32_t* tiles;
+    uint32_t* offsets;
+    uint32_t* block_sums;
+    uint32_t* clamped;   // uchar4 packed
+};
+
+// ---- wave-64 helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+// inclusive prefix sum across the 64 lanes of a wavefront
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Coalesced staging of `nrows` rows of K floats (array-of-structs in HBM) into LDS: the full-block
+// case moves 16 B per lane per instruction; rows are then read back at stride K (conflict-free for
+// K = 3, and as one ds_read_b128 for K = 4).
+template <int K>
+__device__ __forceinline__ void stage_rows(float* lds, const float* __restrict__ src, int base, int nrows, int tid)
+{
+    const float* s = src + (size_t)base * K;
+    if (nrows == kBlock) {
+        const float4* s4 = reinterpret_cast<const float4*>(s);
+        float4* d4 = reinterpret_cast<float4*>(lds);
+        for (int i = tid; i < K * (kBlock / 4); i += kBlock) d4[i] = s4[i];
+    } else {
+        for (int i = tid; i < nrows * K; i += kBlock) lds[i] = s[i];
+    }
+}
+
+// ---- launchers implemented in the individual translation units -------------------------------------
+hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D, const float* shs,
+                                     const float* colors, const float* opac, const float* scales,
+                                     const float* rots, const float* cov3Dp, int32_t* radii, GeomPtrs gp,
+                                     uint32_t* d_num_rendered, hipStream_t st);
+hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3D, const float* shs,
+                                      const float* scales, const float* rots, const float* cov3Dp,
+                                      const int32_t* radii, const uint32_t* clamped, const float* grad2d,
+                                      float* dmeans2D, float* dmeans3D, float* dopac, float* dcolors, float* dshs,
+                                      float* dscales, float* drots, float* dcov3D, hipStream_t st);
+hipError_t launch_emit(const Cam& cam, int P, GeomPtrs gp, uint64_t* keys, uint32_t* vals, hipStream_t st);
+hipError_t launch_ranges(int64_t D, const uint64_t* keys_sorted, uint2* ranges, hipStream_t st);
+hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
+                                float* out_color, float* out_depth, float* out_opacity, float* final_T,
+                                uint32_t* n_contrib, hipStream_t st);
+hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
+                                 const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
+                                 float* grad2d, hipStream_t st);
+hipError_t launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
+                       float eps, int step, hipStream_t st);
+
+// sort backend (sort_rocprim.hip): stable ascending radix sort of (key64, val32) pairs on bits [0,end_bit)
+size_t sort_temp_bytes(int64_t D, int end_bit);
+hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
+                      const uint32_t* vals_in, uint32_t* vals_out, int64_t D, int end_bit, hipStream_t st);
+
+constexpr int kGradStride = 12;   // floats per Gaussian in the 2-D gradient record:
+                                  // 0,1 dL/dxy(pixel) 2,3,4 dL/dconic(a,b,c) 5 dL/dopacity 6,7,8 dL/drgb
+}  // namespace gs

@@ -1,0 +1,232 @@
+// preprocess.hip -- per-Gaussian forward stage (+ tile-count block sums and their scan).
+//
+// Replaces the "preprocess" + "inclusive scan" work items of the reference's absent CUDA extension
+// (contract: SURVEY App. A.2, call sites src/mapper/splatam/splatam.py:208,212).
+// HBM-bound streaming kernel: one Gaussian per lane, array-of-struct inputs staged through LDS with
+// 16-byte-per-lane coalesced loads, one 48-byte screen-space record written per Gaussian.
+//
+// Bit-level spec: this translation unit is compiled with -ffp-contract=off and every expression is
+// parenthesised exactly as DESIGN.md section 3 states, so radii, tile rects, tile counts and depth-key bits
+// are reproducible to the bit by the CPU oracle.
+#include "gs_common.h"
+
+#pragma clang fp contract(off)
+
+namespace gs {
+
+__device__ __forceinline__ int clamp_tile(float v, int hi)
+{
+    v = fminf(fmaxf(v, -1048576.0f), 1048576.0f);
+    int i = (int)v;
+    return min(hi, max(0, i));
+}
+
+// real-SH basis of the 3DGS family
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* b)
+{
+    b[0] = 0.28209479177387814f;
+    if (deg > 0) {
+        b[1] = -0.4886025119029199f * y; b[2] = 0.4886025119029199f * z; b[3] = -0.4886025119029199f * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = 1.0925484305920792f * xy;
+            b[5] = -1.0925484305920792f * yz;
+            b[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
+            b[7] = -1.0925484305920792f * xz;
+            b[8] = 0.5462742152960396f * (xx - yy);
+            if (deg > 2) {
+                b[9] = -0.5900435899266435f * y * (3.0f * xx - yy);
+                b[10] = 2.890611442640554f * xy * z;
+                b[11] = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
+                b[12] = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                b[13] = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
+                b[14] = 1.445305721320277f * z * (xx - yy);
+                b[15] = -0.5900435899266435f * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
+    Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales,
+    const float* __restrict__ rots, const float* __restrict__ cov3Dp, int32_t* __restrict__ radii, GeomPtrs gp)
+{
+    __shared__ __attribute__((aligned(16))) float s_mean[kBlock * 3];
+    __shared__ __attribute__((aligned(16))) float s_scale[kBlock * 3];
+    __shared__ __attribute__((aligned(16))) float s_rot[kBlock * 4];
+    __shared__ __attribute__((aligned(16))) float s_col[kBlock * 3];
+    __shared__ __attribute__((aligned(16))) float s_cov[kBlock * 6];
+    __shared__ uint32_t s_wsum[kBlock / kWave];
+
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * kBlock;
+    const int nrows = min(kBlock, P - base);
+    const int i = base + tid;
+    stage_rows<3>(s_mean, means3D, base, nrows, tid);
+    if (cov3Dp) stage_rows<6>(s_cov, cov3Dp, base, nrows, tid);
+    else { stage_rows<3>(s_scale, scales, base, nrows, tid); stage_rows<4>(s_rot, rots, base, nrows, tid); }
+    if (!shs) stage_rows<3>(s_col, colors, base, nrows, tid);
+    __syncthreads();
+
+    uint32_t ntiles = 0;
+    if (i < P) {
+        const float* m = cam.view;
+        const float* q = cam.proj;
+        const float px = s_mean[tid * 3], py = s_mean[tid * 3 + 1], pz = s_mean[tid * 3 + 2];
+        const float tx = ((m[0] * px + m[4] * py) + m[8] * pz) + m[12];
+        const float ty = ((m[1] * px + m[5] * py) + m[9] * pz) + m[13];
+        const float tz = ((m[2] * px + m[6] * py) + m[10] * pz) + m[14];
+        int radius = 0;
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+        uint2 rc = make_uint2(0u, 0u);
+        uint32_t clampbits = 0;
+        if (tz > 0.2f) {                              // near cull only -- no far plane
+            const float hx = ((q[0] * px + q[4] * py) + q[8] * pz) + q[12];
+            const float hy = ((q[1] * px + q[5] * py) + q[9] * pz) + q[13];
+            const float hw = ((q[3] * px + q[7] * py) + q[11] * pz) + q[15];
+            const float pw = 1.0f / (hw + 1e-7f);
+            const float ndcx = hx * pw, ndcy = hy * pw;
+            float c0, c1, c2, c3, c4, c5;             // 3-D covariance (upper triangle)
+            if (cov3Dp) {
+                c0 = s_cov[tid * 6]; c1 = s_cov[tid * 6 + 1]; c2 = s_cov[tid * 6 + 2];
+                c3 = s_cov[tid * 6 + 3]; c4 = s_cov[tid * 6 + 4]; c5 = s_cov[tid * 6 + 5];
+            } else {
+                const float sx = cam.mod * s_scale[tid * 3], sy = cam.mod * s_scale[tid * 3 + 1], sz = cam.mod * s_scale[tid * 3 + 2];
+                const float4 rq = reinterpret_cast<const float4*>(s_rot)[tid];
+                const float r = rq.x, x = rq.y, y = rq.z, z = rq.w;
+                const float R00 = 1.0f - 2.0f * (y * y + z * z), R01 = 2.0f * (x * y - r * z), R02 = 2.0f * (x * z + r * y);
+                const float R10 = 2.0f * (x * y + r * z), R11 = 1.0f - 2.0f * (x * x + z * z), R12 = 2.0f * (y * z - r * x);
+                const float R20 = 2.0f * (x * z - r * y), R21 = 2.0f * (y * z + r * x), R22 = 1.0f - 2.0f * (x * x + y * y);
+                const float M00 = R00 * sx, M01 = R01 * sy, M02 = R02 * sz;
+                const float M10 = R10 * sx, M11 = R11 * sy, M12 = R12 * sz;
+                const float M20 = R20 * sx, M21 = R21 * sy, M22 = R22 * sz;
+                c0 = (M00 * M00 + M01 * M01) + M02 * M02;
+                c1 = (M00 * M10 + M01 * M11) + M02 * M12;
+                c2 = (M00 * M20 + M01 * M21) + M02 * M22;
+                c3 = (M10 * M10 + M11 * M11) + M12 * M12;
+                c4 = (M10 * M20 + M11 * M21) + M12 * M22;
+                c5 = (M20 * M20 + M21 * M21) + M22 * M22;
+            }
+            // EWA projection of the covariance
+            const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+            const float txtz = tx / tz, tytz = ty / tz;
+            const float cx_ = fminf(limx, fmaxf(-limx, txtz)) * tz;
+            const float cy_ = fminf(limy, fmaxf(-limy, tytz)) * tz;
+            const float J00 = cam.fx / tz, J02 = -(cam.fx * cx_) / (tz * tz);
+            const float J11 = cam.fy / tz, J12 = -(cam.fy * cy_) / (tz * tz);
+            const float T00 = J00 * m[0] + J02 * m[2], T01 = J00 * m[4] + J02 * m[6], T02 = J00 * m[8] + J02 * m[10];
+            const float T10 = J11 * m[1] + J12 * m[2], T11 = J11 * m[5] + J12 * m[6], T12 = J11 * m[9] + J12 * m[10];
+            const float v00 = (c0 * T00 + c1 * T01) + c2 * T02;
+            const float v01 = (c1 * T00 + c3 * T01) + c4 * T02;
+            const float v02 = (c2 * T00 + c4 * T01) + c5 * T02;
+            const float v10 = (c0 * T10 + c1 * T11) + c2 * T12;
+            const float v11 = (c1 * T10 + c3 * T11) + c4 * T12;
+            const float v12 = (c2 * T10 + c4 * T11) + c5 * T12;
+            const float k00 = ((T00 * v00 + T01 * v01) + T02 * v02) + 0.3f;
+            const float k01 = (T10 * v00 + T11 * v01) + T12 * v02;
+            const float k11 = ((T10 * v10 + T11 * v11) + T12 * v12) + 0.3f;
+            const float det = k00 * k11 - k01 * k01;
+            if (det > 0.0f) {
+                const float det_inv = 1.0f / det;
+                const float mid = 0.5f * (k00 + k11);
+                const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lam = fmaxf(mid + sq, mid - sq);
+                float rf = ceilf(3.0f * sqrtf(lam));
+                rf = fminf(rf, 16777216.0f);
+                const float pxx = ((ndcx + 1.0f) * (float)cam.W - 1.0f) * 0.5f;
+                const float pyy = ((ndcy + 1.0f) * (float)cam.H - 1.0f) * 0.5f;
+                const int x0 = clamp_tile((pxx - rf) / 16.0f, cam.gx), x1 = clamp_tile(((pxx + rf) + 15.0f) / 16.0f, cam.gx);
+                const int y0 = clamp_tile((pyy - rf) / 16.0f, cam.gy), y1 = clamp_tile(((pyy + rf) + 15.0f) / 16.0f, cam.gy);
+                const int area = (x1 - x0) * (y1 - y0);
+                if (area > 0) {
+                    radius = (int)rf;
+                    ntiles = (uint32_t)area;
+                    rc = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+                    const float o = opac[i];
+                    float cr, cg, cb;
+                    if (shs) {
+                        const int M = cam.sh_coeffs, nb = (cam.sh_degree + 1) * (cam.sh_degree + 1);
+                        const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
+                        const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+                        float b[16];
+                        sh_basis(cam.sh_degree, dx * inv, dy * inv, dz * inv, b);
+                        const float* sh = shs + (size_t)i * M * 3;
+                        float acc[3] = {0.f, 0.f, 0.f};
+                        for (int k = 0; k < nb; k++) {
+                            acc[0] += b[k] * sh[3 * k]; acc[1] += b[k] * sh[3 * k + 1]; acc[2] += b[k] * sh[3 * k + 2];
+                        }
+                        acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
+                        clampbits = (acc[0] < 0.f ? 1u : 0u) | (acc[1] < 0.f ? 0x100u : 0u) | (acc[2] < 0.f ? 0x10000u : 0u);
+                        cr = fmaxf(acc[0], 0.f); cg = fmaxf(acc[1], 0.f); cb = fmaxf(acc[2], 0.f);
+                    } else {
+                        cr = s_col[tid * 3]; cg = s_col[tid * 3 + 1]; cb = s_col[tid * 3 + 2];
+                    }
+                    // work-skipping extents: alpha >= 1/255 needs power >= -ln(255 o); the ellipse
+                    // {d : d^T conic d <= 2 tau} has half-extents sqrt(2 tau cov_xx), sqrt(2 tau cov_yy).
+                    // tau carries a 0.02 slack (>> any fp32 rounding of conic / exp); o*255 <= 1 -> never visible.
+                    float ex = -1.0f, ey = -1.0f;
+                    const float o255 = o * 255.0f;
+                    if (o255 > 1.0f) {
+                        const float tau2 = 2.0f * (__logf(o255) + 0.02f);
+                        ex = sqrtf(tau2 * k00) + 0.01f;
+                        ey = sqrtf(tau2 * k11) + 0.01f;
+                    }
+                    g0 = make_float4(pxx, pyy, k11 * det_inv, -k01 * det_inv);
+                    g1 = make_float4(k00 * det_inv, o, cr, cg);
+                    g2 = make_float4(cb, tz, ex, ey);
+                }
+            }
+        }
+        radii[i] = radius;
+        gp.geom[(size_t)i * 3] = g0; gp.geom[(size_t)i * 3 + 1] = g1; gp.geom[(size_t)i * 3 + 2] = g2;
+        gp.rect[i] = rc;
+        gp.tiles[i] = ntiles;
+        if (shs) gp.clamped[i] = clampbits;
+    }
+    // per-block tile count -> block_sums (scanned by scan_block_sums_kernel)
+    const uint32_t ws = wave_sum_u32(ntiles);
+    if ((tid & 63) == 0) s_wsum[tid >> 6] = ws;
+    __syncthreads();
+    if (tid == 0) gp.block_sums[blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+}
+
+// Exclusive scan (in place) of the per-block tile counts; total -> block_sums[n] and *d_total.
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int n, uint32_t* __restrict__ d_total)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const uint32_t v = i < n ? block_sums[i] : 0u;
+        const uint32_t inc = wave_inclusive_scan(v, lane);
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t wprefix = 0;
+        for (int w = 0; w < wave; w++) wprefix += s_w[w];
+        const uint32_t carry = s_carry;
+        if (i < n) block_sums[i] = carry + wprefix + inc - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + wprefix + inc;
+        __syncthreads();
+    }
+    if (tid == 0) { block_sums[n] = s_carry; *d_total = s_carry; }
+}
+
+hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D, const float* shs,
+                                     const float* colors, const float* opac, const float* scales,
+                                     const float* rots, const float* cov3Dp, int32_t* radii, GeomPtrs gp,
+                                     uint32_t* d_num_rendered, hipStream_t st)
+{
+    const int nb = (P + kBlock - 1) / kBlock;
+    if (nb > 0)
+        hipLaunchKernelGGL(preprocess_forward_kernel, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
+                           scales, rots, cov3Dp, radii, gp);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, st, gp.block_sums, nb, d_num_rendered);
+    return hipGetLastError();
+}
+
+}  // namespace gs

@@ -1,0 +1,219 @@
+// preprocess_bwd.hip -- per-Gaussian backward stage: 2-D gradient record (pixel mean, conic, opacity,
+// colour) -> gradients of means3D / scales / rotations / cov3D / opacities / colours / SH / means2D.
+//
+// Replaces the "bwd preprocess" work item of the reference's absent CUDA extension.
+// Contract: SURVEY App. A.2 -- clamped tx/tz, ty/tz are constants for the gradient; dL/dmeans2D is
+// reported in NDC units (pixel gradient x 0.5W, 0.5H), which is what the reference's densifier
+// thresholds (src/mapper/splatam/utils/slam_external.py:100-108).
+// HBM-bound streaming kernel, one Gaussian per lane.
+#include "gs_common.h"
+
+namespace gs {
+
+__device__ __forceinline__ void sh_basis_and_grad(int deg, float x, float y, float z, float* b, float* bx, float* by, float* bz)
+{
+    for (int k = 0; k < 16; k++) { b[k] = 0.f; bx[k] = 0.f; by[k] = 0.f; bz[k] = 0.f; }
+    const float C1 = 0.4886025119029199f;
+    b[0] = 0.28209479177387814f;
+    if (deg > 0) {
+        b[1] = -C1 * y; b[2] = C1 * z; b[3] = -C1 * x;
+        by[1] = -C1; bz[2] = C1; bx[3] = -C1;
+        if (deg > 1) {
+            const float c20 = 1.0925484305920792f, c21 = -1.0925484305920792f, c22 = 0.31539156525252005f,
+                        c23 = -1.0925484305920792f, c24 = 0.5462742152960396f;
+            const float xx = x * x, yy = y * y, zz = z * z;
+            b[4] = c20 * x * y; b[5] = c21 * y * z; b[6] = c22 * (2.f * zz - xx - yy); b[7] = c23 * x * z; b[8] = c24 * (xx - yy);
+            bx[4] = c20 * y; by[4] = c20 * x;
+            by[5] = c21 * z; bz[5] = c21 * y;
+            bx[6] = c22 * (-2.f * x); by[6] = c22 * (-2.f * y); bz[6] = c22 * (4.f * z);
+            bx[7] = c23 * z; bz[7] = c23 * x;
+            bx[8] = c24 * (2.f * x); by[8] = c24 * (-2.f * y);
+            if (deg > 2) {
+                const float c30 = -0.5900435899266435f, c31 = 2.890611442640554f, c32 = -0.4570457994644658f,
+                            c33 = 0.3731763325901154f, c34 = -0.4570457994644658f, c35 = 1.445305721320277f,
+                            c36 = -0.5900435899266435f;
+                b[9] = c30 * y * (3.f * xx - yy); b[10] = c31 * x * y * z; b[11] = c32 * y * (4.f * zz - xx - yy);
+                b[12] = c33 * z * (2.f * zz - 3.f * xx - 3.f * yy); b[13] = c34 * x * (4.f * zz - xx - yy);
+                b[14] = c35 * z * (xx - yy); b[15] = c36 * x * (xx - 3.f * yy);
+                bx[9] = c30 * (6.f * x * y); by[9] = c30 * (3.f * xx - 3.f * yy);
+                bx[10] = c31 * y * z; by[10] = c31 * x * z; bz[10] = c31 * x * y;
+                bx[11] = c32 * (-2.f * x * y); by[11] = c32 * (4.f * zz - xx - 3.f * yy); bz[11] = c32 * (8.f * y * z);
+                bx[12] = c33 * (-6.f * x * z); by[12] = c33 * (-6.f * y * z); bz[12] = c33 * (6.f * zz - 3.f * xx - 3.f * yy);
+                bx[13] = c34 * (4.f * zz - 3.f * xx - yy); by[13] = c34 * (-2.f * x * y); bz[13] = c34 * (8.f * x * z);
+                bx[14] = c35 * (2.f * x * z); by[14] = c35 * (-2.f * y * z); bz[14] = c35 * (xx - yy);
+                bx[15] = c36 * (3.f * xx - 3.f * yy); by[15] = c36 * (-6.f * x * y);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
+    Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov3Dp,
+    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const float* __restrict__ grad2d,
+    float* __restrict__ dmeans2D, float* __restrict__ dmeans3D, float* __restrict__ dopac,
+    float* __restrict__ dcolors, float* __restrict__ dshs, float* __restrict__ dscales,
+    float* __restrict__ drots, float* __restrict__ dcov3D)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    const bool live = radii[i] > 0;
+    const float4* gr4 = reinterpret_cast<const float4*>(grad2d + (size_t)i * kGradStride);
+    const float4 ga = gr4[0], gb = gr4[1], gc = gr4[2];
+    // record: ga = (dx, dy, dA, dB)  gb = (dC, dopacity, dr, dg)  gc = (db, -, -, -)
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float o_m2d[3] = {0.f, 0.f, 0.f}, o_sc[3] = {0.f, 0.f, 0.f}, o_rot[4] = {0.f, 0.f, 0.f, 0.f};
+    float o_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+    const float drgb[3] = {gb.z, gb.w, gc.x};
+    if (live) {
+        const float* m = cam.view;
+        const float* q = cam.proj;
+        // ---- colour / SH ----
+        if (shs) {
+            const int deg = cam.sh_degree, nb = (deg + 1) * (deg + 1), M = cam.sh_coeffs;
+            const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
+            const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+            const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+            float b[16], bx[16], by[16], bz[16];
+            sh_basis_and_grad(deg, ux, uy, uz, b, bx, by, bz);
+            const uint32_t cl = clamped[i];
+            float du[3] = {0.f, 0.f, 0.f};
+            const float* sh = shs + (size_t)i * M * 3;
+            float* dsh = dshs + (size_t)i * M * 3;
+            for (int ch = 0; ch < 3; ch++) {
+                const float g = ((cl >> (8 * ch)) & 1u) ? 0.f : drgb[ch];
+                for (int k = 0; k < nb; k++) {
+                    const float coef = sh[3 * k + ch];
+                    dsh[3 * k + ch] = g * b[k];
+                    du[0] += g * coef * bx[k]; du[1] += g * coef * by[k]; du[2] += g * coef * bz[k];
+                }
+                for (int k = nb; k < M; k++) dsh[3 * k + ch] = 0.f;
+            }
+            const float dot = ux * du[0] + uy * du[1] + uz * du[2];
+            dmean[0] += (du[0] - ux * dot) * inv; dmean[1] += (du[1] - uy * dot) * inv; dmean[2] += (du[2] - uz * dot) * inv;
+        }
+        // ---- recompute forward intermediates ----
+        const float tx = m[0] * px + m[4] * py + m[8] * pz + m[12];
+        const float ty = m[1] * px + m[5] * py + m[9] * pz + m[13];
+        const float tz = m[2] * px + m[6] * py + m[10] * pz + m[14];
+        const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+        const float txtz = tx / tz, tytz = ty / tz;
+        const bool okx = !(txtz < -limx || txtz > limx), oky = !(tytz < -limy || tytz > limy);
+        const float cx_ = fminf(limx, fmaxf(-limx, txtz)) * tz, cy_ = fminf(limy, fmaxf(-limy, tytz)) * tz;
+        const float itz = 1.0f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+        const float J00 = cam.fx * itz, J02 = -(cam.fx * cx_) * itz2, J11 = cam.fy * itz, J12 = -(cam.fy * cy_) * itz2;
+        const float W0[3] = {m[0], m[4], m[8]}, W1[3] = {m[1], m[5], m[9]}, W2[3] = {m[2], m[6], m[10]};
+        float T0[3], T1[3];
+        for (int c = 0; c < 3; c++) { T0[c] = J00 * W0[c] + J02 * W2[c]; T1[c] = J11 * W1[c] + J12 * W2[c]; }
+        // 3-D covariance
+        float S[3][3];
+        float Rm[3][3], s3[3] = {0.f, 0.f, 0.f};
+        float r = 0.f, x = 0.f, y = 0.f, z = 0.f;
+        if (cov3Dp) {
+            const float* c = cov3Dp + (size_t)i * 6;
+            S[0][0] = c[0]; S[0][1] = c[1]; S[0][2] = c[2]; S[1][0] = c[1]; S[1][1] = c[3]; S[1][2] = c[4];
+            S[2][0] = c[2]; S[2][1] = c[4]; S[2][2] = c[5];
+        } else {
+            s3[0] = cam.mod * scales[3 * i]; s3[1] = cam.mod * scales[3 * i + 1]; s3[2] = cam.mod * scales[3 * i + 2];
+            const float4 rq = reinterpret_cast<const float4*>(rots)[i];
+            r = rq.x; x = rq.y; y = rq.z; z = rq.w;
+            Rm[0][0] = 1.f - 2.f * (y * y + z * z); Rm[0][1] = 2.f * (x * y - r * z); Rm[0][2] = 2.f * (x * z + r * y);
+            Rm[1][0] = 2.f * (x * y + r * z); Rm[1][1] = 1.f - 2.f * (x * x + z * z); Rm[1][2] = 2.f * (y * z - r * x);
+            Rm[2][0] = 2.f * (x * z - r * y); Rm[2][1] = 2.f * (y * z + r * x); Rm[2][2] = 1.f - 2.f * (x * x + y * y);
+            for (int a = 0; a < 3; a++)
+                for (int b2 = 0; b2 < 3; b2++) {
+                    float acc = 0.f;
+                    for (int j = 0; j < 3; j++) acc += (Rm[a][j] * s3[j]) * (Rm[b2][j] * s3[j]);
+                    S[a][b2] = acc;
+                }
+        }
+        // 2-D covariance (with the 0.3 low-pass) and conic -> cov2D gradient
+        float ST0[3], ST1[3];                                   // Sigma T0^T, Sigma T1^T
+        for (int a = 0; a < 3; a++) {
+            ST0[a] = S[a][0] * T0[0] + S[a][1] * T0[1] + S[a][2] * T0[2];
+            ST1[a] = S[a][0] * T1[0] + S[a][1] * T1[1] + S[a][2] * T1[2];
+        }
+        const float p_ = T0[0] * ST0[0] + T0[1] * ST0[1] + T0[2] * ST0[2] + 0.3f;
+        const float q_ = T1[0] * ST0[0] + T1[1] * ST0[1] + T1[2] * ST0[2];
+        const float r_ = T1[0] * ST1[0] + T1[1] * ST1[1] + T1[2] * ST1[2] + 0.3f;
+        const float det = p_ * r_ - q_ * q_;
+        const float d2 = 1.0f / (det * det);
+        const float dA = ga.z, dB = ga.w, dC = gb.x;
+        const float dp = (-r_ * r_ * dA + q_ * r_ * dB - q_ * q_ * dC) * d2;
+        const float dq = (2.f * q_ * r_ * dA - (p_ * r_ + q_ * q_) * dB + 2.f * p_ * q_ * dC) * d2;
+        const float dr = (-q_ * q_ * dA + p_ * q_ * dB - p_ * p_ * dC) * d2;
+        const float h = 0.5f * dq;
+        // dL/dSigma = T^T G2 T,  G2 = [[dp,h],[h,dr]]
+        float dS[3][3];
+        for (int a = 0; a < 3; a++)
+            for (int b2 = 0; b2 < 3; b2++)
+                dS[a][b2] = T0[a] * (dp * T0[b2] + h * T1[b2]) + T1[a] * (h * T0[b2] + dr * T1[b2]);
+        o_cov[0] = dS[0][0]; o_cov[3] = dS[1][1]; o_cov[5] = dS[2][2];
+        o_cov[1] = 2.f * dS[0][1]; o_cov[2] = 2.f * dS[0][2]; o_cov[4] = 2.f * dS[1][2];
+        // dL/dT = 2 G2 T Sigma
+        float dT0[3], dT1[3];
+        for (int c = 0; c < 3; c++) {
+            dT0[c] = 2.f * (dp * ST0[c] + h * ST1[c]);
+            dT1[c] = 2.f * (h * ST0[c] + dr * ST1[c]);
+        }
+        float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+        for (int c = 0; c < 3; c++) { dJ00 += dT0[c] * W0[c]; dJ02 += dT0[c] * W2[c]; dJ11 += dT1[c] * W1[c]; dJ12 += dT1[c] * W2[c]; }
+        const float dtx = okx ? -cam.fx * itz2 * dJ02 : 0.f;
+        const float dty = oky ? -cam.fy * itz2 * dJ12 : 0.f;
+        const float dtz = -cam.fx * itz2 * dJ00 - cam.fy * itz2 * dJ11 + 2.f * cam.fx * cx_ * itz3 * dJ02 + 2.f * cam.fy * cy_ * itz3 * dJ12;
+        for (int c = 0; c < 3; c++) dmean[c] += dtx * W0[c] + dty * W1[c] + dtz * W2[c];
+        // ---- mean2D -> mean3D through the projective divide ----
+        const float gxn = ga.x * 0.5f * (float)cam.W, gyn = ga.y * 0.5f * (float)cam.H;
+        o_m2d[0] = gxn; o_m2d[1] = gyn;
+        const float hx = q[0] * px + q[4] * py + q[8] * pz + q[12];
+        const float hy = q[1] * px + q[5] * py + q[9] * pz + q[13];
+        const float hw = q[3] * px + q[7] * py + q[11] * pz + q[15];
+        const float pw = 1.0f / (hw + 1e-7f);
+        const float dhx = gxn * pw, dhy = gyn * pw, dhw = -(gxn * hx + gyn * hy) * pw * pw;
+        for (int c = 0; c < 3; c++) dmean[c] += dhx * q[4 * c] + dhy * q[4 * c + 1] + dhw * q[4 * c + 3];
+        // ---- Sigma -> scale, quaternion ----
+        if (!cov3Dp) {
+            float dR[3][3];
+            for (int j = 0; j < 3; j++) {
+                float accs = 0.f;
+                for (int a = 0; a < 3; a++) {
+                    float acc = 0.f;
+                    for (int b2 = 0; b2 < 3; b2++) acc += dS[a][b2] * Rm[b2][j];
+                    const float dM = 2.f * acc * s3[j];          // dL/dM_aj, M = R diag(s)
+                    accs += dM * Rm[a][j];
+                    dR[a][j] = dM * s3[j];
+                }
+                o_sc[j] = accs * cam.mod;
+            }
+            o_rot[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+            o_rot[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
+            o_rot[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+            o_rot[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        }
+    } else if (shs) {
+        float* dsh = dshs + (size_t)i * cam.sh_coeffs * 3;
+        for (int k = 0; k < cam.sh_coeffs * 3; k++) dsh[k] = 0.f;
+    }
+    for (int c = 0; c < 3; c++) { dmeans2D[3 * i + c] = o_m2d[c]; dmeans3D[3 * i + c] = dmean[c]; }
+    dopac[i] = live ? gb.y : 0.f;
+    if (dcolors) for (int c = 0; c < 3; c++) dcolors[3 * i + c] = live ? drgb[c] : 0.f;
+    if (dscales) for (int c = 0; c < 3; c++) dscales[3 * i + c] = o_sc[c];
+    if (drots) reinterpret_cast<float4*>(drots)[i] = make_float4(o_rot[0], o_rot[1], o_rot[2], o_rot[3]);
+    if (dcov3D) for (int c = 0; c < 6; c++) dcov3D[6 * i + c] = o_cov[c];
+}
+
+hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3D, const float* shs,
+                                      const float* scales, const float* rots, const float* cov3Dp,
+                                      const int32_t* radii, const uint32_t* clamped, const float* grad2d,
+                                      float* dmeans2D, float* dmeans3D, float* dopac, float* dcolors, float* dshs,
+                                      float* dscales, float* drots, float* dcov3D, hipStream_t st)
+{
+    const int nb = (P + kBlock - 1) / kBlock;
+    if (nb > 0)
+        hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
+                           cov3Dp, radii, clamped, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
+    return hipGetLastError();
+}
+
+}  // namespace gs

@@ -1,0 +1,190 @@
+"""Drop-in `GaussianRasterizationSettings` / `GaussianRasterizer` backed by the gfx950 HIP library.
+
+Mirrors the Python API the reference imports from the (absent) `diff_gaussian_rasterization`
+package -- imports at src/mapper/splatam/splatam.py:22-23, utils/recon_helpers.py:2,
+utils/eval_helpers.py:18; settings construction utils/recon_helpers.py:14-27 and
+splatam.py:416-429; calls splatam.py:208,212,338,430,431 with the keyword tensors of
+utils/slam_helpers.py:131-138.  Contract:
+
+    rasterizer = GaussianRasterizer(raster_settings=cam)            # cheap, constructed per call
+    color, radii, depth, opacity = rasterizer(means3D=..., means2D=..., opacities=...,
+                                              colors_precomp=... | shs=...,
+                                              scales=..., rotations=... | cov3D_precomp=...)
+
+`color` [3,H,W] is differentiable w.r.t. means3D, colors_precomp/shs, opacities, scales, rotations,
+cov3D_precomp and the dummy `means2D` [P,3] (NDC-scaled screen-space gradient, read by the reference's
+densifier at utils/slam_external.py:100-108).  `radii` [P] int32 (>0 <=> visible), `depth` [1,H,W]
+(sum z*alpha*T) and `opacity` [1,H,W] (1 - T_final) are non-differentiable, which is all the reference
+needs (they are only read under torch.no_grad(), splatam.py:414,430).
+
+All compute is in libgsplat_hip.so through the C ABI of include/gsplat_hip.h; there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+#: statistics of the most recent forward on this process (read by bench.py / tests)
+last_stats = {"num_rendered": 0, "P": 0}
+#: with raster_settings.debug=True the state buffers of the most recent forward are kept here so
+#: that tests can check the integer artefacts (layouts: include/gsplat_hip.h)
+last_debug = {}
+
+_pinned = {}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32(t, device):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or t.device != device or not t.is_contiguous():
+        t = t.to(device=device, dtype=torch.float32).contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else C.c_void_p(0)
+
+
+def _camera(rs: GaussianRasterizationSettings, device, sh_coeffs: int):
+    keep = dict(bg=_f32(rs.bg, device).reshape(-1), view=_f32(rs.viewmatrix, device).reshape(-1),
+                proj=_f32(rs.projmatrix, device).reshape(-1), campos=_f32(rs.campos, device).reshape(-1))
+    if keep["view"].numel() != 16 or keep["proj"].numel() != 16 or keep["bg"].numel() != 3:
+        raise Exception("GaussianRasterizationSettings: viewmatrix/projmatrix must hold 16 values, bg 3")
+    cam = _lib.GsCamera(int(rs.image_width), int(rs.image_height), int(rs.sh_degree), int(sh_coeffs),
+                        float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier), 0,
+                        keep["bg"].data_ptr(), keep["view"].data_ptr(), keep["proj"].data_ptr(),
+                        keep["campos"].data_ptr())
+    return cam, keep
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs):
+        lib = _lib.get()
+        device = means3D.device
+        if device.type != "cuda" and not _lib.emulated():
+            raise RuntimeError("activesplat_amd rasteriser needs ROCm device tensors (no CPU fallback)")
+        P = int(means3D.shape[0])
+        means3D = _f32(means3D, device)
+        shs, colors_precomp = _f32(shs, device), _f32(colors_precomp, device)
+        opacities, scales = _f32(opacities, device), _f32(scales, device)
+        rotations, cov3D_precomp = _f32(rotations, device), _f32(cov3D_precomp, device)
+        M = 0 if shs is None else int(shs.shape[1])
+        cam, keep = _camera(rs, device, M)
+        W, H = int(rs.image_width), int(rs.image_height)
+        st = _stream(device)
+
+        gl = _lib.GsGeomLayout(); _lib.check(lib.gs_geom_layout(P, C.byref(gl)))
+        il = _lib.GsImageLayout(); _lib.check(lib.gs_image_layout(W, H, C.byref(il)))
+        geom = torch.empty(gl.total_bytes, dtype=torch.uint8, device=device)
+        image = torch.empty(il.total_bytes, dtype=torch.uint8, device=device)
+        radii = torch.empty(P, dtype=torch.int32, device=device)
+        d_num = torch.empty(1, dtype=torch.int32, device=device)
+        if device.type == "cuda":
+            h_num = _pinned.get("h_num")
+            if h_num is None:
+                h_num = _pinned["h_num"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        else:
+            h_num = torch.zeros(1, dtype=torch.int32)
+        _lib.check(lib.gs_preprocess_forward(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
+                                             _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+                                             _ptr(radii), _ptr(geom), _ptr(d_num), _ptr(h_num), st))
+        if device.type == "cuda":
+            torch.cuda.current_stream(device).synchronize()      # the one host sync: D sizes the binning buffers
+        D = int(h_num.item()) & 0xFFFFFFFF
+        bl = _lib.GsBinLayout(); _lib.check(lib.gs_bin_layout(D, W, H, C.byref(bl)))
+        binning = torch.empty(bl.total_bytes, dtype=torch.uint8, device=device)
+        point_list = torch.empty(max(D, 1), dtype=torch.int32, device=device)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=device)
+        depth = torch.empty(1, H, W, dtype=torch.float32, device=device)
+        opacity = torch.empty(1, H, W, dtype=torch.float32, device=device)
+        _lib.check(lib.gs_render_forward(C.byref(cam), P, D, _ptr(geom), _ptr(binning), _ptr(point_list), _ptr(image),
+                                         _ptr(color), _ptr(depth), _ptr(opacity), st))
+        last_stats["num_rendered"], last_stats["P"] = D, P
+        ctx.rs, ctx.D, ctx.keep = rs, D, keep
+        ctx.has = (shs is not None, colors_precomp is not None, scales is not None, rotations is not None,
+                   cov3D_precomp is not None)
+        if rs.debug:
+            last_debug.update(geom=geom, image=image, binning=binning, point_list=point_list, gl=gl, il=il, bl=bl,
+                              D=D, P=P, W=W, H=H)
+        e = torch.empty(0, device=device)
+        ctx.save_for_backward(means3D, shs if shs is not None else e, colors_precomp if colors_precomp is not None else e,
+                              scales if scales is not None else e, rotations if rotations is not None else e,
+                              cov3D_precomp if cov3D_precomp is not None else e, radii, geom, point_list, image)
+        ctx.mark_non_differentiable(radii, depth, opacity)
+        return color, radii, depth, opacity
+
+    @staticmethod
+    def backward(ctx, grad_color, _gr, _gd, _go):
+        lib = _lib.get()
+        means3D, shs, colors, scales, rots, cov3Dp, radii, geom, point_list, image = ctx.saved_tensors
+        has_sh, has_col, has_sc, has_rot, has_cov = ctx.has
+        device = means3D.device
+        P = int(means3D.shape[0])
+        M = int(shs.shape[1]) if has_sh else 0
+        cam, keep = _camera(ctx.rs, device, M)
+        grad_color = _f32(grad_color, device)
+        z = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731  (kernel writes every row)
+        d_m2d, d_m3d, d_op = z(P, 3), z(P, 3), z(P, 1)
+        d_col = z(P, 3) if has_col else None
+        d_shs = z(P, M, 3) if has_sh else None
+        d_sc = z(P, 3) if has_sc else None
+        d_rot = z(P, 4) if has_rot else None
+        d_cov = z(P, 6) if has_cov else None
+        scratch = torch.empty(int(lib.gs_backward_scratch_bytes(P)), dtype=torch.uint8, device=device)
+        _lib.check(lib.gs_render_backward(
+            C.byref(cam), P, ctx.D, _ptr(means3D), _ptr(shs if has_sh else None), _ptr(colors if has_col else None),
+            _ptr(scales if has_sc else None), _ptr(rots if has_rot else None), _ptr(cov3Dp if has_cov else None),
+            _ptr(radii), _ptr(geom), _ptr(point_list), _ptr(image), _ptr(grad_color),
+            _ptr(d_m2d), _ptr(d_m3d), _ptr(d_op), _ptr(d_col), _ptr(d_shs), _ptr(d_sc), _ptr(d_rot), _ptr(d_cov),
+            _ptr(scratch), _stream(device)))
+        return d_m3d, d_m2d, d_shs, d_col, d_op, d_sc, d_rot, d_cov, None
+
+
+def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                     cov3D_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)

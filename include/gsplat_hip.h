@@ -1,0 +1,144 @@
+/*
+ * gsplat_hip.h -- C ABI of libgsplat_hip.so, the MI355X (gfx950) native replacement for the
+ * `_C.rasterize_gaussians{,_backward}` extension entry points that ActiveSplat reaches through
+ * `diff_gaussian_rasterization.GaussianRasterizer`.
+ *
+ * Reference interface replaced (the implementation itself is an un-vendored submodule, reference
+ * .gitmodules:1-3; these are the call sites that define the contract):
+ *   settings      : src/mapper/splatam/utils/recon_helpers.py:14-27 (12-field settings tuple)
+ *   forward call  : src/mapper/splatam/splatam.py:208,212,338,430,431 and
+ *                   src/mapper/splatam/utils/slam_helpers.py:131-138 (keyword tensors)
+ *   backward      : autograd of `color` incl. means2D.grad, src/mapper/splatam/splatam.py:207-209,
+ *                   src/mapper/splatam/__init__.py:470, utils/slam_external.py:100-108
+ *   Adam          : src/mapper/splatam/splatam.py:118-124, src/mapper/splatam/__init__.py:479-480
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name starts with h_ (pinned/pageable host);
+ *   - all float tensors are contiguous fp32, layouts exactly those of the Python API
+ *     (means3D [P,3], shs [P,M,3], colors_precomp [P,3], opacities [P,1], scales [P,3],
+ *      rotations [P,4] (w,x,y,z), cov3D_precomp [P,6]); base pointers 16-byte aligned;
+ *   - `stream` is a hipStream_t; every entry point only enqueues work on it (no implicit sync);
+ *   - return value 0 = success, otherwise a GS_E* code; gs_last_error() gives the message;
+ *   - no torch types, no global mutable state except the last-error string (thread-local).
+ *
+ * Call sequence for one forward:
+ *     gs_preprocess_forward(...)            // per-Gaussian stage + scan; writes D to d_/h_num_rendered
+ *     <caller synchronises `stream`, reads D, allocates binning workspace + point_list>
+ *     gs_render_forward(...)                // emit keys, sort, tile ranges, alpha-blend
+ * and for the backward:
+ *     gs_render_backward(...)               // per-pixel replay -> per-Gaussian grads -> input grads
+ */
+#ifndef GSPLAT_HIP_H
+#define GSPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_OK 0
+#define GS_EINVAL 1      /* bad argument (null pointer, bad size, both/neither of an xor pair) */
+#define GS_ELAUNCH 2     /* a HIP launch / runtime call failed */
+#define GS_ECAPACITY 3   /* workspace too small for this call */
+
+#define GS_TILE 16       /* tile edge in pixels (spec constant) */
+#define GS_GEOM_FLOATS 12
+
+typedef void* gs_stream_t;
+
+/* Mirror of GaussianRasterizationSettings (recon_helpers.py:14-27). bg/viewmatrix/projmatrix/campos
+ * stay device tensors exactly as the reference hands them over (transposed [1,4,4] matrices). */
+typedef struct GsCamera {
+    int32_t image_width;
+    int32_t image_height;
+    int32_t sh_degree;      /* active SH degree 0..3 (only read when shs != NULL) */
+    int32_t sh_coeffs;      /* M = coefficients per Gaussian stored in shs; 0 when colors_precomp */
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t reserved;
+    const float* bg;          /* [3] */
+    const float* viewmatrix;  /* [16] = w2c^T row-major */
+    const float* projmatrix;  /* [16] = (P w2c)^T row-major */
+    const float* campos;      /* [3] */
+} GsCamera;
+
+/* Byte offsets of the arrays inside the caller-allocated state buffers, so that tests (and other
+ * hosts) can inspect the integer artefacts without any private header. */
+typedef struct GsGeomLayout {
+    uint64_t total_bytes;
+    uint64_t geom;          /* float [P][12]: x, y, conic_a, conic_b, conic_c, opacity, r, g, b, depth, ext_x, ext_y */
+    uint64_t rect;          /* uint32 [P][2]: (xmin | xmax<<16), (ymin | ymax<<16) in tiles */
+    uint64_t tiles_touched; /* uint32 [P] */
+    uint64_t offsets;       /* uint32 [P]  inclusive scan of tiles_touched (written by gs_render_forward) */
+    uint64_t block_sums;    /* uint32 [ceil(P/256)+1] exclusive scan of per-block tile counts */
+    uint64_t clamped;       /* uint8  [P][4]: SH colour clamp flags (r,g,b,pad) */
+} GsGeomLayout;
+
+typedef struct GsImageLayout {
+    uint64_t total_bytes;
+    uint64_t ranges;        /* uint32 [tiles][2] : [start,end) into point_list */
+    uint64_t final_T;       /* float  [H*W] */
+    uint64_t n_contrib;     /* uint32 [H*W] : 1-based position in the tile list of the last contributor */
+} GsImageLayout;
+
+typedef struct GsBinLayout {
+    uint64_t total_bytes;
+    uint64_t keys_unsorted; /* uint64 [D] : (tile << 32) | float_bits(view depth) */
+    uint64_t vals_unsorted; /* uint32 [D] : Gaussian index */
+    uint64_t keys_sorted;   /* uint64 [D] */
+    uint64_t sort_temp;     /* scratch of the sort */
+} GsBinLayout;
+
+int gs_geom_layout(int32_t P, GsGeomLayout* out);
+int gs_image_layout(int32_t width, int32_t height, GsImageLayout* out);
+int gs_bin_layout(int64_t D, int32_t width, int32_t height, GsBinLayout* out);
+/* bytes of the scratch gs_render_backward needs (per-Gaussian 2-D gradient records) */
+uint64_t gs_backward_scratch_bytes(int32_t P);
+
+const char* gs_last_error(void);
+const char* gs_version(void);
+
+/* Stage 1: per-Gaussian preprocess (view/projective transform, near cull, 3-D -> 2-D covariance, conic,
+ * radius, tile rect, SH -> RGB) and the tile-count scan.  Writes radii[P] (0 = culled) and the geom
+ * state; the number of tile instances D goes to *d_num_rendered and, if h_num_rendered != NULL, is
+ * copied there asynchronously (read it after synchronising `stream`). Exactly one of
+ * shs/colors_precomp and exactly one of (scales,rotations)/cov3D_precomp must be given. */
+int gs_preprocess_forward(const GsCamera* cam, int32_t P,
+                          const float* means3D, const float* shs, const float* colors_precomp,
+                          const float* opacities, const float* scales, const float* rotations,
+                          const float* cov3D_precomp,
+                          int32_t* radii, void* geom_state, uint32_t* d_num_rendered,
+                          uint32_t* h_num_rendered, gs_stream_t stream);
+
+/* Stage 2: duplicate-with-keys, sort, tile ranges, front-to-back alpha blend.
+ * out_color [3,H,W], out_depth [1,H,W] (sum z*alpha*T), out_opacity [1,H,W] (1 - T_final).
+ * point_list [D] receives the (tile, depth, index)-sorted Gaussian ids (kept for the backward). */
+int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D,
+                      void* geom_state, void* bin_state, uint32_t* point_list, void* image_state,
+                      float* out_color, float* out_depth, float* out_opacity, gs_stream_t stream);
+
+/* Backward of `out_color` w.r.t. every input.  Any dL_d* output pointer may be NULL if that input
+ * was not given (shs vs colors_precomp, scales/rotations vs cov3D_precomp).
+ * dL_dmeans2D [P,3] receives the NDC-scaled screen-space gradient (x*0.5W, y*0.5H, 0). */
+int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D,
+                       const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* scales, const float* rotations, const float* cov3D_precomp,
+                       const int32_t* radii, const void* geom_state, const uint32_t* point_list,
+                       const void* image_state, const float* dL_dcolor,
+                       float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities,
+                       float* dL_dcolors_precomp, float* dL_dshs, float* dL_dscales,
+                       float* dL_drotations, float* dL_dcov3D, void* scratch, gs_stream_t stream);
+
+/* Fused dense Adam step over one flat parameter tensor with torch.optim.Adam semantics
+ * (non-amsgrad, no weight decay): splatam.py:118-124 uses betas (0.9,0.999), eps 1e-15.
+ * `step` is the 1-based step count of this tensor AFTER the increment. */
+int gs_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                 float lr, float beta1, float beta2, float eps, int32_t step, gs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_HIP_H */

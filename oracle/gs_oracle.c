@@ -1,0 +1,556 @@
+/*
+ * gs_oracle.c -- CPU restatement of the tile-based differentiable Gaussian-splatting
+ * rasteriser behind ActiveSplat's `GaussianRasterizer` boundary.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The shipped path is the HIP library
+ * (activesplat_amd/csrc) and never routes through this file.
+ *
+ * PARITY UNPINNED (for the kernel arithmetic): the reference's implementation of this path
+ * lives in an un-vendored submodule (reference .gitmodules:1-3 ->
+ * Li-Yuetao/diff-gaussian-rasterization, no pinned SHA, directory empty), and the reference
+ * holds no tests or golden vectors for it.  This file therefore restates
+ * the *published* algorithm of the 3DGS rasteriser family (SURVEY.md Appendix A.2 [UP]) and
+ * anchors on the reference's own call sites:
+ *   - settings / matrix conventions : src/mapper/splatam/utils/recon_helpers.py:4-28
+ *   - inputs are pre-activated      : src/mapper/splatam/utils/slam_helpers.py:124-139
+ *   - 4-tuple outputs, radii>0 seen : src/mapper/splatam/splatam.py:208-212,296-298
+ *   - means2D.grad[:, :2] consumer  : src/mapper/splatam/utils/slam_external.py:100-108
+ *   - Adam configuration            : src/mapper/splatam/splatam.py:118-124
+ * The caller-side helpers ARE pinned, by golden vectors generated from the reference's
+ * importable Python (tests/golden/make_golden.py).
+ *
+ * One source, two builds: -DGSO_REAL=float (bit-level spec for integer artefacts; compiled
+ * with -ffp-contract=off so that every expression below is evaluated exactly as written) and
+ * -DGSO_REAL=double (gradient oracle).
+ *
+ * Arithmetic spec (DESIGN.md section 3 repeats it): all sums are evaluated left to right as written,
+ * no fused multiply-add, IEEE division and sqrt.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef GSO_REAL
+#define GSO_REAL float
+#endif
+typedef GSO_REAL real;
+
+#define TILE 16
+#define R(x) ((real)(x))
+
+static real r_exp(real x) { return sizeof(real) == 4 ? (real)expf((float)x) : (real)exp((double)x); }
+static real r_sqrt(real x) { return sizeof(real) == 4 ? (real)sqrtf((float)x) : (real)sqrt((double)x); }
+static real r_ceil(real x) { return sizeof(real) == 4 ? (real)ceilf((float)x) : (real)ceil((double)x); }
+static real r_min(real a, real b) { return a < b ? a : b; }
+static real r_max(real a, real b) { return a > b ? a : b; }
+
+typedef struct {
+    int32_t P, W, H;
+    int32_t sh_degree;      /* active degree 0..3 */
+    int32_t sh_coeffs;      /* M: coefficients per Gaussian in `shs` (0 => colors_precomp) */
+    real tanfovx, tanfovy;
+    real scale_modifier;
+    real bg[3];
+    real viewmatrix[16];    /* flat [4,4] exactly as stored in the settings tensor (= w2c^T row-major) */
+    real projmatrix[16];    /* flat [4,4] (= (P * w2c)^T row-major) */
+    real campos[3];
+} GsoCam;
+
+int gso_real_size(void) { return (int)sizeof(real); }
+
+/* ------------------------------------------------------------------------------------------
+ * SH evaluation (SURVEY App. A.2 [UP]: the 3DGS paper's public real-SH basis, +0.5, clamp >=0)
+ * ---------------------------------------------------------------------------------------- */
+static const double SH_C0 = 0.28209479177387814;
+static const double SH_C1 = 0.4886025119029199;
+static const double SH_C2[5] = {1.0925484305920792, -1.0925484305920792, 0.31539156525252005,
+                                -1.0925484305920792, 0.5462742152960396};
+static const double SH_C3[7] = {-0.5900435899266435, 2.890611442640554, -0.4570457994644658,
+                                0.3731763325901154, -0.4570457994644658, 1.445305721320277,
+                                -0.5900435899266435};
+
+/* basis values for unit direction (x,y,z): b[0..(deg+1)^2) */
+static void sh_basis(int deg, real x, real y, real z, real *b)
+{
+    b[0] = R(SH_C0);
+    if (deg > 0) {
+        b[1] = -R(SH_C1) * y; b[2] = R(SH_C1) * z; b[3] = -R(SH_C1) * x;
+        if (deg > 1) {
+            real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = R(SH_C2[0]) * xy;
+            b[5] = R(SH_C2[1]) * yz;
+            b[6] = R(SH_C2[2]) * (R(2) * zz - xx - yy);
+            b[7] = R(SH_C2[3]) * xz;
+            b[8] = R(SH_C2[4]) * (xx - yy);
+            if (deg > 2) {
+                b[9]  = R(SH_C3[0]) * y * (R(3) * xx - yy);
+                b[10] = R(SH_C3[1]) * xy * z;
+                b[11] = R(SH_C3[2]) * y * (R(4) * zz - xx - yy);
+                b[12] = R(SH_C3[3]) * z * (R(2) * zz - R(3) * xx - R(3) * yy);
+                b[13] = R(SH_C3[4]) * x * (R(4) * zz - xx - yy);
+                b[14] = R(SH_C3[5]) * z * (xx - yy);
+                b[15] = R(SH_C3[6]) * x * (xx - R(3) * yy);
+            }
+        }
+    }
+}
+
+/* d(basis)/d(x,y,z) for the gradient through the view direction */
+static void sh_basis_grad(int deg, real x, real y, real z, real *dx, real *dy, real *dz)
+{
+    for (int i = 0; i < 16; i++) dx[i] = dy[i] = dz[i] = 0;
+    if (deg > 0) {
+        dy[1] = -R(SH_C1); dz[2] = R(SH_C1); dx[3] = -R(SH_C1);
+        if (deg > 1) {
+            dx[4] = R(SH_C2[0]) * y; dy[4] = R(SH_C2[0]) * x;
+            dy[5] = R(SH_C2[1]) * z; dz[5] = R(SH_C2[1]) * y;
+            dx[6] = R(SH_C2[2]) * (-R(2) * x); dy[6] = R(SH_C2[2]) * (-R(2) * y); dz[6] = R(SH_C2[2]) * (R(4) * z);
+            dx[7] = R(SH_C2[3]) * z; dz[7] = R(SH_C2[3]) * x;
+            dx[8] = R(SH_C2[4]) * (R(2) * x); dy[8] = R(SH_C2[4]) * (-R(2) * y);
+            if (deg > 2) {
+                real xx = x * x, yy = y * y, zz = z * z;
+                dx[9] = R(SH_C3[0]) * (R(6) * x * y); dy[9] = R(SH_C3[0]) * (R(3) * xx - R(3) * yy);
+                dx[10] = R(SH_C3[1]) * y * z; dy[10] = R(SH_C3[1]) * x * z; dz[10] = R(SH_C3[1]) * x * y;
+                dx[11] = R(SH_C3[2]) * (-R(2) * x * y); dy[11] = R(SH_C3[2]) * (R(4) * zz - xx - R(3) * yy);
+                dz[11] = R(SH_C3[2]) * (R(8) * y * z);
+                dx[12] = R(SH_C3[3]) * (-R(6) * x * z); dy[12] = R(SH_C3[3]) * (-R(6) * y * z);
+                dz[12] = R(SH_C3[3]) * (R(6) * zz - R(3) * xx - R(3) * yy);
+                dx[13] = R(SH_C3[4]) * (R(4) * zz - R(3) * xx - yy); dy[13] = R(SH_C3[4]) * (-R(2) * x * y);
+                dz[13] = R(SH_C3[4]) * (R(8) * x * z);
+                dx[14] = R(SH_C3[5]) * (R(2) * x * z); dy[14] = R(SH_C3[5]) * (-R(2) * y * z);
+                dz[14] = R(SH_C3[5]) * (xx - yy);
+                dx[15] = R(SH_C3[6]) * (R(3) * xx - R(3) * yy); dy[15] = R(SH_C3[6]) * (-R(6) * x * y);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Per-Gaussian preprocess.
+ * Outputs (all caller-allocated, length P unless noted):
+ *   radii[P] (0 = culled), xy[2P] pixel mean, depth[P] view z, cov2d[3P] (after +0.3 low-pass),
+ *   conic_opacity[4P], rgb[3P], clamped[3P] (1 where the SH colour was clamped at 0),
+ *   rect[4P] = (xmin,ymin,xmax,ymax) in tiles, tiles_touched[P], offsets[P] (inclusive scan),
+ *   cov3d[6P] (the 3-D covariance actually used).
+ * Returns D = offsets[P-1] = number of tile instances.
+ * ---------------------------------------------------------------------------------------- */
+static void cov3d_from_scale_rot(const real *s, real mod, const real *q, real *c)
+{
+    real sx = mod * s[0], sy = mod * s[1], sz = mod * s[2];
+    real r = q[0], x = q[1], y = q[2], z = q[3];
+    real R00 = R(1) - R(2) * (y * y + z * z), R01 = R(2) * (x * y - r * z), R02 = R(2) * (x * z + r * y);
+    real R10 = R(2) * (x * y + r * z), R11 = R(1) - R(2) * (x * x + z * z), R12 = R(2) * (y * z - r * x);
+    real R20 = R(2) * (x * z - r * y), R21 = R(2) * (y * z + r * x), R22 = R(1) - R(2) * (x * x + y * y);
+    /* M = R * diag(s) ; Sigma = M M^T */
+    real M00 = R00 * sx, M01 = R01 * sy, M02 = R02 * sz;
+    real M10 = R10 * sx, M11 = R11 * sy, M12 = R12 * sz;
+    real M20 = R20 * sx, M21 = R21 * sy, M22 = R22 * sz;
+    c[0] = (M00 * M00 + M01 * M01) + M02 * M02;
+    c[1] = (M00 * M10 + M01 * M11) + M02 * M12;
+    c[2] = (M00 * M20 + M01 * M21) + M02 * M22;
+    c[3] = (M10 * M10 + M11 * M11) + M12 * M12;
+    c[4] = (M10 * M20 + M11 * M21) + M12 * M22;
+    c[5] = (M20 * M20 + M21 * M21) + M22 * M22;
+}
+
+static int clamp_tile(real v, int hi)
+{
+    /* float -> int with an explicit, platform-independent saturation first */
+    v = r_min(r_max(v, R(-1048576)), R(1048576));
+    int i = (int)v; /* truncation toward zero */
+    if (i < 0) i = 0;
+    if (i > hi) i = hi;
+    return i;
+}
+
+int64_t gso_preprocess(const GsoCam *cam, const real *means3D, const real *shs, const real *colors,
+                       const real *opac, const real *scales, const real *rots, const real *cov3D_precomp,
+                       int32_t *radii, real *xy, real *depth, real *cov2d, real *conic_opacity, real *rgb,
+                       uint8_t *clamped, int32_t *rect, uint32_t *tiles_touched, uint32_t *offsets, real *cov3d)
+{
+    const int P = cam->P, W = cam->W, H = cam->H;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const real *m = cam->viewmatrix, *q = cam->projmatrix;
+    const real fx = (real)W / (R(2) * cam->tanfovx), fy = (real)H / (R(2) * cam->tanfovy);
+    uint32_t run = 0;
+    for (int i = 0; i < P; i++) {
+        radii[i] = 0; tiles_touched[i] = 0;
+        xy[2 * i] = xy[2 * i + 1] = 0; depth[i] = 0;
+        for (int k = 0; k < 3; k++) { cov2d[3 * i + k] = 0; rgb[3 * i + k] = 0; clamped[3 * i + k] = 0; }
+        for (int k = 0; k < 4; k++) { conic_opacity[4 * i + k] = 0; rect[4 * i + k] = 0; }
+        for (int k = 0; k < 6; k++) cov3d[6 * i + k] = 0;
+        const real px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+        const real tx = ((m[0] * px + m[4] * py) + m[8] * pz) + m[12];
+        const real ty = ((m[1] * px + m[5] * py) + m[9] * pz) + m[13];
+        const real tz = ((m[2] * px + m[6] * py) + m[10] * pz) + m[14];
+        if (!(tz > R(0.2))) { offsets[i] = run; continue; }          /* near cull only; no far cull */
+        const real hx = ((q[0] * px + q[4] * py) + q[8] * pz) + q[12];
+        const real hy = ((q[1] * px + q[5] * py) + q[9] * pz) + q[13];
+        const real hw = ((q[3] * px + q[7] * py) + q[11] * pz) + q[15];
+        const real pw = R(1) / (hw + R(1e-7));
+        const real ndcx = hx * pw, ndcy = hy * pw;
+        real c3[6];
+        if (cov3D_precomp) for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * i + k];
+        else cov3d_from_scale_rot(scales + 3 * i, cam->scale_modifier, rots + 4 * i, c3);
+        for (int k = 0; k < 6; k++) cov3d[6 * i + k] = c3[k];
+        /* EWA projection */
+        const real limx = R(1.3) * cam->tanfovx, limy = R(1.3) * cam->tanfovy;
+        const real txtz = tx / tz, tytz = ty / tz;
+        const real cx_ = r_min(limx, r_max(-limx, txtz)) * tz;
+        const real cy_ = r_min(limy, r_max(-limy, tytz)) * tz;
+        const real J00 = fx / tz, J02 = -(fx * cx_) / (tz * tz);
+        const real J11 = fy / tz, J12 = -(fy * cy_) / (tz * tz);
+        /* W_rc = m[4*c + r] */
+        const real T00 = J00 * m[0] + J02 * m[2], T01 = J00 * m[4] + J02 * m[6], T02 = J00 * m[8] + J02 * m[10];
+        const real T10 = J11 * m[1] + J12 * m[2], T11 = J11 * m[5] + J12 * m[6], T12 = J11 * m[9] + J12 * m[10];
+        const real v00 = (c3[0] * T00 + c3[1] * T01) + c3[2] * T02;
+        const real v01 = (c3[1] * T00 + c3[3] * T01) + c3[4] * T02;
+        const real v02 = (c3[2] * T00 + c3[4] * T01) + c3[5] * T02;
+        const real v10 = (c3[0] * T10 + c3[1] * T11) + c3[2] * T12;
+        const real v11 = (c3[1] * T10 + c3[3] * T11) + c3[4] * T12;
+        const real v12 = (c3[2] * T10 + c3[4] * T11) + c3[5] * T12;
+        const real c00 = ((T00 * v00 + T01 * v01) + T02 * v02) + R(0.3);
+        const real c01 = (T10 * v00 + T11 * v01) + T12 * v02;
+        const real c11 = ((T10 * v10 + T11 * v11) + T12 * v12) + R(0.3);
+        const real det = c00 * c11 - c01 * c01;
+        if (!(det > R(0))) { offsets[i] = run; continue; }
+        const real det_inv = R(1) / det;
+        const real mid = R(0.5) * (c00 + c11);
+        const real sq = r_sqrt(r_max(R(0.1), mid * mid - det));
+        const real lam = r_max(mid + sq, mid - sq);
+        real rf = r_ceil(R(3) * r_sqrt(lam));
+        rf = r_min(rf, R(16777216));
+        const real pxx = ((ndcx + R(1)) * (real)W - R(1)) * R(0.5);
+        const real pyy = ((ndcy + R(1)) * (real)H - R(1)) * R(0.5);
+        const int x0 = clamp_tile((pxx - rf) / R(16), gx), x1 = clamp_tile(((pxx + rf) + R(15)) / R(16), gx);
+        const int y0 = clamp_tile((pyy - rf) / R(16), gy), y1 = clamp_tile(((pyy + rf) + R(15)) / R(16), gy);
+        const int area = (x1 - x0) * (y1 - y0);
+        if (area <= 0) { offsets[i] = run; continue; }
+        radii[i] = (int32_t)rf;
+        xy[2 * i] = pxx; xy[2 * i + 1] = pyy; depth[i] = tz;
+        cov2d[3 * i] = c00; cov2d[3 * i + 1] = c01; cov2d[3 * i + 2] = c11;
+        conic_opacity[4 * i] = c11 * det_inv; conic_opacity[4 * i + 1] = -c01 * det_inv;
+        conic_opacity[4 * i + 2] = c00 * det_inv; conic_opacity[4 * i + 3] = opac[i];
+        rect[4 * i] = x0; rect[4 * i + 1] = y0; rect[4 * i + 2] = x1; rect[4 * i + 3] = y1;
+        tiles_touched[i] = (uint32_t)area;
+        if (shs) {
+            const int M = cam->sh_coeffs, nb = (cam->sh_degree + 1) * (cam->sh_degree + 1);
+            real dx = px - cam->campos[0], dy = py - cam->campos[1], dz = pz - cam->campos[2];
+            real inv = R(1) / r_sqrt((dx * dx + dy * dy) + dz * dz);
+            real b[16]; sh_basis(cam->sh_degree, dx * inv, dy * inv, dz * inv, b);
+            for (int ch = 0; ch < 3; ch++) {
+                real acc = 0;
+                for (int k = 0; k < nb; k++) acc += b[k] * shs[((size_t)i * M + k) * 3 + ch];
+                acc += R(0.5);
+                clamped[3 * i + ch] = acc < 0;
+                rgb[3 * i + ch] = acc < 0 ? 0 : acc;
+            }
+        } else {
+            for (int ch = 0; ch < 3; ch++) rgb[3 * i + ch] = colors[3 * i + ch];
+        }
+        run += (uint32_t)area;
+        offsets[i] = run;
+    }
+    return (int64_t)run;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Binning: duplicate with 64-bit keys, stable sort, per-tile ranges.
+ * key = (tile_id << 32) | bits((float)depth)   (positive floats order like their bit patterns)
+ * The stable sort leaves equal keys in ascending Gaussian index.
+ * ---------------------------------------------------------------------------------------- */
+static uint32_t fbits(real d) { float f = (float)d; uint32_t u; memcpy(&u, &f, 4); return u; }
+
+void gso_bin(const GsoCam *cam, const real *depth, const int32_t *rect, const uint32_t *offsets,
+             int64_t D, uint64_t *keys_unsorted, uint32_t *ids_unsorted,
+             uint64_t *keys_sorted, uint32_t *ids_sorted, uint32_t *ranges)
+{
+    const int P = cam->P;
+    const int gx = (cam->W + TILE - 1) / TILE, gy = (cam->H + TILE - 1) / TILE;
+    for (int i = 0; i < P; i++) {
+        const int32_t *rc = rect + 4 * i;
+        if ((rc[2] - rc[0]) * (rc[3] - rc[1]) <= 0) continue;
+        uint32_t off = i == 0 ? 0 : offsets[i - 1];
+        for (int y = rc[1]; y < rc[3]; y++)
+            for (int x = rc[0]; x < rc[2]; x++) {
+                keys_unsorted[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | fbits(depth[i]);
+                ids_unsorted[off] = (uint32_t)i;
+                off++;
+            }
+    }
+    /* stable LSD radix sort, 8 passes of 8 bits */
+    uint64_t *ka = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(D + 1)), *kb = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(D + 1));
+    uint32_t *va = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(D + 1)), *vb = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(D + 1));
+    memcpy(ka, keys_unsorted, sizeof(uint64_t) * (size_t)D);
+    memcpy(va, ids_unsorted, sizeof(uint32_t) * (size_t)D);
+    for (int pass = 0; pass < 8; pass++) {
+        size_t cnt[257]; memset(cnt, 0, sizeof(cnt));
+        for (int64_t j = 0; j < D; j++) cnt[((ka[j] >> (8 * pass)) & 255) + 1]++;
+        for (int b = 0; b < 256; b++) cnt[b + 1] += cnt[b];
+        for (int64_t j = 0; j < D; j++) { size_t d = cnt[(ka[j] >> (8 * pass)) & 255]++; kb[d] = ka[j]; vb[d] = va[j]; }
+        uint64_t *tk = ka; ka = kb; kb = tk; uint32_t *tv = va; va = vb; vb = tv;
+    }
+    memcpy(keys_sorted, ka, sizeof(uint64_t) * (size_t)D);
+    memcpy(ids_sorted, va, sizeof(uint32_t) * (size_t)D);
+    free(ka); free(kb); free(va); free(vb);
+    for (int t = 0; t < gx * gy; t++) ranges[2 * t] = ranges[2 * t + 1] = 0;
+    for (int64_t j = 0; j < D; j++) {
+        uint32_t t = (uint32_t)(keys_sorted[j] >> 32);
+        if (j == 0 || (uint32_t)(keys_sorted[j - 1] >> 32) != t) ranges[2 * t] = (uint32_t)j;
+        if (j == D - 1 || (uint32_t)(keys_sorted[j + 1] >> 32) != t) ranges[2 * t + 1] = (uint32_t)(j + 1);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Forward blend.  NC "colour" channels per Gaussian (3 at the reference boundary).
+ * out_color[NC,H,W] = sum c*alpha*T + T_final*bg ; out_depth = sum z*alpha*T ; out_opacity = 1 - T_final.
+ * ---------------------------------------------------------------------------------------- */
+void gso_blend_forward(const GsoCam *cam, int NC, const real *bg, const uint32_t *ranges, const uint32_t *ids,
+                       const real *xy, const real *depth, const real *conic_opacity, const real *feat,
+                       real *out_color, real *out_depth, real *out_opacity, real *final_T, uint32_t *n_contrib)
+{
+    const int W = cam->W, H = cam->H, gx = (W + TILE - 1) / TILE;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const int t = (y / TILE) * gx + (x / TILE);
+            const uint32_t s = ranges[2 * t], e = ranges[2 * t + 1];
+            real T = 1, C[16], Dp = 0;
+            for (int ch = 0; ch < NC; ch++) C[ch] = 0;
+            uint32_t contributor = 0, last = 0;
+            for (uint32_t j = s; j < e; j++) {
+                contributor++;
+                const uint32_t g = ids[j];
+                const real dx = xy[2 * g] - (real)x, dy = xy[2 * g + 1] - (real)y;
+                const real *co = conic_opacity + 4 * g;
+                const real power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > 0) continue;
+                const real alpha = r_min(R(0.99), co[3] * r_exp(power));
+                if (alpha < R(1.0 / 255.0)) continue;
+                const real test_T = T * (R(1) - alpha);
+                if (test_T < R(0.0001)) break;
+                const real w = alpha * T;
+                for (int ch = 0; ch < NC; ch++) C[ch] += feat[(size_t)NC * g + ch] * w;
+                Dp += depth[g] * w;
+                T = test_T;
+                last = contributor;
+            }
+            const size_t pix = (size_t)y * W + x;
+            final_T[pix] = T; n_contrib[pix] = last;
+            for (int ch = 0; ch < NC; ch++) out_color[(size_t)ch * H * W + pix] = C[ch] + T * bg[ch];
+            out_depth[pix] = Dp; out_opacity[pix] = R(1) - T;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Backward blend: dL/dcolor [NC,H,W] -> per-Gaussian dL/d{mean2D (pixel units), conic (a,b,c true
+ * partials), opacity, feat}.  Back-to-front replay with saved final_T / n_contrib.
+ * The clamp alpha=min(0.99,.) is treated as pass-through for the gradient (SURVEY App. A.2 [UP]).
+ * ---------------------------------------------------------------------------------------- */
+void gso_blend_backward(const GsoCam *cam, int NC, const real *bg, const uint32_t *ranges, const uint32_t *ids,
+                        const real *xy, const real *conic_opacity, const real *feat,
+                        const real *final_T, const uint32_t *n_contrib, const real *dL_dpix,
+                        real *dL_dxy, real *dL_dconic, real *dL_dopacity, real *dL_dfeat)
+{
+    const int W = cam->W, H = cam->H, P = cam->P, gx = (W + TILE - 1) / TILE;
+    memset(dL_dxy, 0, sizeof(real) * 2 * (size_t)P); memset(dL_dconic, 0, sizeof(real) * 3 * (size_t)P);
+    memset(dL_dopacity, 0, sizeof(real) * (size_t)P); memset(dL_dfeat, 0, sizeof(real) * (size_t)NC * P);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const int t = (y / TILE) * gx + (x / TILE);
+            const uint32_t s = ranges[2 * t];
+            const size_t pix = (size_t)y * W + x;
+            const real Tf = final_T[pix];
+            const uint32_t last = n_contrib[pix];
+            real T = Tf, dpx[16], accum[16], lastc[16], last_alpha = 0, bgdot = 0;
+            for (int ch = 0; ch < NC; ch++) {
+                dpx[ch] = dL_dpix[(size_t)ch * H * W + pix]; accum[ch] = 0; lastc[ch] = 0; bgdot += bg[ch] * dpx[ch];
+            }
+            for (uint32_t k = last; k-- > 0;) {
+                const uint32_t g = ids[s + k];
+                const real dx = xy[2 * g] - (real)x, dy = xy[2 * g + 1] - (real)y;
+                const real *co = conic_opacity + 4 * g;
+                const real power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > 0) continue;
+                const real G = r_exp(power);
+                const real alpha = r_min(R(0.99), co[3] * G);
+                if (alpha < R(1.0 / 255.0)) continue;
+                T = T / (R(1) - alpha);
+                const real w = alpha * T;
+                real dL_dalpha = 0;
+                for (int ch = 0; ch < NC; ch++) {
+                    const real c = feat[(size_t)NC * g + ch];
+                    accum[ch] = last_alpha * lastc[ch] + (R(1) - last_alpha) * accum[ch];
+                    lastc[ch] = c;
+                    dL_dalpha += (c - accum[ch]) * dpx[ch];
+                    dL_dfeat[(size_t)NC * g + ch] += w * dpx[ch];
+                }
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-Tf / (R(1) - alpha)) * bgdot;
+                const real dL_dG = co[3] * dL_dalpha;
+                const real gdx = G * dx, gdy = G * dy;
+                /* d = mean - pixel, so dG/dmean = dG/dd */
+                dL_dxy[2 * g] += dL_dG * (-gdx * co[0] - gdy * co[1]);
+                dL_dxy[2 * g + 1] += dL_dG * (-gdy * co[2] - gdx * co[1]);
+                dL_dconic[3 * g] += R(-0.5) * gdx * dx * dL_dG;
+                dL_dconic[3 * g + 1] += -gdx * dy * dL_dG;
+                dL_dconic[3 * g + 2] += R(-0.5) * gdy * dy * dL_dG;
+                dL_dopacity[g] += G * dL_dalpha;
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Backward of the per-Gaussian preprocess.
+ * In : dL_dxy (pixel units), dL_dconic (a,b,c), dL_drgb (after SH / precomputed colour).
+ * Out: dL_dmeans2D[3P] (NDC-scaled: x*0.5W, y*0.5H, 0 -- what the reference's densifier reads,
+ *      slam_external.py:100-108), dL_dmeans3D[3P], dL_dscales[3P], dL_drots[4P], dL_dcov3D[6P],
+ *      dL_dshs[P*M*3], dL_dcolors[3P].
+ * Clamped tx/tz, ty/tz are constants for the gradient (SURVEY App. A.2 [UP]).
+ * ---------------------------------------------------------------------------------------- */
+void gso_preprocess_backward(const GsoCam *cam, const real *means3D, const real *shs, const real *scales,
+                             const real *rots, const int32_t *radii, const real *cov3d, const uint8_t *clamped,
+                             const real *dL_dxy, const real *dL_dconic, const real *dL_drgb,
+                             real *dL_dmeans2D, real *dL_dmeans3D, real *dL_dscales, real *dL_drots,
+                             real *dL_dcov3D, real *dL_dshs, real *dL_dcolors)
+{
+    const int P = cam->P, W = cam->W, H = cam->H;
+    const real *m = cam->viewmatrix, *q = cam->projmatrix;
+    const real fx = (real)W / (R(2) * cam->tanfovx), fy = (real)H / (R(2) * cam->tanfovy);
+    const int M = cam->sh_coeffs;
+    for (int i = 0; i < P; i++) {
+        for (int k = 0; k < 3; k++) { dL_dmeans2D[3 * i + k] = 0; dL_dmeans3D[3 * i + k] = 0; dL_dscales[3 * i + k] = 0; dL_dcolors[3 * i + k] = 0; }
+        for (int k = 0; k < 4; k++) dL_drots[4 * i + k] = 0;
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = 0;
+        if (shs) for (int k = 0; k < M * 3; k++) dL_dshs[(size_t)i * M * 3 + k] = 0;
+        if (radii[i] <= 0) continue;
+        const real px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+        real dmean[3] = {0, 0, 0};
+        /* ---- colour ---- */
+        if (shs) {
+            const int deg = cam->sh_degree, nb = (deg + 1) * (deg + 1);
+            real dx = px - cam->campos[0], dy = py - cam->campos[1], dz = pz - cam->campos[2];
+            real n2 = (dx * dx + dy * dy) + dz * dz, inv = R(1) / r_sqrt(n2);
+            real ux = dx * inv, uy = dy * inv, uz = dz * inv;
+            real b[16], bx[16], by[16], bz[16];
+            sh_basis(deg, ux, uy, uz, b); sh_basis_grad(deg, ux, uy, uz, bx, by, bz);
+            real du[3] = {0, 0, 0};
+            for (int ch = 0; ch < 3; ch++) {
+                real g = clamped[3 * i + ch] ? 0 : dL_drgb[3 * i + ch];
+                for (int k = 0; k < nb; k++) {
+                    real coef = shs[((size_t)i * M + k) * 3 + ch];
+                    dL_dshs[((size_t)i * M + k) * 3 + ch] = g * b[k];
+                    du[0] += g * coef * bx[k]; du[1] += g * coef * by[k]; du[2] += g * coef * bz[k];
+                }
+            }
+            /* through u = d/|d| :  dd = (du - u (u.du)) / |d| */
+            real dot = ux * du[0] + uy * du[1] + uz * du[2];
+            dmean[0] += (du[0] - ux * dot) * inv; dmean[1] += (du[1] - uy * dot) * inv; dmean[2] += (du[2] - uz * dot) * inv;
+        } else {
+            for (int ch = 0; ch < 3; ch++) dL_dcolors[3 * i + ch] = dL_drgb[3 * i + ch];
+        }
+        /* ---- recompute forward intermediates ---- */
+        const real tx = ((m[0] * px + m[4] * py) + m[8] * pz) + m[12];
+        const real ty = ((m[1] * px + m[5] * py) + m[9] * pz) + m[13];
+        const real tz = ((m[2] * px + m[6] * py) + m[10] * pz) + m[14];
+        const real limx = R(1.3) * cam->tanfovx, limy = R(1.3) * cam->tanfovy;
+        const real txtz = tx / tz, tytz = ty / tz;
+        const int okx = !(txtz < -limx || txtz > limx), oky = !(tytz < -limy || tytz > limy);
+        const real cx_ = r_min(limx, r_max(-limx, txtz)) * tz, cy_ = r_min(limy, r_max(-limy, tytz)) * tz;
+        const real J00 = fx / tz, J02 = -(fx * cx_) / (tz * tz), J11 = fy / tz, J12 = -(fy * cy_) / (tz * tz);
+        const real Wm[3][3] = {{m[0], m[4], m[8]}, {m[1], m[5], m[9]}, {m[2], m[6], m[10]}};
+        real T[2][3];
+        for (int c = 0; c < 3; c++) { T[0][c] = J00 * Wm[0][c] + J02 * Wm[2][c]; T[1][c] = J11 * Wm[1][c] + J12 * Wm[2][c]; }
+        const real *c3 = cov3d + 6 * i;
+        const real S[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+        real p_ = 0.3, q_ = 0, r_ = 0.3;
+        for (int a = 0; a < 3; a++) for (int b2 = 0; b2 < 3; b2++) {
+            p_ += T[0][a] * S[a][b2] * T[0][b2]; q_ += T[0][a] * S[a][b2] * T[1][b2]; r_ += T[1][a] * S[a][b2] * T[1][b2];
+        }
+        const real det = p_ * r_ - q_ * q_, d2 = R(1) / (det * det);
+        const real dA = dL_dconic[3 * i], dB = dL_dconic[3 * i + 1], dC = dL_dconic[3 * i + 2];
+        const real dp = (-r_ * r_ * dA + q_ * r_ * dB - q_ * q_ * dC) * d2;
+        const real dq = (R(2) * q_ * r_ * dA - (p_ * r_ + q_ * q_) * dB + R(2) * p_ * q_ * dC) * d2;
+        const real dr = (-q_ * q_ * dA + p_ * q_ * dB - p_ * p_ * dC) * d2;
+        const real G2[2][2] = {{dp, R(0.5) * dq}, {R(0.5) * dq, dr}};
+        /* dL/dSigma = T^T G2 T */
+        real dS[3][3];
+        for (int a = 0; a < 3; a++) for (int b2 = 0; b2 < 3; b2++) {
+            real acc = 0;
+            for (int u = 0; u < 2; u++) for (int v = 0; v < 2; v++) acc += T[u][a] * G2[u][v] * T[v][b2];
+            dS[a][b2] = acc;
+        }
+        dL_dcov3D[6 * i + 0] = dS[0][0]; dL_dcov3D[6 * i + 3] = dS[1][1]; dL_dcov3D[6 * i + 5] = dS[2][2];
+        dL_dcov3D[6 * i + 1] = R(2) * dS[0][1]; dL_dcov3D[6 * i + 2] = R(2) * dS[0][2]; dL_dcov3D[6 * i + 4] = R(2) * dS[1][2];
+        /* dL/dT = 2 G2 T Sigma */
+        real dT[2][3];
+        for (int u = 0; u < 2; u++) for (int c = 0; c < 3; c++) {
+            real acc = 0;
+            for (int v = 0; v < 2; v++) for (int a = 0; a < 3; a++) acc += G2[u][v] * T[v][a] * S[a][c];
+            dT[u][c] = R(2) * acc;
+        }
+        real dJ00 = 0, dJ02 = 0, dJ11 = 0, dJ12 = 0;
+        for (int c = 0; c < 3; c++) { dJ00 += dT[0][c] * Wm[0][c]; dJ02 += dT[0][c] * Wm[2][c]; dJ11 += dT[1][c] * Wm[1][c]; dJ12 += dT[1][c] * Wm[2][c]; }
+        const real tz2 = R(1) / (tz * tz), tz3 = tz2 / tz;
+        const real dtx = okx ? -fx * tz2 * dJ02 : 0;
+        const real dty = oky ? -fy * tz2 * dJ12 : 0;
+        const real dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + R(2) * fx * cx_ * tz3 * dJ02 + R(2) * fy * cy_ * tz3 * dJ12;
+        for (int c = 0; c < 3; c++) dmean[c] += dtx * Wm[0][c] + dty * Wm[1][c] + dtz * Wm[2][c];
+        /* ---- mean2D -> mean3D through the projective divide ---- */
+        const real gxn = dL_dxy[2 * i] * R(0.5) * (real)W, gyn = dL_dxy[2 * i + 1] * R(0.5) * (real)H;
+        dL_dmeans2D[3 * i] = gxn; dL_dmeans2D[3 * i + 1] = gyn;
+        const real hx = ((q[0] * px + q[4] * py) + q[8] * pz) + q[12];
+        const real hy = ((q[1] * px + q[5] * py) + q[9] * pz) + q[13];
+        const real hw = ((q[3] * px + q[7] * py) + q[11] * pz) + q[15];
+        const real pw = R(1) / (hw + R(1e-7));
+        const real dhx = gxn * pw, dhy = gyn * pw, dhw = -(gxn * hx + gyn * hy) * pw * pw;
+        for (int c = 0; c < 3; c++) dmean[c] += dhx * q[4 * c] + dhy * q[4 * c + 1] + dhw * q[4 * c + 3];
+        for (int c = 0; c < 3; c++) dL_dmeans3D[3 * i + c] = dmean[c];
+        /* ---- Sigma -> scale, quaternion ---- */
+        if (scales && rots) {
+            const real mod = cam->scale_modifier;
+            const real s[3] = {mod * scales[3 * i], mod * scales[3 * i + 1], mod * scales[3 * i + 2]};
+            const real r = rots[4 * i], x = rots[4 * i + 1], y = rots[4 * i + 2], z = rots[4 * i + 3];
+            const real Rm[3][3] = {{R(1) - R(2) * (y * y + z * z), R(2) * (x * y - r * z), R(2) * (x * z + r * y)},
+                                   {R(2) * (x * y + r * z), R(1) - R(2) * (x * x + z * z), R(2) * (y * z - r * x)},
+                                   {R(2) * (x * z - r * y), R(2) * (y * z + r * x), R(1) - R(2) * (x * x + y * y)}};
+            real dM[3][3], dR[3][3];
+            for (int a = 0; a < 3; a++) for (int j = 0; j < 3; j++) {
+                real acc = 0;
+                for (int b2 = 0; b2 < 3; b2++) acc += dS[a][b2] * Rm[b2][j] * s[j];   /* (dS M)_aj */
+                dM[a][j] = R(2) * acc;
+            }
+            for (int j = 0; j < 3; j++) {
+                real acc = 0;
+                for (int a = 0; a < 3; a++) { acc += dM[a][j] * Rm[a][j]; dR[a][j] = dM[a][j] * s[j]; }
+                dL_dscales[3 * i + j] = acc * mod;
+            }
+            dL_drots[4 * i + 0] = R(2) * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+            dL_drots[4 * i + 1] = R(2) * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - R(2) * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - R(2) * x * dR[2][2]);
+            dL_drots[4 * i + 2] = R(2) * (-R(2) * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - R(2) * y * dR[2][2]);
+            dL_drots[4 * i + 3] = R(2) * (-R(2) * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - R(2) * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Dense Adam step with torch.optim.Adam (non-amsgrad, no weight decay) semantics, as configured by
+ * the reference at src/mapper/splatam/splatam.py:118-124 (eps 1e-15, betas (0.9,0.999)).
+ *   m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2
+ *   p <- p - (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * `step` is t AFTER the increment (t >= 1).
+ * ---------------------------------------------------------------------------------------- */
+void gso_adam(int64_t n, real *p, const real *g, real *m, real *v, real lr, real b1, real b2, real eps, int32_t step)
+{
+    const real bc1 = R(1) - (real)pow((double)b1, (double)step);
+    const real bc2s = r_sqrt(R(1) - (real)pow((double)b2, (double)step));
+    const real step_size = lr / bc1;
+    for (int64_t i = 0; i < n; i++) {
+        m[i] = b1 * m[i] + (R(1) - b1) * g[i];
+        v[i] = b2 * v[i] + (R(1) - b2) * g[i] * g[i];
+        const real denom = r_sqrt(v[i]) / bc2s + eps;
+        p[i] = p[i] - step_size * (m[i] / denom);
+    }
+}

@@ -1,0 +1,53 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle32():
+    from oracle.gs_oracle import Oracle
+    return Oracle("f32")
+
+
+@pytest.fixture(scope="session")
+def oracle64():
+    from oracle.gs_oracle import Oracle
+    return Oracle("f64")
+
+
+@pytest.fixture(scope="session")
+def emu_lib_path():
+    """Host-emulated build of the kernel sources (tests/hipemu) -- a debugging aid, CPU only."""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "hipemu")
+    subprocess.check_call(["make", "-C", d, "-j8"], stdout=subprocess.DEVNULL)
+    return os.path.join(d, "libgsplat_emu.so")
+
+
+@pytest.fixture()
+def emu(emu_lib_path):
+    """Bind activesplat_amd to the emulated kernels for the duration of one test."""
+    from activesplat_amd import _lib
+    _lib.load_for_tests(emu_lib_path)
+    yield "cpu"
+    _lib.unload_for_tests()
+
+
+@pytest.fixture()
+def hip():
+    """Bind activesplat_amd to the real HIP library on cuda:0 (GPU tests)."""
+    import torch
+    from activesplat_amd import _lib
+    _lib.unload_for_tests()
+    assert torch.cuda.is_available(), "GPU test without a GPU"
+    _lib.get()
+    return "cuda"

@@ -1,0 +1,117 @@
+"""Parity cases shared by the host-emulated kernel tests (CPU) and the GPU tests: each case builds a
+settings tuple + rendervars, runs the product path and the fp32 C oracle on identical inputs, and
+checks: integer artefacts bit-exact (radii, tile rects, tile counts, scan offsets, sorted keys, sorted
+ids incl. index tie-break, tile ranges, n_contrib), images within the stated fp32 tolerance
+(atol 1e-5 + rtol 1e-4; >= 99.9 % of pixels, the rest are alpha = 1/255 /
+T = 1e-4 threshold flips caused by exp() ULP differences, each bounded by one alpha*colour step),
+gradients vs the fp64 oracle (rtol 1e-3, atol 1e-6 |g|_inf on >= 99.5 % of elements and relative
+L2 error < 1e-3)."""
+import numpy as np
+import torch
+
+from tests import util
+
+FWD_RTOL, FWD_ATOL = 1e-4, 1e-5
+GRAD_RTOL = 1e-3
+
+
+def build_case(name, device):
+    W, H, N, kw, mutate = 96, 80, 2500, {}, None
+    if name == "basic":
+        pass
+    elif name == "ragged_image":            # 50x37: partial tiles on both edges
+        W, H, N = 50, 37, 800
+    elif name == "tiny_lookaround":         # the reference's 120x150 visibility views
+        W, H, N = 120, 150, 1500
+    elif name == "posed_white_bg":
+        kw = dict(w2c=util.pose(0.25, (0.1, -0.05, 0.3)), bg=(1.0, 1.0, 1.0))
+    elif name == "scale_modifier":
+        kw = dict(scale_modifier=0.37, bg=(0.2, 0.1, 0.4))
+    elif name == "behind_camera":           # about half the Gaussians are near-culled
+        kw = dict(w2c=util.pose(0.0, (0.0, 0.0, -2.0)))
+    elif name == "all_culled":              # D == 0
+        kw = dict(w2c=util.pose(0.0, (0.0, 0.0, -100.0)), bg=(0.3, 0.6, 0.9))
+    elif name == "huge_gaussians":          # few Gaussians covering hundreds of tiles each
+        N, kw = 40, dict(scale_jitter=0.1)
+        mutate = lambda rv: rv.update(scales=rv["scales"] * 60.0)  # noqa: E731
+    elif name == "dense_overdraw":          # early termination (T < 1e-4) everywhere
+        W, H, N = 48, 48, 6000
+        mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.5 + 0.5)  # noqa: E731
+    elif name == "low_opacity":             # many Gaussians below the 1/255 threshold
+        mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.02)  # noqa: E731
+    elif name == "one_gaussian":
+        N = 1
+    elif name == "not_multiple_of_block":
+        N = 257
+    elif name in ("sh0", "sh1", "sh2", "sh3"):
+        kw = dict(sh_degree=int(name[2]), w2c=util.pose(-0.15, (0.05, 0.0, 0.1)))
+    elif name == "cov3d_precomp":
+        pass
+    else:
+        raise KeyError(name)
+    rs, rv = util.scene(N, W, H, seed=abs(hash(name)) % 1000 if False else sum(map(ord, name)), device=device, **kw)
+    if mutate:
+        mutate(rv)
+    if name == "cov3d_precomp":
+        from oracle.dense_torch import build_cov3d
+        S = build_cov3d(rv["scales"].cpu(), rv["rotations"].cpu(), 1.0)
+        cov = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).float()
+        rv.pop("scales"); rv.pop("rotations")
+        rv["cov3D_precomp"] = cov.to(device)
+    return rs, rv
+
+
+CASES = ["basic", "ragged_image", "tiny_lookaround", "posed_white_bg", "scale_modifier", "behind_camera", "all_culled",
+         "huge_gaussians", "dense_overdraw", "low_opacity", "one_gaussian", "not_multiple_of_block", "sh0", "sh1", "sh2",
+         "sh3", "cov3d_precomp"]
+
+
+def check_forward(rs, rv, oracle32, exact_float=False):
+    got = util.run_product(rs, rv)
+    art = util.artefacts()
+    ref = util.run_oracle(oracle32, rs, rv)
+    # ---- integer artefacts: bit-exact ----
+    assert got["D"] == ref["D"]
+    assert np.array_equal(got["radii"], ref["radii"])
+    live = ref["radii"] > 0
+    assert np.array_equal(art["tiles_touched"], ref["tiles_touched"])
+    assert np.array_equal(art["rect"][live], ref["rect"][live])
+    assert np.array_equal(art["offsets"], ref["offsets"])
+    assert np.array_equal(art["keys_sorted"], ref["keys_sorted"])
+    assert np.array_equal(art["point_list"], ref["ids_sorted"])
+    assert np.array_equal(art["ranges"], ref["ranges"])
+    # per-Gaussian floats produced by the contraction-free TU are bit-exact too
+    assert np.array_equal(art["geom"][live, 0:2], ref["xy"][live])
+    assert np.array_equal(art["geom"][live, 9], ref["depth"][live])
+    assert np.array_equal(art["geom"][live][:, [2, 3, 4, 5]], ref["conic_opacity"][live])
+    # ---- images ----
+    for k_got, k_ref in (("color", "color"), ("depth", "out_depth"), ("opacity", "opacity")):
+        a, b = got[k_got], ref[k_ref]
+        if exact_float:
+            assert np.array_equal(a, b), k_got
+        else:
+            scale = max(1.0, float(np.abs(b).max()))
+            assert util.close_frac(a, b, FWD_RTOL, FWD_ATOL * scale) >= 0.999, k_got
+            assert np.abs(a - b).max() <= 0.02 * scale, k_got
+    assert util.psnr(got["color"], ref["color"]) >= 60.0
+    nc_equal = np.mean(art["n_contrib"] == ref["n_contrib"])
+    assert nc_equal == 1.0 if exact_float else nc_equal >= 0.999
+    return got, ref
+
+
+def check_backward(rs, rv, oracle64, seed=0):
+    H, W = int(rs.image_height), int(rs.image_width)
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(seed))
+    got = util.run_product(rs, rv, dL)
+    ref = util.run_oracle(oracle64, rs, rv, dL)
+    for k, g in got["grads"].items():
+        r = ref["grads"][k].reshape(g.shape)
+        gmax = float(np.abs(r).max())
+        if gmax == 0.0:
+            assert np.abs(g).max() == 0.0, k
+            continue
+        assert np.isfinite(g).all(), k
+        assert util.close_frac(g, r, GRAD_RTOL, 1e-6 * gmax) >= 0.995, (k, util.close_frac(g, r, GRAD_RTOL, 1e-6 * gmax))
+        rel = np.linalg.norm(g.astype(np.float64) - r) / np.linalg.norm(r)
+        assert rel < 1e-3, (k, rel)
+    return got, ref

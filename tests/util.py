@@ -1,0 +1,91 @@
+"""Shared helpers of the parity tests: run the product path (HIP on the GPU, or the host-emulated
+kernels on CPU) and the oracle on the same inputs, and decode the integer artefacts from the state
+buffers through the layouts published in include/gsplat_hip.h."""
+import numpy as np
+import torch
+
+from activesplat_amd import rasterizer as R
+from activesplat_amd import synthetic as syn
+from activesplat_amd.camera import setup_camera
+
+
+def cam_dict(rs):
+    return dict(W=int(rs.image_width), H=int(rs.image_height), tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy),
+                bg=rs.bg.detach().cpu().numpy(), scale_modifier=float(rs.scale_modifier),
+                viewmatrix=rs.viewmatrix.detach().cpu().contiguous().numpy().reshape(4, 4),
+                projmatrix=rs.projmatrix.detach().cpu().contiguous().numpy().reshape(4, 4),
+                campos=rs.campos.detach().cpu().numpy(), sh_degree=int(rs.sh_degree))
+
+
+def pose(yaw=0.0, t=(0.0, 0.0, 0.0)):
+    c, s = np.cos(yaw), np.sin(yaw)
+    w2c = np.eye(4)
+    w2c[:3, :3] = [[c, 0, s], [0, 1, 0], [-s, 0, c]]
+    w2c[:3, 3] = t
+    return w2c
+
+
+def scene(N, W, H, seed=0, device="cpu", w2c=None, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degree=None, **kw):
+    K = syn.intrinsics(W, H)
+    rs = setup_camera(W, H, K, np.eye(4) if w2c is None else w2c, device=device, bg=bg, scale_modifier=scale_modifier,
+                      sh_degree=0 if sh_degree is None else sh_degree)
+    rs = rs._replace(debug=True)
+    p = syn.make_params(N, W, H, seed=seed, sh_degree=sh_degree, **kw)
+    rv = {k: v.to(device) for k, v in syn.activate(p).items()}
+    return rs, rv
+
+
+def run_product(rs, rv, dL=None):
+    """-> dict(color, radii, depth, opacity[, grads])"""
+    inp = {k: v.detach().clone().requires_grad_(dL is not None) for k, v in rv.items()}
+    P = inp["means3D"].shape[0]
+    m2d = torch.zeros(P, 3, device=inp["means3D"].device, requires_grad=dL is not None)
+    color, radii, depth, opacity = R.GaussianRasterizer(raster_settings=rs)(means2D=m2d, **inp)
+    out = dict(color=color.detach().cpu().numpy(), radii=radii.cpu().numpy(), depth=depth.cpu().numpy(),
+               opacity=opacity.cpu().numpy(), D=R.last_stats["num_rendered"])
+    if dL is not None:
+        color.backward(dL.to(color.device))
+        out["grads"] = {k: v.grad.detach().cpu().numpy() for k, v in inp.items()}
+        out["grads"]["means2D"] = m2d.grad.detach().cpu().numpy()
+    return out
+
+
+def run_oracle(oracle, rs, rv, dL=None):
+    n = lambda k: rv[k].detach().cpu().numpy() if k in rv else None  # noqa: E731
+    f = oracle.forward(cam_dict(rs), n("means3D"), n("opacities"), colors=n("colors_precomp"), shs=n("shs"),
+                       scales=n("scales"), rotations=n("rotations"), cov3D_precomp=n("cov3D_precomp"))
+    if dL is not None:
+        f["grads"] = oracle.backward(f, dL.detach().cpu().numpy())
+    return f
+
+
+def artefacts():
+    """Integer artefacts of the most recent debug forward, decoded via the published layouts."""
+    d = R.last_debug
+    P, D, W, H = d["P"], d["D"], d["W"], d["H"]
+    gl, il, bl = d["gl"], d["il"], d["bl"]
+    geom = d["geom"].cpu().numpy(); image = d["image"].cpu().numpy(); binning = d["binning"].cpu().numpy()
+
+    def view(buf, off, dtype, n):
+        return np.frombuffer(buf.tobytes()[off:off + n * np.dtype(dtype).itemsize], dtype=dtype).copy()
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    rect_packed = view(geom, gl.rect, np.uint32, 2 * P).reshape(P, 2)
+    rect = np.stack([rect_packed[:, 0] & 0xFFFF, rect_packed[:, 1] & 0xFFFF, rect_packed[:, 0] >> 16,
+                     rect_packed[:, 1] >> 16], 1).astype(np.int32)
+    return dict(geom=view(geom, gl.geom, np.float32, 12 * P).reshape(P, 12), rect=rect,
+                tiles_touched=view(geom, gl.tiles_touched, np.uint32, P), offsets=view(geom, gl.offsets, np.uint32, P),
+                keys_sorted=view(binning, bl.keys_sorted, np.uint64, D), point_list=d["point_list"].cpu().numpy()[:D].astype(np.uint32),
+                ranges=view(image, il.ranges, np.uint32, 2 * tiles).reshape(tiles, 2),
+                final_T=view(image, il.final_T, np.float32, W * H).reshape(H, W),
+                n_contrib=view(image, il.n_contrib, np.uint32, W * H).reshape(H, W))
+
+
+def close_frac(a, b, rtol, atol):
+    """fraction of elements of a within atol + rtol*|b| of b"""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.mean(np.abs(a - b) <= atol + rtol * np.abs(b)))
+
+
+def psnr(a, b):
+    mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
+    return 120.0 if mse == 0 else 10 * np.log10(1.0 / mse)
