@@ -37,7 +37,8 @@ class GsBinLayout(C.Structure):
 
 # every symbol include/gsplat_hip.h declares (tests check the library exports all of them)
 SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
-           "gs_version", "gs_preprocess_forward", "gs_render_forward", "gs_render_backward", "gs_adam_step")
+           "gs_version", "gs_preprocess_forward", "gs_render_forward", "gs_render_backward", "gs_adam_step",
+           "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect")
 
 
 def _bind(lib):
@@ -53,6 +54,12 @@ def _bind(lib):
     lib.gs_render_forward.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 7 + [vp]
     lib.gs_render_backward.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 6 + [vp] * 5 + [vp] * 8 + [vp, vp]
     lib.gs_adam_step.argtypes = [i64, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp]
+    lib.gs_profile_enable.argtypes = [i32]
+    lib.gs_profile_stage_count.restype = i32
+    lib.gs_profile_stage_name.argtypes = [i32]
+    lib.gs_profile_stage_name.restype = C.c_char_p
+    lib.gs_profile_collect.argtypes = [vp, vp, i32]
+    lib.gs_profile_collect.restype = C.c_int
     for n in ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_preprocess_forward", "gs_render_forward",
               "gs_render_backward", "gs_adam_step"):
         getattr(lib, n).restype = C.c_int
@@ -92,3 +99,13 @@ def emulated() -> bool:
 def check(rc: int):
     if rc != 0:
         raise Exception(get().gs_last_error().decode())
+
+
+def profile_collect():
+    """-> {stage_name: (total_ms, calls)} since gs_profile_enable(1); synchronises the recorded events."""
+    lib = get()
+    n = lib.gs_profile_stage_count()
+    ms = (C.c_float * n)()
+    calls = (C.c_int32 * n)()
+    check(lib.gs_profile_collect(ms, calls, n))
+    return {lib.gs_profile_stage_name(i).decode(): (float(ms[i]), int(calls[i])) for i in range(n)}

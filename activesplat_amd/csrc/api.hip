@@ -17,6 +17,33 @@ int fail(int code, const char* fmt, const char* a = "")
 
 uint64_t align_up(uint64_t v, uint64_t a = 256) { return (v + a - 1) / a * a; }
 
+// ---- optional per-stage timing with HIP events on the caller's stream (bench.py roofline leg) ----
+enum Stage { ST_PREPROCESS = 0, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_ADAM, ST_COUNT };
+const char* kStageNames[ST_COUNT] = {"preprocess_forward+scan", "emit", "sort", "ranges", "blend_forward",
+                                     "blend_backward", "preprocess_backward", "adam"};
+constexpr int kMaxPairs = 8192;
+struct Prof {
+    bool on = false;
+    int n = 0;
+    hipEvent_t ev[kMaxPairs][2];
+    int stage[kMaxPairs];
+    int created = 0;
+} g_prof;
+
+struct ScopedStage {
+    int idx = -1;
+    hipStream_t st;
+    ScopedStage(int stage, hipStream_t s) : st(s)
+    {
+        if (!g_prof.on || g_prof.n >= kMaxPairs) return;
+        idx = g_prof.n++;
+        if (idx >= g_prof.created) { (void)hipEventCreate(&g_prof.ev[idx][0]); (void)hipEventCreate(&g_prof.ev[idx][1]); g_prof.created = idx + 1; }
+        g_prof.stage[idx] = stage;
+        (void)hipEventRecord(g_prof.ev[idx][0], st);
+    }
+    ~ScopedStage() { if (idx >= 0) (void)hipEventRecord(g_prof.ev[idx][1], st); }
+};
+
 int tile_bits(int tiles)
 {
     int b = 1;
@@ -57,6 +84,31 @@ extern "C" {
 
 const char* gs_last_error(void) { return g_err; }
 const char* gs_version(void) { return "activesplat_amd gsplat_hip 0.1 (gfx950)"; }
+
+int gs_profile_enable(int32_t on)
+{
+    g_prof.on = on != 0;
+    g_prof.n = 0;
+    return GS_OK;
+}
+
+int32_t gs_profile_stage_count(void) { return ST_COUNT; }
+
+const char* gs_profile_stage_name(int32_t stage) { return stage >= 0 && stage < ST_COUNT ? kStageNames[stage] : ""; }
+
+int gs_profile_collect(float* ms_sum, int32_t* calls, int32_t n_stages)
+{
+    if (!ms_sum || !calls || n_stages < ST_COUNT) return fail(GS_EINVAL, "gs_profile_collect: bad argument");
+    for (int i = 0; i < n_stages; i++) { ms_sum[i] = 0.f; calls[i] = 0; }
+    for (int i = 0; i < g_prof.n; i++) {
+        if (hipEventSynchronize(g_prof.ev[i][1]) != hipSuccess) return fail(GS_ELAUNCH, "gs_profile_collect: event sync failed");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]) != hipSuccess) return fail(GS_ELAUNCH, "gs_profile_collect: elapsed failed");
+        ms_sum[g_prof.stage[i]] += ms; calls[g_prof.stage[i]]++;
+    }
+    g_prof.n = 0;
+    return GS_OK;
+}
 
 int gs_geom_layout(int32_t P, GsGeomLayout* out)
 {
@@ -121,8 +173,12 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, 
         return fail(GS_EINVAL, "gs_preprocess_forward: sh_degree / sh_coeffs / campos inconsistent");
     hipStream_t st = (hipStream_t)stream;
     gs::GeomPtrs gp = carve_geom(geom_state, P);
-    hipError_t e = gs::launch_preprocess_forward(k, P, means3D, shs, colors_precomp, opacities, scales, rotations,
-                                                 cov3D_precomp, radii, gp, d_num_rendered, st);
+    hipError_t e;
+    {
+        ScopedStage ps(ST_PREPROCESS, st);
+        e = gs::launch_preprocess_forward(k, P, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                          cov3D_precomp, radii, gp, d_num_rendered, st);
+    }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: %s", hipGetErrorString(e));
     if (h_num_rendered) {
         e = hipMemcpyAsync(h_num_rendered, d_num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
@@ -156,16 +212,22 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, void* geom_stat
         char* bb = (char*)bin_state;
         uint64_t* ku = (uint64_t*)(bb + BL.keys_unsorted); uint32_t* vu = (uint32_t*)(bb + BL.vals_unsorted);
         uint64_t* ks = (uint64_t*)(bb + BL.keys_sorted);
-        e = gs::launch_emit(k, P, gp, ku, vu, st);
+        { ScopedStage ps(ST_EMIT, st); e = gs::launch_emit(k, P, gp, ku, vu, st); }
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: emit %s", hipGetErrorString(e));
         const int end_bit = 32 + tile_bits(k.gx * k.gy);
-        e = gs::sort_pairs(bb + BL.sort_temp, (size_t)(BL.total_bytes - BL.sort_temp), ku, ks, vu, point_list, D, end_bit, st);
+        {
+            ScopedStage ps(ST_SORT, st);
+            e = gs::sort_pairs(bb + BL.sort_temp, (size_t)(BL.total_bytes - BL.sort_temp), ku, ks, vu, point_list, D, end_bit, st);
+        }
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: sort %s", hipGetErrorString(e));
-        e = gs::launch_ranges(D, ks, ranges, st);
+        { ScopedStage ps(ST_RANGES, st); e = gs::launch_ranges(D, ks, ranges, st); }
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: ranges %s", hipGetErrorString(e));
     }
-    e = gs::launch_blend_forward(k, ranges, point_list, gp.geom, out_color, out_depth, out_opacity,
-                                 (float*)(ib + IL.final_T), (uint32_t*)(ib + IL.n_contrib), st);
+    {
+        ScopedStage ps(ST_BLEND_FWD, st);
+        e = gs::launch_blend_forward(k, ranges, point_list, gp.geom, out_color, out_depth, out_opacity,
+                                     (float*)(ib + IL.final_T), (uint32_t*)(ib + IL.n_contrib), st);
+    }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: blend %s", hipGetErrorString(e));
     return GS_OK;
 }
@@ -196,13 +258,17 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* m
     hipError_t e = hipMemsetAsync(grad2d, 0, (size_t)P * gs::kGradStride * 4, st);
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_backward: memset %s", hipGetErrorString(e));
     if (D > 0) {
+        ScopedStage ps(ST_BLEND_BWD, st);
         e = gs::launch_blend_backward(k, (const uint2*)(ib + IL.ranges), point_list, gp.geom, (const float*)(ib + IL.final_T),
                                       (const uint32_t*)(ib + IL.n_contrib), dL_dcolor, grad2d, st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_backward: blend %s", hipGetErrorString(e));
     }
-    e = gs::launch_preprocess_backward(k, P, means3D, shs, scales, rotations, cov3D_precomp, radii, gp.clamped, grad2d,
-                                       dL_dmeans2D, dL_dmeans3D, dL_dopacities, dL_dcolors_precomp, dL_dshs, dL_dscales,
-                                       dL_drotations, dL_dcov3D, st);
+    {
+        ScopedStage ps(ST_PREPROCESS_BWD, st);
+        e = gs::launch_preprocess_backward(k, P, means3D, shs, scales, rotations, cov3D_precomp, radii, gp.clamped, grad2d,
+                                           dL_dmeans2D, dL_dmeans3D, dL_dopacities, dL_dcolors_precomp, dL_dshs, dL_dscales,
+                                           dL_drotations, dL_dcov3D, st);
+    }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_backward: preprocess %s", hipGetErrorString(e));
     return GS_OK;
 }
@@ -212,7 +278,11 @@ int gs_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, flo
 {
     if (n < 0 || step < 1) return fail(GS_EINVAL, "gs_adam_step: bad n/step");
     if (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq)) return fail(GS_EINVAL, "gs_adam_step: null pointer");
-    hipError_t e = gs::launch_adam(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, (hipStream_t)stream);
+    hipError_t e;
+    {
+        ScopedStage ps(ST_ADAM, (hipStream_t)stream);
+        e = gs::launch_adam(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_adam_step: %s", hipGetErrorString(e));
     return GS_OK;
 }

@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the rasteriser hot path (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one forward (colour + radii + depth + opacity) + one backward (all input gradients incl.
+means2D) of BASELINE.json configs[1]: 500k synthetic Gaussians, one 640x480 view, SH degree 0
+(colors_precomp), inputs and dL/dcolor already resident in HBM.  With N > 1 every
+rank renders its own keyframe of the same replicated scene (weak scaling: one keyframe per rank per
+step), accumulates the 14-float/Gaussian gradient locally and all-reduces it over RCCL every
+`--accum` steps (8 = the 8 keyframes per GPU of configs[3]).  Rank 0 prints ONE JSON line.
+
+Extra legs (rank 0, N = 1 only, after the timed region):
+  roofline     : per-stage hipEvent timing through the C ABI's gs_profile_* hooks over a second pass of
+                 the same K steps; the dominant stage's algorithmic bytes / its
+                 average duration against the 8 TB/s HBM peak.
+  cpu_baseline : the C oracle (oracle/gs_oracle.c, 1 host core) on the same workload, 1 frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def stage_bytes(P, D, npix):
+    """Algorithmic HBM bytes per launch of each stage: the per-unit figures of SURVEY.md section 8d
+    (b_g = 292 B/Gaussian, b_i = 160 B/instance, b_p = 48 B/pixel) split by stage."""
+    return {
+        "preprocess_forward+scan": P * (56 + 48 + 8),          # read inputs 56, write record 48, scan 8
+        "emit": P * 20 + D * 12,                               # read rect/tiles/depth 20, write key+value 12
+        "sort": D * 24,                                        # ideal one-pass: read 12 + write 12
+        "ranges": D * 8,
+        "blend_forward": D * 40 + npix * 28,                   # record gather 40; write colour 12 + depth 4 + opacity 4 + T 4 + n 4
+        "blend_backward": D * (40 + 36) + npix * 20,           # record gather 40 + grad accumulation 36; read dL 12 + T 4 + n 4
+        "preprocess_backward": P * (56 + 36 + 68),             # read inputs 56 + reduced 2-D grads 36, write grads 68
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--gaussians", type=int, default=500_000)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--accum", type=int, default=8, help="keyframes accumulated per rank between gradient all-reduces")
+    ap.add_argument("--no-extras", action="store_true", help="skip the roofline and cpu_baseline legs")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    dist_on = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+
+    from activesplat_amd import GaussianRasterizer, _lib, setup_camera
+    from activesplat_amd import rasterizer as R
+    from activesplat_amd import synthetic as syn
+    _lib.get()                                              # fail loudly if the HIP library is missing
+
+    W, H, N = args.width, args.height, args.gaussians
+    K = syn.intrinsics(W, H)
+    # rank r looks at the replicated scene from a slightly different yaw (its own keyframe)
+    yaw = np.deg2rad(2.0) * (rank - (world - 1) / 2.0)
+    c, s = np.cos(yaw), np.sin(yaw)
+    w2c = np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], dtype=np.float64)
+    cam = setup_camera(W, H, K, w2c, device=dev)
+    params = syn.make_params(N, W, H, seed=0)
+    rv = {k: v.to(dev).requires_grad_(True) for k, v in syn.activate(params).items()}
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    keys = ["means3D", "colors_precomp", "rotations", "opacities", "scales"]
+    flat = torch.zeros(N, 14, device=dev)                   # accumulated per-Gaussian gradient (3+3+4+1+3)
+
+    def step(i):
+        m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
+        color, radii, depth, opacity = GaussianRasterizer(raster_settings=cam)(means2D=m2d, **rv)
+        grads = torch.autograd.grad(color, [rv[k] for k in keys] + [m2d], dL)
+        if dist_on:
+            flat.add_(torch.cat(grads[:5], dim=1))
+            if (i + 1) % args.accum == 0:
+                dist.all_reduce(flat)
+                flat.zero_()
+        return grads
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    if dist_on and args.steps % args.accum:
+        dist.all_reduce(flat)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    D = R.last_stats["num_rendered"]
+    ms_per_step = dt / args.steps * 1e3
+    fps = world * args.steps / dt
+    out = {
+        "metric": "render+backward frames/sec at 640x480, N Gaussians", "value": round(fps, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: 500k Gaussians, 640x480 RGB+depth forward+backward, SH degree 0",
+                   "gaussians": N, "width": W, "height": H, "tile_instances_D": int(D),
+                   "keyframes_per_rank_per_step": 1, "grad_allreduce_every": args.accum if dist_on else None,
+                   "parallelism": f"keyframe-sharded x{world}" if dist_on else "single GPU"},
+    }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        lib = _lib.get()
+        # ---- roofline leg: per-stage hipEvents over a second pass of the same K steps ----
+        lib.gs_profile_enable(1)
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        prof = _lib.profile_collect()
+        lib.gs_profile_enable(0)
+        sb = stage_bytes(N, D, W * H)
+        stages = {k: {"avg_us": round(ms / max(c, 1) * 1e3, 2), "calls": c, "alg_bytes": sb.get(k),
+                      "frac_hbm": round(sb[k] / (ms / c * 1e-3) / HBM_PEAK, 4) if c and k in sb and ms > 0 else None}
+                  for k, (ms, c) in prof.items() if c}
+        dom = max((k for k in stages if k in sb), key=lambda k: stages[k]["avg_us"])
+        ach = sb[dom] / (stages[dom]["avg_us"] * 1e-6)
+        frame_bytes = N * 292 + D * 160 + W * H * 48
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9,
+                           "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": None,
+                           "alg_bytes_per_launch": sb[dom], "avg_us": stages[dom]["avg_us"],
+                           "frame_alg_bytes": frame_bytes,
+                           "frame_frac": round(frame_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 5),
+                           "stages": stages}
+        # ---- cpu_baseline leg: the C oracle on one host core, same workload, one frame ----
+        try:
+            from oracle.gs_oracle import Oracle
+            from tests import util
+            o = Oracle("f32")
+            rv_cpu = {k: v.detach().cpu() for k, v in rv.items()}
+            t1 = time.perf_counter()
+            f = util.run_oracle(o, cam, rv_cpu, dL.cpu())
+            tc = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(1.0 / tc, 5), "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": f"1 frame forward+backward of the same workload (N={N}, {W}x{H}, D={f['D']}) "
+                                             f"by oracle/gs_oracle.c (fp32, gcc -O2), {tc:.1f} s; host has {os.cpu_count()} cores"}
+        except Exception as e:      # the baseline is a report, never a reason to lose the measurement
+            out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,6 +101,15 @@ uint64_t gs_backward_scratch_bytes(int32_t P);
 const char* gs_last_error(void);
 const char* gs_version(void);
 
+/* Optional per-stage timing (hipEvents recorded on the caller's stream around each stage's launches).
+ * Off by default; bench.py switches it on for its roofline leg.  gs_profile_collect synchronises the
+ * recorded events, sums elapsed ms and call counts per stage into arrays of gs_profile_stage_count()
+ * entries, and clears the log. */
+int gs_profile_enable(int32_t on);
+int32_t gs_profile_stage_count(void);
+const char* gs_profile_stage_name(int32_t stage);
+int gs_profile_collect(float* ms_sum, int32_t* calls, int32_t n_stages);
+
 /* Stage 1: per-Gaussian preprocess (view/projective transform, near cull, 3-D -> 2-D covariance, conic,
  * radius, tile rect, SH -> RGB) and the tile-count scan.  Writes radii[P] (0 = culled) and the geom
  * state; the number of tile instances D goes to *d_num_rendered and, if h_num_rendered != NULL, is

@@ -1,0 +1,114 @@
+"""GPU (-m gpu): the parity tests proper.  The HIP path (through the C ABI) vs the oracle on identical
+seeded inputs: every edge case of tests/parity_cases.py, a mid-size scene, BASELINE configs[1] at full
+size (500k Gaussians, 640x480), and size-independent properties at full size."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests import parity_cases as pc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", pc.CASES)
+def test_forward_matches_oracle(hip, oracle32, case):
+    rs, rv = pc.build_case(case, hip)
+    pc.check_forward(rs, rv, oracle32)
+
+
+@pytest.mark.parametrize("case", pc.CASES)
+def test_backward_matches_fp64_oracle(hip, oracle64, case):
+    rs, rv = pc.build_case(case, hip)
+    pc.check_backward(rs, rv, oracle64)
+
+
+def test_midsize_scene_forward_backward(hip, oracle32, oracle64):
+    rs, rv = util.scene(60_000, 320, 240, seed=11, device=hip, w2c=util.pose(0.05, (0.02, 0.0, 0.1)), bg=(0.05, 0.1, 0.2))
+    pc.check_forward(rs, rv, oracle32)
+    pc.check_backward(rs, rv, oracle64)
+
+
+def test_full_size_config1_against_oracle(hip, oracle32):
+    """BASELINE configs[1]: 500k Gaussians, 640x480, SH-0 -- forward vs the fp32 oracle (integers exact),
+    backward vs the fp32 oracle build (same decisions), a few seconds of CPU."""
+    rs, rv = util.scene(500_000, 640, 480, seed=0, device=hip)
+    got, ref = pc.check_forward(rs, rv, oracle32)
+    dL = torch.randn(3, 480, 640, generator=torch.Generator().manual_seed(1))
+    g = util.run_product(rs, rv, dL)["grads"]
+    r = oracle32.backward(ref, dL.numpy())
+    for k, a in g.items():
+        b = r[k].reshape(a.shape)
+        rel = np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64))
+        assert rel < 2e-3, (k, rel)
+        assert util.close_frac(a, b, 5e-3, 1e-5 * float(np.abs(b).max())) > 0.99, k
+
+
+def test_full_size_properties(hip):
+    """Size-independent properties at BASELINE size (no oracle): sortedness of the keys, ranges partition
+    [0,D), sum(tiles_touched) == D == offsets[-1], silhouette channel == opacity output, depth channel ==
+    depth output, determinism of the forward, linearity of the backward in dL/dcolor."""
+    N, W, H = 500_000, 640, 480
+    rs, rv = util.scene(N, W, H, seed=0, device=hip)
+    z = rv["means3D"][:, 2]
+    rv["colors_precomp"] = torch.stack([z, torch.ones_like(z), z * z], 1).contiguous()   # w2c = I: z_cam = z
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(3))
+    a = util.run_product(rs, rv, dL)
+    art = util.artefacts()
+    D = a["D"]
+    keys = art["keys_sorted"]
+    assert (keys[1:] >= keys[:-1]).all()
+    assert int(art["tiles_touched"].sum()) == D == int(art["offsets"][-1])
+    rg = art["ranges"]; ne = rg[rg[:, 1] > rg[:, 0]]
+    assert ne[0, 0] == 0 and ne[-1, 1] == D and (ne[1:, 0] == ne[:-1, 1]).all()
+    tile_of = (keys >> np.uint64(32)).astype(np.int64)
+    assert (np.repeat(np.arange(len(rg)), (rg[:, 1] - rg[:, 0]).astype(np.int64)) == tile_of).all()
+    np.testing.assert_allclose(a["color"][1], a["opacity"][0], atol=3e-6)
+    np.testing.assert_allclose(a["color"][0], a["depth"][0], rtol=1e-5, atol=3e-5)
+    assert ((a["radii"] > 0) == (art["tiles_touched"] > 0)).all()
+    b = util.run_product(rs, rv, 2.0 * dL)
+    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["radii"], b["radii"])      # deterministic forward
+    for k in ("means3D", "opacities", "scales", "means2D"):
+        ga, gb = a["grads"][k].astype(np.float64), b["grads"][k].astype(np.float64)
+        assert np.linalg.norm(gb - 2 * ga) / np.linalg.norm(2 * ga) < 1e-4, k                      # atomics reorder sums only
+
+
+def test_adam_matches_torch_on_gpu(hip):
+    from activesplat_amd import _lib
+    lib = _lib.get()
+    torch.manual_seed(0)
+    n = 14 * 100_003
+    p = torch.randn(n, device=hip); ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([{"params": [ref], "lr": 1e-3}], lr=0.0, eps=1e-15)
+    m, v = torch.zeros(n, device=hip), torch.zeros(n, device=hip)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for step in range(1, 5):
+        g = torch.randn(n, device=hip)
+        ref.grad = g.clone(); opt.step()
+        _lib.check(lib.gs_adam_step(n, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 1e-3, 0.9, 0.999, 1e-15, step, st))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(p.cpu().numpy(), ref.detach().cpu().numpy(), rtol=3e-6, atol=1e-7)
+
+
+def test_reference_call_pattern_two_passes(hip, oracle32):
+    """The reference's get_loss call pattern (splatam.py:208-212): RGB pass + [z,1,z^2] pass on the same
+    geometry, both differentiated, means2D.grad retained from the RGB pass only."""
+    from activesplat_amd import GaussianRasterizer
+    rs, rv = util.scene(20_000, 256, 256, seed=5, device=hip)
+    rs = rs._replace(debug=False)
+    inp = {k: v.clone().requires_grad_(True) for k, v in rv.items()}
+    m2d = torch.zeros(20_000, 3, device=hip, requires_grad=True)
+    im, radius, _, _ = GaussianRasterizer(raster_settings=rs)(means2D=m2d, **inp)
+    z = inp["means3D"][:, 2:3]
+    ds = dict(inp, colors_precomp=torch.cat([z, torch.ones_like(z), z * z], 1))
+    m2d_b = torch.zeros(20_000, 3, device=hip, requires_grad=True)
+    depth_sil, _, _, _ = GaussianRasterizer(raster_settings=rs)(means2D=m2d_b, **ds)
+    loss = im.abs().mean() + (depth_sil[0] - 2.0).abs().mean()
+    loss.backward()
+    seen = radius > 0
+    assert torch.isfinite(m2d.grad).all() and m2d.grad[seen, :2].abs().sum() > 0 and (m2d.grad[:, 2] == 0).all()
+    assert torch.max(radius[seen], torch.zeros_like(radius[seen], dtype=torch.float32)).numel() == int(seen.sum())
+    for k in ("means3D", "scales", "rotations", "opacities", "colors_precomp"):
+        assert torch.isfinite(inp[k].grad).all() and inp[k].grad.abs().sum() > 0
