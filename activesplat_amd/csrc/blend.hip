@@ -13,6 +13,8 @@
 //     then walks only the set bits of its own masks with scalar find-first-set -- a wave-uniform loop,
 //     no divergence, LDS broadcast reads.  Skipped records can never pass the alpha>=1/255 test, so the
 //     result is identical to evaluating all of them.
+#include <stdlib.h>
+
 #include "gs_common.h"
 
 namespace gs {
@@ -113,9 +115,53 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
 
 // ---------------------------------------------------------------------------------------------------
 // Backward: back-to-front replay.  Per (wavefront, record) the nine per-pixel partials are reduced
-// across the 64 lanes and accumulated with one hardware fp32 atomic per component into the 48-byte
-// per-Gaussian gradient record (device-scope atomics: correct across the 8 XCDs' private L2s).
+// across the 64 lanes and accumulated with one hardware fp32 atomic instruction (9 lanes, one
+// component each) into the 48-byte per-Gaussian gradient record (device-scope atomics: correct across
+// the 8 XCDs' private L2s).
+//
+// Wave-64 reduction of 9 values in ~32 VALU instead of 9 x 6 shuffle+add: a TRANSPOSED butterfly.
+//   level 32: v_permlane32_swap pairs two values -> one register whose halves hold one value each
+//   level 16: v_permlane16_swap pairs two such registers -> one register whose 4 rows hold 4 values
+//   in-row  : 4 DPP adds (quad_perm xor1, xor2, row_half_mirror, row_mirror) finish 4 values at once
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_add(float x, const int ctrl_tag)
+{
+    // ctrl must be a literal: dispatch on the four controls used
+    if (ctrl_tag == 0) return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xf, 0xf, true));   // quad_perm:[1,0,3,2]
+    if (ctrl_tag == 1) return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x4E, 0xf, 0xf, true));   // quad_perm:[2,3,0,1]
+    if (ctrl_tag == 2) return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x140, 0xf, 0xf, true));                     // row_mirror
+}
+__device__ __forceinline__ float row_sum16(float x)
+{
+    x = dpp_add(x, 0); x = dpp_add(x, 1); x = dpp_add(x, 2); x = dpp_add(x, 3);
+    return x;     // every lane of a 16-lane row holds the row total
+}
+__device__ __forceinline__ float fold32(float a, float b)     // lanes 0-31: a[l]+a[l+32], lanes 32-63: b[l-32]+b[l]
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold16(float a, float b)     // rows (0,2): a.r+a.(r+1), rows (1,3): b.(r-1)+b.r
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// In: 9 per-lane partials.  Out: the wave total of component c in the lane `red9_lane(c)`;
+// returns this lane's value and writes the component it carries (or -1) to comp.
+__device__ __forceinline__ float wave_reduce9(const float (&v)[9], int lane, int& comp)
+{
+    const float q0123 = row_sum16(fold16(fold32(v[0], v[1]), fold32(v[2], v[3])));   // rows: V0, V2, V1, V3
+    const float q4567 = row_sum16(fold16(fold32(v[4], v[5]), fold32(v[6], v[7])));   // rows: V4, V6, V5, V7
+    const float h8 = fold32(v[8], v[8]);
+    const float q8 = row_sum16(fold16(h8, h8));                                       // every lane: V8
+    const int row = lane >> 4, c = lane & 15;
+    const int rowcomp = ((row & 1) << 1) | (row >> 1);                                // 0,2,1,3
+    comp = c == 0 ? rowcomp : (c == 1 ? 4 + rowcomp : (lane == 2 ? 8 : -1));
+    return c == 0 ? q0123 : (c == 1 ? q4567 : q8);
+}
+
+template <int VARIANT>   // 0 = shipped (transposed reduce + atomics); 1..3 = ablations (see launch_blend_backward)
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -192,35 +238,48 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                 const float alpha = fminf(0.99f, a1.y * G);
                 const bool ok = p < last && power <= 0.0f && alpha >= kAlphaMin;
                 if (!__any(ok)) continue;
-                float gx_ = 0.f, gy_ = 0.f, ga = 0.f, gb = 0.f, gc = 0.f, go = 0.f, gr = 0.f, gg = 0.f, gbl = 0.f;
+                float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // gx gy ga gb gc go gr gg gbl
                 if (ok) {
-                    T = T * __builtin_amdgcn_rcpf(1.0f - alpha);
+                    const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    T = T * rcp;
                     const float w = alpha * T;
                     acc0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0;
                     acc1 = last_alpha * lc1 + (1.0f - last_alpha) * acc1;
                     acc2 = last_alpha * lc2 + (1.0f - last_alpha) * acc2;
                     lc0 = a1.z; lc1 = a1.w; lc2 = a2.x;
                     float dL_dalpha = ((lc0 - acc0) * d0 + (lc1 - acc1) * d1 + (lc2 - acc2) * d2) * T;
-                    gr = w * d0; gg = w * d1; gbl = w * d2;
+                    v[6] = w * d0; v[7] = w * d1; v[8] = w * d2;
                     last_alpha = alpha;
-                    dL_dalpha += (-Tf * __builtin_amdgcn_rcpf(1.0f - alpha)) * bgdot;
+                    dL_dalpha -= Tf * rcp * bgdot;
                     const float dL_dG = a1.y * dL_dalpha;
                     const float gdx = G * dx, gdy = G * dy;
-                    gx_ = dL_dG * (-gdx * a0.z - gdy * a0.w);
-                    gy_ = dL_dG * (-gdy * a1.x - gdx * a0.w);
-                    ga = -0.5f * gdx * dx * dL_dG;
-                    gb = -gdx * dy * dL_dG;
-                    gc = -0.5f * gdy * dy * dL_dG;
-                    go = G * dL_dalpha;
+                    v[0] = dL_dG * (-gdx * a0.z - gdy * a0.w);
+                    v[1] = dL_dG * (-gdy * a1.x - gdx * a0.w);
+                    v[2] = -0.5f * gdx * dx * dL_dG;
+                    v[3] = -gdx * dy * dL_dG;
+                    v[4] = -0.5f * gdy * dy * dL_dG;
+                    v[5] = G * dL_dalpha;
                 }
-                gx_ = wave_sum(gx_); gy_ = wave_sum(gy_); ga = wave_sum(ga); gb = wave_sum(gb); gc = wave_sum(gc);
-                go = wave_sum(go); gr = wave_sum(gr); gg = wave_sum(gg); gbl = wave_sum(gbl);
-                if (lane < 9) {
-                    float v = gx_;
-                    v = lane == 1 ? gy_ : v; v = lane == 2 ? ga : v; v = lane == 3 ? gb : v; v = lane == 4 ? gc : v;
-                    v = lane == 5 ? go : v; v = lane == 6 ? gr : v; v = lane == 7 ? gg : v; v = lane == 8 ? gbl : v;
-                    atomicAdd(grad2d + (size_t)s_id[j] * kGradStride + lane, v);
+                if (VARIANT == 3) {            // ablation: no reduction, no atomics (keep the partials live)
+#pragma unroll
+                    for (int k = 0; k < 9; k++) asm volatile("" ::"v"(v[k]));
+                    continue;
                 }
+                if (VARIANT == 1) {            // ablation: round-1 reduction (9 x 6 shuffles)
+#pragma unroll
+                    for (int k = 0; k < 9; k++) v[k] = wave_sum(v[k]);
+                    if (lane < 9) {
+                        float x = v[0];
+#pragma unroll
+                        for (int k = 1; k < 9; k++) x = lane == k ? v[k] : x;
+                        atomicAdd(grad2d + (size_t)s_id[j] * kGradStride + lane, x);
+                    }
+                    continue;
+                }
+                int comp;
+                const float x = wave_reduce9(v, lane, comp);
+                if (VARIANT == 2) { asm volatile("" ::"v"(x)); continue; }   // ablation: reduce, no atomics
+                if (comp >= 0) atomicAdd(grad2d + (size_t)s_id[j] * kGradStride + comp, x);
             }
         }
     }
@@ -239,8 +298,14 @@ hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  float* grad2d, hipStream_t st)
 {
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(cam.gx * cam.gy), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
-                       final_T, n_contrib, dL_dcolor, grad2d);
+    // GS_BWD_VARIANT (development only): 1 = shuffle reduction, 2 = no atomics, 3 = no reduction/atomics
+    const char* ev = getenv("GS_BWD_VARIANT");
+    const int variant = ev ? atoi(ev) : 0;
+    const dim3 grid(cam.gx * cam.gy), block(kBlock);
+    if (variant == 1) hipLaunchKernelGGL(blend_backward_kernel<1>, grid, block, 0, st, cam, ranges, point_list, geom, final_T, n_contrib, dL_dcolor, grad2d);
+    else if (variant == 2) hipLaunchKernelGGL(blend_backward_kernel<2>, grid, block, 0, st, cam, ranges, point_list, geom, final_T, n_contrib, dL_dcolor, grad2d);
+    else if (variant == 3) hipLaunchKernelGGL(blend_backward_kernel<3>, grid, block, 0, st, cam, ranges, point_list, geom, final_T, n_contrib, dL_dcolor, grad2d);
+    else hipLaunchKernelGGL(blend_backward_kernel<0>, grid, block, 0, st, cam, ranges, point_list, geom, final_T, n_contrib, dL_dcolor, grad2d);
     return hipGetLastError();
 }
 

@@ -1,0 +1,54 @@
+"""Development helper: per-stage hipEvent timings of the C2 workload under environment-variable
+kernel variants (GS_*_VARIANT), all in one process.  Usage: python scripts/stage_times.py VAR=v1,v2 ..."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from activesplat_amd import GaussianRasterizer, _lib, setup_camera  # noqa: E402
+from activesplat_amd import synthetic as syn  # noqa: E402
+
+
+def run(N=500_000, W=640, H=480, steps=30, warmup=5, backward=True):
+    dev = torch.device("cuda")
+    cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=dev)
+    rv = {k: v.to(dev).requires_grad_(True) for k, v in syn.activate(syn.make_params(N, W, H, seed=0)).items()}
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    lib = _lib.get()
+
+    def step():
+        m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
+        color, _, _, _ = GaussianRasterizer(raster_settings=cam)(means2D=m2d, **rv)
+        if backward:
+            torch.autograd.grad(color, list(rv.values()) + [m2d], dL)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e6
+    lib.gs_profile_enable(1)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    prof = _lib.profile_collect()
+    lib.gs_profile_enable(0)
+    return wall, {k: ms / c * 1e3 for k, (ms, c) in prof.items() if c}
+
+
+if __name__ == "__main__":
+    sweeps = [a.split("=") for a in sys.argv[1:] if "=" in a]
+    N = int(os.environ.get("N", 500_000))
+    if not sweeps:
+        sweeps = [["GS_NONE", "0"]]
+    for var, vals in sweeps:
+        for v in vals.split(","):
+            os.environ[var] = v
+            wall, st = run(N=N)
+            print(f"{var}={v} N={N} wall_us={wall:.1f} " + " ".join(f"{k}={u:.1f}" for k, u in st.items()), flush=True)
+        os.environ.pop(var, None)

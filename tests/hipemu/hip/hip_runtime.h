@@ -222,6 +222,29 @@ static inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, in
     if (!valid) return bound_ctrl ? 0 : old;
     return hipemu::unpack<int>(o[s]);
 }
+typedef unsigned hipemu_v2u __attribute__((vector_size(8)));
+// v_permlane32_swap: lanes 32-63 of a swap with lanes 0-31 of b.  Returns {new a, new b}.
+static inline hipemu_v2u hipemu_permlane32_swap(unsigned a, unsigned b)
+{
+    unsigned lane = hipemu::lane_id();
+    const unsigned long long* o = hipemu::wave_exchange(((unsigned long long)b << 32) | a, 10, nullptr);
+    hipemu_v2u r;
+    if (lane < 32) { r[0] = a; r[1] = (unsigned)(o[lane + 32] & 0xffffffffu); }          // b_lo <- a_hi
+    else { r[0] = (unsigned)(o[lane - 32] >> 32); r[1] = b; }                             // a_hi <- b_lo
+    return r;
+}
+// v_permlane16_swap: odd rows of a swap with even rows of b.
+static inline hipemu_v2u hipemu_permlane16_swap(unsigned a, unsigned b)
+{
+    unsigned lane = hipemu::lane_id();
+    const unsigned long long* o = hipemu::wave_exchange(((unsigned long long)b << 32) | a, 11, nullptr);
+    hipemu_v2u r;
+    if (((lane >> 4) & 1) == 0) { r[0] = a; r[1] = (unsigned)(o[lane + 16] & 0xffffffffu); }  // b even row <- a odd row
+    else { r[0] = (unsigned)(o[lane - 16] >> 32); r[1] = b; }                                  // a odd row <- b even row
+    return r;
+}
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) hipemu_permlane32_swap(a, b)
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) hipemu_permlane16_swap(a, b)
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp(old, src, ctrl, rm, bm, bc)
 #define __builtin_amdgcn_mov_dpp(src, ctrl, rm, bm, bc) hipemu_update_dpp(0, src, ctrl, rm, bm, bc)
 
