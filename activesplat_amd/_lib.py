@@ -24,7 +24,8 @@ class GsCamera(C.Structure):
 
 
 class GsGeomLayout(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "geom", "rect", "tiles_touched", "offsets", "block_sums", "clamped")]
+    _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "geom", "rect", "tiles_touched", "offsets", "block_sums", "clamped",
+                                          "tile_total", "tile_base")]
 
 
 class GsImageLayout(C.Structure):
@@ -32,26 +33,32 @@ class GsImageLayout(C.Structure):
 
 
 class GsBinLayout(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "keys_unsorted", "vals_unsorted", "keys_sorted", "sort_temp")]
+    _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "path", "pairs", "keys_unsorted", "vals_unsorted", "keys_sorted",
+                                          "sort_temp")]
+
+
+SORT_AUTO, SORT_TILE_LDS, SORT_RADIX = 0, 1, 2
 
 
 # every symbol include/gsplat_hip.h declares (tests check the library exports all of them)
 SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
-           "gs_version", "gs_preprocess_forward", "gs_render_forward", "gs_render_backward", "gs_adam_step",
+           "gs_version", "gs_set_sort_path", "gs_preprocess_forward", "gs_render_forward", "gs_render_backward", "gs_adam_step",
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect")
 
 
 def _bind(lib):
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
-    lib.gs_geom_layout.argtypes = [i32, C.POINTER(GsGeomLayout)]
+    lib.gs_geom_layout.argtypes = [i32, i32, i32, C.POINTER(GsGeomLayout)]
+    lib.gs_set_sort_path.argtypes = [i32]
+    lib.gs_set_sort_path.restype = C.c_int
     lib.gs_image_layout.argtypes = [i32, i32, C.POINTER(GsImageLayout)]
-    lib.gs_bin_layout.argtypes = [i64, i32, i32, C.POINTER(GsBinLayout)]
+    lib.gs_bin_layout.argtypes = [i64, C.c_uint32, i32, i32, C.POINTER(GsBinLayout)]
     lib.gs_backward_scratch_bytes.argtypes = [i32]
     lib.gs_backward_scratch_bytes.restype = C.c_uint64
     lib.gs_last_error.restype = C.c_char_p
     lib.gs_version.restype = C.c_char_p
-    lib.gs_preprocess_forward.argtypes = [C.POINTER(GsCamera), i32] + [vp] * 7 + [vp, vp, vp, vp, vp]
-    lib.gs_render_forward.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 7 + [vp]
+    lib.gs_preprocess_forward.argtypes = [C.POINTER(GsCamera), i32] + [vp] * 7 + [vp, vp, vp, vp, vp, vp]
+    lib.gs_render_forward.argtypes = [C.POINTER(GsCamera), i32, i64, C.c_uint32] + [vp] * 7 + [vp]
     lib.gs_render_backward.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 6 + [vp] * 5 + [vp] * 8 + [vp, vp]
     lib.gs_adam_step.argtypes = [i64, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp]
     lib.gs_profile_enable.argtypes = [i32]

@@ -18,9 +18,17 @@ int fail(int code, const char* fmt, const char* a = "")
 uint64_t align_up(uint64_t v, uint64_t a = 256) { return (v + a - 1) / a * a; }
 
 // ---- optional per-stage timing with HIP events on the caller's stream (bench.py roofline leg) ----
-enum Stage { ST_PREPROCESS = 0, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_ADAM, ST_COUNT };
-const char* kStageNames[ST_COUNT] = {"preprocess_forward+scan", "emit", "sort", "ranges", "blend_forward",
-                                     "blend_backward", "preprocess_backward", "adam"};
+enum Stage { ST_PREPROCESS = 0, ST_TILE_COUNT, ST_EMIT, ST_SORT, ST_RANGES, ST_TILE_SCATTER_SORT, ST_BLEND_FWD, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_ADAM, ST_COUNT };
+const char* kStageNames[ST_COUNT] = {"preprocess_forward+scan", "tile_count+scan", "emit", "sort", "ranges",
+                                     "tile_scatter+sort", "blend_forward", "blend_backward", "preprocess_backward", "adam"};
+int g_sort_path = GS_SORT_AUTO;
+
+int choose_path(int tiles, uint32_t max_tile_instances)
+{
+    const bool fits = tiles <= gs::kMaxLdsTiles && max_tile_instances <= (uint32_t)gs::kSortCapMax;
+    if (g_sort_path == GS_SORT_RADIX) return GS_SORT_RADIX;
+    return fits ? GS_SORT_TILE_LDS : GS_SORT_RADIX;
+}
 constexpr int kMaxPairs = 8192;
 struct Prof {
     bool on = false;
@@ -66,15 +74,16 @@ bool make_cam(const GsCamera* c, gs::Cam& k)
     return true;
 }
 
-gs::GeomPtrs carve_geom(void* base, int32_t P)
+gs::GeomPtrs carve_geom(void* base, int32_t P, const gs::Cam& k)
 {
     GsGeomLayout L;
-    gs_geom_layout(P, &L);
+    gs_geom_layout(P, k.W, k.H, &L);
     char* b = (char*)base;
     gs::GeomPtrs g;
     g.geom = (float4*)(b + L.geom); g.rect = (uint2*)(b + L.rect); g.tiles = (uint32_t*)(b + L.tiles_touched);
     g.offsets = (uint32_t*)(b + L.offsets); g.block_sums = (uint32_t*)(b + L.block_sums);
     g.clamped = (uint32_t*)(b + L.clamped);
+    g.tile_total = (uint32_t*)(b + L.tile_total); g.tile_base = (uint32_t*)(b + L.tile_base);
     return g;
 }
 
@@ -110,11 +119,20 @@ int gs_profile_collect(float* ms_sum, int32_t* calls, int32_t n_stages)
     return GS_OK;
 }
 
-int gs_geom_layout(int32_t P, GsGeomLayout* out)
+int gs_set_sort_path(int32_t path)
 {
-    if (!out || P < 0) return fail(GS_EINVAL, "gs_geom_layout: bad argument");
+    if (path < GS_SORT_AUTO || path > GS_SORT_RADIX) return fail(GS_EINVAL, "gs_set_sort_path: bad path");
+    g_sort_path = path;
+    return GS_OK;
+}
+
+int gs_geom_layout(int32_t P, int32_t width, int32_t height, GsGeomLayout* out)
+{
+    if (!out || P < 0 || width <= 0 || height <= 0) return fail(GS_EINVAL, "gs_geom_layout: bad argument");
     const uint64_t n = (uint64_t)(P > 0 ? P : 1);
     const uint64_t nb = (n + gs::kBlock - 1) / gs::kBlock;
+    const uint64_t tiles = (uint64_t)((width + gs::kTile - 1) / gs::kTile) * ((height + gs::kTile - 1) / gs::kTile);
+    const uint64_t rows = (n + 1023) / 1024;   // sized for the smallest binning chunk
     uint64_t o = 0;
     out->geom = o; o = align_up(o + n * GS_GEOM_FLOATS * 4);
     out->rect = o; o = align_up(o + n * 8);
@@ -122,6 +140,8 @@ int gs_geom_layout(int32_t P, GsGeomLayout* out)
     out->offsets = o; o = align_up(o + n * 4);
     out->block_sums = o; o = align_up(o + (nb + 1) * 4);
     out->clamped = o; o = align_up(o + n * 4);
+    out->tile_total = o; o = align_up(o + tiles * 4);
+    out->tile_base = o; o = align_up(o + (tiles <= (uint64_t)gs::kMaxLdsTiles ? rows * tiles * 4 : 4));
     out->total_bytes = o;
     return GS_OK;
 }
@@ -139,16 +159,22 @@ int gs_image_layout(int32_t width, int32_t height, GsImageLayout* out)
     return GS_OK;
 }
 
-int gs_bin_layout(int64_t D, int32_t width, int32_t height, GsBinLayout* out)
+int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t height, GsBinLayout* out)
 {
     if (!out || D < 0 || width <= 0 || height <= 0) return fail(GS_EINVAL, "gs_bin_layout: bad argument");
     const int tiles = ((width + gs::kTile - 1) / gs::kTile) * ((height + gs::kTile - 1) / gs::kTile);
     const uint64_t n = (uint64_t)(D > 0 ? D : 1);
+    memset(out, 0, sizeof(*out));
+    out->path = (uint64_t)choose_path(tiles, max_tile_instances);
     uint64_t o = 0;
-    out->keys_unsorted = o; o = align_up(o + n * 8);
-    out->vals_unsorted = o; o = align_up(o + n * 4);
-    out->keys_sorted = o; o = align_up(o + n * 8);
-    out->sort_temp = o; o = align_up(o + gs::sort_temp_bytes(D, 32 + tile_bits(tiles)));
+    if (out->path == GS_SORT_TILE_LDS) {
+        out->pairs = o; o = align_up(o + n * 8);
+    } else {
+        out->keys_unsorted = o; o = align_up(o + n * 8);
+        out->vals_unsorted = o; o = align_up(o + n * 4);
+        out->keys_sorted = o; o = align_up(o + n * 8);
+        out->sort_temp = o; o = align_up(o + gs::sort_temp_bytes(D, 32 + tile_bits(tiles)));
+    }
     out->total_bytes = o;
     return GS_OK;
 }
@@ -158,11 +184,11 @@ uint64_t gs_backward_scratch_bytes(int32_t P) { return align_up((uint64_t)(P > 0
 int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, const float* shs,
                           const float* colors_precomp, const float* opacities, const float* scales,
                           const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_state,
-                          uint32_t* d_num_rendered, uint32_t* h_num_rendered, gs_stream_t stream)
+                          void* image_state, uint32_t* d_counts, uint32_t* h_counts, gs_stream_t stream)
 {
     gs::Cam k;
     if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_preprocess_forward: invalid camera settings");
-    if (P < 0 || !geom_state || !d_num_rendered) return fail(GS_EINVAL, "gs_preprocess_forward: null state pointer");
+    if (P < 0 || !geom_state || !image_state || !d_counts) return fail(GS_EINVAL, "gs_preprocess_forward: null state pointer");
     if (P > 0 && (!means3D || !opacities || !radii)) return fail(GS_EINVAL, "gs_preprocess_forward: null input pointer");
     if ((shs == nullptr) == (colors_precomp == nullptr) && P > 0)
         return fail(GS_EINVAL, "Please provide excatly one of either SHs or precomputed colors!");
@@ -172,23 +198,34 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, 
     if (shs && (k.sh_degree < 0 || k.sh_degree > 3 || k.sh_coeffs < (k.sh_degree + 1) * (k.sh_degree + 1) || !k.campos))
         return fail(GS_EINVAL, "gs_preprocess_forward: sh_degree / sh_coeffs / campos inconsistent");
     hipStream_t st = (hipStream_t)stream;
-    gs::GeomPtrs gp = carve_geom(geom_state, P);
+    gs::GeomPtrs gp = carve_geom(geom_state, P, k);
+    GsImageLayout IL; gs_image_layout(k.W, k.H, &IL);
+    uint2* ranges = (uint2*)((char*)image_state + IL.ranges);
+    const int tiles = k.gx * k.gy;
     hipError_t e;
     {
         ScopedStage ps(ST_PREPROCESS, st);
         e = gs::launch_preprocess_forward(k, P, means3D, shs, colors_precomp, opacities, scales, rotations,
-                                          cov3D_precomp, radii, gp, d_num_rendered, st);
+                                          cov3D_precomp, radii, gp, d_counts, st);
     }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: %s", hipGetErrorString(e));
-    if (h_num_rendered) {
-        e = hipMemcpyAsync(h_num_rendered, d_num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (tiles <= gs::kMaxLdsTiles) {          // tile counting: ranges, D and the largest tile list
+        ScopedStage ps(ST_TILE_COUNT, st);
+        e = gs::launch_tile_count(k, P, gp, gp.tile_total, gp.tile_base, ranges, d_counts, st);
+        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: tile count %s", hipGetErrorString(e));
+    } else {                                   // too many tiles for the LDS histogram: radix path, counts = {D, 2^32-1}
+        e = hipMemsetAsync(d_counts + 1, 0xff, sizeof(uint32_t), st);
+        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: memset %s", hipGetErrorString(e));
+    }
+    if (h_counts) {
+        e = hipMemcpyAsync(h_counts, d_counts, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: D2H %s", hipGetErrorString(e));
     }
     return GS_OK;
 }
 
-int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, void* geom_state, void* bin_state,
-                      uint32_t* point_list, void* image_state, float* out_color, float* out_depth,
+int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_tile_instances, void* geom_state,
+                      void* bin_state, uint32_t* point_list, void* image_state, float* out_color, float* out_depth,
                       float* out_opacity, gs_stream_t stream)
 {
     gs::Cam k;
@@ -198,30 +235,40 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, void* geom_stat
     if (D > 0 && (!bin_state || !point_list)) return fail(GS_EINVAL, "gs_render_forward: null binning workspace");
     if (D >= (int64_t)1 << 32) return fail(GS_ECAPACITY, "gs_render_forward: more than 2^32 tile instances");
     hipStream_t st = (hipStream_t)stream;
-    gs::GeomPtrs gp = carve_geom(geom_state, P);
+    gs::GeomPtrs gp = carve_geom(geom_state, P, k);
     GsImageLayout IL; gs_image_layout(k.W, k.H, &IL);
     char* ib = (char*)image_state;
     uint2* ranges = (uint2*)(ib + IL.ranges);
-    hipError_t e = hipMemsetAsync(ranges, 0, (size_t)k.gx * k.gy * 8, st);
-    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: memset %s", hipGetErrorString(e));
-    if (D == 0) {   // nothing visible: the emitter still writes the (all-zero) scan offsets
-        e = gs::launch_emit(k, P, gp, nullptr, nullptr, st);
-        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: emit %s", hipGetErrorString(e));
-    } else {
-        GsBinLayout BL; gs_bin_layout(D, k.W, k.H, &BL);
-        char* bb = (char*)bin_state;
-        uint64_t* ku = (uint64_t*)(bb + BL.keys_unsorted); uint32_t* vu = (uint32_t*)(bb + BL.vals_unsorted);
-        uint64_t* ks = (uint64_t*)(bb + BL.keys_sorted);
-        { ScopedStage ps(ST_EMIT, st); e = gs::launch_emit(k, P, gp, ku, vu, st); }
-        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: emit %s", hipGetErrorString(e));
-        const int end_bit = 32 + tile_bits(k.gx * k.gy);
-        {
-            ScopedStage ps(ST_SORT, st);
-            e = gs::sort_pairs(bb + BL.sort_temp, (size_t)(BL.total_bytes - BL.sort_temp), ku, ks, vu, point_list, D, end_bit, st);
+    GsBinLayout BL; gs_bin_layout(D, max_tile_instances, k.W, k.H, &BL);
+    char* bb = (char*)bin_state;
+    hipError_t e;
+    if (BL.path == GS_SORT_TILE_LDS) {
+        if (D > 0) {          // ranges were written by gs_preprocess_forward
+            ScopedStage ps(ST_TILE_SCATTER_SORT, st);
+            e = gs::launch_tile_scatter_sort(k, P, gp, gp.tile_base, ranges, max_tile_instances,
+                                             (unsigned long long*)(bb + BL.pairs), point_list, st);
+            if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: tile scatter/sort %s", hipGetErrorString(e));
         }
-        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: sort %s", hipGetErrorString(e));
-        { ScopedStage ps(ST_RANGES, st); e = gs::launch_ranges(D, ks, ranges, st); }
-        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: ranges %s", hipGetErrorString(e));
+    } else {
+        e = hipMemsetAsync(ranges, 0, (size_t)k.gx * k.gy * 8, st);
+        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: memset %s", hipGetErrorString(e));
+        if (D == 0) {   // nothing visible: the emitter still writes the (all-zero) scan offsets
+            e = gs::launch_emit(k, P, gp, nullptr, nullptr, st);
+            if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: emit %s", hipGetErrorString(e));
+        } else {
+            uint64_t* ku = (uint64_t*)(bb + BL.keys_unsorted); uint32_t* vu = (uint32_t*)(bb + BL.vals_unsorted);
+            uint64_t* ks = (uint64_t*)(bb + BL.keys_sorted);
+            { ScopedStage ps(ST_EMIT, st); e = gs::launch_emit(k, P, gp, ku, vu, st); }
+            if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: emit %s", hipGetErrorString(e));
+            const int end_bit = 32 + tile_bits(k.gx * k.gy);
+            {
+                ScopedStage ps(ST_SORT, st);
+                e = gs::sort_pairs(bb + BL.sort_temp, (size_t)(BL.total_bytes - BL.sort_temp), ku, ks, vu, point_list, D, end_bit, st);
+            }
+            if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: sort %s", hipGetErrorString(e));
+            { ScopedStage ps(ST_RANGES, st); e = gs::launch_ranges(D, ks, ranges, st); }
+            if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: ranges %s", hipGetErrorString(e));
+        }
     }
     {
         ScopedStage ps(ST_BLEND_FWD, st);
@@ -251,7 +298,7 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* m
     if (cov3D_precomp ? !dL_dcov3D : (!scales || !rotations || !dL_dscales || !dL_drotations))
         return fail(GS_EINVAL, "gs_render_backward: missing covariance inputs/outputs");
     hipStream_t st = (hipStream_t)stream;
-    gs::GeomPtrs gp = carve_geom(const_cast<void*>(geom_state), P);
+    gs::GeomPtrs gp = carve_geom(const_cast<void*>(geom_state), P, k);
     GsImageLayout IL; gs_image_layout(k.W, k.H, &IL);
     const char* ib = (const char*)image_state;
     float* grad2d = (float*)scratch;

@@ -12,6 +12,9 @@ constexpr int kTile = GS_TILE;      // 16x16 pixel tile = one 256-thread workgro
 constexpr int kBlock = 256;
 constexpr int kWave = 64;           // CDNA wavefront
 constexpr int kQuad = 8;            // each wavefront owns one 8x8 pixel quadrant of the tile
+constexpr int kBinChunk = 2048;     // Gaussians per tile-binning workgroup (LDS-private histogram)
+constexpr int kMaxLdsTiles = 8192;  // tile-binning path needs the tile histogram in LDS (32 KiB)
+constexpr int kSortCapMax = 8192;   // largest per-tile list the LDS sort takes; beyond -> device radix sort
 
 // By-value kernel argument; matrices stay in device memory exactly where the caller's settings
 // tensors put them (uniform loads -> scalar cache).
@@ -36,6 +39,8 @@ struct GeomPtrs {
     uint32_t* offsets;
     uint32_t* block_sums;
     uint32_t* clamped;   // uchar4 packed
+    uint32_t* tile_total;  // [tiles]
+    uint32_t* tile_base;   // [ceil(P/kBinChunk)][tiles]
 };
 
 // ---- wave-64 helpers ---------------------------------------------------------------------------
@@ -88,6 +93,11 @@ hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3
                                       const int32_t* radii, const uint32_t* clamped, const float* grad2d,
                                       float* dmeans2D, float* dmeans3D, float* dopac, float* dcolors, float* dshs,
                                       float* dscales, float* drots, float* dcov3D, hipStream_t st);
+hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,
+                             uint2* ranges, uint32_t* d_counts, hipStream_t st);
+hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_base, const uint2* ranges,
+                                    uint32_t max_tile_instances, unsigned long long* pairs, uint32_t* point_list,
+                                    hipStream_t st);
 hipError_t launch_emit(const Cam& cam, int P, GeomPtrs gp, uint64_t* keys, uint32_t* vals, hipStream_t st);
 hipError_t launch_ranges(int64_t D, const uint64_t* keys_sorted, uint2* ranges, hipStream_t st);
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,

@@ -1,0 +1,224 @@
+// tilebin.hip -- tile binning without a global sort: count -> scan -> scatter -> per-tile LDS sort.
+//
+// Replaces the duplicateWithKeys + 64-bit device radix sort + identifyTileRanges work items of the
+// reference's absent CUDA extension when every tile list fits LDS; the result
+// (point_list, ranges) is identical: per tile, instances in ascending (view depth bits, Gaussian index).
+//
+// Why not a device-wide radix sort on MI355X: for ~1M (key,value) pairs the 6-pass sort is launch/latency
+// bound (198 us measured, 1.8 % of HBM peak).  The instances only need to be GROUPED by tile and ordered
+// by depth WITHIN a tile, so:
+//   tile_count   : workgroups of 4096 Gaussians expand rect -> tile ids with the wavefront prefix-sum
+//                  emitter and count into an LDS-private histogram (LDS atomics); one global atomic per
+//                  (workgroup, tile) reserves the workgroup's slice of the tile segment.  (Direct global
+//                  atomics per instance measured 61-140 us for 1.2M instances on 1200 counters.)
+//   tile_scan    : exclusive scan of the per-tile totals -> ranges[tile], D, max instances per tile.
+//   tile_scatter : same expansion; LDS returning atomics hand out slots inside the reserved slices;
+//                  one 8-byte (depth_bits<<32 | id) store per instance.
+//   tile_sort    : one workgroup per tile, bitonic sort of the 64-bit pairs in LDS (keys are unique, so
+//                  the result does not depend on the atomics' arrival order), writes point_list.
+#include <stdlib.h>
+
+#include "gs_common.h"
+
+namespace gs {
+
+// one wavefront expands its 64 Gaussians' rects; f(tile, owner_slot, k) is called once per instance
+template <class F>
+__device__ __forceinline__ void expand_wave(const uint32_t* incl_w, const uint32_t* s_x0w, const uint32_t* s_y0,
+                                            int wave, int lane, uint32_t total, int gx, F f)
+{
+    for (uint32_t t0 = 0; t0 < total; t0 += kWave) {
+        const uint32_t t = t0 + lane;
+        if (t < total) {
+            int lo = 0, hi = 63;
+#pragma unroll
+            for (int s = 0; s < 6; s++) {
+                const int mid = (lo + hi) >> 1;
+                if (incl_w[mid] > t) hi = mid; else lo = mid + 1;
+            }
+            const int j = wave * kWave + lo;
+            const uint32_t k = t - (lo ? incl_w[lo - 1] : 0u);
+            const uint32_t xw = s_x0w[j];
+            const uint32_t w = xw >> 16, x0 = xw & 0xffffu;
+            const uint32_t tile = (s_y0[j] + k / w) * (uint32_t)gx + x0 + k % w;
+            f(tile, j);
+        }
+    }
+}
+
+template <bool SCATTER, int THREADS>
+__global__ __launch_bounds__(THREADS) void tile_bin_kernel(Cam cam, int P, GeomPtrs gp, int tiles, int chunk,
+                                                          uint32_t* __restrict__ tile_total,
+                                                          uint32_t* __restrict__ tile_base,
+                                                          const uint2* __restrict__ ranges,
+                                                          unsigned long long* __restrict__ pairs)
+{
+    __shared__ uint32_t s_hist[kMaxLdsTiles];      // count pass: histogram; scatter pass: cursors
+    __shared__ uint32_t s_incl[THREADS];
+    __shared__ uint32_t s_x0w[THREADS];
+    __shared__ uint32_t s_y0[THREADS];
+    __shared__ uint32_t s_depth[THREADS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* my_base = tile_base + (size_t)blockIdx.x * tiles;
+    for (int t = tid; t < tiles; t += THREADS) s_hist[t] = SCATTER ? ranges[t].x + my_base[t] : 0u;
+    __syncthreads();
+    const int cbase = blockIdx.x * chunk;
+    for (int r = 0; r < chunk / THREADS; r++) {
+        const int i = cbase + r * THREADS + tid;
+        if (cbase + r * THREADS >= P) break;                      // uniform
+        uint32_t n = 0;
+        if (i < P) {
+            n = gp.tiles[i];
+            if (n) {
+                const uint2 rc = gp.rect[i];
+                const uint32_t x0 = rc.x & 0xffffu, x1 = rc.x >> 16;
+                s_x0w[tid] = x0 | ((x1 - x0) << 16);
+                s_y0[tid] = rc.y & 0xffffu;
+                if (SCATTER) s_depth[tid] = __float_as_uint(gp.geom[(size_t)i * 3 + 2].y);
+            }
+        }
+        const uint32_t incl = wave_inclusive_scan(n, lane);
+        s_incl[tid] = incl;
+        const uint32_t total = __shfl(incl, 63);
+        __syncthreads();
+        const int gbase = cbase + r * THREADS;
+        expand_wave(s_incl + wave * kWave, s_x0w, s_y0, wave, lane, total, cam.gx, [&](uint32_t tile, int j) {
+            if (SCATTER) {
+                const uint32_t slot = atomicAdd(&s_hist[tile], 1u);
+                pairs[slot] = ((unsigned long long)s_depth[j] << 32) | (uint32_t)(gbase + j);
+            } else {
+                atomicAdd(&s_hist[tile], 1u);
+            }
+        });
+        __syncthreads();
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (int t = tid; t < tiles; t += THREADS) {
+            const uint32_t c = s_hist[t];
+            my_base[t] = c ? atomicAdd(&tile_total[t], c) : 0u;
+        }
+    }
+}
+
+// exclusive scan of the per-tile totals: ranges[t] = [start, start+count); counts[0] = D, counts[1] = max
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ tile_total, int tiles,
+                                                         uint2* __restrict__ ranges, uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_m[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    uint32_t vmax = 0;
+    __syncthreads();
+    for (int base = 0; base < tiles; base += 1024) {
+        const int i = base + tid;
+        const uint32_t v = i < tiles ? tile_total[i] : 0u;
+        vmax = max(vmax, v);
+        const uint32_t inc = wave_inclusive_scan(v, lane);
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t wprefix = 0;
+        for (int w = 0; w < wave; w++) wprefix += s_w[w];
+        const uint32_t carry = s_carry;
+        const uint32_t start = carry + wprefix + inc - v;
+        if (i < tiles) ranges[i] = make_uint2(start, start + v);
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + wprefix + inc;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor(vmax, m));
+    if (lane == 0) s_m[wave] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t mx = 0;
+        for (int w = 0; w < 16; w++) mx = max(mx, s_m[w]);
+        counts[0] = s_carry; counts[1] = mx;
+    }
+}
+
+// one workgroup per tile: bitonic sort of (depth_bits<<32 | id) in LDS; ids -> point_list
+template <int CAP, int THREADS>
+__global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restrict__ ranges,
+                                                             unsigned long long* __restrict__ pairs,
+                                                             uint32_t* __restrict__ point_list)
+{
+    __shared__ unsigned long long s_k[CAP];
+    const int tid = threadIdx.x;
+    const uint2 range = ranges[blockIdx.x];
+    const uint32_t n = range.y - range.x;
+    if (n == 0) return;
+    uint32_t npow = 2;
+    while (npow < n) npow <<= 1;
+    for (uint32_t i = tid; i < npow; i += THREADS) s_k[i] = i < n ? pairs[range.x + i] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= npow; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < (npow >> 1); i += THREADS) {
+                const uint32_t a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const uint32_t b = a | j;
+                const unsigned long long ka = s_k[a], kb = s_k[b];
+                const bool up = (a & k) == 0;
+                if ((ka > kb) == up) { s_k[a] = kb; s_k[b] = ka; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < n; i += THREADS) {
+        const unsigned long long v = s_k[i];
+        pairs[range.x + i] = v;
+        point_list[range.x + i] = (uint32_t)v;
+    }
+}
+
+// development knob: GS_BIN_VARIANT = threads*10000 + chunk (e.g. 10244096); default 1024 threads x 4096 Gaussians
+static void bin_config(int& threads, int& chunk)
+{
+    threads = 1024; chunk = kBinChunk;
+    const char* ev = getenv("GS_BIN_VARIANT");
+    if (ev) { const int v = atoi(ev); threads = v / 10000; chunk = v % 10000; }
+    if (chunk < 1024) chunk = 1024;
+}
+
+template <bool SCATTER>
+static void launch_bin(int threads, int nb, hipStream_t st, Cam cam, int P, GeomPtrs gp, int tiles, int chunk,
+                       uint32_t* tile_total, uint32_t* tile_base, const uint2* ranges, unsigned long long* pairs)
+{
+    if (threads == 256) hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 256>), dim3(nb), dim3(256), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs);
+    else if (threads == 512) hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 512>), dim3(nb), dim3(512), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs);
+    else hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 1024>), dim3(nb), dim3(1024), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs);
+}
+
+hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,
+                             uint2* ranges, uint32_t* d_counts, hipStream_t st)
+{
+    const int tiles = cam.gx * cam.gy;
+    hipError_t e = hipMemsetAsync(tile_total, 0, (size_t)tiles * 4, st);
+    if (e != hipSuccess) return e;
+    int threads, chunk; bin_config(threads, chunk);
+    const int nb = (P + chunk - 1) / chunk;
+    if (nb > 0) launch_bin<false>(threads, nb, st, cam, P, gp, tiles, chunk, tile_total, tile_base, nullptr, nullptr);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_total, tiles, ranges, d_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_base, const uint2* ranges,
+                                    uint32_t max_tile_instances, unsigned long long* pairs, uint32_t* point_list,
+                                    hipStream_t st)
+{
+    const int tiles = cam.gx * cam.gy;
+    int threads, chunk; bin_config(threads, chunk);
+    const int nb = (P + chunk - 1) / chunk;
+    if (nb > 0) launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs);
+    if (getenv("GS_SKIP_TILE_SORT")) return hipGetLastError();     // development: time the scatter alone
+    if (max_tile_instances <= 2048)
+        hipLaunchKernelGGL((tile_sort_kernel<2048, 256>), dim3(tiles), dim3(256), 0, st, ranges, pairs, point_list);
+    else
+        hipLaunchKernelGGL((tile_sort_kernel<kSortCapMax, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list);
+    return hipGetLastError();
+}
+
+}  // namespace gs

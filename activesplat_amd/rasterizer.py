@@ -101,33 +101,34 @@ class _RasterizeGaussians(torch.autograd.Function):
         W, H = int(rs.image_width), int(rs.image_height)
         st = _stream(device)
 
-        gl = _lib.GsGeomLayout(); _lib.check(lib.gs_geom_layout(P, C.byref(gl)))
+        gl = _lib.GsGeomLayout(); _lib.check(lib.gs_geom_layout(P, W, H, C.byref(gl)))
         il = _lib.GsImageLayout(); _lib.check(lib.gs_image_layout(W, H, C.byref(il)))
         geom = torch.empty(gl.total_bytes, dtype=torch.uint8, device=device)
         image = torch.empty(il.total_bytes, dtype=torch.uint8, device=device)
         radii = torch.empty(P, dtype=torch.int32, device=device)
-        d_num = torch.empty(1, dtype=torch.int32, device=device)
+        d_num = torch.empty(2, dtype=torch.int32, device=device)
         if device.type == "cuda":
             h_num = _pinned.get("h_num")
             if h_num is None:
-                h_num = _pinned["h_num"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+                h_num = _pinned["h_num"] = torch.zeros(2, dtype=torch.int32).pin_memory()
         else:
-            h_num = torch.zeros(1, dtype=torch.int32)
+            h_num = torch.zeros(2, dtype=torch.int32)
         _lib.check(lib.gs_preprocess_forward(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
                                              _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
-                                             _ptr(radii), _ptr(geom), _ptr(d_num), _ptr(h_num), st))
+                                             _ptr(radii), _ptr(geom), _ptr(image), _ptr(d_num), _ptr(h_num), st))
         if device.type == "cuda":
             torch.cuda.current_stream(device).synchronize()      # the one host sync: D sizes the binning buffers
-        D = int(h_num.item()) & 0xFFFFFFFF
-        bl = _lib.GsBinLayout(); _lib.check(lib.gs_bin_layout(D, W, H, C.byref(bl)))
+        D = int(h_num[0].item()) & 0xFFFFFFFF
+        max_tile = int(h_num[1].item()) & 0xFFFFFFFF
+        bl = _lib.GsBinLayout(); _lib.check(lib.gs_bin_layout(D, max_tile, W, H, C.byref(bl)))
         binning = torch.empty(bl.total_bytes, dtype=torch.uint8, device=device)
         point_list = torch.empty(max(D, 1), dtype=torch.int32, device=device)
         color = torch.empty(3, H, W, dtype=torch.float32, device=device)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=device)
         opacity = torch.empty(1, H, W, dtype=torch.float32, device=device)
-        _lib.check(lib.gs_render_forward(C.byref(cam), P, D, _ptr(geom), _ptr(binning), _ptr(point_list), _ptr(image),
+        _lib.check(lib.gs_render_forward(C.byref(cam), P, D, max_tile, _ptr(geom), _ptr(binning), _ptr(point_list), _ptr(image),
                                          _ptr(color), _ptr(depth), _ptr(opacity), st))
-        last_stats["num_rendered"], last_stats["P"] = D, P
+        last_stats["num_rendered"], last_stats["P"], last_stats["max_tile_instances"] = D, P, max_tile
         ctx.rs, ctx.D, ctx.keep = rs, D, keep
         ctx.has = (shs is not None, colors_precomp is not None, scales is not None, rotations is not None,
                    cov3D_precomp is not None)

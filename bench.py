@@ -37,8 +37,10 @@ def stage_bytes(P, D, npix):
     (b_g = 292 B/Gaussian, b_i = 160 B/instance, b_p = 48 B/pixel) split by stage."""
     return {
         "preprocess_forward+scan": P * (56 + 48 + 8),          # read inputs 56, write record 48, scan 8
-        "emit": P * 20 + D * 12,                               # read rect/tiles/depth 20, write key+value 12
-        "sort": D * 24,                                        # ideal one-pass: read 12 + write 12
+        "tile_count+scan": P * 12,                             # read rect + tile count
+        "tile_scatter+sort": P * 20 + D * 12 + D * 24,         # = emit (read 20/Gaussian, write key+value 12) + ideal one-pass sort 24
+        "emit": P * 20 + D * 12,                               # (radix path) read rect/tiles/depth 20, write key+value 12
+        "sort": D * 24,                                        # (radix path) ideal one-pass: read 12 + write 12
         "ranges": D * 8,
         "blend_forward": D * 40 + npix * 28,                   # record gather 40; write colour 12 + depth 4 + opacity 4 + T 4 + n 4
         "blend_backward": D * (40 + 36) + npix * 20,           # record gather 40 + grad accumulation 36; read dL 12 + T 4 + n 4

@@ -22,9 +22,10 @@
  *   - no torch types, no global mutable state except the last-error string (thread-local).
  *
  * Call sequence for one forward:
- *     gs_preprocess_forward(...)            // per-Gaussian stage + scan; writes D to d_/h_num_rendered
- *     <caller synchronises `stream`, reads D, allocates binning workspace + point_list>
- *     gs_render_forward(...)                // emit keys, sort, tile ranges, alpha-blend
+ *     gs_preprocess_forward(...)            // per-Gaussian stage + tile counting; writes the counts
+ *                                           // {D, max instances per tile} to d_counts / h_counts
+ *     <caller synchronises `stream`, reads the counts, allocates binning workspace + point_list>
+ *     gs_render_forward(...)                // scatter into tile segments, per-tile depth sort, alpha-blend
  * and for the backward:
  *     gs_render_backward(...)               // per-pixel replay -> per-Gaussian grads -> input grads
  */
@@ -72,9 +73,11 @@ typedef struct GsGeomLayout {
     uint64_t geom;          /* float [P][12]: x, y, conic_a, conic_b, conic_c, opacity, r, g, b, depth, ext_x, ext_y */
     uint64_t rect;          /* uint32 [P][2]: (xmin | xmax<<16), (ymin | ymax<<16) in tiles */
     uint64_t tiles_touched; /* uint32 [P] */
-    uint64_t offsets;       /* uint32 [P]  inclusive scan of tiles_touched (written by gs_render_forward) */
+    uint64_t offsets;       /* uint32 [P]  inclusive scan of tiles_touched (radix-sort path only) */
     uint64_t block_sums;    /* uint32 [ceil(P/256)+1] exclusive scan of per-block tile counts */
     uint64_t clamped;       /* uint8  [P][4]: SH colour clamp flags (r,g,b,pad) */
+    uint64_t tile_total;    /* uint32 [tiles]: instances per tile */
+    uint64_t tile_base;     /* uint32 [ceil(P/4096)][tiles]: slice reserved by each binning workgroup */
 } GsGeomLayout;
 
 typedef struct GsImageLayout {
@@ -84,17 +87,25 @@ typedef struct GsImageLayout {
     uint64_t n_contrib;     /* uint32 [H*W] : 1-based position in the tile list of the last contributor */
 } GsImageLayout;
 
+#define GS_SORT_AUTO 0
+#define GS_SORT_TILE_LDS 1   /* count/scatter into tile segments + per-tile LDS bitonic sort */
+#define GS_SORT_RADIX 2      /* duplicate with 64-bit keys + device radix sort (any tile size) */
+
 typedef struct GsBinLayout {
     uint64_t total_bytes;
-    uint64_t keys_unsorted; /* uint64 [D] : (tile << 32) | float_bits(view depth) */
-    uint64_t vals_unsorted; /* uint32 [D] : Gaussian index */
-    uint64_t keys_sorted;   /* uint64 [D] */
-    uint64_t sort_temp;     /* scratch of the sort */
+    uint64_t path;          /* GS_SORT_TILE_LDS or GS_SORT_RADIX: what gs_render_forward will run */
+    uint64_t pairs;         /* TILE_LDS: uint64 [D] : (float_bits(view depth) << 32) | Gaussian index, tile-major, sorted */
+    uint64_t keys_unsorted; /* RADIX: uint64 [D] : (tile << 32) | float_bits(view depth) */
+    uint64_t vals_unsorted; /* RADIX: uint32 [D] : Gaussian index */
+    uint64_t keys_sorted;   /* RADIX: uint64 [D] */
+    uint64_t sort_temp;     /* RADIX: scratch of the sort */
 } GsBinLayout;
 
-int gs_geom_layout(int32_t P, GsGeomLayout* out);
+int gs_geom_layout(int32_t P, int32_t width, int32_t height, GsGeomLayout* out);
 int gs_image_layout(int32_t width, int32_t height, GsImageLayout* out);
-int gs_bin_layout(int64_t D, int32_t width, int32_t height, GsBinLayout* out);
+int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t height, GsBinLayout* out);
+/* Force a binning path (GS_SORT_*; default GS_SORT_AUTO picks TILE_LDS when every tile list fits LDS). */
+int gs_set_sort_path(int32_t path);
 /* bytes of the scratch gs_render_backward needs (per-Gaussian 2-D gradient records) */
 uint64_t gs_backward_scratch_bytes(int32_t P);
 
@@ -111,21 +122,22 @@ const char* gs_profile_stage_name(int32_t stage);
 int gs_profile_collect(float* ms_sum, int32_t* calls, int32_t n_stages);
 
 /* Stage 1: per-Gaussian preprocess (view/projective transform, near cull, 3-D -> 2-D covariance, conic,
- * radius, tile rect, SH -> RGB) and the tile-count scan.  Writes radii[P] (0 = culled) and the geom
- * state; the number of tile instances D goes to *d_num_rendered and, if h_num_rendered != NULL, is
- * copied there asynchronously (read it after synchronising `stream`). Exactly one of
- * shs/colors_precomp and exactly one of (scales,rotations)/cov3D_precomp must be given. */
+ * radius, tile rect, SH -> RGB), tile counting and the tile-range scan.  Writes radii[P] (0 = culled),
+ * the geom state and the tile ranges (image state); d_counts[0] = D (number of tile instances),
+ * d_counts[1] = largest per-tile instance count; if h_counts != NULL both are copied there
+ * asynchronously (read them after synchronising `stream`). Exactly one of shs/colors_precomp and
+ * exactly one of (scales,rotations)/cov3D_precomp must be given. */
 int gs_preprocess_forward(const GsCamera* cam, int32_t P,
                           const float* means3D, const float* shs, const float* colors_precomp,
                           const float* opacities, const float* scales, const float* rotations,
                           const float* cov3D_precomp,
-                          int32_t* radii, void* geom_state, uint32_t* d_num_rendered,
-                          uint32_t* h_num_rendered, gs_stream_t stream);
+                          int32_t* radii, void* geom_state, void* image_state, uint32_t* d_counts,
+                          uint32_t* h_counts, gs_stream_t stream);
 
-/* Stage 2: duplicate-with-keys, sort, tile ranges, front-to-back alpha blend.
+/* Stage 2: bin the instances by tile and depth-sort every tile list, then front-to-back alpha blend.
  * out_color [3,H,W], out_depth [1,H,W] (sum z*alpha*T), out_opacity [1,H,W] (1 - T_final).
  * point_list [D] receives the (tile, depth, index)-sorted Gaussian ids (kept for the backward). */
-int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D,
+int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_tile_instances,
                       void* geom_state, void* bin_state, uint32_t* point_list, void* image_state,
                       float* out_color, float* out_depth, float* out_opacity, gs_stream_t stream);
 

@@ -66,6 +66,12 @@ CASES = ["basic", "ragged_image", "tiny_lookaround", "posed_white_bg", "scale_mo
          "sh3", "cov3d_precomp"]
 
 
+def set_sort_path(path):
+    """path: 'auto' | 'tile_lds' | 'radix' -- forces the binning path of the library under test."""
+    from activesplat_amd import _lib
+    _lib.check(_lib.get().gs_set_sort_path({"auto": 0, "tile_lds": 1, "radix": 2}[path]))
+
+
 def check_forward(rs, rv, oracle32, exact_float=False):
     got = util.run_product(rs, rv)
     art = util.artefacts()
@@ -76,10 +82,15 @@ def check_forward(rs, rv, oracle32, exact_float=False):
     live = ref["radii"] > 0
     assert np.array_equal(art["tiles_touched"], ref["tiles_touched"])
     assert np.array_equal(art["rect"][live], ref["rect"][live])
-    assert np.array_equal(art["offsets"], ref["offsets"])
+    if art["offsets"] is not None:                     # radix-sort path only
+        assert np.array_equal(art["offsets"], ref["offsets"])
+    else:
+        assert np.array_equal(art["pairs_ids"], art["point_list"])
     assert np.array_equal(art["keys_sorted"], ref["keys_sorted"])
     assert np.array_equal(art["point_list"], ref["ids_sorted"])
-    assert np.array_equal(art["ranges"], ref["ranges"])
+    rg = art["ranges"].copy()
+    rg[rg[:, 0] == rg[:, 1]] = 0                       # an empty tile is [s,s) on the scan path, [0,0) in the oracle
+    assert np.array_equal(rg, ref["ranges"])
     # per-Gaussian floats produced by the contraction-free TU are bit-exact too
     assert np.array_equal(art["geom"][live, 0:2], ref["xy"][live])
     assert np.array_equal(art["geom"][live, 9], ref["depth"][live])

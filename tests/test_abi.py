@@ -31,8 +31,8 @@ def test_hip_library_loads_and_exports_every_symbol():
     assert b"gfx950" in lib.gs_version()
     import ctypes as C
     gl = _lib.GsGeomLayout()
-    assert lib.gs_geom_layout(1000, C.byref(gl)) == 0 and gl.total_bytes >= 1000 * (48 + 8 + 4 + 4)
-    assert lib.gs_geom_layout(-1, C.byref(gl)) != 0 and b"bad argument" in lib.gs_last_error()
+    assert lib.gs_geom_layout(1000, 640, 480, C.byref(gl)) == 0 and gl.total_bytes >= 1000 * (48 + 8 + 4 + 4)
+    assert lib.gs_geom_layout(-1, 640, 480, C.byref(gl)) != 0 and b"bad argument" in lib.gs_last_error()
 
 
 def test_no_cpu_fallback_and_argument_errors():

@@ -16,6 +16,18 @@ from tests import util
 def test_emulated_forward_matches_oracle(emu, oracle32, case):
     rs, rv = pc.build_case(case, emu)
     pc.check_forward(rs, rv, oracle32, exact_float=True)
+    assert util.artefacts()["path"] == 1        # tile-binning + LDS sort path
+
+
+@pytest.mark.parametrize("case", ["basic", "ragged_image", "all_culled", "huge_gaussians", "dense_overdraw", "one_gaussian"])
+def test_emulated_forward_radix_path_matches_oracle(emu, oracle32, case):
+    rs, rv = pc.build_case(case, emu)
+    pc.set_sort_path("radix")
+    try:
+        pc.check_forward(rs, rv, oracle32, exact_float=True)
+        assert util.artefacts()["path"] == 2
+    finally:
+        pc.set_sort_path("auto")
 
 
 @pytest.mark.parametrize("case", ["basic", "ragged_image", "posed_white_bg", "scale_modifier", "dense_overdraw",

@@ -72,12 +72,22 @@ def artefacts():
     rect_packed = view(geom, gl.rect, np.uint32, 2 * P).reshape(P, 2)
     rect = np.stack([rect_packed[:, 0] & 0xFFFF, rect_packed[:, 1] & 0xFFFF, rect_packed[:, 0] >> 16,
                      rect_packed[:, 1] >> 16], 1).astype(np.int32)
-    return dict(geom=view(geom, gl.geom, np.float32, 12 * P).reshape(P, 12), rect=rect,
-                tiles_touched=view(geom, gl.tiles_touched, np.uint32, P), offsets=view(geom, gl.offsets, np.uint32, P),
-                keys_sorted=view(binning, bl.keys_sorted, np.uint64, D), point_list=d["point_list"].cpu().numpy()[:D].astype(np.uint32),
-                ranges=view(image, il.ranges, np.uint32, 2 * tiles).reshape(tiles, 2),
-                final_T=view(image, il.final_T, np.float32, W * H).reshape(H, W),
-                n_contrib=view(image, il.n_contrib, np.uint32, W * H).reshape(H, W))
+    ranges = view(image, il.ranges, np.uint32, 2 * tiles).reshape(tiles, 2)
+    out = dict(geom=view(geom, gl.geom, np.float32, 12 * P).reshape(P, 12), rect=rect, path=int(bl.path),
+               tiles_touched=view(geom, gl.tiles_touched, np.uint32, P),
+               point_list=d["point_list"].cpu().numpy()[:D].astype(np.uint32), ranges=ranges,
+               final_T=view(image, il.final_T, np.float32, W * H).reshape(H, W),
+               n_contrib=view(image, il.n_contrib, np.uint32, W * H).reshape(H, W))
+    if bl.path == 1:      # GS_SORT_TILE_LDS: pairs = (depth_bits << 32 | id), tile-major; rebuild the 64-bit keys
+        pairs = view(binning, bl.pairs, np.uint64, D)
+        tile_of = np.repeat(np.arange(tiles, dtype=np.uint64), (ranges[:, 1] - ranges[:, 0]).astype(np.int64))
+        out["keys_sorted"] = (tile_of << np.uint64(32)) | (pairs >> np.uint64(32))
+        out["pairs_ids"] = (pairs & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        out["offsets"] = None
+    else:
+        out["keys_sorted"] = view(binning, bl.keys_sorted, np.uint64, D)
+        out["offsets"] = view(geom, gl.offsets, np.uint32, P)
+    return out
 
 
 def close_frac(a, b, rtol, atol):
