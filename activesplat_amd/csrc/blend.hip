@@ -4,35 +4,62 @@
 // (contract SURVEY App. A.2; consumers src/mapper/splatam/splatam.py:208-212,430-431).
 //
 // MI355X design (wave-64 first, not a 32-wide warp tiling):
-//   * one 16x16 tile per 256-thread workgroup; each of the 4 wavefronts owns one 8x8 pixel QUADRANT
-//     (lane = pixel), so a wavefront is the unit of work skipping;
-//   * the tile's depth-sorted instance list is staged through LDS 256 records at a time (one 48-byte
-//     record gather per lane);
-//   * while staging, every lane tests ITS record's alpha>=1/255 bounding box against the four quadrants;
-//     64-bit __ballot masks (one per producer wave x consumer quadrant) go to LDS, and each wavefront
-//     then walks only the set bits of its own masks with scalar find-first-set -- a wave-uniform loop,
-//     no divergence, LDS broadcast reads.  Skipped records can never pass the alpha>=1/255 test, so the
-//     result is identical to evaluating all of them.
-#include <stdlib.h>
-
+//   * one 16x16 tile per 256-thread workgroup, but the 4 wavefronts are INDEPENDENT: each owns one 8x8
+//     pixel quadrant (lane = pixel), walks the tile's depth-sorted instance list on its own and never
+//     meets a workgroup barrier -- a quadrant that saturates (T < 1e-4) or whose contributors end early
+//     simply finishes.  Sharing a workgroup keeps the four walkers of a tile on one CU, so the 48-byte
+//     record gathers of three of them hit that CU's L1.
+//   * 64 records at a time: every lane gathers one record and tests ITS alpha>=1/255 bounding box
+//     against the wave's quadrant; one 64-bit __ballot gives the hit mask.  Hit records are staged into
+//     the wave's private LDS slice (3 KiB) and the wave then walks only the set bits with scalar
+//     find-first-set -- a wave-uniform loop, LDS broadcast reads, no divergence.  Skipped records can
+//     never pass the alpha>=1/255 test, so the result is identical to evaluating all of them.
+//   * the loop is software-pipelined: ids two chunks ahead, records one chunk ahead.
+//   * blockIdx -> tile mapping is XCD-aware: the dispatcher places block b on XCD b%8, so XCD x is
+//     given the contiguous band of tiles [x*ceil(T/8), (x+1)*ceil(T/8)) and neighbouring tiles (which
+//     share Gaussians) reuse records in one 4 MiB L2.
 #include "gs_common.h"
 
 namespace gs {
 
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTmin = 0.0001f;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr uint32_t kNoId = 0xffffffffu;
 
-// bit q set <=> the record's alpha-visible box overlaps quadrant q of the tile at pixel origin (ox,oy)
-__device__ __forceinline__ uint32_t quadrant_bits(const float4& q0, const float4& q2, float ox, float oy)
+struct TileCtx {
+    int tile, tx, ty, px, py;
+    float qx0, qy0, pxf, pyf;
+    bool inside;
+};
+
+__device__ __forceinline__ bool tile_ctx(const Cam& cam, int wave, int lane, TileCtx& c)
+{
+    const int ntiles = cam.gx * cam.gy, per = (ntiles + 7) >> 3;
+    c.tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);          // XCD-aware band mapping
+    if ((int)(blockIdx.x >> 3) >= per || c.tile >= ntiles) return false;
+    c.tx = c.tile % cam.gx; c.ty = c.tile / cam.gx;
+    const int qx = c.tx * kTile + (wave & 1) * kQuad, qy = c.ty * kTile + (wave >> 1) * kQuad;
+    c.px = qx + (lane & 7); c.py = qy + (lane >> 3);
+    c.qx0 = (float)qx; c.qy0 = (float)qy; c.pxf = (float)c.px; c.pyf = (float)c.py;
+    c.inside = c.px < cam.W && c.py < cam.H;
+    return true;
+}
+
+// does the record's alpha-visible box overlap the 8x8 quadrant at pixel origin (qx0,qy0)?
+__device__ __forceinline__ bool quadrant_hit(const float4& q0, const float4& q2, float qx0, float qy0)
 {
     const float ex = q2.z, ey = q2.w;
-    if (!(ex >= 0.0f)) return 0u;
-    const float xlo = q0.x - ex, xhi = q0.x + ex, ylo = q0.y - ey, yhi = q0.y + ey;
-    const bool cx0 = (xhi >= ox) && (xlo <= ox + 7.0f);
-    const bool cx1 = (xhi >= ox + 8.0f) && (xlo <= ox + 15.0f);
-    const bool cy0 = (yhi >= oy) && (ylo <= oy + 7.0f);
-    const bool cy1 = (yhi >= oy + 8.0f) && (ylo <= oy + 15.0f);
-    return (cx0 && cy0 ? 1u : 0u) | (cx1 && cy0 ? 2u : 0u) | (cx0 && cy1 ? 4u : 0u) | (cx1 && cy1 ? 8u : 0u);
+    return ex >= 0.0f && (q0.x + ex >= qx0) && (q0.x - ex <= qx0 + 7.0f) && (q0.y + ey >= qy0) && (q0.y - ey <= qy0 + 7.0f);
+}
+
+// LDS staging form: the conic pre-scaled so that the inner loop is  p = (A dx + B dy) dx + C dy dy ; G = 2^p
+__device__ __forceinline__ void stage_record(float4* s0, float4* s1, float4* s2, int lane, const float4& q0,
+                                             const float4& q1, const float4& q2, uint32_t id)
+{
+    s0[lane] = make_float4(q0.x, q0.y, -0.5f * kLog2e * q0.z, -kLog2e * q0.w);
+    s1[lane] = make_float4(-0.5f * kLog2e * q1.x, q1.y, q1.z, q1.w);
+    s2[lane] = make_float4(q2.x, q2.y, __uint_as_float(id), 0.0f);
 }
 
 __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
@@ -40,69 +67,62 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
 {
-    __shared__ float4 s_q0[kBlock];
-    __shared__ float4 s_q1[kBlock];
-    __shared__ float4 s_q2[kBlock];
-    __shared__ unsigned long long s_mask[4][4];      // [consumer quadrant][producer wave]
-
+    __shared__ float4 s_rec[kBlock / kWave][3][kWave];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x;
-    const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const float ox = (float)(tx * kTile), oy = (float)(ty * kTile);
-    const int px = tx * kTile + (wave & 1) * kQuad + (lane & 7);
-    const int py = ty * kTile + (wave >> 1) * kQuad + (lane >> 3);
-    const bool inside = px < cam.W && py < cam.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = ranges[tile];
+    TileCtx c;
+    if (!tile_ctx(cam, wave, lane, c)) return;
+    float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
+    const uint2 range = ranges[c.tile];
+    const uint32_t n = range.y - range.x;
+    const uint32_t* list = point_list + range.x;
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0;
-    bool done = !inside;
+    bool done = !c.inside;
 
-    for (uint32_t base = range.x; base < range.y; base += kBlock) {
-        if (__syncthreads_and(done)) break;          // also fences the previous batch's LDS reads
-        const uint32_t idx = base + tid;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-        uint32_t bits = 0;
-        if (idx < range.y) {
-            const uint32_t g = point_list[idx];
-            q0 = geom[(size_t)g * 3]; q1 = geom[(size_t)g * 3 + 1]; q2 = geom[(size_t)g * 3 + 2];
-            bits = quadrant_bits(q0, q2, ox, oy);
-        }
-        s_q0[tid] = q0; s_q1[tid] = q1; s_q2[tid] = q2;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const unsigned long long m = __ballot((bits >> q) & 1u);
-            if (lane == 0) s_mask[q][wave] = m;
-        }
-        __syncthreads();
-        if (__all(done)) continue;                    // this quadrant is finished; keep staging for the others
-        for (int s = 0; s < 4; s++) {
-            const unsigned long long mv = s_mask[wave][s];
-            uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mv);
-            uint32_t mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mv >> 32));
-            unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+    if (!__all(done)) {
+        // pipeline prologue: ids of chunks 0 and 1, records of chunk 0
+        uint32_t id_next = (uint32_t)lane < n ? list[lane] : kNoId;
+        uint32_t id_next2 = (uint32_t)lane + 64u < n ? list[lane + 64] : kNoId;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
+        if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
+        for (uint32_t base = 0; base < n; base += kWave) {
+            const float4 q0 = r0, q1 = r1, q2 = r2;
+            const uint32_t id_cur = id_next;
+            // issue the next chunk's record gather and the ids two chunks ahead
+            id_next = id_next2;
+            id_next2 = base + 128u + (uint32_t)lane < n ? list[base + 128u + lane] : kNoId;
+            r2 = make_float4(0.f, 0.f, -1.f, -1.f);
+            if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
+
+            const bool hit = id_cur != kNoId && quadrant_hit(q0, q2, c.qx0, c.qy0);
+            unsigned long long m = __ballot(hit);
+            if (m == 0ull) continue;
+            stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
+            __builtin_amdgcn_wave_barrier();
             while (m) {
-                const int j = s * kWave + (__ffsll(m) - 1);
+                const int j = __ffsll(m) - 1;
                 m &= m - 1;
-                const float4 a0 = s_q0[j], a1 = s_q1[j], a2 = s_q2[j];
-                const float dx = a0.x - pxf, dy = a0.y - pyf;
-                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-                const float alpha = fminf(0.99f, a1.y * __expf(power));
-                bool ok = !done && power <= 0.0f && alpha >= kAlphaMin;
+                const float4 a0 = s0[j], a1 = s1[j], a2 = s2[j];
+                const float dx = a0.x - c.pxf, dy = a0.y - c.pyf;
+                const float p = (a0.z * dx + a0.w * dy) * dx + (a1.x * dy) * dy;
+                const float alpha = fminf(0.99f, a1.y * __builtin_amdgcn_exp2f(p));
+                bool ok = !done && p <= 0.0f && alpha >= kAlphaMin;
                 const float test_T = T * (1.0f - alpha);
                 if (ok && test_T < kTmin) { done = true; ok = false; }
                 if (ok) {
                     const float w = alpha * T;
                     C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w; Dp += a2.y * w;
                     T = test_T;
-                    last = (base - range.x) + (uint32_t)j + 1u;
+                    last = base + (uint32_t)j + 1u;
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            if (__all(done)) break;
         }
     }
-    if (inside) {
-        const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
+    if (c.inside) {
+        const size_t pix = (size_t)c.py * cam.W + c.px, HW = (size_t)cam.H * cam.W;
         final_T[pix] = T;
         n_contrib[pix] = last;
         out_color[pix] = C0 + T * cam.bg[0];
@@ -114,10 +134,10 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Backward: back-to-front replay.  Per (wavefront, record) the nine per-pixel partials are reduced
-// across the 64 lanes and accumulated with one hardware fp32 atomic instruction (9 lanes, one
-// component each) into the 48-byte per-Gaussian gradient record (device-scope atomics: correct across
-// the 8 XCDs' private L2s).
+// Backward: back-to-front replay, same independent-quadrant walk as the forward.  Per (wavefront, record)
+// the nine per-pixel partials are reduced across the 64 lanes and accumulated with one hardware fp32
+// atomic instruction (9 lanes, one component each) into the 48-byte per-Gaussian gradient record
+// (device-scope atomics: correct across the 8 XCDs' private L2s).
 //
 // Wave-64 reduction of 9 values in ~32 VALU instead of 9 x 6 shuffle+add: a TRANSPOSED butterfly.
 //   level 32: v_permlane32_swap pairs two values -> one register whose halves hold one value each
@@ -161,127 +181,90 @@ __device__ __forceinline__ float wave_reduce9(const float (&v)[9], int lane, int
     return c == 0 ? q0123 : (c == 1 ? q4567 : q8);
 }
 
-template <int VARIANT>   // 0 = shipped (transposed reduce + atomics); 1..3 = ablations (see launch_blend_backward)
+
+// Per-Gaussian 2-D gradient record accumulated by the backward blend (raw moments; the conic algebra is
+// finished per Gaussian in preprocess_bwd.hip):  with Z = G dL/dG, d = mean - pixel
+//   0: sum Z dx   1: sum Z dy   2: sum Z dx dx   3: sum Z dx dy   4: sum Z dy dy   5: sum G dL/dalpha   6..8: sum w dL/dC
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, float* __restrict__ grad2d)
 {
-    __shared__ float4 s_q0[kBlock];
-    __shared__ float4 s_q1[kBlock];
-    __shared__ float4 s_q2[kBlock];
-    __shared__ uint32_t s_id[kBlock];
-    __shared__ unsigned long long s_mask[4][4];
-    __shared__ uint32_t s_wmax[4];
-
+    __shared__ float4 s_rec[kBlock / kWave][3][kWave];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x;
-    const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const float ox = (float)(tx * kTile), oy = (float)(ty * kTile);
-    const int px = tx * kTile + (wave & 1) * kQuad + (lane & 7);
-    const int py = ty * kTile + (wave >> 1) * kQuad + (lane >> 3);
-    const bool inside = px < cam.W && py < cam.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = ranges[tile];
-    const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
+    TileCtx c;
+    if (!tile_ctx(cam, wave, lane, c)) return;
+    float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
+    const uint2 range = ranges[c.tile];
+    const uint32_t* list = point_list + range.x;
+    const size_t pix = (size_t)c.py * cam.W + c.px, HW = (size_t)cam.H * cam.W;
 
-    const float Tf = inside ? final_T[pix] : 0.f;
-    const uint32_t last = inside ? n_contrib[pix] : 0u;
-    const float d0 = inside ? dL_dcolor[pix] : 0.f, d1 = inside ? dL_dcolor[HW + pix] : 0.f,
-                d2 = inside ? dL_dcolor[2 * HW + pix] : 0.f;
+    const float Tf = c.inside ? final_T[pix] : 0.f;
+    const uint32_t last = c.inside ? n_contrib[pix] : 0u;
+    const float d0 = c.inside ? dL_dcolor[pix] : 0.f, d1 = c.inside ? dL_dcolor[HW + pix] : 0.f,
+                d2 = c.inside ? dL_dcolor[2 * HW + pix] : 0.f;
     const float bgdot = cam.bg[0] * d0 + cam.bg[1] * d1 + cam.bg[2] * d2;
     float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
 
-    // the deepest contributor of any pixel of this tile bounds the replay
-    uint32_t wm = last;
+    // the deepest contributor of any pixel of this quadrant bounds the replay
+    uint32_t wmax = last;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) wm = max(wm, (uint32_t)__shfl_xor(wm, m));
-    if (lane == 0) s_wmax[wave] = wm;
-    __syncthreads();
-    const uint32_t kmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-    if (kmax == 0) return;
-    const uint32_t wave_max = s_wmax[wave];
+    for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor(wmax, m));
+    if (wmax == 0) return;
 
-    for (int b = (int)((kmax - 1) / kBlock); b >= 0; b--) {
-        __syncthreads();                                // previous batch fully consumed
-        const uint32_t pos = (uint32_t)b * kBlock + tid;
-        const uint32_t idx = range.x + pos;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-        uint32_t bits = 0, g = 0;
-        if (pos < kmax && idx < range.y) {
-            g = point_list[idx];
-            q0 = geom[(size_t)g * 3]; q1 = geom[(size_t)g * 3 + 1]; q2 = geom[(size_t)g * 3 + 2];
-            bits = quadrant_bits(q0, q2, ox, oy);
-        }
-        s_q0[tid] = q0; s_q1[tid] = q1; s_q2[tid] = q2; s_id[tid] = g;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const unsigned long long m = __ballot((bits >> q) & 1u);
-            if (lane == 0) s_mask[q][wave] = m;
-        }
-        __syncthreads();
-        if ((uint32_t)b * kBlock >= wave_max) continue;   // nothing of this batch reaches this quadrant
-        for (int s = 3; s >= 0; s--) {
-            const unsigned long long mv = s_mask[wave][s];
-            uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mv);
-            uint32_t mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mv >> 32));
-            unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
-            while (m) {
-                const int bit = 63 - __clzll(m);
-                m &= ~(1ull << bit);
-                const int j = s * kWave + bit;
-                const uint32_t p = (uint32_t)b * kBlock + (uint32_t)j;        // 0-based position in the tile list
-                const float4 a0 = s_q0[j], a1 = s_q1[j], a2 = s_q2[j];
-                const float dx = a0.x - pxf, dy = a0.y - pyf;
-                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-                const float G = __expf(power);
-                const float alpha = fminf(0.99f, a1.y * G);
-                const bool ok = p < last && power <= 0.0f && alpha >= kAlphaMin;
-                if (!__any(ok)) continue;
-                float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // gx gy ga gb gc go gr gg gbl
-                if (ok) {
-                    const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);
-                    T = T * rcp;
-                    const float w = alpha * T;
-                    acc0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0;
-                    acc1 = last_alpha * lc1 + (1.0f - last_alpha) * acc1;
-                    acc2 = last_alpha * lc2 + (1.0f - last_alpha) * acc2;
-                    lc0 = a1.z; lc1 = a1.w; lc2 = a2.x;
-                    float dL_dalpha = ((lc0 - acc0) * d0 + (lc1 - acc1) * d1 + (lc2 - acc2) * d2) * T;
-                    v[6] = w * d0; v[7] = w * d1; v[8] = w * d2;
-                    last_alpha = alpha;
-                    dL_dalpha -= Tf * rcp * bgdot;
-                    const float dL_dG = a1.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    v[0] = dL_dG * (-gdx * a0.z - gdy * a0.w);
-                    v[1] = dL_dG * (-gdy * a1.x - gdx * a0.w);
-                    v[2] = -0.5f * gdx * dx * dL_dG;
-                    v[3] = -gdx * dy * dL_dG;
-                    v[4] = -0.5f * gdy * dy * dL_dG;
-                    v[5] = G * dL_dalpha;
-                }
-                if (VARIANT == 3) {            // ablation: no reduction, no atomics (keep the partials live)
-#pragma unroll
-                    for (int k = 0; k < 9; k++) asm volatile("" ::"v"(v[k]));
-                    continue;
-                }
-                if (VARIANT == 1) {            // ablation: round-1 reduction (9 x 6 shuffles)
-#pragma unroll
-                    for (int k = 0; k < 9; k++) v[k] = wave_sum(v[k]);
-                    if (lane < 9) {
-                        float x = v[0];
-#pragma unroll
-                        for (int k = 1; k < 9; k++) x = lane == k ? v[k] : x;
-                        atomicAdd(grad2d + (size_t)s_id[j] * kGradStride + lane, x);
-                    }
-                    continue;
-                }
-                int comp;
-                const float x = wave_reduce9(v, lane, comp);
-                if (VARIANT == 2) { asm volatile("" ::"v"(x)); continue; }   // ablation: reduce, no atomics
-                if (comp >= 0) atomicAdd(grad2d + (size_t)s_id[j] * kGradStride + comp, x);
+    const int cmax = (int)((wmax - 1) / kWave);
+    // pipeline prologue (walking chunks downwards): ids of chunks cmax and cmax-1, records of chunk cmax
+    uint32_t id_next = (uint32_t)cmax * kWave + lane < wmax ? list[cmax * kWave + lane] : kNoId;
+    uint32_t id_next2 = cmax >= 1 ? list[(cmax - 1) * kWave + lane] : kNoId;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
+    if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
+    for (int ch = cmax; ch >= 0; ch--) {
+        const float4 q0 = r0, q1 = r1, q2 = r2;
+        const uint32_t id_cur = id_next;
+        id_next = id_next2;
+        id_next2 = ch >= 2 ? list[(ch - 2) * kWave + lane] : kNoId;
+        r2 = make_float4(0.f, 0.f, -1.f, -1.f);
+        if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
+
+        const bool hit = id_cur != kNoId && quadrant_hit(q0, q2, c.qx0, c.qy0);
+        unsigned long long m = __ballot(hit);
+        if (m == 0ull) continue;
+        stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
+        __builtin_amdgcn_wave_barrier();
+        while (m) {
+            const int j = 63 - __clzll(m);
+            m &= ~(1ull << j);
+            const uint32_t pos = (uint32_t)ch * kWave + (uint32_t)j;          // 0-based position in the tile list
+            const float4 a0 = s0[j], a1 = s1[j], a2 = s2[j];
+            const float dx = a0.x - c.pxf, dy = a0.y - c.pyf;
+            const float p = (a0.z * dx + a0.w * dy) * dx + (a1.x * dy) * dy;
+            const float G = __builtin_amdgcn_exp2f(p);
+            const float alpha = fminf(0.99f, a1.y * G);
+            const bool ok = pos < last && p <= 0.0f && alpha >= kAlphaMin;
+            if (!__any(ok)) continue;
+            float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);
+                T = T * rcp;
+                const float w = alpha * T;
+                acc0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0;
+                acc1 = last_alpha * lc1 + (1.0f - last_alpha) * acc1;
+                acc2 = last_alpha * lc2 + (1.0f - last_alpha) * acc2;
+                lc0 = a1.z; lc1 = a1.w; lc2 = a2.x;
+                float dL_dalpha = ((lc0 - acc0) * d0 + (lc1 - acc1) * d1 + (lc2 - acc2) * d2) * T;
+                v[6] = w * d0; v[7] = w * d1; v[8] = w * d2;
+                last_alpha = alpha;
+                dL_dalpha -= Tf * rcp * bgdot;
+                const float GdA = G * dL_dalpha;
+                const float Z = a1.y * GdA;                 // G dL/dG
+                const float zx = Z * dx, zy = Z * dy;
+                v[0] = zx; v[1] = zy; v[2] = zx * dx; v[3] = zx * dy; v[4] = zy * dy; v[5] = GdA;
             }
+            int comp;
+            const float x = wave_reduce9(v, lane, comp);
+            if (comp >= 0) atomicAdd(grad2d + (size_t)__float_as_uint(a2.z) * kGradStride + comp, x);
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -289,7 +272,8 @@ hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint3
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
                                 uint32_t* n_contrib, hipStream_t st)
 {
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(cam.gx * cam.gy), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
+    const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
                        out_color, out_depth, out_opacity, final_T, n_contrib);
     return hipGetLastError();
 }
@@ -298,14 +282,9 @@ hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  float* grad2d, hipStream_t st)
 {
-    // GS_BWD_VARIANT (development only): 1 = shuffle reduction, 2 = no atomics, 3 = no reduction/atomics
-    const char* ev = getenv("GS_BWD_VARIANT");
-    const int variant = ev ? atoi(ev) : 0;
-    const dim3 grid(cam.gx * cam.gy), block(kBlock);
-    if (variant == 1) hipLaunchKernelGGL(blend_backward_kernel<1>, grid, block, 0, st, cam, ranges, point_list, geom, final_T, n_contrib, dL_dcolor, grad2d);
-    else if (variant == 2) hipLaunchKernelGGL(blend_backward_kernel<2>, grid, block, 0, st, cam, ranges, point_list, geom, final_T, n_contrib, dL_dcolor, grad2d);
-    else if (variant == 3) hipLaunchKernelGGL(blend_backward_kernel<3>, grid, block, 0, st, cam, ranges, point_list, geom, final_T, n_contrib, dL_dcolor, grad2d);
-    else hipLaunchKernelGGL(blend_backward_kernel<0>, grid, block, 0, st, cam, ranges, point_list, geom, final_T, n_contrib, dL_dcolor, grad2d);
+    const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
+    hipLaunchKernelGGL(blend_backward_kernel, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
+                       final_T, n_contrib, dL_dcolor, grad2d);
     return hipGetLastError();
 }
 

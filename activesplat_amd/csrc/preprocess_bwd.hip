@@ -60,7 +60,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     const bool live = radii[i] > 0;
     const float4* gr4 = reinterpret_cast<const float4*>(grad2d + (size_t)i * kGradStride);
     const float4 ga = gr4[0], gb = gr4[1], gc = gr4[2];
-    // record: ga = (dx, dy, dA, dB)  gb = (dC, dopacity, dr, dg)  gc = (db, -, -, -)
+    // record (raw moments from blend_backward_kernel, Z = G dL/dG, d = mean - pixel):
+    //   ga = (sum Z dx, sum Z dy, sum Z dx dx, sum Z dx dy)  gb = (sum Z dy dy, sum G dL/dalpha, dr, dg)  gc = (db, -, -, -)
     float dmean[3] = {0.f, 0.f, 0.f};
     float o_m2d[3] = {0.f, 0.f, 0.f}, o_sc[3] = {0.f, 0.f, 0.f}, o_rot[4] = {0.f, 0.f, 0.f, 0.f};
     float o_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
         const float r_ = T1[0] * ST1[0] + T1[1] * ST1[1] + T1[2] * ST1[2] + 0.3f;
         const float det = p_ * r_ - q_ * q_;
         const float d2 = 1.0f / (det * det);
-        const float dA = ga.z, dB = ga.w, dC = gb.x;
+        const float dA = -0.5f * ga.z, dB = -ga.w, dC = -0.5f * gb.x;      // true partials w.r.t. conic (a, b, c)
         const float dp = (-r_ * r_ * dA + q_ * r_ * dB - q_ * q_ * dC) * d2;
         const float dq = (2.f * q_ * r_ * dA - (p_ * r_ + q_ * q_) * dB + 2.f * p_ * q_ * dC) * d2;
         const float dr = (-q_ * q_ * dA + p_ * q_ * dB - p_ * p_ * dC) * d2;
@@ -164,7 +165,11 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
         const float dtz = -cam.fx * itz2 * dJ00 - cam.fy * itz2 * dJ11 + 2.f * cam.fx * cx_ * itz3 * dJ02 + 2.f * cam.fy * cy_ * itz3 * dJ12;
         for (int c = 0; c < 3; c++) dmean[c] += dtx * W0[c] + dty * W1[c] + dtz * W2[c];
         // ---- mean2D -> mean3D through the projective divide ----
-        const float gxn = ga.x * 0.5f * (float)cam.W, gyn = ga.y * 0.5f * (float)cam.H;
+        // dL/dmean2D (pixels) = -(conic d-moments): (-(a M1x + b M1y), -(c M1y + b M1x)); conic = 1/det (r, -q, p)
+        const float idet = 1.0f / det;
+        const float ca = r_ * idet, cb = -q_ * idet, cc = p_ * idet;
+        const float gxp = -(ca * ga.x + cb * ga.y), gyp = -(cc * ga.y + cb * ga.x);
+        const float gxn = gxp * 0.5f * (float)cam.W, gyn = gyp * 0.5f * (float)cam.H;
         o_m2d[0] = gxn; o_m2d[1] = gyn;
         const float hx = q[0] * px + q[4] * py + q[8] * pz + q[12];
         const float hy = q[1] * px + q[5] * py + q[9] * pz + q[13];

@@ -186,6 +186,8 @@ template <class T> static inline T hipemu_readlane(T v, int l)
     const unsigned long long* o = hipemu::wave_exchange(hipemu::pack(v), 8, nullptr);
     return hipemu::unpack<T>(o[l & 63]);
 }
+static inline void hipemu_wave_barrier() { hipemu::wave_exchange(0ull, 12, nullptr); }
+#define __builtin_amdgcn_wave_barrier() hipemu_wave_barrier()
 #define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane(v)
 #define __builtin_amdgcn_readlane(v, l) hipemu_readlane(v, l)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

@@ -2,8 +2,8 @@
 whole C-ABI pipeline (preprocess -> scan -> emit -> sort stand-in -> ranges -> blend -> backward) and
 must agree with the oracle.  This is a kernel-logic check for the container without a GPU; the
 parity tests proper are tests/test_gpu_parity.py (-m gpu), which run the same cases on the MI355X.
-On the host the emulated build uses the same libm expf and no FMA contraction, so even the images
-are bit-identical to the fp32 oracle."""
+Integer artefacts and the per-Gaussian screen-space records are bit-identical to the fp32 oracle; the
+images are compared at the same fp32 tolerance as on the GPU (the blend evaluates 2^(log2e-scaled power))."""
 import numpy as np
 import pytest
 import torch
@@ -15,7 +15,7 @@ from tests import util
 @pytest.mark.parametrize("case", pc.CASES)
 def test_emulated_forward_matches_oracle(emu, oracle32, case):
     rs, rv = pc.build_case(case, emu)
-    pc.check_forward(rs, rv, oracle32, exact_float=True)
+    pc.check_forward(rs, rv, oracle32)
     assert util.artefacts()["path"] == 1        # tile-binning + LDS sort path
 
 
@@ -24,7 +24,7 @@ def test_emulated_forward_radix_path_matches_oracle(emu, oracle32, case):
     rs, rv = pc.build_case(case, emu)
     pc.set_sort_path("radix")
     try:
-        pc.check_forward(rs, rv, oracle32, exact_float=True)
+        pc.check_forward(rs, rv, oracle32)
         assert util.artefacts()["path"] == 2
     finally:
         pc.set_sort_path("auto")
