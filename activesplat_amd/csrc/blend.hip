@@ -100,21 +100,40 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
             if (m == 0ull) continue;
             stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
             __builtin_amdgcn_wave_barrier();
+            // two hit records per LDS wait; the blend itself is branch-free (predicated weights)
             while (m) {
-                const int j = __ffsll(m) - 1;
+                const int j1 = __ffsll(m) - 1;
                 m &= m - 1;
-                const float4 a0 = s0[j], a1 = s1[j], a2 = s2[j];
-                const float dx = a0.x - c.pxf, dy = a0.y - c.pyf;
-                const float p = (a0.z * dx + a0.w * dy) * dx + (a1.x * dy) * dy;
-                const float alpha = fminf(0.99f, a1.y * __builtin_amdgcn_exp2f(p));
-                bool ok = !done && p <= 0.0f && alpha >= kAlphaMin;
-                const float test_T = T * (1.0f - alpha);
-                if (ok && test_T < kTmin) { done = true; ok = false; }
-                if (ok) {
-                    const float w = alpha * T;
+                const bool two = m != 0ull;
+                const int j2 = two ? __ffsll(m) - 1 : j1;
+                m &= m - 1;
+                const float4 a0 = s0[j1], a1 = s1[j1], a2 = s2[j1];
+                const float4 b0 = s0[j2], b1 = s1[j2], b2 = s2[j2];
+                {
+                    const float dx = a0.x - c.pxf, dy = a0.y - c.pyf;
+                    const float p = (a0.z * dx + a0.w * dy) * dx + (a1.x * dy) * dy;
+                    const float alpha = fminf(0.99f, a1.y * __builtin_amdgcn_exp2f(p));
+                    const float test_T = T * (1.0f - alpha);
+                    const bool vis = !done && p <= 0.0f && alpha >= kAlphaMin;
+                    const bool ok = vis && test_T >= kTmin;
+                    done = done || (vis && !ok);
+                    const float w = ok ? alpha * T : 0.0f;
                     C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w; Dp += a2.y * w;
-                    T = test_T;
-                    last = base + (uint32_t)j + 1u;
+                    T = ok ? test_T : T;
+                    last = ok ? base + (uint32_t)j1 + 1u : last;
+                }
+                {
+                    const float dx = b0.x - c.pxf, dy = b0.y - c.pyf;
+                    const float p = (b0.z * dx + b0.w * dy) * dx + (b1.x * dy) * dy;
+                    const float alpha = fminf(0.99f, b1.y * __builtin_amdgcn_exp2f(p));
+                    const float test_T = T * (1.0f - alpha);
+                    const bool vis = two && !done && p <= 0.0f && alpha >= kAlphaMin;
+                    const bool ok = vis && test_T >= kTmin;
+                    done = done || (vis && !ok);
+                    const float w = ok ? alpha * T : 0.0f;
+                    C0 += b1.z * w; C1 += b1.w * w; C2 += b2.x * w; Dp += b2.y * w;
+                    T = ok ? test_T : T;
+                    last = ok ? base + (uint32_t)j2 + 1u : last;
                 }
             }
             __builtin_amdgcn_wave_barrier();
