@@ -43,7 +43,8 @@ SORT_AUTO, SORT_TILE_LDS, SORT_RADIX = 0, 1, 2
 # every symbol include/gsplat_hip.h declares (tests check the library exports all of them)
 SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
            "gs_version", "gs_set_sort_path", "gs_preprocess_forward", "gs_render_forward", "gs_render_backward", "gs_adam_step",
-           "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect")
+           "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
+           "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows")
 
 
 def _bind(lib):
@@ -60,13 +61,19 @@ def _bind(lib):
     lib.gs_preprocess_forward.argtypes = [C.POINTER(GsCamera), i32] + [vp] * 7 + [vp, vp, vp, vp, vp, vp]
     lib.gs_render_forward.argtypes = [C.POINTER(GsCamera), i32, i64, C.c_uint32] + [vp] * 7 + [vp]
     lib.gs_render_backward.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 6 + [vp] * 5 + [vp] * 8 + [vp, vp]
-    lib.gs_adam_step.argtypes = [i64, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp]
+    lib.gs_adam_step.argtypes = [i64, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, i32, vp]
     lib.gs_profile_enable.argtypes = [i32]
     lib.gs_profile_stage_count.restype = i32
     lib.gs_profile_stage_name.argtypes = [i32]
     lib.gs_profile_stage_name.restype = C.c_char_p
     lib.gs_profile_collect.argtypes = [vp, vp, i32]
     lib.gs_profile_collect.restype = C.c_int
+    lib.gs_compact_scratch_bytes.argtypes = [i64]
+    lib.gs_compact_scratch_bytes.restype = C.c_uint64
+    lib.gs_compact_index.argtypes = [i64, vp, vp, vp, vp, vp]
+    lib.gs_compact_index.restype = C.c_int
+    lib.gs_gather_rows.argtypes = [i64, i32, vp, vp, vp, vp]
+    lib.gs_gather_rows.restype = C.c_int
     for n in ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_preprocess_forward", "gs_render_forward",
               "gs_render_backward", "gs_adam_step"):
         getattr(lib, n).restype = C.c_int

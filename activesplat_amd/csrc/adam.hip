@@ -42,20 +42,20 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n, float* __restri
     if (blockIdx.x == 0 && t < n) adam_elem(p[t], g[t], m[t], v[t], one_m_b1, b2, one_m_b2, step_size, inv_bc2s, eps);
 }
 
-hipError_t launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
-                       float eps, int step, hipStream_t st)
+hipError_t launch_adam(int64_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2,
+                       double eps, int step, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
     // bias corrections on the host in double, as torch does for python-scalar steps
-    const double bc1 = 1.0 - pow((double)b1, (double)step);
-    const double bc2 = 1.0 - pow((double)b2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
+    const double bc1 = 1.0 - pow(b1, (double)step);
+    const double bc2 = 1.0 - pow(b2, (double)step);
+    const float step_size = (float)(lr / bc1);
     const float inv_bc2s = (float)(1.0 / sqrt(bc2));
     int64_t nb = ((n >> 2) + kBlock - 1) / kBlock;
     if (nb < 1) nb = 1;
     if (nb > 256 * 8) nb = 256 * 8;          // grid-stride: 8 workgroups per CU
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, n, p, g, m, v, 1.0f - b1, b2, 1.0f - b2,
-                       step_size, inv_bc2s, eps);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, n, p, g, m, v, (float)(1.0 - b1), (float)b2,
+                       (float)(1.0 - b2), step_size, inv_bc2s, (float)eps);
     return hipGetLastError();
 }
 

@@ -320,8 +320,8 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* m
     return GS_OK;
 }
 
-int gs_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
-                 float beta1, float beta2, float eps, int32_t step, gs_stream_t stream)
+int gs_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr,
+                 double beta1, double beta2, double eps, int32_t step, gs_stream_t stream)
 {
     if (n < 0 || step < 1) return fail(GS_EINVAL, "gs_adam_step: bad n/step");
     if (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq)) return fail(GS_EINVAL, "gs_adam_step: null pointer");
@@ -331,6 +331,25 @@ int gs_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, flo
         e = gs::launch_adam(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, (hipStream_t)stream);
     }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_adam_step: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+uint64_t gs_compact_scratch_bytes(int64_t n) { return align_up(gs::compact_scratch_bytes(n > 0 ? n : 1)); }
+
+int gs_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32_t* d_count, void* scratch, gs_stream_t stream)
+{
+    if (n < 0 || !d_count || !scratch || (n > 0 && (!keep || !src_index))) return fail(GS_EINVAL, "gs_compact_index: bad argument");
+    if (n >= (int64_t)1 << 32) return fail(GS_ECAPACITY, "gs_compact_index: more than 2^32 rows");
+    hipError_t e = gs::launch_compact_index(n, keep, src_index, d_count, scratch, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_compact_index: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_gather_rows(int64_t n_out, int32_t row_floats, const uint32_t* src_index, const float* src, float* dst, gs_stream_t stream)
+{
+    if (n_out < 0 || row_floats <= 0 || (n_out > 0 && (!src_index || !src || !dst))) return fail(GS_EINVAL, "gs_gather_rows: bad argument");
+    hipError_t e = gs::launch_gather_rows(n_out, row_floats, src_index, src, dst, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_gather_rows: %s", hipGetErrorString(e));
     return GS_OK;
 }
 

@@ -1,0 +1,104 @@
+// compact.hip -- stream compaction of per-Gaussian rows (prune / densify surgery).
+//
+// Replaces the boolean-mask indexing + torch.cat + Parameter re-creation the reference performs on every
+// per-Gaussian tensor AND its Adam moments (src/mapper/splatam/utils/slam_external.py:143-164 remove_points,
+// :126-140 cat_params_to_optimizer, :171-247 prune_gaussians / densify).  Two primitives:
+//   compact_index : keep-mask -> ordered list of kept row indices (+ count), wavefront ballot/popcount scan
+//   gather_rows   : dst[r][:] = src[index[r]][:] for any row width (params 3/4/1 floats, moments, statistics)
+// HBM-bound streaming; one index build serves every tensor of the surgery.
+#include "gs_common.h"
+
+namespace gs {
+
+constexpr int kCompactBlock = 1024;
+
+__global__ __launch_bounds__(kCompactBlock) void compact_count_kernel(int64_t n, const uint8_t* __restrict__ keep,
+                                                                      uint32_t* __restrict__ block_counts)
+{
+    __shared__ uint32_t s_w[kCompactBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kCompactBlock + tid;
+    const unsigned long long m = __ballot(i < n && keep[i] != 0);
+    if (lane == 0) s_w[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t c = 0;
+        for (int w = 0; w < kCompactBlock / kWave; w++) c += s_w[w];
+        block_counts[blockIdx.x] = c;
+    }
+}
+
+__global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t* __restrict__ block_counts, int nb, uint32_t* __restrict__ d_count)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + tid;
+        const uint32_t v = i < nb ? block_counts[i] : 0u;
+        const uint32_t inc = wave_inclusive_scan(v, lane);
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t wprefix = 0;
+        for (int w = 0; w < wave; w++) wprefix += s_w[w];
+        const uint32_t carry = s_carry;
+        if (i < nb) block_counts[i] = carry + wprefix + inc - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + wprefix + inc;
+        __syncthreads();
+    }
+    if (tid == 0) *d_count = s_carry;
+}
+
+__global__ __launch_bounds__(kCompactBlock) void compact_write_kernel(int64_t n, const uint8_t* __restrict__ keep,
+                                                                      const uint32_t* __restrict__ block_offsets,
+                                                                      uint32_t* __restrict__ src_index)
+{
+    __shared__ uint32_t s_w[kCompactBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kCompactBlock + tid;
+    const bool k = i < n && keep[i] != 0;
+    const unsigned long long m = __ballot(k);
+    if (lane == 0) s_w[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = block_offsets[blockIdx.x];
+    for (int w = 0; w < wave; w++) off += s_w[w];
+    if (k) src_index[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(int64_t total, int row_floats, const uint32_t* __restrict__ src_index,
+                                                              const float* __restrict__ src, float* __restrict__ dst)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / row_floats;
+        const int c = (int)(e - r * row_floats);
+        dst[e] = src[(int64_t)src_index[r] * row_floats + c];
+    }
+}
+
+uint64_t compact_scratch_bytes(int64_t n) { return (uint64_t)((n + kCompactBlock - 1) / kCompactBlock + 1) * 4; }
+
+hipError_t launch_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32_t* d_count, void* scratch, hipStream_t st)
+{
+    const int nb = (int)((n + kCompactBlock - 1) / kCompactBlock);
+    uint32_t* bc = (uint32_t*)scratch;
+    if (nb > 0) hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(kCompactBlock), 0, st, n, keep, bc);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, bc, nb, d_count);
+    if (nb > 0) hipLaunchKernelGGL(compact_write_kernel, dim3(nb), dim3(kCompactBlock), 0, st, n, keep, bc, src_index);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(int64_t n_out, int row_floats, const uint32_t* src_index, const float* src, float* dst, hipStream_t st)
+{
+    const int64_t total = n_out * row_floats;
+    if (total <= 0) return hipSuccess;
+    int64_t nb = (total + kBlock - 1) / kBlock;
+    if (nb > 256 * 16) nb = 256 * 16;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, total, row_floats, src_index, src, dst);
+    return hipGetLastError();
+}
+
+}  // namespace gs

@@ -106,8 +106,12 @@ hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint3
 hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  float* grad2d, hipStream_t st);
-hipError_t launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
-                       float eps, int step, hipStream_t st);
+hipError_t launch_adam(int64_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2,
+                       double eps, int step, hipStream_t st);
+
+uint64_t compact_scratch_bytes(int64_t n);
+hipError_t launch_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32_t* d_count, void* scratch, hipStream_t st);
+hipError_t launch_gather_rows(int64_t n_out, int row_floats, const uint32_t* src_index, const float* src, float* dst, hipStream_t st);
 
 // sort backend (sort_rocprim.hip): stable ascending radix sort of (key64, val32) pairs on bits [0,end_bit)
 size_t sort_temp_bytes(int64_t D, int end_bit);

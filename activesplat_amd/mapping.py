@@ -1,0 +1,276 @@
+"""Caller-side helpers of the rasteriser hot path: frame transforms, activations, loss, map growth.
+
+Host-side mirror (PyTorch plumbing, explicit `device`, no hard-coded .cuda()) of the reference
+functions that produce every tensor handed to / consumed from the rasteriser:
+
+  build_rotation                          src/mapper/splatam/utils/slam_external.py:25-42
+  quat_mult, l1_loss_v1                   src/mapper/splatam/utils/slam_helpers.py:5-6,21-28
+  transform_to_frame                      slam_helpers.py:252-304
+  transformed_params2rendervar            slam_helpers.py:124-139
+  get_depth_and_silhouette,
+  transformed_params2depthplussilhouette  slam_helpers.py:196-213,234-249
+  get_rendervars, render                  src/mapper/splatam/splatam.py:436-468,413-434
+  calc_ssim                               slam_external.py:54-97
+  get_loss (mapping branch)               splatam.py:172-301
+  get_pointcloud, initialize_params,
+  initialize_new_params, add_new_gaussians splatam.py:25-115,304-379
+
+Same names, argument meaning and results (pinned by tests/golden/*.npz generated from the reference);
+the reference's unused per-iteration setup_camera call (splatam.py:205) is omitted.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .camera import setup_camera
+from .rasterizer import GaussianRasterizationSettings as Camera
+from .rasterizer import GaussianRasterizer as Renderer
+
+_GAUSSIAN_KEYS = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales")
+
+
+def build_rotation(q: torch.Tensor) -> torch.Tensor:
+    q = q / q.norm(dim=1, keepdim=True)
+    r, x, y, z = q.unbind(1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+
+
+def quat_mult(q1: torch.Tensor, q2: torch.Tensor) -> torch.Tensor:
+    w1, x1, y1, z1 = q1.unbind(-1)
+    w2, x2, y2, z2 = q2.unbind(-1)
+    return torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                        w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
+
+
+def l1_loss_v1(x, y):
+    return (x - y).abs().mean()
+
+
+def transform_to_frame(params, time_idx, gaussians_grad, camera_grad):
+    """World -> camera frame `time_idx` for isotropic or anisotropic Gaussians (slam_helpers.py:252-304)."""
+    cam_rot = params["cam_unnorm_rots"][..., time_idx]
+    cam_tran = params["cam_trans"][..., time_idx]
+    if not camera_grad:
+        cam_rot, cam_tran = cam_rot.detach(), cam_tran.detach()
+    cam_rot = F.normalize(cam_rot)
+    dev = cam_rot.device
+    rel_w2c = torch.eye(4, device=dev, dtype=torch.float32)
+    rel_w2c[:3, :3] = build_rotation(cam_rot)
+    rel_w2c[:3, 3] = cam_tran
+    pts, rots = params["means3D"], params["unnorm_rotations"]
+    if not gaussians_grad:
+        pts, rots = pts.detach(), rots.detach()
+    out = {"means3D": pts @ rel_w2c[:3, :3].T + rel_w2c[:3, 3]}
+    if params["log_scales"].shape[1] == 1:          # isotropic: rotation is irrelevant
+        out["unnorm_rotations"] = rots
+    else:
+        out["unnorm_rotations"] = quat_mult(cam_rot, F.normalize(rots))
+    return out
+
+
+def _log_scales3(params):
+    ls = params["log_scales"]
+    return torch.tile(ls, (1, 3)) if ls.shape[1] == 1 else ls
+
+
+def transformed_params2rendervar(params, transformed_gaussians):
+    m = transformed_gaussians["means3D"]
+    return {"means3D": m, "colors_precomp": params["rgb_colors"],
+            "rotations": F.normalize(transformed_gaussians["unnorm_rotations"]),
+            "opacities": torch.sigmoid(params["logit_opacities"]), "scales": torch.exp(_log_scales3(params)),
+            "means2D": torch.zeros_like(params["means3D"], requires_grad=True) + 0}
+
+
+def get_depth_and_silhouette(pts_3D, w2c):
+    """Per-Gaussian "colour" [z_cam, 1, z_cam^2] for the depth/silhouette pass (slam_helpers.py:196-213)."""
+    w2c = torch.as_tensor(w2c, dtype=torch.float32, device=pts_3D.device)
+    z = pts_3D @ w2c[2, :3] + w2c[2, 3]
+    return torch.stack([z, torch.ones_like(z), z * z], dim=1)
+
+
+def transformed_params2depthplussilhouette(params, w2c, transformed_gaussians):
+    m = transformed_gaussians["means3D"]
+    return {"means3D": m, "colors_precomp": get_depth_and_silhouette(m, w2c),
+            "rotations": F.normalize(transformed_gaussians["unnorm_rotations"]),
+            "opacities": torch.sigmoid(params["logit_opacities"]), "scales": torch.exp(_log_scales3(params)),
+            "means2D": torch.zeros_like(params["means3D"], requires_grad=True) + 0}
+
+
+def get_rendervars(params, w2c):
+    """World-frame rendervars for the no-grad consumers (splatam.py:436-468)."""
+    base = {"means3D": params["means3D"], "rotations": F.normalize(params["unnorm_rotations"]),
+            "opacities": torch.sigmoid(params["logit_opacities"]), "scales": torch.exp(_log_scales3(params))}
+    rv = dict(base, colors_precomp=params["rgb_colors"], means2D=torch.zeros_like(params["means3D"]))
+    dv = dict(base, colors_precomp=get_depth_and_silhouette(params["means3D"], w2c),
+              means2D=torch.zeros_like(params["means3D"]))
+    return rv, dv
+
+
+def render(w2c, k, rendervar, depth_rendervar, cfg, scale_modifier=1.0, device=None, with_silhouette=True):
+    """No-grad render (splatam.py:413-434): im on white, built-in depth & opacity, silhouette channel.
+    with_silhouette=False skips the second raster pass, whose only product every reference caller discards
+    (SURVEY App. E5)."""
+    with torch.no_grad():
+        device = rendervar["means3D"].device if device is None else device
+        cam = setup_camera(cfg["viz_w"], cfg["viz_h"], k, w2c, cfg["viz_near"], cfg["viz_far"],
+                           scale_modifier=scale_modifier, device=device)
+        white = cam._replace(bg=torch.ones(3, dtype=torch.float32, device=device))
+        im, _, depth, opacity = Renderer(raster_settings=white)(**rendervar)
+        sil = None
+        if with_silhouette:
+            depth_sil, _, _, _ = Renderer(raster_settings=cam)(**depth_rendervar)
+            sil = depth_sil[1].unsqueeze(0)
+        return im, depth, opacity, sil
+
+
+# ---------------------------------------------------------------------------------------------------
+# loss (splatam.py:172-301, mapping branch) -- SSIM: 11x11 Gaussian window sigma 1.5, C1 1e-4, C2 9e-4
+# ---------------------------------------------------------------------------------------------------
+_WINDOWS = {}
+
+
+def _window(channel, device, dtype):
+    key = (channel, str(device), dtype)
+    if key not in _WINDOWS:
+        g = torch.tensor([math.exp(-(x - 5) ** 2 / (2 * 1.5 ** 2)) for x in range(11)], dtype=torch.float32)
+        g = (g / g.sum()).unsqueeze(1)
+        _WINDOWS[key] = (g @ g.T).expand(channel, 1, 11, 11).contiguous().to(device=device, dtype=dtype)
+    return _WINDOWS[key]
+
+
+def calc_ssim(img1, img2):
+    ch = img1.size(-3)
+    w = _window(ch, img1.device, img1.dtype)
+    conv = lambda x: F.conv2d(x, w, padding=5, groups=ch)  # noqa: E731
+    mu1, mu2 = conv(img1), conv(img2)
+    s11 = conv(img1 * img1) - mu1 * mu1
+    s22 = conv(img2 * img2) - mu2 * mu2
+    s12 = conv(img1 * img2) - mu1 * mu2
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s11 + s22 + c2))).mean()
+
+
+def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_for_loss=True, sil_thres=0.99,
+             use_l1=True, ignore_outlier_depth_loss=False, do_ba=False):
+    """Mapping loss: two raster passes on the same geometry (RGB, then [z,1,z^2]); masked depth L1 +
+    0.8 L1 + 0.2 (1 - SSIM) on colour; updates variables['means2D'|'seen'|'max_2D_radius']."""
+    tg = transform_to_frame(params, iter_time_idx, gaussians_grad=True, camera_grad=do_ba)
+    rendervar = transformed_params2rendervar(params, tg)
+    depth_sil_rendervar = transformed_params2depthplussilhouette(params, curr_data["w2c"], tg)
+    rendervar["means2D"].retain_grad()
+    im, radius, _, _ = Renderer(raster_settings=curr_data["cam"])(**rendervar)
+    variables["means2D"] = rendervar["means2D"]          # densification reads the colour pass' gradient only
+    depth_sil, _, _, _ = Renderer(raster_settings=curr_data["cam"])(**depth_sil_rendervar)
+    depth = depth_sil[0].unsqueeze(0)
+    depth_sq = depth_sil[2].unsqueeze(0)
+    uncertainty = (depth_sq - depth ** 2).detach()
+    mask = curr_data["depth"] > 0
+    if ignore_outlier_depth_loss:
+        err = (curr_data["depth"] - depth).abs() * mask
+        mask = mask & (err < 10 * err.median())
+    mask = (mask & ~torch.isnan(depth) & ~torch.isnan(uncertainty)).detach()
+    losses = {}
+    if use_l1:
+        losses["depth"] = (curr_data["depth"] - depth).abs()[mask].mean()
+    losses["im"] = 0.8 * l1_loss_v1(im, curr_data["im"]) + 0.2 * (1.0 - calc_ssim(im, curr_data["im"]))
+    weighted = {k: v * loss_weights[k] for k, v in losses.items()}
+    loss = sum(weighted.values())
+    seen = radius > 0
+    variables["max_2D_radius"][seen] = torch.max(radius[seen].to(variables["max_2D_radius"].dtype),
+                                                 variables["max_2D_radius"][seen])
+    variables["seen"] = seen
+    weighted["loss"] = loss
+    return loss, variables, weighted
+
+
+# ---------------------------------------------------------------------------------------------------
+# map initialisation / growth (splatam.py:25-115,304-379)
+# ---------------------------------------------------------------------------------------------------
+def get_pointcloud(color, depth, intrinsics, w2c, transform_pts=True, mask=None, compute_mean_sq_dist=False):
+    H, W = color.shape[1], color.shape[2]
+    dev = color.device
+    fx, fy, cx, cy = intrinsics[0][0], intrinsics[1][1], intrinsics[0][2], intrinsics[1][2]
+    xs = (torch.arange(W, device=dev, dtype=torch.float32) - cx) / fx
+    ys = (torch.arange(H, device=dev, dtype=torch.float32) - cy) / fy
+    xx = xs[None, :].expand(H, W).reshape(-1)
+    yy = ys[:, None].expand(H, W).reshape(-1)
+    z = depth[0].reshape(-1)
+    pts = torch.stack((xx * z, yy * z, z), dim=-1)
+    if transform_pts:
+        c2w = torch.inverse(torch.as_tensor(w2c, dtype=torch.float32, device=dev))
+        pts = pts @ c2w[:3, :3].T + c2w[:3, 3]
+    cld = torch.cat((pts, color.permute(1, 2, 0).reshape(-1, 3)), -1)
+    msd = (z / ((fx + fy) / 2)) ** 2                         # "projective": farther -> larger radius
+    if mask is not None:
+        cld, msd = cld[mask], msd[mask]
+    return (cld, msd) if compute_mean_sq_dist else cld
+
+
+def _new_gaussians(pt_cld, mean3_sq_dist, gaussian_distribution):
+    n, dev = pt_cld.shape[0], pt_cld.device
+    if gaussian_distribution not in ("isotropic", "anisotropic"):
+        raise ValueError(f"Unknown gaussian_distribution {gaussian_distribution}")
+    ls = torch.log(torch.sqrt(mean3_sq_dist))[:, None]
+    rots = torch.zeros(n, 4, device=dev)
+    rots[:, 0] = 1.0
+    return {"means3D": pt_cld[:, :3], "rgb_colors": pt_cld[:, 3:6], "unnorm_rotations": rots,
+            "logit_opacities": torch.zeros(n, 1, device=dev),
+            "log_scales": ls if gaussian_distribution == "isotropic" else torch.tile(ls, (1, 3))}
+
+
+def _as_params(d):
+    return {k: torch.nn.Parameter(v.float().contiguous().requires_grad_(True)) for k, v in d.items()}
+
+
+def initialize_params(init_pt_cld, num_frames, mean3_sq_dist, gaussian_distribution):
+    d = _new_gaussians(init_pt_cld, mean3_sq_dist, gaussian_distribution)
+    dev = init_pt_cld.device
+    cam_rots = torch.zeros(1, 4, num_frames, device=dev)
+    cam_rots[:, 0, :] = 1.0
+    d["cam_unnorm_rots"] = cam_rots
+    d["cam_trans"] = torch.zeros(1, 3, num_frames, device=dev)
+    params = _as_params(d)
+    n = params["means3D"].shape[0]
+    variables = {k: torch.zeros(n, device=dev) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+    return params, variables
+
+
+def initialize_new_params(new_pt_cld, mean3_sq_dist, gaussian_distribution):
+    return _as_params(_new_gaussians(new_pt_cld, mean3_sq_dist, gaussian_distribution))
+
+
+def add_new_gaussians(params, variables, curr_data, sil_thres, time_idx, gaussian_distribution):
+    """Silhouette / depth-error driven growth (splatam.py:332-379)."""
+    tg = transform_to_frame(params, time_idx, gaussians_grad=False, camera_grad=False)
+    dsv = transformed_params2depthplussilhouette(params, curr_data["w2c"], tg)
+    with torch.no_grad():
+        depth_sil, _, _, _ = Renderer(raster_settings=curr_data["cam"])(**dsv)
+    sil, render_depth = depth_sil[1], depth_sil[0]
+    gt_depth = curr_data["depth"][0]
+    depth_error = (gt_depth - render_depth).abs() * (gt_depth > 0)
+    behind = (render_depth > gt_depth) & (depth_error > 2 * depth_error.median())
+    non_presence = (sil < sil_thres) | (behind & (sil > sil_thres) & (gt_depth < 5))
+    non_presence = non_presence.reshape(-1)
+    if non_presence.sum() > 0:
+        dev = gt_depth.device
+        cam_rot = F.normalize(params["cam_unnorm_rots"][..., time_idx].detach())
+        curr_w2c = torch.eye(4, device=dev)
+        curr_w2c[:3, :3] = build_rotation(cam_rot)
+        curr_w2c[:3, 3] = params["cam_trans"][..., time_idx].detach()
+        non_presence = non_presence & (gt_depth > 0).reshape(-1)
+        new_cld, msd = get_pointcloud(curr_data["im"], curr_data["depth"], curr_data["intrinsics"], curr_w2c,
+                                      mask=non_presence, compute_mean_sq_dist=True)
+        new_params = initialize_new_params(new_cld, msd, gaussian_distribution)
+        for k, v in new_params.items():
+            params[k] = torch.nn.Parameter(torch.cat((params[k], v), dim=0).requires_grad_(True))
+        n = params["means3D"].shape[0]
+        for k in ("means2D_gradient_accum", "denom", "max_2D_radius"):
+            variables[k] = torch.zeros(n, device=dev)
+        variables["timestep"] = torch.cat((variables["timestep"], time_idx * torch.ones(new_cld.shape[0], device=dev)), dim=0)
+    return params, variables

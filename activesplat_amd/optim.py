@@ -1,0 +1,261 @@
+"""Per-Gaussian optimiser: fused Adam + prune / densify surgery on the HIP library.
+
+Host-side mirror of the reference's optimiser handling (same names, argument meaning and results; pinned
+by tests/golden/adam.npz and prune.npz generated from the reference):
+
+  initialize_optimizer            src/mapper/splatam/splatam.py:118-124
+                                  (torch.optim.Adam(param_groups, lr=0.0, eps=1e-15): one group per key, betas
+                                  (0.9, 0.999), no weight decay; tensors whose .grad is None are skipped)
+  accumulate_mean2d_gradient      src/mapper/splatam/utils/slam_external.py:100-108
+  update_params_and_optimizer     :111-123     cat_params_to_optimizer  :126-140
+  remove_points                   :143-164     inverse_sigmoid          :167
+  prune_gaussians                 :171-192     densify                  :195-247
+
+What is native here: GaussianAdam.step() is ONE fused HIP kernel per parameter tensor (gs_adam_step, 28 B of
+HBM traffic per element) instead of torch's multi-kernel foreach path, and every row surgery is a
+gs_compact_index + gs_gather_rows pair shared by the parameter, both Adam moments and the densification
+statistics.  The optimiser keeps torch.optim's `param_groups` / `state[param]` layout so that code written
+against the reference's surgery functions keeps working.
+
+densify: the reference's slam_external.densify only executes for isotropic scales without a 'timestep'
+variable.  This mirror reproduces that case exactly and defines the missing ones the way
+the reference's own dead copy (utils/gs_external.py:191-253) and the original 3DGS do: anisotropic split
+noise uses the per-axis scales, clones and splits inherit the parent's timestep.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_SKIP = ("cam_unnorm_rots", "cam_trans")
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else C.c_void_p(0)
+
+
+class GaussianAdam:
+    """Drop-in for torch.optim.Adam(param_groups, lr=0.0, eps=1e-15) as the reference configures it."""
+
+    def __init__(self, param_groups, lr=0.0, betas=(0.9, 0.999), eps=1e-15):
+        self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)
+        self.param_groups = []
+        for g in param_groups:
+            g = dict(g)
+            g.setdefault("lr", lr); g.setdefault("betas", betas); g.setdefault("eps", eps)
+            g["params"] = list(g["params"])
+            self.param_groups.append(g)
+        self.state = {}
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        lib = _lib.get()
+        for g in self.param_groups:
+            b1, b2 = g["betas"]
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_contiguous() or p.dtype != torch.float32:
+                    raise RuntimeError("GaussianAdam needs contiguous fp32 parameters")
+                st = self.state.get(p)
+                if st is None or len(st) == 0:
+                    st = self.state[p] = {"step": torch.tensor(0.0), "exp_avg": torch.zeros_like(p),
+                                          "exp_avg_sq": torch.zeros_like(p)}
+                st["step"] = st["step"] + 1
+                grad = p.grad.contiguous().float()
+                _lib.check(lib.gs_adam_step(p.numel(), p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                            st["exp_avg_sq"].data_ptr(), float(g["lr"]), float(b1), float(b2),
+                                            float(g["eps"]), int(st["step"].item()), _stream(p)))
+
+
+def initialize_optimizer(params, lrs_dict, tracking=False):
+    groups = [{"params": [v], "name": k, "lr": lrs_dict[k]} for k, v in params.items()]
+    return GaussianAdam(groups) if tracking else GaussianAdam(groups, lr=0.0, eps=1e-15)
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+def accumulate_mean2d_gradient(variables):
+    g = variables["means2D"].grad
+    if g is None or g.shape[0] != variables["means2D"].shape[0] or g.shape[1] < 2:
+        return variables
+    seen = variables["seen"]
+    if seen.sum() > 0:
+        variables["means2D_gradient_accum"][seen] += torch.norm(g[seen, :2], dim=-1)
+        variables["denom"][seen] += 1
+    return variables
+
+
+# ---- row surgery on the HIP library ---------------------------------------------------------------------
+def build_index(keep: torch.Tensor) -> torch.Tensor:
+    """keep mask [n] (bool) -> int32 tensor of kept row indices, ascending (gs_compact_index)."""
+    lib = _lib.get()
+    n = keep.numel()
+    k8 = keep.to(torch.uint8).contiguous()
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=keep.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=keep.device)
+    scratch = torch.empty(int(lib.gs_compact_scratch_bytes(n)), dtype=torch.uint8, device=keep.device)
+    _lib.check(lib.gs_compact_index(n, k8.data_ptr(), idx.data_ptr(), cnt.data_ptr(), scratch.data_ptr(), _stream(keep)))
+    return idx[: int(cnt.item())]
+
+
+def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """dst[r] = src[index[r]] for a contiguous fp32 tensor whose first dimension is the Gaussian (gs_gather_rows)."""
+    lib = _lib.get()
+    src = src.detach().contiguous().float()
+    n_out = index.numel()
+    row = src.numel() // max(src.shape[0], 1)
+    dst = torch.empty((n_out,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    if n_out:
+        _lib.check(lib.gs_gather_rows(n_out, row, index.data_ptr(), src.data_ptr(), dst.data_ptr(), _stream(src)))
+    return dst
+
+
+def _replace_param(optimizer, group, new_tensor, new_state):
+    old = group["params"][0]
+    optimizer.state.pop(old, None)
+    p = torch.nn.Parameter(new_tensor.requires_grad_(True))
+    group["params"][0] = p
+    if new_state is not None:
+        optimizer.state[p] = new_state
+    return p
+
+
+def _group(optimizer, name):
+    return [g for g in optimizer.param_groups if g["name"] == name][0]
+
+
+def update_params_and_optimizer(new_params, params, optimizer):
+    """Replace tensors wholesale; moments restart from zero, the step counter is kept (slam_external.py:111-123)."""
+    for k, v in new_params.items():
+        g = _group(optimizer, k)
+        st = optimizer.state.get(g["params"][0], None)
+        new_st = None if st is None else dict(st, exp_avg=torch.zeros_like(v), exp_avg_sq=torch.zeros_like(v))
+        params[k] = _replace_param(optimizer, g, v.detach().clone(), new_st)
+    return params
+
+
+def cat_params_to_optimizer(new_params, params, optimizer):
+    """Append rows; new rows get zero moments, the per-tensor step counter is preserved (slam_external.py:126-140)."""
+    for k, v in new_params.items():
+        g = _group(optimizer, k)
+        old = g["params"][0]
+        st = optimizer.state.get(old, None)
+        new_st = None
+        if st is not None and len(st):
+            new_st = dict(st, exp_avg=torch.cat((st["exp_avg"], torch.zeros_like(v)), dim=0),
+                          exp_avg_sq=torch.cat((st["exp_avg_sq"], torch.zeros_like(v)), dim=0))
+        params[k] = _replace_param(optimizer, g, torch.cat((old.detach(), v.detach()), dim=0), new_st)
+    return params
+
+
+def remove_points(to_remove, params, variables, optimizer):
+    """Compact every per-Gaussian tensor, its Adam moments and the statistics with ONE index build."""
+    index = build_index(~to_remove)
+    for k in [k for k in params.keys() if k not in _SKIP]:
+        g = _group(optimizer, k)
+        old = g["params"][0]
+        st = optimizer.state.get(old, None)
+        new_st = None
+        if st is not None and len(st):
+            new_st = dict(st, exp_avg=gather_rows(st["exp_avg"], index), exp_avg_sq=gather_rows(st["exp_avg_sq"], index))
+        params[k] = _replace_param(optimizer, g, gather_rows(old, index), new_st)
+    for k in ("means2D_gradient_accum", "denom", "max_2D_radius", "timestep"):
+        if k in variables:
+            variables[k] = gather_rows(variables[k], index)
+    return params, variables
+
+
+def _too_big(params, variables, factor):
+    return torch.exp(params["log_scales"]).max(dim=1).values > factor * variables["scene_radius"]
+
+
+def prune_gaussians(params, variables, optimizer, iter, prune_dict):
+    if iter <= prune_dict["stop_after"]:
+        if iter >= prune_dict["start_after"] and iter % prune_dict["prune_every"] == 0:
+            thr = prune_dict["final_removal_opacity_threshold"] if iter == prune_dict["stop_after"] \
+                else prune_dict["removal_opacity_threshold"]
+            to_remove = (torch.sigmoid(params["logit_opacities"]) < thr).squeeze(-1)
+            if iter >= prune_dict["remove_big_after"]:
+                to_remove = to_remove | _too_big(params, variables, 0.1)
+            params, variables = remove_points(to_remove, params, variables, optimizer)
+        if iter > 0 and iter % prune_dict["reset_opacities_every"] == 0 and prune_dict["reset_opacities"]:
+            new = {"logit_opacities": inverse_sigmoid(torch.ones_like(params["logit_opacities"]) * 0.01)}
+            params = update_params_and_optimizer(new, params, optimizer)
+    return params, variables
+
+
+def densify(params, variables, optimizer, iter, densify_dict, samples=None):
+    """Clone small / split large high-gradient Gaussians, then cull (slam_external.py:195-247).
+    `samples` optionally injects the N(0, scale) split offsets ([n_split * num_to_split_into, 3]) so that a run
+    can be replayed exactly; otherwise torch.normal draws them."""
+    if iter > densify_dict["stop_after"]:
+        return params, variables
+    variables = accumulate_mean2d_gradient(variables)
+    grad_thresh = densify_dict["grad_thresh"]
+    if iter >= densify_dict["start_after"] and iter % densify_dict["densify_every"] == 0:
+        keys = [k for k in params.keys() if k not in _SKIP]
+        dev = params["means3D"].device
+        grads = variables["means2D_gradient_accum"] / variables["denom"]
+        grads[grads.isnan()] = 0.0
+        small = torch.exp(params["log_scales"]).max(dim=1).values <= 0.01 * variables["scene_radius"]
+        to_clone = (grads >= grad_thresh) & small
+        clone_idx = build_index(to_clone)
+        new_params = {k: gather_rows(params[k], clone_idx) for k in keys}
+        ts = variables.get("timestep")
+        if ts is not None:
+            ts = torch.cat((ts, gather_rows(ts, clone_idx)))
+        params = cat_params_to_optimizer(new_params, params, optimizer)
+        num_pts = params["means3D"].shape[0]
+        padded = torch.zeros(num_pts, device=dev)
+        padded[: grads.shape[0]] = grads
+        to_split = (padded >= grad_thresh) & (torch.exp(params["log_scales"]).max(dim=1).values > 0.01 * variables["scene_radius"])
+        n = densify_dict["num_to_split_into"]
+        split_idx = build_index(to_split).repeat(n)
+        new_params = {k: gather_rows(params[k], split_idx) for k in keys}
+        stds = torch.exp(new_params["log_scales"])
+        stds = stds.repeat(1, 3) if stds.shape[1] == 1 else stds          # anisotropic: per-axis
+        if samples is None:
+            samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
+        rots = build_rotation_from(new_params["unnorm_rotations"])
+        new_params["means3D"] = new_params["means3D"] + torch.bmm(rots, samples.to(dev).unsqueeze(-1)).squeeze(-1)
+        new_params["log_scales"] = torch.log(torch.exp(new_params["log_scales"]) / (0.8 * n))
+        if ts is not None:
+            ts = torch.cat((ts, gather_rows(ts, split_idx)))
+        params = cat_params_to_optimizer(new_params, params, optimizer)
+        num_pts = params["means3D"].shape[0]
+        for k in ("means2D_gradient_accum", "denom", "max_2D_radius"):
+            variables[k] = torch.zeros(num_pts, device=dev)
+        if ts is not None:
+            variables["timestep"] = ts
+        to_remove = torch.cat((to_split, torch.zeros(split_idx.numel(), dtype=torch.bool, device=dev)))
+        params, variables = remove_points(to_remove, params, variables, optimizer)
+        thr = densify_dict["final_removal_opacity_threshold"] if iter == densify_dict["stop_after"] \
+            else densify_dict["removal_opacity_threshold"]
+        to_remove = (torch.sigmoid(params["logit_opacities"]) < thr).squeeze(-1)
+        if iter >= densify_dict["remove_big_after"]:
+            to_remove = to_remove | _too_big(params, variables, 0.1)
+        params, variables = remove_points(to_remove, params, variables, optimizer)
+    if iter > 0 and iter % densify_dict["reset_opacities_every"] == 0 and densify_dict.get("reset_opacities", False):
+        new = {"logit_opacities": inverse_sigmoid(torch.ones_like(params["logit_opacities"]) * 0.01)}
+        params = update_params_and_optimizer(new, params, optimizer)
+    return params, variables
+
+
+def build_rotation_from(q):
+    from .mapping import build_rotation
+    return build_rotation(q)

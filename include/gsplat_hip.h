@@ -155,9 +155,23 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D,
 
 /* Fused dense Adam step over one flat parameter tensor with torch.optim.Adam semantics
  * (non-amsgrad, no weight decay): splatam.py:118-124 uses betas (0.9,0.999), eps 1e-15.
- * `step` is the 1-based step count of this tensor AFTER the increment. */
+ * `step` is the 1-based step count of this tensor AFTER the increment.  Hyper-parameters are doubles (as the
+ * Python floats torch receives): 1-beta, the bias corrections and lr/(1-beta1^t) are formed in double and
+ * rounded to fp32 once, exactly like torch's scalar handling. */
 int gs_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                 float lr, float beta1, float beta2, float eps, int32_t step, gs_stream_t stream);
+                 double lr, double beta1, double beta2, double eps, int32_t step, gs_stream_t stream);
+
+/* Stream compaction for prune / densify surgery (replaces the boolean-mask gathers of
+ * src/mapper/splatam/utils/slam_external.py:143-164 remove_points and the torch.cat appends of
+ * :126-140): gs_compact_index turns a keep mask [n] (uint8) into the ascending list of kept row indices
+ * src_index[0..count) and writes count to *d_count; gs_gather_rows then copies dst[r][:] = src[src_index[r]][:]
+ * for a tensor of `row_floats` floats per row (one index build serves params, Adam moments and statistics;
+ * an index list with repeats implements clone / split). */
+uint64_t gs_compact_scratch_bytes(int64_t n);
+int gs_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32_t* d_count, void* scratch,
+                     gs_stream_t stream);
+int gs_gather_rows(int64_t n_out, int32_t row_floats, const uint32_t* src_index, const float* src, float* dst,
+                   gs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,272 @@
+"""CPU: the host-side mirrors in activesplat_amd reproduce the golden vectors captured from the
+reference's own Python (tests/golden/make_golden.py).  Device work (fused Adam,
+row compaction) goes through the C ABI of the host-emulated kernel build."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def T(a):
+    return torch.tensor(np.asarray(a))
+
+
+def test_setup_camera_matches_reference():
+    from activesplat_amd import setup_camera
+    d = load("camera.npz")
+    for i in range(3):
+        W, H = (int(v) for v in d[f"c{i}_WH"])
+        near, far = (float(v) for v in d[f"c{i}_nearfar"])
+        cam = setup_camera(W, H, d[f"c{i}_K"], d[f"c{i}_w2c"], near, far, scale_modifier=float(d[f"c{i}_mod"]), device="cpu")
+        assert (cam.image_width, cam.image_height) == (W, H) and cam.sh_degree == 0
+        assert not cam.prefiltered and not cam.debug
+        np.testing.assert_allclose(cam.viewmatrix.numpy(), d[f"c{i}_view"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(cam.projmatrix.numpy(), d[f"c{i}_proj"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose([cam.tanfovx, cam.tanfovy], d[f"c{i}_tanfov"], rtol=1e-6)
+        np.testing.assert_allclose(cam.campos.numpy(), d[f"c{i}_campos"], atol=1e-5)
+        np.testing.assert_array_equal(cam.bg.numpy(), d[f"c{i}_bg"])
+    assert abs(float(d["c0_tanfov"][0]) - 1.0) < 1e-7 and abs(float(d["c0_tanfov"][1]) - 0.75) < 1e-7
+
+
+def test_rotations_match_reference():
+    from activesplat_amd import mapping as M
+    d = load("rot.npz")
+    np.testing.assert_allclose(M.build_rotation(T(d["q1"])).numpy(), d["build_rotation"], atol=1e-6)
+    np.testing.assert_allclose(M.quat_mult(T(d["q1"]), T(d["q2"])).numpy(), d["quat_mult"], atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["aniso", "iso"])
+def test_transform_and_rendervars_match_reference(tag):
+    from activesplat_amd import mapping as M
+    d = load("transform.npz")
+    keys = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales", "cam_unnorm_rots", "cam_trans")
+    params = {k: T(d[f"{tag}_{k}"]) for k in keys}
+    tg = M.transform_to_frame(params, 3, gaussians_grad=True, camera_grad=False)
+    np.testing.assert_allclose(tg["means3D"].numpy(), d[f"{tag}_tg_means3D"], atol=2e-6)
+    np.testing.assert_allclose(tg["unnorm_rotations"].numpy(), d[f"{tag}_tg_rots"], atol=2e-6)
+    rv = M.transformed_params2rendervar(params, tg)
+    for k in ("means3D", "colors_precomp", "rotations", "opacities", "scales", "means2D"):
+        np.testing.assert_allclose(rv[k].detach().numpy(), d[f"{tag}_rv_{k}"], atol=2e-6, rtol=1e-6)
+    assert rv["means2D"].requires_grad and rv["scales"].shape[1] == 3
+    dv = M.transformed_params2depthplussilhouette(params, T(d[f"{tag}_w2c"]), tg)
+    np.testing.assert_allclose(dv["colors_precomp"].numpy(), d[f"{tag}_dv_colors"], atol=3e-6, rtol=1e-6)
+    rv2, dv2 = M.get_rendervars(params, d[f"{tag}_w2c"])
+    np.testing.assert_allclose(rv2["scales"].numpy(), d[f"{tag}_grv_scales"], rtol=1e-6)
+    np.testing.assert_allclose(rv2["rotations"].numpy(), d[f"{tag}_grv_rot"], atol=1e-6)
+    np.testing.assert_allclose(dv2["colors_precomp"].numpy(), d[f"{tag}_grv_dcolors"], atol=3e-6, rtol=1e-6)
+
+
+def test_loss_matches_reference(monkeypatch):
+    """get_loss given fixed rendered images: value, split, gradient w.r.t. the renders, seen / max_2D_radius."""
+    from activesplat_amd import mapping as M
+    d = load("loss.npz")
+    im_r, ds_r = T(d["im_r"]).requires_grad_(True), T(d["ds_r"]).requires_grad_(True)
+    np.testing.assert_allclose(M.l1_loss_v1(im_r, T(d["gt_im"])).item(), d["l1"], rtol=1e-6)
+    np.testing.assert_allclose(M.calc_ssim(im_r, T(d["gt_im"])).item(), d["ssim"], rtol=1e-5)
+    outs = [(im_r, T(d["radius"]), None, None), (ds_r, None, None, None)]
+
+    class Stub(torch.nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+
+        def forward(self, **kw):
+            return outs.pop(0)
+    monkeypatch.setattr(M, "Renderer", Stub)
+    N = d["radius"].shape[0]
+    g = torch.Generator().manual_seed(0)
+    params = dict(means3D=torch.randn(N, 3, generator=g), rgb_colors=torch.rand(N, 3, generator=g), unnorm_rotations=torch.randn(N, 4, generator=g),
+                  logit_opacities=torch.randn(N, 1, generator=g), log_scales=torch.randn(N, 3, generator=g), cam_unnorm_rots=torch.randn(1, 4, 3, generator=g),
+                  cam_trans=torch.randn(1, 3, 3, generator=g))
+    variables = dict(max_2D_radius=T(d["max2d_before"]).clone(), means2D_gradient_accum=torch.zeros(N), denom=torch.zeros(N))
+    curr = dict(cam=None, im=T(d["gt_im"]), depth=T(d["gt_depth"]), w2c=torch.eye(4))
+    loss, variables, wl = M.get_loss(params, curr, variables, 1, dict(im=0.5, depth=1.0), True, 0.99, True, False)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), d["loss"], rtol=2e-6)
+    np.testing.assert_allclose(wl["im"].item(), d["loss_im"], rtol=2e-6)
+    np.testing.assert_allclose(wl["depth"].item(), d["loss_depth"], rtol=2e-6)
+    np.testing.assert_allclose(im_r.grad.numpy(), d["d_im"], atol=1e-9, rtol=2e-4)
+    np.testing.assert_allclose(ds_r.grad.numpy(), d["d_ds"], atol=1e-9, rtol=1e-5)
+    np.testing.assert_array_equal(variables["seen"].numpy(), d["seen"])
+    np.testing.assert_allclose(variables["max_2D_radius"].numpy(), d["max2d_after"])
+
+
+KEYS = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales", "cam_unnorm_rots", "cam_trans")
+
+
+def _optimizer_from(d, prefix, emu_unused=None):
+    from activesplat_amd import optim as O
+    params = {k: torch.nn.Parameter(T(d[f"{prefix}p0_{k}"]).clone()) for k in KEYS}
+    lrs = dict(means3D=0.0001, rgb_colors=0.0025, unnorm_rotations=0.001, logit_opacities=0.05, log_scales=0.001,
+               cam_unnorm_rots=0.0, cam_trans=0.0)
+    return params, O.initialize_optimizer(params, lrs, tracking=False)
+
+
+def test_fused_adam_matches_reference_optimizer(emu):
+    """3 steps of the mapper's Adam groups (camera groups have no grad and must be skipped entirely)."""
+    d = load("adam.npz")
+    params, opt = _optimizer_from(d, "")
+    assert opt.defaults["eps"] == float(d["eps"]) == 1e-15 and tuple(opt.defaults["betas"]) == tuple(d["betas"])
+    assert float(d["weight_decay"]) == 0 and not bool(d["amsgrad"])
+    for s in range(1, 4):
+        for k, p in params.items():
+            p.grad = None if k.startswith("cam_") else T(d[f"g{s}_{k}"])
+        opt.step()
+        for k, p in params.items():
+            np.testing.assert_allclose(p.detach().numpy(), d[f"p{s}_{k}"], rtol=3e-6, atol=1e-7, err_msg=f"{k} step {s}")
+            if k.startswith("cam_"):
+                assert p not in opt.state or not opt.state[p]
+            else:
+                st = opt.state[p]
+                np.testing.assert_allclose(st["exp_avg"].numpy(), d[f"m{s}_{k}"], rtol=2e-6, atol=1e-9)
+                np.testing.assert_allclose(st["exp_avg_sq"].numpy(), d[f"v{s}_{k}"], rtol=2e-6, atol=1e-12)
+                assert float(st["step"]) == float(d[f"t{s}_{k}"]) == s
+        opt.zero_grad(set_to_none=True)
+        assert all(p.grad is None for p in params.values())
+
+
+def _seed_state(opt, params, d, prefix, tag):
+    for k, p in params.items():
+        if f"{prefix}{tag}_{k}".replace("_p0", "") and f"{prefix}m0_{k}" in d:
+            opt.state[p] = {"step": torch.tensor(1.0), "exp_avg": T(d[f"{prefix}m0_{k}"]).clone(), "exp_avg_sq": T(d[f"{prefix}v0_{k}"]).clone()}
+
+
+@pytest.mark.parametrize("tag", ["aniso", "iso"])
+def test_prune_cat_reset_match_reference(emu, tag):
+    from activesplat_amd import optim as O
+    d = load("prune.npz")
+    params, opt = _optimizer_from(d, f"{tag}_")
+    _seed_state(opt, params, d, f"{tag}_", "p0")
+    variables = {k: T(d[f"{tag}_var0_{k}"]).clone() for k in ("means2D_gradient_accum", "denom", "max_2D_radius", "timestep", "scene_radius")}
+    pdict = {k: d[f"{tag}_pdict_{k}"].item() for k in ("start_after", "remove_big_after", "stop_after", "prune_every", "removal_opacity_threshold",
+                                                     "final_removal_opacity_threshold", "reset_opacities", "reset_opacities_every")}
+    params, variables = O.prune_gaussians(params, variables, opt, 0, pdict)
+    assert params["means3D"].shape[0] == d[f"{tag}_p1_means3D"].shape[0] < d[f"{tag}_p0_means3D"].shape[0]
+    for k in KEYS:
+        np.testing.assert_array_equal(params[k].detach().numpy(), d[f"{tag}_p1_{k}"])
+        if not k.startswith("cam_"):
+            st = opt.state[params[k]]
+            np.testing.assert_array_equal(st["exp_avg"].numpy(), d[f"{tag}_m1_{k}"])
+            np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), d[f"{tag}_v1_{k}"])
+            assert float(st["step"]) == float(d[f"{tag}_t1_{k}"])
+    for k in ("means2D_gradient_accum", "denom", "max_2D_radius", "timestep"):
+        np.testing.assert_array_equal(variables[k].numpy(), d[f"{tag}_var1_{k}"])
+    newp = {k: T(d[f"{tag}_new_{k}"]) for k in KEYS[:5]}
+    params = O.cat_params_to_optimizer(newp, params, opt)
+    for k in KEYS[:5]:
+        np.testing.assert_array_equal(params[k].detach().numpy(), d[f"{tag}_p2_{k}"])
+        st = opt.state[params[k]]
+        np.testing.assert_array_equal(st["exp_avg"].numpy(), d[f"{tag}_m2_{k}"])
+        np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), d[f"{tag}_v2_{k}"])
+        assert float(st["step"]) == float(d[f"{tag}_t2_{k}"])
+    newo = {"logit_opacities": O.inverse_sigmoid(torch.ones_like(params["logit_opacities"]) * 0.01)}
+    params = O.update_params_and_optimizer(newo, params, opt)
+    np.testing.assert_allclose(params["logit_opacities"].detach().numpy(), d[f"{tag}_p3_logit_opacities"], rtol=1e-6)
+    st = opt.state[params["logit_opacities"]]
+    assert float(st["exp_avg"].abs().sum()) == 0 and float(st["step"]) == float(d[f"{tag}_t3_logit_opacities"])
+
+
+def test_densify_matches_reference_isotropic(emu):
+    """The one variant of the reference's densify that runs as shipped (isotropic, no timestep), with the
+    recorded normal samples injected."""
+    from activesplat_amd import optim as O
+    d = load("prune.npz")
+    params, opt = _optimizer_from(d, "den_")
+    _seed_state(opt, params, d, "den_", "p0")
+    N = params["means3D"].shape[0]
+    m2d = torch.zeros(N, 2, requires_grad=True)
+    m2d.grad = T(d["den_m2d_grad"])
+    variables = dict(means2D=m2d, seen=T(d["den_seen"]), means2D_gradient_accum=T(d["den_accum0"]).clone(), denom=T(d["den_denom0"]).clone(),
+                     max_2D_radius=torch.zeros(N), scene_radius=T(d["den_scene_radius"]))
+    ddict = {k: d[f"den_ddict_{k}"].item() for k in ("start_after", "remove_big_after", "stop_after", "densify_every", "grad_thresh", "num_to_split_into",
+                                                    "removal_opacity_threshold", "final_removal_opacity_threshold", "reset_opacities", "reset_opacities_every")}
+    params, variables = O.densify(params, variables, opt, 10, ddict, samples=T(d["den_samples"]))
+    assert params["means3D"].shape[0] == d["den_p1_means3D"].shape[0] != N
+    for k in KEYS:
+        np.testing.assert_allclose(params[k].detach().numpy(), d[f"den_p1_{k}"], rtol=1e-6, atol=1e-7, err_msg=k)
+        if not k.startswith("cam_"):
+            st = opt.state[params[k]]
+            np.testing.assert_array_equal(st["exp_avg"].numpy(), d[f"den_m1_{k}"])
+            np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), d[f"den_v1_{k}"])
+            assert float(st["step"]) == float(d[f"den_t1_{k}"])
+    for k, g in (("means2D_gradient_accum", "den_accum1"), ("denom", "den_denom1"), ("max_2D_radius", "den_max2d1")):
+        np.testing.assert_array_equal(variables[k].numpy(), d[g])
+
+
+def test_densify_anisotropic_with_timestep_runs(emu):
+    """The cases the reference cannot execute: per-axis split noise, timestep inherited."""
+    from activesplat_amd import optim as O
+    g = torch.Generator().manual_seed(0)
+    N = 400
+    params = {k: torch.nn.Parameter(v) for k, v in dict(
+        means3D=torch.randn(N, 3, generator=g), rgb_colors=torch.rand(N, 3, generator=g), unnorm_rotations=torch.randn(N, 4, generator=g),
+        logit_opacities=torch.randn(N, 1, generator=g) * 2, log_scales=torch.randn(N, 3, generator=g) * 0.7 - 4.0,
+        cam_unnorm_rots=torch.randn(1, 4, 2, generator=g), cam_trans=torch.randn(1, 3, 2, generator=g)).items()}
+    lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
+    opt = O.initialize_optimizer(params, lrs)
+    for k, p in params.items():
+        p.grad = None if k.startswith("cam_") else torch.randn(p.shape, generator=g)
+    opt.step()
+    m2d = torch.zeros(N, 3, requires_grad=True); m2d.grad = torch.randn(N, 3, generator=g) * 3e-4
+    variables = dict(means2D=m2d, seen=torch.rand(N, generator=g) > 0.3, means2D_gradient_accum=torch.rand(N, generator=g) * 4e-4,
+                     denom=(torch.rand(N, generator=g) * 3).floor(), max_2D_radius=torch.zeros(N), timestep=torch.arange(N).float(),
+                     scene_radius=torch.tensor(2.0))
+    ddict = dict(start_after=0, remove_big_after=0, stop_after=100, densify_every=10, grad_thresh=0.0002, num_to_split_into=2,
+                 removal_opacity_threshold=0.005, final_removal_opacity_threshold=0.005, reset_opacities=False, reset_opacities_every=3000)
+    params, variables = O.densify(params, variables, opt, 10, ddict)
+    n = params["means3D"].shape[0]
+    assert n != N and all(params[k].shape[0] == n for k in KEYS[:5])
+    assert all(variables[k].shape[0] == n for k in ("means2D_gradient_accum", "denom", "max_2D_radius", "timestep"))
+    assert all(opt.state[params[k]]["exp_avg"].shape == params[k].shape for k in KEYS[:5])
+    assert variables["timestep"].max() <= N - 1 and torch.isfinite(params["means3D"]).all()
+
+
+def test_pointcloud_and_growth_match_reference(monkeypatch):
+    from activesplat_amd import mapping as M
+    d = load("pointcloud.npz")
+    color, depth, K, w2c, mask = T(d["color"]), T(d["depth"]), T(d["K"]), T(d["w2c"]), T(d["mask"])
+    pc, msd = M.get_pointcloud(color, depth, K, w2c, mask=mask, compute_mean_sq_dist=True)
+    np.testing.assert_allclose(pc.numpy(), d["pc"], atol=2e-6, rtol=1e-6)
+    np.testing.assert_allclose(msd.numpy(), d["msd"], rtol=1e-6)
+    for tag in ("anisotropic", "isotropic"):
+        p, v = M.initialize_params(pc, 3, msd, tag)
+        for k in KEYS:
+            np.testing.assert_allclose(p[k].detach().numpy(), d[f"init_{tag}_{k}"], atol=2e-6, rtol=1e-6)
+            assert isinstance(p[k], torch.nn.Parameter)
+        for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep"):
+            np.testing.assert_array_equal(v[k].numpy(), d[f"initvar_{tag}_{k}"])
+    # add_new_gaussians with the recorded silhouette render
+    p = {k: torch.nn.Parameter(T(d[f"add_p0_{k}"]).clone()) for k in KEYS}
+    n0 = p["means3D"].shape[0]
+    v = {k: torch.zeros(n0) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+    calls = []
+
+    class Stub(torch.nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+
+        def forward(self, **kw):
+            calls.append(kw)
+            return T(d["add_depth_sil"]), None, None, None
+    monkeypatch.setattr(M, "Renderer", Stub)
+    curr = dict(cam=None, im=color, depth=depth, intrinsics=K, w2c=torch.eye(4))
+    p2, v2 = M.add_new_gaussians(p, v, curr, 0.5, 1, "anisotropic")
+    np.testing.assert_allclose(calls[0]["colors_precomp"].numpy(), d["add_call_colors"], atol=3e-6, rtol=1e-6)
+    for k in KEYS:
+        np.testing.assert_allclose(p2[k].detach().numpy(), d[f"add_p1_{k}"], atol=3e-6, rtol=1e-6, err_msg=k)
+    for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep"):
+        np.testing.assert_array_equal(v2[k].numpy(), d[f"add_var1_{k}"])
+
+
+def test_keyframe_selection_matches_reference():
+    from activesplat_amd.keyframes import keyframe_selection_overlap
+    d = load("keyframe.npz")
+    kfs = [{"id": i, "est_w2c": T(w)} for i, w in enumerate(d["kf_w2c"])]
+    sel = keyframe_selection_overlap(T(d["gt_depth"]), T(d["w2c"]), T(d["K"]), kfs, 4, pixels=200, sampled=T(d["sampled"]), shuffle=False)
+    assert [int(s) for s in sel] == [int(s) for s in d["selected"]]
