@@ -1,0 +1,169 @@
+"""Mapping-loop harness: this build's counterpart of the reference's `SplaTAM.__mapping`
+(src/mapper/splatam/__init__.py:254-542), which cannot be imported or shipped (it pulls in cv2, open3d, rospy,
+habitat).  It reproduces the CALL PATTERN and SCHEDULE of the hot loop, nothing of the ROS/GUI shell:
+
+  frame 0                       : back-project the RGB-D frame -> initialize_params; scene_radius = max depth / 3
+                                  (__init__.py:382-386, config/splatam/online_habitat_sim.py:6)
+  every frame                   : write the ground-truth pose into params['cam_*'][..., id] (tracking is skipped,
+                                  __init__.py:400-405)
+  frames with id == 0 or (id+1) % map_every == 0
+                                : add_new_gaussians (id > 0), keyframe_selection_overlap over keyframe_list[:-1]
+                                  (window = mapping_window_size - 2, + last keyframe + current frame), FRESH Adam
+                                  (__init__.py:408-440)
+  iterations                    : iter_per_frame = mapping_iters // map_every, or mapping_iters when that is 0 and
+                                  id % map_every == 0 (__init__.py:395-397); each: np.random.randint keyframe pick,
+                                  get_loss (two raster passes), backward, optional prune / densify, Adam step,
+                                  zero_grad(set_to_none) (__init__.py:447-480)
+  keyframes                     : appended when id == 0, (id+1) % keyframe_every == 0 or id == step_num - 2
+                                  (__init__.py:514-524)
+
+Inputs are already-resized frames (`color [3,H,W]` in 0..1, `depth [1,H,W]` metres, pose relative to frame 0 as
+quaternion (w,x,y,z) + translation of the w2c) -- the cv2 resize / PNG / manifest work of the reference is I/O
+outside the hot path.  Defaults are the shipped configuration (config/splatam/online_habitat_sim.py,
+config/datasets/gibson.json).
+"""
+from __future__ import annotations
+
+import copy
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import mapping as M
+from . import optim as O
+from .camera import setup_camera
+from .keyframes import keyframe_selection_overlap
+
+DEFAULT_CONFIG = dict(
+    seed=0, gaussian_distribution="anisotropic", scene_radius_depth_ratio=3, mean_sq_dist_method="projective",
+    map_every=5, keyframe_every=5, mapping_window_size=12, mapping_iters=2, step_num=1000,
+    mapping=dict(
+        loss_weights=dict(im=0.5, depth=1.0), sil_thres=0.98, use_sil_for_loss=False, use_l1=True,
+        ignore_outlier_depth_loss=False, add_new_gaussians=True, prune_gaussians=False,
+        use_gaussian_splatting_densification=False,
+        lrs=dict(means3D=0.0001, rgb_colors=0.0025, unnorm_rotations=0.001, logit_opacities=0.05, log_scales=0.001,
+                 cam_unnorm_rots=0.0, cam_trans=0.0),
+        pruning_dict=dict(start_after=0, remove_big_after=0, stop_after=20, prune_every=20, removal_opacity_threshold=0.005,
+                          final_removal_opacity_threshold=0.005, reset_opacities=False, reset_opacities_every=500),
+        densify_dict=dict(start_after=500, remove_big_after=3000, stop_after=5000, densify_every=100, grad_thresh=0.0002,
+                          num_to_split_into=2, removal_opacity_threshold=0.005, final_removal_opacity_threshold=0.005,
+                          reset_opacities=False, reset_opacities_every=3000)),
+    viz=dict(viz_near=0.01, viz_far=100.0),
+)
+
+
+class SplatMapper:
+    def __init__(self, intrinsics, width, height, config=None, device=None):
+        self.cfg = copy.deepcopy(DEFAULT_CONFIG)
+        if config:
+            for k, v in config.items():
+                if isinstance(v, dict) and isinstance(self.cfg.get(k), dict):
+                    self.cfg[k].update(v)
+                else:
+                    self.cfg[k] = v
+        self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.W, self.H = int(width), int(height)
+        self.intrinsics = torch.as_tensor(np.asarray(intrinsics), dtype=torch.float32, device=self.device)
+        self.first_frame_w2c = torch.eye(4, device=self.device)
+        self.cam = setup_camera(self.W, self.H, np.asarray(intrinsics), np.eye(4), device=self.device)
+        self.params = self.variables = self.optimizer = None
+        self.keyframe_list, self.selected_keyframes = [], []
+        self.rng = np.random.RandomState(self.cfg["seed"])
+        self.stats = dict(iters=0, iter_time=0.0, frames=0, frame_time=0.0)
+        self.last_losses = None
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _w2c(self, frame_id):
+        rot = F.normalize(self.params["cam_unnorm_rots"][..., frame_id].detach())
+        w2c = torch.eye(4, device=self.device)
+        w2c[:3, :3] = M.build_rotation(rot)
+        w2c[:3, 3] = self.params["cam_trans"][..., frame_id].detach()
+        return w2c
+
+    def _data(self, color, depth, frame_id):
+        return {"cam": self.cam, "im": color, "depth": depth, "id": frame_id, "intrinsics": self.intrinsics,
+                "w2c": self.first_frame_w2c}
+
+    # -- one frame of the mapper (reference: SplaTAM.__mapping) ----------------------------------------
+    def run(self, frame):
+        cfg, mc = self.cfg, self.cfg["mapping"]
+        fid = int(frame["id"])
+        color = frame["color"].to(self.device).float()
+        depth = frame["depth"].to(self.device).float()
+        quat = torch.as_tensor(frame["quat"], dtype=torch.float32, device=self.device)
+        pos = torch.as_tensor(frame["position"], dtype=torch.float32, device=self.device)
+        if fid == 0:
+            init_w2c = torch.eye(4, device=self.device)
+            init_w2c[:3, :3] = M.build_rotation(quat.view(1, 4))
+            init_w2c[:3, 3] = pos
+            mask = (depth > 0).reshape(-1)
+            cld, msd = M.get_pointcloud(color, depth, self.intrinsics, init_w2c, mask=mask, compute_mean_sq_dist=True)
+            self.params, self.variables = M.initialize_params(cld, cfg["step_num"], msd, cfg["gaussian_distribution"])
+            self.variables["scene_radius"] = torch.max(depth) / cfg["scene_radius_depth_ratio"]
+        map_every = cfg["map_every"]
+        iter_per_frame = int(cfg["mapping_iters"] // map_every)
+        if iter_per_frame == 0 and fid % map_every == 0:
+            iter_per_frame = cfg["mapping_iters"]
+        with torch.no_grad():                                    # tracking skip: ground-truth pose
+            self.params["cam_unnorm_rots"][..., fid] = quat
+            self.params["cam_trans"][..., fid] = pos
+        if fid == 0 or (fid + 1) % map_every == 0:
+            if mc["add_new_gaussians"] and fid > 0:
+                self.params, self.variables = M.add_new_gaussians(self.params, self.variables, self._data(color, depth, fid),
+                                                                  mc["sil_thres"], fid, cfg["gaussian_distribution"])
+            with torch.no_grad():
+                sel = keyframe_selection_overlap(depth, self._w2c(fid), self.intrinsics, self.keyframe_list[:-1],
+                                                 cfg["mapping_window_size"] - 2)
+                self.selected_keyframes = [int(s) for s in sel]
+                if len(self.keyframe_list) > 0:
+                    self.selected_keyframes.append(len(self.keyframe_list) - 1)
+                self.selected_keyframes.append(-1)
+            self.optimizer = O.initialize_optimizer(self.params, mc["lrs"], tracking=False)
+        t_frame = time.perf_counter()
+        for it in range(iter_per_frame):
+            t0 = time.perf_counter()
+            pick = self.selected_keyframes[self.rng.randint(0, len(self.selected_keyframes))]
+            if pick == -1:
+                it_id, it_color, it_depth = fid, color, depth
+            else:
+                kf = self.keyframe_list[pick]
+                it_id, it_color, it_depth = kf["id"], kf["color"], kf["depth"]
+            loss, self.variables, losses = M.get_loss(self.params, self._data(it_color, it_depth, it_id), self.variables, it_id,
+                                                      mc["loss_weights"], mc["use_sil_for_loss"], mc["sil_thres"], mc["use_l1"],
+                                                      mc["ignore_outlier_depth_loss"])
+            loss.backward()
+            with torch.no_grad():
+                if mc["prune_gaussians"]:
+                    self.params, self.variables = O.prune_gaussians(self.params, self.variables, self.optimizer, it, mc["pruning_dict"])
+                if mc["use_gaussian_splatting_densification"]:
+                    self.params, self.variables = O.densify(self.params, self.variables, self.optimizer, it, mc["densify_dict"])
+                self.optimizer.step()
+                self.optimizer.zero_grad(set_to_none=True)
+            self.last_losses = {k: float(v.detach()) for k, v in losses.items()}
+            self.stats["iters"] += 1
+            self.stats["iter_time"] += time.perf_counter() - t0
+        if iter_per_frame > 0:
+            self.stats["frames"] += 1
+            self.stats["frame_time"] += time.perf_counter() - t_frame
+        if fid == 0 or (fid + 1) % cfg["keyframe_every"] == 0 or fid == cfg["step_num"] - 2:
+            with torch.no_grad():
+                self.keyframe_list.append({"id": fid, "est_w2c": self._w2c(fid), "color": color, "depth": depth})
+        return self.params
+
+    # -- no-grad consumers (reference: render_rgbd / get_*_invisibility, __init__.py:604-838) ----------------
+    @torch.no_grad()
+    def render_rgbd(self, w2c, scale_modifier=1.0, width=None, height=None, intrinsics=None):
+        k = self.intrinsics.cpu().numpy() if intrinsics is None else np.asarray(intrinsics)
+        cfgv = dict(self.cfg["viz"], viz_w=width or self.W, viz_h=height or self.H)
+        rv, dv = M.get_rendervars(self.params, w2c)
+        im, depth, opacity, _ = M.render(w2c, k, rv, dv, cfgv, scale_modifier=scale_modifier, device=self.device,
+                                         with_silhouette=False)
+        return im, depth, opacity
+
+    @torch.no_grad()
+    def invisibility(self, w2c, width=120, height=150, intrinsics=None):
+        """1 - opacity, the quantity the planner scores view points with (__init__.py:739,795)."""
+        _, _, opacity = self.render_rgbd(w2c, width=width, height=height, intrinsics=intrinsics)
+        return 1.0 - opacity

@@ -84,3 +84,29 @@ def keyframe_w2c(i, K):
     c, s = math.cos(a), math.sin(a)
     c2w = np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], dtype=np.float64)
     return np.linalg.inv(c2w)
+
+
+def quat_from_yaw(a):
+    """(w, x, y, z) of a rotation by `a` radians about +y."""
+    return np.array([math.cos(a / 2), 0.0, math.sin(a / 2), 0.0], dtype=np.float32)
+
+
+def orbit_sequence(gt_params, num_frames, W, H, device, yaw_step_deg=10.0, K=None):
+    """Synthetic RGB-D sequence for the mapper harness (substitute for Habitat/Gibson):
+    an in-place spin (10 degree turns, like config/env/activesplat_pointnav.yaml) inside a fixed ground-truth
+    Gaussian scene, rendered with this package's rasteriser.  Yields the dicts SplatMapper.run() takes; the
+    pose is the w2c of the frame relative to frame 0 as quaternion + translation."""
+    from .camera import setup_camera
+    from .rasterizer import GaussianRasterizer
+    K = intrinsics(W, H) if K is None else K
+    rv = {k: v.to(device) for k, v in activate(gt_params).items()}
+    for i in range(num_frames):
+        a = math.radians(yaw_step_deg) * i
+        c, s = math.cos(a), math.sin(a)
+        w2c = np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], dtype=np.float64)
+        cam = setup_camera(W, H, K, w2c, device=device)
+        with torch.no_grad():
+            m2d = torch.zeros_like(rv["means3D"])
+            color, _, depth, opacity = GaussianRasterizer(raster_settings=cam)(means2D=m2d, **rv)
+        d = torch.where(opacity > 0.5, depth / opacity.clamp_min(1e-6), torch.zeros_like(depth))
+        yield dict(id=i, color=color.clamp(0, 1), depth=d, quat=quat_from_yaw(a), position=np.zeros(3, np.float32), w2c=w2c)

@@ -1,0 +1,112 @@
+"""GPU (-m gpu): fused Adam, row compaction / surgery and the mapper harness on the real HIP library."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(n, dev, seed=0, iso=False):
+    g = torch.Generator().manual_seed(seed)
+    d = dict(means3D=torch.randn(n, 3, generator=g), rgb_colors=torch.rand(n, 3, generator=g), unnorm_rotations=torch.randn(n, 4, generator=g),
+             logit_opacities=torch.randn(n, 1, generator=g) * 3, log_scales=torch.randn(n, 1 if iso else 3, generator=g) - 2.0,
+             cam_unnorm_rots=torch.randn(1, 4, 2, generator=g), cam_trans=torch.randn(1, 3, 2, generator=g))
+    return {k: torch.nn.Parameter(v.to(dev)) for k, v in d.items()}
+
+
+LRS = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
+
+
+def test_gaussian_adam_equals_torch_adam_on_gpu(hip):
+    from activesplat_amd import optim as O
+    n = 300_007
+    pa, pb = _params(n, hip), _params(n, hip)
+    oa = O.initialize_optimizer(pa, LRS)
+    ob = torch.optim.Adam([{"params": [v], "name": k, "lr": LRS[k]} for k, v in pb.items()], lr=0.0, eps=1e-15)
+    g = torch.Generator(device=hip).manual_seed(1)
+    for step in range(4):
+        for k in pa:
+            if k.startswith("cam_"):
+                pa[k].grad = pb[k].grad = None
+            else:
+                gr = torch.randn(pa[k].shape, generator=g, device=hip) * 10.0 ** (step - 2)
+                pa[k].grad, pb[k].grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+        for k in pa:
+            np.testing.assert_allclose(pa[k].detach().cpu().numpy(), pb[k].detach().cpu().numpy(), rtol=3e-6, atol=1e-7, err_msg=k)
+    for k in ("means3D", "log_scales"):
+        np.testing.assert_allclose(oa.state[pa[k]]["exp_avg_sq"].cpu().numpy(), ob.state[pb[k]]["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("iso", [False, True])
+def test_remove_points_equals_boolean_indexing(hip, iso):
+    from activesplat_amd import optim as O
+    n = 123_457
+    params = _params(n, hip, seed=2, iso=iso)
+    opt = O.initialize_optimizer(params, LRS)
+    for k, p in params.items():
+        p.grad = None if k.startswith("cam_") else torch.randn_like(p)
+    opt.step()
+    variables = dict(means2D_gradient_accum=torch.rand(n, device=hip), denom=torch.rand(n, device=hip), max_2D_radius=torch.rand(n, device=hip),
+                     timestep=torch.arange(n, device=hip).float())
+    to_remove = torch.rand(n, device=hip) < 0.37
+    keep = ~to_remove
+    want = {k: v.detach()[keep].clone() for k, v in params.items() if not k.startswith("cam_")}
+    want_m = {k: opt.state[v]["exp_avg"][keep].clone() for k, v in params.items() if not k.startswith("cam_")}
+    want_v = {k: v[keep].clone() for k, v in variables.items()}
+    params, variables = O.remove_points(to_remove, params, variables, opt)
+    for k in want:
+        assert torch.equal(params[k].detach(), want[k]) and torch.equal(opt.state[params[k]]["exp_avg"], want_m[k])
+        assert isinstance(params[k], torch.nn.Parameter) and params[k].requires_grad
+    for k in want_v:
+        assert torch.equal(variables[k], want_v[k])
+    # edge cases: remove nothing / everything
+    none = torch.zeros(params["means3D"].shape[0], dtype=torch.bool, device=hip)
+    n1 = params["means3D"].shape[0]
+    params, variables = O.remove_points(none, params, variables, opt)
+    assert params["means3D"].shape[0] == n1
+    params, variables = O.remove_points(~none, params, variables, opt)
+    assert params["means3D"].shape[0] == 0 and variables["denom"].shape[0] == 0
+
+
+def test_densify_and_prune_on_gpu(hip):
+    from activesplat_amd import optim as O
+    n = 50_000
+    params = _params(n, hip, seed=3)
+    with torch.no_grad():
+        params["log_scales"] -= 2.0
+    opt = O.initialize_optimizer(params, LRS)
+    for k, p in params.items():
+        p.grad = None if k.startswith("cam_") else torch.randn_like(p)
+    opt.step()
+    m2d = torch.zeros(n, 3, device=hip, requires_grad=True)
+    m2d.grad = torch.randn(n, 3, device=hip) * 3e-4
+    variables = dict(means2D=m2d, seen=torch.rand(n, device=hip) > 0.3, means2D_gradient_accum=torch.rand(n, device=hip) * 4e-4,
+                     denom=(torch.rand(n, device=hip) * 3).floor(), max_2D_radius=torch.zeros(n, device=hip),
+                     timestep=torch.arange(n, device=hip).float(), scene_radius=torch.tensor(2.0, device=hip))
+    ddict = dict(start_after=0, remove_big_after=0, stop_after=100, densify_every=10, grad_thresh=0.0002, num_to_split_into=2,
+                 removal_opacity_threshold=0.005, final_removal_opacity_threshold=0.005, reset_opacities=False, reset_opacities_every=3000)
+    params, variables = O.densify(params, variables, opt, 10, ddict)
+    m = params["means3D"].shape[0]
+    assert m != n and all(params[k].shape[0] == m for k in ("rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"))
+    assert all(variables[k].shape[0] == m for k in ("means2D_gradient_accum", "denom", "max_2D_radius", "timestep"))
+    assert (torch.sigmoid(params["logit_opacities"]) >= 0.005).all() and torch.isfinite(params["means3D"]).all()
+    pdict = dict(start_after=0, remove_big_after=0, stop_after=20, prune_every=20, removal_opacity_threshold=0.3,
+                 final_removal_opacity_threshold=0.3, reset_opacities=True, reset_opacities_every=20)
+    params, variables = O.prune_gaussians(params, variables, opt, 20, pdict)
+    assert params["means3D"].shape[0] < m
+    np.testing.assert_allclose(torch.sigmoid(params["logit_opacities"]).cpu().numpy(), 0.01, rtol=1e-5)    # reset after the prune
+
+
+def test_mapper_harness_gpu(hip):
+    from tests import util
+    from tests.test_mapper import run_harness
+    mp, seq, log = run_harness(hip, n_gt=150_000, W=256, H=256, frames=11)
+    assert [e["iters"] for e in log] == [2, 0, 0, 0, 0, 2, 0, 0, 0, 0, 2]
+    assert log[4]["grew"] > 0 and log[9]["grew"] > 0 and len(mp.keyframe_list) == 3
+    for fr in (seq[0], seq[9]):
+        im, depth, opacity = mp.render_rgbd(fr["w2c"])
+        seen = (fr["depth"] > 0)[0]
+        assert util.psnr(im[:, seen].cpu().numpy(), fr["color"][:, seen].cpu().numpy()) > 18.0
+        err = ((depth / opacity.clamp_min(1e-6))[0][seen] - fr["depth"][0][seen]).abs().median()
+        assert float(err) < 0.1
