@@ -95,7 +95,7 @@ def test_densify_and_prune_on_gpu(hip):
                  final_removal_opacity_threshold=0.3, reset_opacities=True, reset_opacities_every=20)
     params, variables = O.prune_gaussians(params, variables, opt, 20, pdict)
     assert params["means3D"].shape[0] < m
-    np.testing.assert_allclose(torch.sigmoid(params["logit_opacities"]).cpu().numpy(), 0.01, rtol=1e-5)    # reset after the prune
+    np.testing.assert_allclose(torch.sigmoid(params["logit_opacities"]).detach().cpu().numpy(), 0.01, rtol=1e-5)    # reset after the prune
 
 
 def test_mapper_harness_gpu(hip):
