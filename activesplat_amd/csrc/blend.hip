@@ -153,56 +153,70 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Backward: back-to-front replay, same independent-quadrant walk as the forward.  Per (wavefront, record)
-// the nine per-pixel partials are reduced across the 64 lanes and accumulated with one hardware fp32
-// atomic instruction (9 lanes, one component each) into the 48-byte per-Gaussian gradient record
-// (device-scope atomics: correct across the 8 XCDs' private L2s).
-//
-// Wave-64 reduction of 9 values in ~32 VALU instead of 9 x 6 shuffle+add: a TRANSPOSED butterfly.
-//   level 32: v_permlane32_swap pairs two values -> one register whose halves hold one value each
-//   level 16: v_permlane16_swap pairs two such registers -> one register whose 4 rows hold 4 values
-//   in-row  : 4 DPP adds (quad_perm xor1, xor2, row_half_mirror, row_mirror) finish 4 values at once
+// Backward: back-to-front replay.  Same independent-quadrant walk as the forward, but each wavefront
+// runs FOUR record streams at once, one per 16-lane DPP row:
+//   row r of the wave = the 4x4 pixel sub-block r of the quadrant (lane -> pixel mapping below);
+//   while staging 64 records every lane tests its record's alpha-visible box against the four
+//   sub-blocks -> four 64-bit ballots (scalar registers); each row walks ITS OWN hit mask (scalar
+//   find-first-set per row, lane picks its row's record index with v_cndmask), so one pass of the loop
+//   body evaluates up to four different records on 16 pixels each.  With sigma ~ 1 px splats a record
+//   touches 2.1 of the 4 sub-blocks of a quadrant on average: 0.65x the loop trips of one record per
+//   wave (measured on BASELINE configs[1]).
+//   The nine per-pixel partials are then reduced WITHIN each row only, by a transposed DPP butterfly
+//   (row_reduce9: 27 VALU, no cross-row traffic, the totals land one component per lane) and one
+//   hardware fp32 atomic instruction carries 4 rows x 9 components into the per-Gaussian gradient
+//   records.  The records are 64-byte aligned (kGradStride = 16 floats): device-scope atomics are
+//   read-modify-writes of whole lines at the memory side on this multi-XCD part, and a 48-byte stride
+//   that lets half the records straddle two lines cost +100 us per launch.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dpp_add(float x, const int ctrl_tag)
+// Transposed in-row butterfly: the 16-lane row sums of NINE values in 27 VALU (instead of 9 x 4 DPP adds
+// plus an 8-deep select chain).  At every level two registers are merged into one: each lane keeps the
+// register its half is responsible for and receives, through one DPP add, the partner lane's copy of
+// the same register.  Partner maps: lane^8 (row_ror:8), mirror within 8 (row_half_mirror), lane^2 and
+// lane^1 (quad_perm).  Afterwards lane l of the row holds the row total of component row_comp(l).
+#define GS_DPP_ADD(keep, send, ctrl) ((keep) + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), ctrl, 0xf, 0xf, true)))
+__device__ __forceinline__ float row_reduce9(const float (&v)[9], bool b8, bool b4, bool b2, bool b1)
 {
-    // ctrl must be a literal: dispatch on the four controls used
-    if (ctrl_tag == 0) return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xf, 0xf, true));   // quad_perm:[1,0,3,2]
-    if (ctrl_tag == 1) return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x4E, 0xf, 0xf, true));   // quad_perm:[2,3,0,1]
-    if (ctrl_tag == 2) return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x141, 0xf, 0xf, true));  // row_half_mirror
-    return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x140, 0xf, 0xf, true));                     // row_mirror
+    // level A: partner lane^8
+    const float a0 = GS_DPP_ADD(b8 ? v[1] : v[0], b8 ? v[0] : v[1], 0x128);     // row_ror:8
+    const float a1 = GS_DPP_ADD(b8 ? v[3] : v[2], b8 ? v[2] : v[3], 0x128);
+    const float a2 = GS_DPP_ADD(b8 ? v[5] : v[4], b8 ? v[4] : v[5], 0x128);
+    const float a3 = GS_DPP_ADD(b8 ? v[7] : v[6], b8 ? v[6] : v[7], 0x128);
+    const float a4 = GS_DPP_ADD(v[8], v[8], 0x128);
+    // level B: partner = mirror within the 8-lane half
+    const float c0 = GS_DPP_ADD(b4 ? a1 : a0, b4 ? a0 : a1, 0x141);             // row_half_mirror
+    const float c1 = GS_DPP_ADD(b4 ? a3 : a2, b4 ? a2 : a3, 0x141);
+    const float c2 = GS_DPP_ADD(a4, a4, 0x141);
+    // level C: partner lane^2
+    const float e0 = GS_DPP_ADD(b2 ? c1 : c0, b2 ? c0 : c1, 0x4E);              // quad_perm:[2,3,0,1]
+    const float e1 = GS_DPP_ADD(c2, c2, 0x4E);
+    // level D: partner lane^1
+    return GS_DPP_ADD(b1 ? e1 : e0, b1 ? e0 : e1, 0xB1);                         // quad_perm:[1,0,3,2]
 }
-__device__ __forceinline__ float row_sum16(float x)
+// component carried by lane l16 of a row after row_reduce9 (odd lanes all hold component 8: use lane 1)
+__device__ __forceinline__ int row_comp(int l16)
 {
-    x = dpp_add(x, 0); x = dpp_add(x, 1); x = dpp_add(x, 2); x = dpp_add(x, 3);
-    return x;     // every lane of a 16-lane row holds the row total
-}
-__device__ __forceinline__ float fold32(float a, float b)     // lanes 0-31: a[l]+a[l+32], lanes 32-63: b[l-32]+b[l]
-{
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float fold16(float a, float b)     // rows (0,2): a.r+a.(r+1), rows (1,3): b.(r-1)+b.r
-{
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// In: 9 per-lane partials.  Out: the wave total of component c in the lane `red9_lane(c)`;
-// returns this lane's value and writes the component it carries (or -1) to comp.
-__device__ __forceinline__ float wave_reduce9(const float (&v)[9], int lane, int& comp)
-{
-    const float q0123 = row_sum16(fold16(fold32(v[0], v[1]), fold32(v[2], v[3])));   // rows: V0, V2, V1, V3
-    const float q4567 = row_sum16(fold16(fold32(v[4], v[5]), fold32(v[6], v[7])));   // rows: V4, V6, V5, V7
-    const float h8 = fold32(v[8], v[8]);
-    const float q8 = row_sum16(fold16(h8, h8));                                       // every lane: V8
-    const int row = lane >> 4, c = lane & 15;
-    const int rowcomp = ((row & 1) << 1) | (row >> 1);                                // 0,2,1,3
-    comp = c == 0 ? rowcomp : (c == 1 ? 4 + rowcomp : (lane == 2 ? 8 : -1));
-    return c == 0 ? q0123 : (c == 1 ? q4567 : q8);
+    if (l16 & 1) return l16 == 1 ? 8 : -1;
+    return ((l16 & 2) ? 4 : 0) + ((l16 & 4) ? 2 : 0) + ((l16 & 8) ? 1 : 0);
 }
 
+// does the record's alpha-visible box overlap the 4x4 sub-block at pixel origin (x0,y0)?
+__device__ __forceinline__ bool subblock_hit(const float4& q0, const float4& q2, float x0, float y0)
+{
+    const float ex = q2.z, ey = q2.w;
+    return ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) && (q0.y - ey <= y0 + 3.0f);
+}
 
-// Per-Gaussian 2-D gradient record accumulated by the backward blend (raw moments; the conic algebra is
-// finished per Gaussian in preprocess_bwd.hip):  with Z = G dL/dG, d = mean - pixel
+// pop the highest set bit of a wave-uniform mask; returns its index (0 when the mask is empty)
+__device__ __forceinline__ int pop_high(unsigned long long& m)
+{
+    const int j = m ? 63 - __clzll(m) : 0;
+    m &= ~(1ull << j);
+    return j;
+}
+
+// Per-Gaussian 2-D gradient record accumulated here (raw moments; the conic algebra is finished per
+// Gaussian in preprocess_bwd.hip):  with Z = G dL/dG, d = mean - pixel
 //   0: sum Z dx   1: sum Z dy   2: sum Z dx dx   3: sum Z dx dy   4: sum Z dy dy   5: sum G dL/dalpha   6..8: sum w dL/dC
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -213,17 +227,22 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
     if (!tile_ctx(cam, wave, lane, c)) return;
+    // lane -> pixel: row (lane>>4) = 4x4 sub-block, (lane&15) = pixel inside it
+    const int row = lane >> 4, l16 = lane & 15;
+    const int px = (int)c.qx0 + (row & 1) * 4 + (l16 & 3), py = (int)c.qy0 + (row >> 1) * 4 + (l16 >> 2);
+    const bool inside = px < cam.W && py < cam.H;
+    const float pxf = (float)px, pyf = (float)py;
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
     const uint2 range = ranges[c.tile];
     const uint32_t* list = point_list + range.x;
-    const size_t pix = (size_t)c.py * cam.W + c.px, HW = (size_t)cam.H * cam.W;
+    const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
 
-    const float Tf = c.inside ? final_T[pix] : 0.f;
-    const uint32_t last = c.inside ? n_contrib[pix] : 0u;
-    const float d0 = c.inside ? dL_dcolor[pix] : 0.f, d1 = c.inside ? dL_dcolor[HW + pix] : 0.f,
-                d2 = c.inside ? dL_dcolor[2 * HW + pix] : 0.f;
-    const float bgdot = cam.bg[0] * d0 + cam.bg[1] * d1 + cam.bg[2] * d2;
-    float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+    const float Tf = inside ? final_T[pix] : 0.f;
+    const uint32_t last = inside ? n_contrib[pix] : 0u;
+    const float d0 = inside ? dL_dcolor[pix] : 0.f, d1 = inside ? dL_dcolor[HW + pix] : 0.f,
+                d2 = inside ? dL_dcolor[2 * HW + pix] : 0.f;
+    const float tfbg = Tf * (cam.bg[0] * d0 + cam.bg[1] * d1 + cam.bg[2] * d2);    // background term of dL/dalpha
+    float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
 
     // the deepest contributor of any pixel of this quadrant bounds the replay
     uint32_t wmax = last;
@@ -231,6 +250,9 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor(wmax, m));
     if (wmax == 0) return;
 
+    const uint32_t row8 = (uint32_t)row * 8u;
+    const bool b8 = (l16 & 8) != 0, b4 = (l16 & 4) != 0, b2 = (l16 & 2) != 0, b1 = (l16 & 1) != 0;
+    const int my_comp = row_comp(l16);
     const int cmax = (int)((wmax - 1) / kWave);
     // pipeline prologue (walking chunks downwards): ids of chunks cmax and cmax-1, records of chunk cmax
     uint32_t id_next = (uint32_t)cmax * kWave + lane < wmax ? list[cmax * kWave + lane] : kNoId;
@@ -245,43 +267,52 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         r2 = make_float4(0.f, 0.f, -1.f, -1.f);
         if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
 
-        const bool hit = id_cur != kNoId && quadrant_hit(q0, q2, c.qx0, c.qy0);
-        unsigned long long m = __ballot(hit);
-        if (m == 0ull) continue;
+        const bool live = id_cur != kNoId;
+        unsigned long long m0 = __ballot(live && subblock_hit(q0, q2, c.qx0, c.qy0));
+        unsigned long long m1 = __ballot(live && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0));
+        unsigned long long m2 = __ballot(live && subblock_hit(q0, q2, c.qx0, c.qy0 + 4.0f));
+        unsigned long long m3 = __ballot(live && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0 + 4.0f));
+        const unsigned long long hit_any = m0 | m1 | m2 | m3;
+        if (hit_any == 0ull) continue;
         stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
         __builtin_amdgcn_wave_barrier();
-        while (m) {
-            const int j = 63 - __clzll(m);
-            m &= ~(1ull << j);
+        while ((m0 | m1 | m2 | m3) != 0ull) {
+            // scalar side: each row pops the deepest remaining record of ITS mask; the four indices and
+            // valid bits travel to the lanes packed in two scalar registers (one v_bfe each)
+            const uint32_t vbits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
+            const uint32_t jpack = (uint32_t)pop_high(m0) | ((uint32_t)pop_high(m1) << 8) | ((uint32_t)pop_high(m2) << 16) |
+                                   ((uint32_t)pop_high(m3) << 24);
+            const int j = (int)((jpack >> row8) & 0xffu);
+            const bool valid = ((vbits >> row) & 1u) != 0u;
             const uint32_t pos = (uint32_t)ch * kWave + (uint32_t)j;          // 0-based position in the tile list
             const float4 a0 = s0[j], a1 = s1[j], a2 = s2[j];
-            const float dx = a0.x - c.pxf, dy = a0.y - c.pyf;
+            const float dx = a0.x - pxf, dy = a0.y - pyf;
             const float p = (a0.z * dx + a0.w * dy) * dx + (a1.x * dy) * dy;
             const float G = __builtin_amdgcn_exp2f(p);
             const float alpha = fminf(0.99f, a1.y * G);
-            const bool ok = pos < last && p <= 0.0f && alpha >= kAlphaMin;
-            if (!__any(ok)) continue;
-            float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);
-                T = T * rcp;
-                const float w = alpha * T;
-                acc0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0;
-                acc1 = last_alpha * lc1 + (1.0f - last_alpha) * acc1;
-                acc2 = last_alpha * lc2 + (1.0f - last_alpha) * acc2;
-                lc0 = a1.z; lc1 = a1.w; lc2 = a2.x;
-                float dL_dalpha = ((lc0 - acc0) * d0 + (lc1 - acc1) * d1 + (lc2 - acc2) * d2) * T;
-                v[6] = w * d0; v[7] = w * d1; v[8] = w * d2;
-                last_alpha = alpha;
-                dL_dalpha -= Tf * rcp * bgdot;
-                const float GdA = G * dL_dalpha;
-                const float Z = a1.y * GdA;                 // G dL/dG
-                const float zx = Z * dx, zy = Z * dy;
-                v[0] = zx; v[1] = zy; v[2] = zx * dx; v[3] = zx * dy; v[4] = zy * dy; v[5] = GdA;
-            }
-            int comp;
-            const float x = wave_reduce9(v, lane, comp);
-            if (comp >= 0) atomicAdd(grad2d + (size_t)__float_as_uint(a2.z) * kGradStride + comp, x);
+            const bool ok = valid && pos < last && p <= 0.0f && alpha >= kAlphaMin;
+            const unsigned long long okm = __ballot(ok);
+            if (okm == 0ull) continue;
+            // branch-free replay step.  `acc` is the colour composited BEHIND the current record; after the
+            // record's gradient is taken it absorbs the record: acc += alpha (c - acc).  Lanes that do not
+            // contribute run with alpha = 0, G = 0 (T, acc unchanged, all partials zero).
+            const float a_eff = ok ? alpha : 0.0f;
+            const float G_eff = ok ? G : 0.0f;
+            const float rcp = __builtin_amdgcn_rcpf(1.0f - a_eff);
+            T = T * rcp;                                          // transmittance in front of this record
+            const float df0 = a1.z - acc0, df1 = a1.w - acc1, df2 = a2.x - acc2;
+            const float dL_dalpha = (df0 * d0 + df1 * d1 + df2 * d2) * T - tfbg * rcp;
+            const float w = a_eff * T;
+            acc0 += a_eff * df0; acc1 += a_eff * df1; acc2 += a_eff * df2;
+            const float GdA = G_eff * dL_dalpha;
+            const float Z = a1.y * GdA;                           // G dL/dG
+            const float zx = Z * dx, zy = Z * dy;
+            const float v[9] = {zx, zy, zx * dx, zx * dy, zy * dy, GdA, w * d0, w * d1, w * d2};
+            const float x = row_reduce9(v, b8, b4, b2, b1);
+            // every row that had a contributing pixel adds its 9 components to ITS record: one hardware fp32 atomic
+            // instruction, 9 lanes per row, each record's components inside one 64-byte line (kGradStride = 16)
+            const bool row_any = ((okm >> (row * 16)) & 0xffffull) != 0ull;
+            if (row_any && my_comp >= 0) atomicAdd(grad2d + (size_t)__float_as_uint(a2.z) * kGradStride + my_comp, x);
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -118,6 +118,7 @@ size_t sort_temp_bytes(int64_t D, int end_bit);
 hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
                       const uint32_t* vals_in, uint32_t* vals_out, int64_t D, int end_bit, hipStream_t st);
 
-constexpr int kGradStride = 12;   // floats per Gaussian in the 2-D gradient record:
+constexpr int kGradStride = 16;   // floats per Gaussian in the 2-D gradient record (64 B = one cache line, so an
+                                  // atomic flush of the 9 components is ONE memory-side read-modify-write):
                                   // 0,1 dL/dxy(pixel) 2,3,4 dL/dconic(a,b,c) 5 dL/dopacity 6,7,8 dL/drgb
 }  // namespace gs
