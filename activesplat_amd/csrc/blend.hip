@@ -62,6 +62,27 @@ __device__ __forceinline__ void stage_record(float4* s0, float4* s1, float4* s2,
     s2[lane] = make_float4(q2.x, q2.y, __uint_as_float(id), 0.0f);
 }
 
+// does the record's alpha-visible box overlap the 4x4 sub-block at pixel origin (x0,y0)?
+__device__ __forceinline__ bool subblock_hit(const float4& q0, const float4& q2, float x0, float y0)
+{
+    const float ex = q2.z, ey = q2.w;
+    return ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) && (q0.y - ey <= y0 + 3.0f);
+}
+
+// pop the lowest / highest set bit of a wave-uniform mask; returns its index (0 when the mask is empty)
+__device__ __forceinline__ int pop_low(unsigned long long& m)
+{
+    const int j = m ? __ffsll(m) - 1 : 0;
+    m &= m - 1;
+    return j;
+}
+__device__ __forceinline__ int pop_high(unsigned long long& m)
+{
+    const int j = m ? 63 - __clzll(m) : 0;
+    m &= ~(1ull << j);
+    return j;
+}
+
 __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -71,6 +92,9 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
     if (!tile_ctx(cam, wave, lane, c)) return;
+    const int px = c.px, py = c.py;
+    const bool inside = c.inside;
+    const float pxf = c.pxf, pyf = c.pyf;
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
     const uint2 range = ranges[c.tile];
     const uint32_t n = range.y - range.x;
@@ -78,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0;
-    bool done = !c.inside;
+    bool done = !inside;
 
     if (!__all(done)) {
         // pipeline prologue: ids of chunks 0 and 1, records of chunk 0
@@ -95,53 +119,53 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
             r2 = make_float4(0.f, 0.f, -1.f, -1.f);
             if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
 
-            const bool hit = id_cur != kNoId && quadrant_hit(q0, q2, c.qx0, c.qy0);
-            unsigned long long m = __ballot(hit);
-            if (m == 0ull) continue;
-            stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
-            __builtin_amdgcn_wave_barrier();
-            // two hit records per LDS wait; the blend itself is branch-free (predicated weights)
-            while (m) {
-                const int j1 = __ffsll(m) - 1;
-                m &= m - 1;
-                const bool two = m != 0ull;
-                const int j2 = two ? __ffsll(m) - 1 : j1;
-                m &= m - 1;
-                const float4 a0 = s0[j1], a1 = s1[j1], a2 = s2[j1];
-                const float4 b0 = s0[j2], b1 = s1[j2], b2 = s2[j2];
-                {
-                    const float dx = a0.x - c.pxf, dy = a0.y - c.pyf;
-                    const float p = (a0.z * dx + a0.w * dy) * dx + (a1.x * dy) * dy;
-                    const float alpha = fminf(0.99f, a1.y * __builtin_amdgcn_exp2f(p));
-                    const float test_T = T * (1.0f - alpha);
-                    const bool vis = !done && p <= 0.0f && alpha >= kAlphaMin;
-                    const bool ok = vis && test_T >= kTmin;
-                    done = done || (vis && !ok);
-                    const float w = ok ? alpha * T : 0.0f;
-                    C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w; Dp += a2.y * w;
-                    T = ok ? test_T : T;
-                    last = ok ? base + (uint32_t)j1 + 1u : last;
-                }
-                {
-                    const float dx = b0.x - c.pxf, dy = b0.y - c.pyf;
-                    const float p = (b0.z * dx + b0.w * dy) * dx + (b1.x * dy) * dy;
-                    const float alpha = fminf(0.99f, b1.y * __builtin_amdgcn_exp2f(p));
-                    const float test_T = T * (1.0f - alpha);
-                    const bool vis = two && !done && p <= 0.0f && alpha >= kAlphaMin;
-                    const bool ok = vis && test_T >= kTmin;
-                    done = done || (vis && !ok);
-                    const float w = ok ? alpha * T : 0.0f;
-                    C0 += b1.z * w; C1 += b1.w * w; C2 += b2.x * w; Dp += b2.y * w;
-                    T = ok ? test_T : T;
-                    last = ok ? base + (uint32_t)j2 + 1u : last;
+            const bool live = id_cur != kNoId;
+            {
+                unsigned long long m = __ballot(live && quadrant_hit(q0, q2, c.qx0, c.qy0));
+                if (m == 0ull) continue;
+                stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
+                __builtin_amdgcn_wave_barrier();
+                // two hit records per LDS wait; the blend itself is branch-free (predicated weights)
+                while (m) {
+                    const int j1 = pop_low(m);
+                    const bool two = m != 0ull;
+                    const int j2 = two ? pop_low(m) : j1;
+                    const float4 a0 = s0[j1], a1 = s1[j1], a2 = s2[j1];
+                    const float4 b0 = s0[j2], b1 = s1[j2], b2 = s2[j2];
+                    {
+                        const float dx = a0.x - pxf, dy = a0.y - pyf;
+                        const float p = (a0.z * dx + a0.w * dy) * dx + (a1.x * dy) * dy;
+                        const float alpha = fminf(0.99f, a1.y * __builtin_amdgcn_exp2f(p));
+                        const float test_T = T * (1.0f - alpha);
+                        const bool vis = !done && p <= 0.0f && alpha >= kAlphaMin;
+                        const bool ok = vis && test_T >= kTmin;
+                        done = done || (vis && !ok);
+                        const float w = ok ? alpha * T : 0.0f;
+                        C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w; Dp += a2.y * w;
+                        T = ok ? test_T : T;
+                        last = ok ? base + (uint32_t)j1 + 1u : last;
+                    }
+                    {
+                        const float dx = b0.x - pxf, dy = b0.y - pyf;
+                        const float p = (b0.z * dx + b0.w * dy) * dx + (b1.x * dy) * dy;
+                        const float alpha = fminf(0.99f, b1.y * __builtin_amdgcn_exp2f(p));
+                        const float test_T = T * (1.0f - alpha);
+                        const bool vis = two && !done && p <= 0.0f && alpha >= kAlphaMin;
+                        const bool ok = vis && test_T >= kTmin;
+                        done = done || (vis && !ok);
+                        const float w = ok ? alpha * T : 0.0f;
+                        C0 += b1.z * w; C1 += b1.w * w; C2 += b2.x * w; Dp += b2.y * w;
+                        T = ok ? test_T : T;
+                        last = ok ? base + (uint32_t)j2 + 1u : last;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
             if (__all(done)) break;
         }
     }
-    if (c.inside) {
-        const size_t pix = (size_t)c.py * cam.W + c.px, HW = (size_t)cam.H * cam.W;
+    if (inside) {
+        const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
         final_T[pix] = T;
         n_contrib[pix] = last;
         out_color[pix] = C0 + T * cam.bg[0];
@@ -198,21 +222,6 @@ __device__ __forceinline__ int row_comp(int l16)
 {
     if (l16 & 1) return l16 == 1 ? 8 : -1;
     return ((l16 & 2) ? 4 : 0) + ((l16 & 4) ? 2 : 0) + ((l16 & 8) ? 1 : 0);
-}
-
-// does the record's alpha-visible box overlap the 4x4 sub-block at pixel origin (x0,y0)?
-__device__ __forceinline__ bool subblock_hit(const float4& q0, const float4& q2, float x0, float y0)
-{
-    const float ex = q2.z, ey = q2.w;
-    return ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) && (q0.y - ey <= y0 + 3.0f);
-}
-
-// pop the highest set bit of a wave-uniform mask; returns its index (0 when the mask is empty)
-__device__ __forceinline__ int pop_high(unsigned long long& m)
-{
-    const int j = m ? 63 - __clzll(m) : 0;
-    m &= ~(1ull << j);
-    return j;
 }
 
 // Per-Gaussian 2-D gradient record accumulated here (raw moments; the conic algebra is finished per
