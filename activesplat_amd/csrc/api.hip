@@ -214,6 +214,8 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, 
         e = gs::launch_tile_count(k, P, gp, gp.tile_total, gp.tile_base, ranges, d_counts, st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: tile count %s", hipGetErrorString(e));
     } else {                                   // too many tiles for the LDS histogram: radix path, counts = {D, 2^32-1}
+        e = gs::launch_scan_block_sums(P, gp, d_counts, st);
+        if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: scan %s", hipGetErrorString(e));
         e = hipMemsetAsync(d_counts + 1, 0xff, sizeof(uint32_t), st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: memset %s", hipGetErrorString(e));
     }
@@ -252,6 +254,10 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_ti
     } else {
         e = hipMemsetAsync(ranges, 0, (size_t)k.gx * k.gy * 8, st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: memset %s", hipGetErrorString(e));
+        if (k.gx * k.gy <= gs::kMaxLdsTiles) {   // per-Gaussian offsets were not needed before the sync: scan them now
+            e = gs::launch_scan_block_sums(P, gp, gp.block_sums + (P + gs::kBlock - 1) / gs::kBlock, st);
+            if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: scan %s", hipGetErrorString(e));
+        }
         if (D == 0) {   // nothing visible: the emitter still writes the (all-zero) scan offsets
             e = gs::launch_emit(k, P, gp, nullptr, nullptr, st);
             if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: emit %s", hipGetErrorString(e));

@@ -88,6 +88,7 @@ hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D
                                      const float* colors, const float* opac, const float* scales,
                                      const float* rots, const float* cov3Dp, int32_t* radii, GeomPtrs gp,
                                      uint32_t* d_num_rendered, hipStream_t st);
+hipError_t launch_scan_block_sums(int P, GeomPtrs gp, uint32_t* d_total, hipStream_t st);
 hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3D, const float* shs,
                                       const float* scales, const float* rots, const float* cov3Dp,
                                       const int32_t* radii, const uint32_t* clamped, const float* grad2d,

@@ -62,6 +62,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     const int tid = threadIdx.x;
     const int base = blockIdx.x * kBlock;
     const int nrows = min(kBlock, P - base);
+    // the per-tile instance counters of the binning stage are zeroed here (saves a memset launch)
+    if (base + tid < cam.gx * cam.gy) gp.tile_total[base + tid] = 0u;
     const int i = base + tid;
     stage_rows<3>(s_mean, means3D, base, nrows, tid);
     if (cov3Dp) stage_rows<6>(s_cov, cov3Dp, base, nrows, tid);
@@ -225,7 +227,19 @@ hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D
     if (nb > 0)
         hipLaunchKernelGGL(preprocess_forward_kernel, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
                            scales, rots, cov3Dp, radii, gp);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, st, gp.block_sums, nb, d_num_rendered);
+    // tile_total must be zero even when the grid above does not cover every tile (tiny P, many tiles)
+    if ((size_t)nb * kBlock < (size_t)cam.gx * cam.gy) {
+        hipError_t e = hipMemsetAsync(gp.tile_total, 0, (size_t)cam.gx * cam.gy * 4, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipGetLastError();
+}
+
+// per-Gaussian offsets (radix path only): exclusive scan of the per-block tile counts, total -> *d_total
+hipError_t launch_scan_block_sums(int P, GeomPtrs gp, uint32_t* d_total, hipStream_t st)
+{
+    const int nb = (P + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, st, gp.block_sums, nb, d_total);
     return hipGetLastError();
 }
 

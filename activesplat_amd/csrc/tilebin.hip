@@ -140,38 +140,112 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restr
     }
 }
 
-// one workgroup per tile: bitonic sort of (depth_bits<<32 | id) in LDS; ids -> point_list
+// One workgroup per tile: bitonic sort of (depth_bits<<32 | id), REGISTER-BLOCKED: every thread owns E
+// consecutive keys.  All steps with stride < E (and the whole first log2(E) levels) are compare-exchanges
+// between a thread's own registers -- no LDS, no barrier; a step with stride >= E pairs each thread with
+// ONE partner thread (t ^ stride/E): it publishes its E keys to LDS, reads the partner's E keys and keeps
+// the element-wise min or max.  Two LDS buffers alternate, so such a step costs one barrier.  For 2048 keys
+// on 256 threads: 36 barrier steps instead of 66, and 8x fewer LDS accesses.
+__device__ __forceinline__ void cmpswap(unsigned long long& a, unsigned long long& b, bool up)
+{
+    const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
+    a = up ? lo : hi;
+    b = up ? hi : lo;
+}
+
+template <int E, int THREADS>
+__device__ __forceinline__ void bitonic_sort_block(unsigned long long (&k)[E], unsigned long long* buf0, unsigned long long* buf1, int tid)
+{
+    const uint32_t base = (uint32_t)tid * E;
+    // levels that fit inside one thread
+#pragma unroll
+    for (int kk = 2; kk <= E; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                if ((i & j) == 0) cmpswap(k[i], k[i | j], ((base + i) & kk) == 0);
+            }
+        }
+    }
+    int flip = 0;
+    for (uint32_t kk = 2 * E; kk <= (uint32_t)E * THREADS; kk <<= 1) {
+        for (uint32_t j = kk >> 1; j >= (uint32_t)E; j >>= 1) {
+            unsigned long long* buf = flip ? buf1 : buf0;
+            flip ^= 1;
+            // LDS layout is TRANSPOSED ([i][thread]): lane-contiguous 8-byte accesses, no bank conflicts
+#pragma unroll
+            for (int i = 0; i < E; i++) buf[i * THREADS + tid] = k[i];
+            __syncthreads();
+            const int ptid = tid ^ (int)(j / E);                  // partner thread (j is a multiple of E)
+            const bool lower = (base & j) == 0;
+            const bool up = (base & kk) == 0;                     // same for all E keys of a thread (kk >= 2E)
+            const bool take_min = lower == up;
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                const unsigned long long o = buf[i * THREADS + ptid];
+                k[i] = take_min ? (k[i] < o ? k[i] : o) : (k[i] < o ? o : k[i]);
+            }
+        }
+        const bool up = (base & kk) == 0;
+#pragma unroll
+        for (int j = E >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                if ((i & j) == 0) cmpswap(k[i], k[i | j], up);
+            }
+        }
+    }
+}
+
+template <int E, int THREADS>
+__device__ __forceinline__ void tile_sort_impl(const uint2 range, uint32_t n, unsigned long long* __restrict__ pairs,
+                                               uint32_t* __restrict__ point_list, unsigned long long* buf0,
+                                               unsigned long long* buf1, int tid)
+{
+    unsigned long long k[E];
+    const uint32_t base = (uint32_t)tid * E;
+    // coalesced global reads, then each thread picks up its E consecutive keys from LDS
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const uint32_t e = (uint32_t)i * THREADS + tid;
+        buf0[e] = e < n ? pairs[range.x + e] : ~0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < E; i++) k[i] = buf0[base + i];
+    __syncthreads();
+    bitonic_sort_block<E, THREADS>(k, buf0, buf1, tid);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < E; i++) buf0[base + i] = k[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const uint32_t e = (uint32_t)i * THREADS + tid;
+        if (e < n) {
+            const unsigned long long v = buf0[e];
+            pairs[range.x + e] = v;
+            point_list[range.x + e] = (uint32_t)v;
+        }
+    }
+}
+
 template <int CAP, int THREADS>
 __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restrict__ ranges,
                                                              unsigned long long* __restrict__ pairs,
                                                              uint32_t* __restrict__ point_list)
 {
-    __shared__ unsigned long long s_k[CAP];
+    __shared__ unsigned long long s_a[CAP];
+    __shared__ unsigned long long s_b[CAP];
     const int tid = threadIdx.x;
     const uint2 range = ranges[blockIdx.x];
     const uint32_t n = range.y - range.x;
-    if (n == 0) return;
-    uint32_t npow = 2;
-    while (npow < n) npow <<= 1;
-    for (uint32_t i = tid; i < npow; i += THREADS) s_k[i] = i < n ? pairs[range.x + i] : ~0ull;
-    __syncthreads();
-    for (uint32_t k = 2; k <= npow; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < (npow >> 1); i += THREADS) {
-                const uint32_t a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                const uint32_t b = a | j;
-                const unsigned long long ka = s_k[a], kb = s_k[b];
-                const bool up = (a & k) == 0;
-                if ((ka > kb) == up) { s_k[a] = kb; s_k[b] = ka; }
-            }
-            __syncthreads();
-        }
-    }
-    for (uint32_t i = tid; i < n; i += THREADS) {
-        const unsigned long long v = s_k[i];
-        pairs[range.x + i] = v;
-        point_list[range.x + i] = (uint32_t)v;
-    }
+    if (n == 0) return;                                       // uniform
+    constexpr int EMAX = CAP / THREADS;                       // 8
+    if (n <= (uint32_t)THREADS * (EMAX / 4)) tile_sort_impl<EMAX / 4, THREADS>(range, n, pairs, point_list, s_a, s_b, tid);
+    else if (n <= (uint32_t)THREADS * (EMAX / 2)) tile_sort_impl<EMAX / 2, THREADS>(range, n, pairs, point_list, s_a, s_b, tid);
+    else tile_sort_impl<EMAX, THREADS>(range, n, pairs, point_list, s_a, s_b, tid);
 }
 
 // development knob: GS_BIN_VARIANT = threads*10000 + chunk (e.g. 10244096); default 1024 threads x 4096 Gaussians
@@ -195,9 +269,7 @@ static void launch_bin(int threads, int nb, hipStream_t st, Cam cam, int P, Geom
 hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,
                              uint2* ranges, uint32_t* d_counts, hipStream_t st)
 {
-    const int tiles = cam.gx * cam.gy;
-    hipError_t e = hipMemsetAsync(tile_total, 0, (size_t)tiles * 4, st);
-    if (e != hipSuccess) return e;
+    const int tiles = cam.gx * cam.gy;       // tile_total was zeroed by the preprocess stage
     int threads, chunk; bin_config(threads, chunk);
     const int nb = (P + chunk - 1) / chunk;
     if (nb > 0) launch_bin<false>(threads, nb, st, cam, P, gp, tiles, chunk, tile_total, tile_base, nullptr, nullptr);

@@ -140,6 +140,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                               scales if scales is not None else e, rotations if rotations is not None else e,
                               cov3D_precomp if cov3D_precomp is not None else e, radii, geom, point_list, image)
         ctx.mark_non_differentiable(radii, depth, opacity)
+        ctx.set_materialize_grads(False)          # no zero-filled grad tensors for the non-differentiable outputs
         return color, radii, depth, opacity
 
     @staticmethod
@@ -151,6 +152,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         P = int(means3D.shape[0])
         M = int(shs.shape[1]) if has_sh else 0
         cam, keep = _camera(ctx.rs, device, M)
+        if grad_color is None:
+            grad_color = torch.zeros(3, int(ctx.rs.image_height), int(ctx.rs.image_width), device=device)
         grad_color = _f32(grad_color, device)
         z = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731  (kernel writes every row)
         d_m2d, d_m3d, d_op = z(P, 3), z(P, 3), z(P, 1)
