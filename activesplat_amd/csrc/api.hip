@@ -195,7 +195,7 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, 
     const bool have_sr = scales != nullptr && rotations != nullptr;
     if (P > 0 && (have_sr == (cov3D_precomp != nullptr) || ((scales != nullptr) != (rotations != nullptr))))
         return fail(GS_EINVAL, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
-    if (shs && (k.sh_degree < 0 || k.sh_degree > 3 || k.sh_coeffs < (k.sh_degree + 1) * (k.sh_degree + 1) || !k.campos))
+    if (shs && (k.sh_degree < 0 || k.sh_degree > 3 || k.sh_coeffs < (k.sh_degree + 1) * (k.sh_degree + 1) || k.sh_coeffs > 16 || !k.campos))
         return fail(GS_EINVAL, "gs_preprocess_forward: sh_degree / sh_coeffs / campos inconsistent");
     hipStream_t st = (hipStream_t)stream;
     gs::GeomPtrs gp = carve_geom(geom_state, P, k);

@@ -83,6 +83,32 @@ __device__ __forceinline__ void stage_rows(float* lds, const float* __restrict__
     }
 }
 
+// SH coefficient rows ([P][M][3] floats, M*3 = K floats per Gaussian, 192 B at degree 3) are moved between HBM
+// and a wave's threads through an LDS slab with an ODD row stride (conflict-free lane = row access): one
+// wavefront's 64 rows at a time, all 256 threads of the workgroup doing the coalesced global side.
+constexpr int kShPad = 49;          // LDS row stride for up to 48 floats (16 coefficients x RGB)
+__device__ __forceinline__ int sh_row_stride(int K) { return K | 1; }
+// global rows [row0, row0+nrows) -> LDS (padded); nrows <= 64
+__device__ __forceinline__ void sh_rows_to_lds(float* lds, const float* __restrict__ src, int row0, int nrows, int K, int tid)
+{
+    const int stride = sh_row_stride(K);
+    const float* s = src + (size_t)row0 * K;
+    for (int e = tid; e < nrows * K; e += kBlock) {
+        const int r = e / K;
+        lds[r * stride + (e - r * K)] = s[e];
+    }
+}
+// LDS (padded) -> global rows
+__device__ __forceinline__ void sh_rows_from_lds(const float* lds, float* __restrict__ dst, int row0, int nrows, int K, int tid)
+{
+    const int stride = sh_row_stride(K);
+    float* d = dst + (size_t)row0 * K;
+    for (int e = tid; e < nrows * K; e += kBlock) {
+        const int r = e / K;
+        d[e] = lds[r * stride + (e - r * K)];
+    }
+}
+
 // ---- launchers implemented in the individual translation units -------------------------------------
 hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D, const float* shs,
                                      const float* colors, const float* opac, const float* scales,

@@ -47,6 +47,7 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
+template <bool HAS_SH>
 __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales,
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     __shared__ __attribute__((aligned(16))) float s_col[kBlock * 3];
     __shared__ __attribute__((aligned(16))) float s_cov[kBlock * 6];
     __shared__ uint32_t s_wsum[kBlock / kWave];
+    __shared__ float s_sh[HAS_SH ? kWave * kShPad : 1];
 
     const int tid = threadIdx.x;
     const int base = blockIdx.x * kBlock;
@@ -68,8 +70,38 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     stage_rows<3>(s_mean, means3D, base, nrows, tid);
     if (cov3Dp) stage_rows<6>(s_cov, cov3Dp, base, nrows, tid);
     else { stage_rows<3>(s_scale, scales, base, nrows, tid); stage_rows<4>(s_rot, rots, base, nrows, tid); }
-    if (!shs) stage_rows<3>(s_col, colors, base, nrows, tid);
+    if (!HAS_SH) stage_rows<3>(s_col, colors, base, nrows, tid);
     __syncthreads();
+
+    // SH -> RGB for every Gaussian of the workgroup, one wavefront's 64 coefficient rows per LDS pass
+    // (coalesced global reads by all 256 threads; lane = row reads at an odd stride are conflict-free)
+    float sh_rgb[3] = {0.f, 0.f, 0.f};
+    uint32_t sh_clamp = 0;
+    if (HAS_SH) {
+        const int M = cam.sh_coeffs, K = M * 3, nbasis = (cam.sh_degree + 1) * (cam.sh_degree + 1);
+        const int stride = sh_row_stride(K);
+        for (int w = 0; w < kBlock / kWave; w++) {
+            const int row0 = base + w * kWave;
+            if (row0 >= P) break;                                  // uniform
+            __syncthreads();
+            sh_rows_to_lds(s_sh, shs, row0, min(kWave, P - row0), K, tid);
+            __syncthreads();
+            if ((tid >> 6) == w && base + tid < P) {
+                const float dx = s_mean[tid * 3] - cam.campos[0], dy = s_mean[tid * 3 + 1] - cam.campos[1], dz = s_mean[tid * 3 + 2] - cam.campos[2];
+                const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+                float b[16];
+                sh_basis(cam.sh_degree, dx * inv, dy * inv, dz * inv, b);
+                const float* sh = s_sh + (tid & 63) * stride;
+                float acc[3] = {0.f, 0.f, 0.f};
+                for (int k = 0; k < nbasis; k++) {
+                    acc[0] += b[k] * sh[3 * k]; acc[1] += b[k] * sh[3 * k + 1]; acc[2] += b[k] * sh[3 * k + 2];
+                }
+                acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
+                sh_clamp = (acc[0] < 0.f ? 1u : 0u) | (acc[1] < 0.f ? 0x100u : 0u) | (acc[2] < 0.f ? 0x10000u : 0u);
+                sh_rgb[0] = fmaxf(acc[0], 0.f); sh_rgb[1] = fmaxf(acc[1], 0.f); sh_rgb[2] = fmaxf(acc[2], 0.f);
+            }
+        }
+    }
 
     uint32_t ntiles = 0;
     if (i < P) {
@@ -147,20 +179,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
                     rc = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
                     const float o = opac[i];
                     float cr, cg, cb;
-                    if (shs) {
-                        const int M = cam.sh_coeffs, nb = (cam.sh_degree + 1) * (cam.sh_degree + 1);
-                        const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
-                        const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
-                        float b[16];
-                        sh_basis(cam.sh_degree, dx * inv, dy * inv, dz * inv, b);
-                        const float* sh = shs + (size_t)i * M * 3;
-                        float acc[3] = {0.f, 0.f, 0.f};
-                        for (int k = 0; k < nb; k++) {
-                            acc[0] += b[k] * sh[3 * k]; acc[1] += b[k] * sh[3 * k + 1]; acc[2] += b[k] * sh[3 * k + 2];
-                        }
-                        acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
-                        clampbits = (acc[0] < 0.f ? 1u : 0u) | (acc[1] < 0.f ? 0x100u : 0u) | (acc[2] < 0.f ? 0x10000u : 0u);
-                        cr = fmaxf(acc[0], 0.f); cg = fmaxf(acc[1], 0.f); cb = fmaxf(acc[2], 0.f);
+                    if (HAS_SH) {
+                        clampbits = sh_clamp;
+                        cr = sh_rgb[0]; cg = sh_rgb[1]; cb = sh_rgb[2];
                     } else {
                         cr = s_col[tid * 3]; cg = s_col[tid * 3 + 1]; cb = s_col[tid * 3 + 2];
                     }
@@ -184,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
         gp.geom[(size_t)i * 3] = g0; gp.geom[(size_t)i * 3 + 1] = g1; gp.geom[(size_t)i * 3 + 2] = g2;
         gp.rect[i] = rc;
         gp.tiles[i] = ntiles;
-        if (shs) gp.clamped[i] = clampbits;
+        if (HAS_SH) gp.clamped[i] = clampbits;
     }
     // per-block tile count -> block_sums (scanned by scan_block_sums_kernel)
     const uint32_t ws = wave_sum_u32(ntiles);
@@ -224,8 +245,11 @@ hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D
                                      uint32_t* d_num_rendered, hipStream_t st)
 {
     const int nb = (P + kBlock - 1) / kBlock;
-    if (nb > 0)
-        hipLaunchKernelGGL(preprocess_forward_kernel, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
+    if (nb > 0 && shs)
+        hipLaunchKernelGGL(preprocess_forward_kernel<true>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
+                           scales, rots, cov3Dp, radii, gp);
+    else if (nb > 0)
+        hipLaunchKernelGGL(preprocess_forward_kernel<false>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
                            scales, rots, cov3Dp, radii, gp);
     // tile_total must be zero even when the grid above does not cover every tile (tiny P, many tiles)
     if ((size_t)nb * kBlock < (size_t)cam.gx * cam.gy) {

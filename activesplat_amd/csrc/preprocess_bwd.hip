@@ -47,6 +47,7 @@ __device__ __forceinline__ void sh_basis_and_grad(int deg, float x, float y, flo
     }
 }
 
+template <bool HAS_SH>
 __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov3Dp,
@@ -55,45 +56,68 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     float* __restrict__ dcolors, float* __restrict__ dshs, float* __restrict__ dscales,
     float* __restrict__ drots, float* __restrict__ dcov3D)
 {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= P) return;
-    const bool live = radii[i] > 0;
-    const float4* gr4 = reinterpret_cast<const float4*>(grad2d + (size_t)i * kGradStride);
+    __shared__ float s_sh[HAS_SH ? kWave * kShPad : 1];       // coefficient rows of one wavefront's Gaussians
+    __shared__ float s_dsh[HAS_SH ? kWave * kShPad : 1];      // their gradients
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kBlock + tid;
+    const bool in_range = i < P;
+    if (!HAS_SH && !in_range) return;
+    const int ic = in_range ? i : P - 1;                       // clamped index: out-of-range lanes only help with the SH slabs
+    const bool live = in_range && radii[ic] > 0;
+    const float4* gr4 = reinterpret_cast<const float4*>(grad2d + (size_t)ic * kGradStride);
     const float4 ga = gr4[0], gb = gr4[1], gc = gr4[2];
+    float dmean[3] = {0.f, 0.f, 0.f};
     // record (raw moments from blend_backward_kernel, Z = G dL/dG, d = mean - pixel):
     //   ga = (sum Z dx, sum Z dy, sum Z dx dx, sum Z dx dy)  gb = (sum Z dy dy, sum G dL/dalpha, dr, dg)  gc = (db, -, -, -)
-    float dmean[3] = {0.f, 0.f, 0.f};
     float o_m2d[3] = {0.f, 0.f, 0.f}, o_sc[3] = {0.f, 0.f, 0.f}, o_rot[4] = {0.f, 0.f, 0.f, 0.f};
     float o_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+    const float px = means3D[3 * ic], py = means3D[3 * ic + 1], pz = means3D[3 * ic + 2];
     const float drgb[3] = {gb.z, gb.w, gc.x};
+    // ---- colour / SH: one wavefront's 64 coefficient rows per LDS pass, coalesced global traffic by all threads ----
+    if (HAS_SH) {
+        const int deg = cam.sh_degree, nb = (deg + 1) * (deg + 1), M = cam.sh_coeffs, K = M * 3;
+        const int stride = sh_row_stride(K);
+        for (int w = 0; w < kBlock / kWave; w++) {
+            const int row0 = blockIdx.x * kBlock + w * kWave;
+            if (row0 >= P) break;                                  // uniform
+            const int nrows = min(kWave, P - row0);
+            __syncthreads();
+            sh_rows_to_lds(s_sh, shs, row0, nrows, K, tid);
+            __syncthreads();
+            if ((tid >> 6) == w && in_range) {
+                float* dsh = s_dsh + (tid & 63) * stride;
+                if (live) {
+                    const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
+                    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+                    const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+                    float b[16], bx[16], by[16], bz[16];
+                    sh_basis_and_grad(deg, ux, uy, uz, b, bx, by, bz);
+                    const uint32_t cl = clamped[i];
+                    float du[3] = {0.f, 0.f, 0.f};
+                    const float* sh = s_sh + (tid & 63) * stride;
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float g = ((cl >> (8 * ch)) & 1u) ? 0.f : drgb[ch];
+                        for (int k = 0; k < nb; k++) {
+                            const float coef = sh[3 * k + ch];
+                            dsh[3 * k + ch] = g * b[k];
+                            du[0] += g * coef * bx[k]; du[1] += g * coef * by[k]; du[2] += g * coef * bz[k];
+                        }
+                        for (int k = nb; k < M; k++) dsh[3 * k + ch] = 0.f;
+                    }
+                    const float dot = ux * du[0] + uy * du[1] + uz * du[2];
+                    dmean[0] += (du[0] - ux * dot) * inv; dmean[1] += (du[1] - uy * dot) * inv; dmean[2] += (du[2] - uz * dot) * inv;
+                } else {
+                    for (int k = 0; k < K; k++) dsh[k] = 0.f;
+                }
+            }
+            __syncthreads();
+            sh_rows_from_lds(s_dsh, dshs, row0, nrows, K, tid);
+        }
+        if (!in_range) return;
+    }
     if (live) {
         const float* m = cam.view;
         const float* q = cam.proj;
-        // ---- colour / SH ----
-        if (shs) {
-            const int deg = cam.sh_degree, nb = (deg + 1) * (deg + 1), M = cam.sh_coeffs;
-            const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
-            const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-            const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
-            float b[16], bx[16], by[16], bz[16];
-            sh_basis_and_grad(deg, ux, uy, uz, b, bx, by, bz);
-            const uint32_t cl = clamped[i];
-            float du[3] = {0.f, 0.f, 0.f};
-            const float* sh = shs + (size_t)i * M * 3;
-            float* dsh = dshs + (size_t)i * M * 3;
-            for (int ch = 0; ch < 3; ch++) {
-                const float g = ((cl >> (8 * ch)) & 1u) ? 0.f : drgb[ch];
-                for (int k = 0; k < nb; k++) {
-                    const float coef = sh[3 * k + ch];
-                    dsh[3 * k + ch] = g * b[k];
-                    du[0] += g * coef * bx[k]; du[1] += g * coef * by[k]; du[2] += g * coef * bz[k];
-                }
-                for (int k = nb; k < M; k++) dsh[3 * k + ch] = 0.f;
-            }
-            const float dot = ux * du[0] + uy * du[1] + uz * du[2];
-            dmean[0] += (du[0] - ux * dot) * inv; dmean[1] += (du[1] - uy * dot) * inv; dmean[2] += (du[2] - uz * dot) * inv;
-        }
         // ---- recompute forward intermediates ----
         const float tx = m[0] * px + m[4] * py + m[8] * pz + m[12];
         const float ty = m[1] * px + m[5] * py + m[9] * pz + m[13];
@@ -196,9 +220,6 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
             o_rot[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
             o_rot[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         }
-    } else if (shs) {
-        float* dsh = dshs + (size_t)i * cam.sh_coeffs * 3;
-        for (int k = 0; k < cam.sh_coeffs * 3; k++) dsh[k] = 0.f;
     }
     for (int c = 0; c < 3; c++) { dmeans2D[3 * i + c] = o_m2d[c]; dmeans3D[3 * i + c] = dmean[c]; }
     dopac[i] = live ? gb.y : 0.f;
@@ -215,8 +236,11 @@ hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3
                                       float* dscales, float* drots, float* dcov3D, hipStream_t st)
 {
     const int nb = (P + kBlock - 1) / kBlock;
-    if (nb > 0)
-        hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
+    if (nb > 0 && shs)
+        hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
+                           cov3Dp, radii, clamped, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
+    else if (nb > 0)
+        hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
                            cov3Dp, radii, clamped, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
     return hipGetLastError();
 }

@@ -14,8 +14,9 @@ from activesplat_amd import synthetic as syn  # noqa: E402
 
 def run(N=500_000, W=640, H=480, steps=30, warmup=5, backward=True):
     dev = torch.device("cuda")
-    cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=dev)
-    rv = {k: v.to(dev).requires_grad_(True) for k, v in syn.activate(syn.make_params(N, W, H, seed=0)).items()}
+    sh = os.environ.get("SH")
+    cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=dev, sh_degree=int(sh) if sh else 0)
+    rv = {k: v.to(dev).requires_grad_(True) for k, v in syn.activate(syn.make_params(N, W, H, seed=0, sh_degree=int(sh) if sh else None)).items()}
     dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
     lib = _lib.get()
 
@@ -50,5 +51,6 @@ if __name__ == "__main__":
         for v in vals.split(","):
             os.environ[var] = v
             wall, st = run(N=N)
-            print(f"{var}={v} N={N} wall_us={wall:.1f} " + " ".join(f"{k}={u:.1f}" for k, u in st.items()), flush=True)
+            from activesplat_amd import rasterizer as R
+            print(f"{var}={v} N={N} D={R.last_stats['num_rendered']} maxtile={R.last_stats.get('max_tile_instances')} wall_us={wall:.1f} " + " ".join(f"{k}={u:.1f}" for k, u in st.items()), flush=True)
         os.environ.pop(var, None)
