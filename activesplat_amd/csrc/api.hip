@@ -228,7 +228,7 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, 
 
 int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_tile_instances, void* geom_state,
                       void* bin_state, uint32_t* point_list, void* image_state, float* out_color, float* out_depth,
-                      float* out_opacity, gs_stream_t stream)
+                      float* out_opacity, float* out_depth_sq, gs_stream_t stream)
 {
     gs::Cam k;
     if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_render_forward: invalid camera settings");
@@ -279,7 +279,7 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_ti
     {
         ScopedStage ps(ST_BLEND_FWD, st);
         e = gs::launch_blend_forward(k, ranges, point_list, gp.geom, out_color, out_depth, out_opacity,
-                                     (float*)(ib + IL.final_T), (uint32_t*)(ib + IL.n_contrib), st);
+                                     (float*)(ib + IL.final_T), (uint32_t*)(ib + IL.n_contrib), out_depth_sq, st);
     }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: blend %s", hipGetErrorString(e));
     return GS_OK;
@@ -289,7 +289,7 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* m
                        const float* colors_precomp, const float* scales, const float* rotations,
                        const float* cov3D_precomp, const int32_t* radii, const void* geom_state,
                        const uint32_t* point_list, const void* image_state, const float* dL_dcolor,
-                       float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities, float* dL_dcolors_precomp,
+                       const float* dL_ddepth, float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities, float* dL_dcolors_precomp,
                        float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* scratch,
                        gs_stream_t stream)
 {
@@ -313,7 +313,7 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* m
     if (D > 0) {
         ScopedStage ps(ST_BLEND_BWD, st);
         e = gs::launch_blend_backward(k, (const uint2*)(ib + IL.ranges), point_list, gp.geom, (const float*)(ib + IL.final_T),
-                                      (const uint32_t*)(ib + IL.n_contrib), dL_dcolor, grad2d, st);
+                                      (const uint32_t*)(ib + IL.n_contrib), dL_dcolor, dL_ddepth, grad2d, st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_backward: blend %s", hipGetErrorString(e));
     }
     {

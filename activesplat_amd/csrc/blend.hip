@@ -83,10 +83,12 @@ __device__ __forceinline__ int pop_high(unsigned long long& m)
     return j;
 }
 
+template <bool DEPTH_SQ>     // also accumulate sum z^2 alpha T (third channel of the reference's depth/silhouette pass)
 __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
-    float* __restrict__ out_opacity, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
+    float* __restrict__ out_opacity, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+    float* __restrict__ out_depth_sq)
 {
     __shared__ float4 s_rec[kBlock / kWave][3][kWave];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     const uint32_t n = range.y - range.x;
     const uint32_t* list = point_list + range.x;
 
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Dq = 0.f;
     uint32_t last = 0;
     bool done = !inside;
 
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
                         done = done || (vis && !ok);
                         const float w = ok ? alpha * T : 0.0f;
                         C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w; Dp += a2.y * w;
+                        if (DEPTH_SQ) Dq += a2.y * a2.y * w;
                         T = ok ? test_T : T;
                         last = ok ? base + (uint32_t)j1 + 1u : last;
                     }
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
                         done = done || (vis && !ok);
                         const float w = ok ? alpha * T : 0.0f;
                         C0 += b1.z * w; C1 += b1.w * w; C2 += b2.x * w; Dp += b2.y * w;
+                        if (DEPTH_SQ) Dq += b2.y * b2.y * w;
                         T = ok ? test_T : T;
                         last = ok ? base + (uint32_t)j2 + 1u : last;
                     }
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
         out_color[2 * HW + pix] = C2 + T * cam.bg[2];
         out_depth[pix] = Dp;
         out_opacity[pix] = 1.0f - T;
+        if (DEPTH_SQ) out_depth_sq[pix] = Dq;
     }
 }
 
@@ -193,20 +198,20 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
 //   read-modify-writes of whole lines at the memory side on this multi-XCD part, and a 48-byte stride
 //   that lets half the records straddle two lines cost +100 us per launch.
 // ---------------------------------------------------------------------------------------------------
-// Transposed in-row butterfly: the 16-lane row sums of NINE values in 27 VALU (instead of 9 x 4 DPP adds
+// Transposed in-row butterfly: the 16-lane row sums of up to TEN values in 29 VALU (instead of 9 x 4 DPP adds
 // plus an 8-deep select chain).  At every level two registers are merged into one: each lane keeps the
 // register its half is responsible for and receives, through one DPP add, the partner lane's copy of
 // the same register.  Partner maps: lane^8 (row_ror:8), mirror within 8 (row_half_mirror), lane^2 and
 // lane^1 (quad_perm).  Afterwards lane l of the row holds the row total of component row_comp(l).
 #define GS_DPP_ADD(keep, send, ctrl) ((keep) + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), ctrl, 0xf, 0xf, true)))
-__device__ __forceinline__ float row_reduce9(const float (&v)[9], bool b8, bool b4, bool b2, bool b1)
+__device__ __forceinline__ float row_reduce10(const float (&v)[10], bool b8, bool b4, bool b2, bool b1)
 {
     // level A: partner lane^8
     const float a0 = GS_DPP_ADD(b8 ? v[1] : v[0], b8 ? v[0] : v[1], 0x128);     // row_ror:8
     const float a1 = GS_DPP_ADD(b8 ? v[3] : v[2], b8 ? v[2] : v[3], 0x128);
     const float a2 = GS_DPP_ADD(b8 ? v[5] : v[4], b8 ? v[4] : v[5], 0x128);
     const float a3 = GS_DPP_ADD(b8 ? v[7] : v[6], b8 ? v[6] : v[7], 0x128);
-    const float a4 = GS_DPP_ADD(v[8], v[8], 0x128);
+    const float a4 = GS_DPP_ADD(b8 ? v[9] : v[8], b8 ? v[8] : v[9], 0x128);
     // level B: partner = mirror within the 8-lane half
     const float c0 = GS_DPP_ADD(b4 ? a1 : a0, b4 ? a0 : a1, 0x141);             // row_half_mirror
     const float c1 = GS_DPP_ADD(b4 ? a3 : a2, b4 ? a2 : a3, 0x141);
@@ -217,20 +222,24 @@ __device__ __forceinline__ float row_reduce9(const float (&v)[9], bool b8, bool 
     // level D: partner lane^1
     return GS_DPP_ADD(b1 ? e1 : e0, b1 ? e0 : e1, 0xB1);                         // quad_perm:[1,0,3,2]
 }
-// component carried by lane l16 of a row after row_reduce9 (odd lanes all hold component 8: use lane 1)
-__device__ __forceinline__ int row_comp(int l16)
+// component carried by lane l16 of a row after row_reduce10 (odd lanes hold component 8 (lanes 1..7) or
+// 9 (lanes 9..15): lanes 1 and 9 are used)
+__device__ __forceinline__ int row_comp(int l16, bool with9)
 {
-    if (l16 & 1) return l16 == 1 ? 8 : -1;
+    if (l16 & 1) return l16 == 1 ? 8 : ((l16 == 9 && with9) ? 9 : -1);
     return ((l16 & 2) ? 4 : 0) + ((l16 & 4) ? 2 : 0) + ((l16 & 8) ? 1 : 0);
 }
 
 // Per-Gaussian 2-D gradient record accumulated here (raw moments; the conic algebra is finished per
 // Gaussian in preprocess_bwd.hip):  with Z = G dL/dG, d = mean - pixel
 //   0: sum Z dx   1: sum Z dy   2: sum Z dx dx   3: sum Z dx dy   4: sum Z dy dy   5: sum G dL/dalpha   6..8: sum w dL/dC
+//   9: sum w dL/d(depth)   (DEPTH_GRAD: the depth output is one more blended channel whose per-Gaussian value
+//      is the view-space z; this is the fused replacement of the reference's second, [z,1,z^2] raster pass)
+template <bool DEPTH_GRAD>
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dcolor, float* __restrict__ grad2d)
+    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, float* __restrict__ grad2d)
 {
     __shared__ float4 s_rec[kBlock / kWave][3][kWave];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -250,8 +259,9 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const uint32_t last = inside ? n_contrib[pix] : 0u;
     const float d0 = inside ? dL_dcolor[pix] : 0.f, d1 = inside ? dL_dcolor[HW + pix] : 0.f,
                 d2 = inside ? dL_dcolor[2 * HW + pix] : 0.f;
+    const float dz_ = (DEPTH_GRAD && inside) ? dL_ddepth[pix] : 0.f;
     const float tfbg = Tf * (cam.bg[0] * d0 + cam.bg[1] * d1 + cam.bg[2] * d2);    // background term of dL/dalpha
-    float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accz = 0.f;
 
     // the deepest contributor of any pixel of this quadrant bounds the replay
     uint32_t wmax = last;
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
 
     const uint32_t row8 = (uint32_t)row * 8u;
     const bool b8 = (l16 & 8) != 0, b4 = (l16 & 4) != 0, b2 = (l16 & 2) != 0, b1 = (l16 & 1) != 0;
-    const int my_comp = row_comp(l16);
+    const int my_comp = row_comp(l16, DEPTH_GRAD);
     const int cmax = (int)((wmax - 1) / kWave);
     // pipeline prologue (walking chunks downwards): ids of chunks cmax and cmax-1, records of chunk cmax
     uint32_t id_next = (uint32_t)cmax * kWave + lane < wmax ? list[cmax * kWave + lane] : kNoId;
@@ -310,16 +320,22 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             const float rcp = __builtin_amdgcn_rcpf(1.0f - a_eff);
             T = T * rcp;                                          // transmittance in front of this record
             const float df0 = a1.z - acc0, df1 = a1.w - acc1, df2 = a2.x - acc2;
-            const float dL_dalpha = (df0 * d0 + df1 * d1 + df2 * d2) * T - tfbg * rcp;
+            float dot = df0 * d0 + df1 * d1 + df2 * d2;
+            if (DEPTH_GRAD) {
+                const float dfz = a2.y - accz;
+                dot += dfz * dz_;
+                accz += a_eff * dfz;
+            }
+            const float dL_dalpha = dot * T - tfbg * rcp;
             const float w = a_eff * T;
             acc0 += a_eff * df0; acc1 += a_eff * df1; acc2 += a_eff * df2;
             const float GdA = G_eff * dL_dalpha;
             const float Z = a1.y * GdA;                           // G dL/dG
             const float zx = Z * dx, zy = Z * dy;
-            const float v[9] = {zx, zy, zx * dx, zx * dy, zy * dy, GdA, w * d0, w * d1, w * d2};
-            const float x = row_reduce9(v, b8, b4, b2, b1);
-            // every row that had a contributing pixel adds its 9 components to ITS record: one hardware fp32 atomic
-            // instruction, 9 lanes per row, each record's components inside one 64-byte line (kGradStride = 16)
+            const float v[10] = {zx, zy, zx * dx, zx * dy, zy * dy, GdA, w * d0, w * d1, w * d2, DEPTH_GRAD ? w * dz_ : 0.0f};
+            const float x = row_reduce10(v, b8, b4, b2, b1);
+            // every row that had a contributing pixel adds its 9 (10) components to ITS record: one hardware fp32 atomic
+            // instruction, 9-10 lanes per row, each record's components inside one 64-byte line (kGradStride = 16)
             const bool row_any = ((okm >> (row * 16)) & 0xffffull) != 0ull;
             if (row_any && my_comp >= 0) atomicAdd(grad2d + (size_t)__float_as_uint(a2.z) * kGradStride + my_comp, x);
         }
@@ -329,21 +345,29 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
 
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
-                                uint32_t* n_contrib, hipStream_t st)
+                                uint32_t* n_contrib, float* out_depth_sq, hipStream_t st)
 {
     const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
-                       out_color, out_depth, out_opacity, final_T, n_contrib);
+    if (out_depth_sq)
+        hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
+                           out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq);
+    else
+        hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
+                           out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq);
     return hipGetLastError();
 }
 
 hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                 float* grad2d, hipStream_t st)
+                                 const float* dL_ddepth, float* grad2d, hipStream_t st)
 {
     const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
-                       final_T, n_contrib, dL_dcolor, grad2d);
+    if (dL_ddepth)
+        hipLaunchKernelGGL(blend_backward_kernel<true>, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
+                           final_T, n_contrib, dL_dcolor, dL_ddepth, grad2d);
+    else
+        hipLaunchKernelGGL(blend_backward_kernel<false>, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
+                           final_T, n_contrib, dL_dcolor, dL_ddepth, grad2d);
     return hipGetLastError();
 }
 

@@ -129,10 +129,10 @@ hipError_t launch_emit(const Cam& cam, int P, GeomPtrs gp, uint64_t* keys, uint3
 hipError_t launch_ranges(int64_t D, const uint64_t* keys_sorted, uint2* ranges, hipStream_t st);
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
-                                uint32_t* n_contrib, hipStream_t st);
+                                uint32_t* n_contrib, float* out_depth_sq, hipStream_t st);
 hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                 float* grad2d, hipStream_t st);
+                                 const float* dL_ddepth, float* grad2d, hipStream_t st);
 hipError_t launch_adam(int64_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2,
                        double eps, int step, hipStream_t st);
 
@@ -147,5 +147,5 @@ hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, ui
 
 constexpr int kGradStride = 16;   // floats per Gaussian in the 2-D gradient record (64 B = one cache line, so an
                                   // atomic flush of the 9 components is ONE memory-side read-modify-write):
-                                  // 0,1 dL/dxy(pixel) 2,3,4 dL/dconic(a,b,c) 5 dL/dopacity 6,7,8 dL/drgb
+                                  // raw moments, see blend.hip: 0..4 geometry, 5 opacity, 6..8 colour, 9 view depth
 }  // namespace gs

@@ -188,6 +188,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
         const float dty = oky ? -cam.fy * itz2 * dJ12 : 0.f;
         const float dtz = -cam.fx * itz2 * dJ00 - cam.fy * itz2 * dJ11 + 2.f * cam.fx * cx_ * itz3 * dJ02 + 2.f * cam.fy * cy_ * itz3 * dJ12;
         for (int c = 0; c < 3; c++) dmean[c] += dtx * W0[c] + dty * W1[c] + dtz * W2[c];
+        // gradient of the blended depth output w.r.t. this Gaussian's view depth z = W2 . p + t_z (zero unless the
+        // fused RGB-D backward ran)
+        for (int c = 0; c < 3; c++) dmean[c] += gc.y * W2[c];
         // ---- mean2D -> mean3D through the projective divide ----
         // dL/dmean2D (pixels) = -(conic d-moments): (-(a M1x + b M1y), -(c M1y + b M1x)); conic = 1/det (r, -q, p)
         const float idet = 1.0f / det;

@@ -29,6 +29,7 @@ import torch.nn.functional as F
 from .camera import setup_camera
 from .rasterizer import GaussianRasterizationSettings as Camera
 from .rasterizer import GaussianRasterizer as Renderer
+from .rasterizer import render_rgbd
 
 _GAUSSIAN_KEYS = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales")
 
@@ -157,18 +158,25 @@ def calc_ssim(img1, img2):
 
 
 def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_for_loss=True, sil_thres=0.99,
-             use_l1=True, ignore_outlier_depth_loss=False, do_ba=False):
-    """Mapping loss: two raster passes on the same geometry (RGB, then [z,1,z^2]); masked depth L1 +
-    0.8 L1 + 0.2 (1 - SSIM) on colour; updates variables['means2D'|'seen'|'max_2D_radius']."""
+             use_l1=True, ignore_outlier_depth_loss=False, do_ba=False, fused=False):
+    """Mapping loss: masked depth L1 + 0.8 L1 + 0.2 (1 - SSIM) on colour; updates
+    variables['means2D'|'seen'|'max_2D_radius'].
+    fused=False: the reference's two raster passes on the same geometry (RGB, then [z,1,z^2]).
+    fused=True : ONE pass (rasterizer.render_rgbd) -- valid because curr_data['w2c'] is the settings' view
+                 matrix at every reference call site; means2D.grad then also carries the depth term (the
+                 reference's densifier sees the colour pass only)."""
     tg = transform_to_frame(params, iter_time_idx, gaussians_grad=True, camera_grad=do_ba)
     rendervar = transformed_params2rendervar(params, tg)
-    depth_sil_rendervar = transformed_params2depthplussilhouette(params, curr_data["w2c"], tg)
     rendervar["means2D"].retain_grad()
-    im, radius, _, _ = Renderer(raster_settings=curr_data["cam"])(**rendervar)
+    if fused:
+        im, radius, depth, _sil, depth_sq = render_rgbd(curr_data["cam"], **rendervar)
+    else:
+        depth_sil_rendervar = transformed_params2depthplussilhouette(params, curr_data["w2c"], tg)
+        im, radius, _, _ = Renderer(raster_settings=curr_data["cam"])(**rendervar)
+        depth_sil, _, _, _ = Renderer(raster_settings=curr_data["cam"])(**depth_sil_rendervar)
+        depth = depth_sil[0].unsqueeze(0)
+        depth_sq = depth_sil[2].unsqueeze(0)
     variables["means2D"] = rendervar["means2D"]          # densification reads the colour pass' gradient only
-    depth_sil, _, _, _ = Renderer(raster_settings=curr_data["cam"])(**depth_sil_rendervar)
-    depth = depth_sil[0].unsqueeze(0)
-    depth_sq = depth_sil[2].unsqueeze(0)
     uncertainty = (depth_sq - depth ** 2).detach()
     mask = curr_data["depth"] > 0
     if ignore_outlier_depth_loss:

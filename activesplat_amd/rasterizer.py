@@ -85,8 +85,12 @@ def _camera(rs: GaussianRasterizationSettings, device, sh_coeffs: int):
 
 
 class _RasterizeGaussians(torch.autograd.Function):
+    """fused=False: the reference contract (color differentiable; radii, depth, opacity not).
+    fused=True : one pass also yields the reference's SECOND raster pass -- depth (differentiable), silhouette
+                 (= opacity) and depth^2 -- see render_rgbd()."""
+
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs):
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, fused=False):
         lib = _lib.get()
         device = means3D.device
         if device.type != "cuda" and not _lib.emulated():
@@ -126,10 +130,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         color = torch.empty(3, H, W, dtype=torch.float32, device=device)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=device)
         opacity = torch.empty(1, H, W, dtype=torch.float32, device=device)
+        depth_sq = torch.empty(1, H, W, dtype=torch.float32, device=device) if fused else None
         _lib.check(lib.gs_render_forward(C.byref(cam), P, D, max_tile, _ptr(geom), _ptr(binning), _ptr(point_list), _ptr(image),
-                                         _ptr(color), _ptr(depth), _ptr(opacity), st))
+                                         _ptr(color), _ptr(depth), _ptr(opacity), _ptr(depth_sq), st))
         last_stats["num_rendered"], last_stats["P"], last_stats["max_tile_instances"] = D, P, max_tile
-        ctx.rs, ctx.D, ctx.keep = rs, D, keep
+        ctx.rs, ctx.D, ctx.keep, ctx.fused = rs, D, keep, fused
         ctx.has = (shs is not None, colors_precomp is not None, scales is not None, rotations is not None,
                    cov3D_precomp is not None)
         if rs.debug:
@@ -139,12 +144,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means3D, shs if shs is not None else e, colors_precomp if colors_precomp is not None else e,
                               scales if scales is not None else e, rotations if rotations is not None else e,
                               cov3D_precomp if cov3D_precomp is not None else e, radii, geom, point_list, image)
-        ctx.mark_non_differentiable(radii, depth, opacity)
         ctx.set_materialize_grads(False)          # no zero-filled grad tensors for the non-differentiable outputs
+        if fused:
+            ctx.mark_non_differentiable(radii, opacity, depth_sq)
+            return color, radii, depth, opacity, depth_sq
+        ctx.mark_non_differentiable(radii, depth, opacity)
         return color, radii, depth, opacity
 
     @staticmethod
-    def backward(ctx, grad_color, _gr, _gd, _go):
+    def backward(ctx, grad_color, _gr=None, grad_depth=None, _go=None, _gq=None):
         lib = _lib.get()
         means3D, shs, colors, scales, rots, cov3Dp, radii, geom, point_list, image = ctx.saved_tensors
         has_sh, has_col, has_sc, has_rot, has_cov = ctx.has
@@ -155,6 +163,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if grad_color is None:
             grad_color = torch.zeros(3, int(ctx.rs.image_height), int(ctx.rs.image_width), device=device)
         grad_color = _f32(grad_color, device)
+        grad_depth = _f32(grad_depth, device) if (ctx.fused and grad_depth is not None) else None
         z = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731  (kernel writes every row)
         d_m2d, d_m3d, d_op = z(P, 3), z(P, 3), z(P, 1)
         d_col = z(P, 3) if has_col else None
@@ -166,16 +175,39 @@ class _RasterizeGaussians(torch.autograd.Function):
         _lib.check(lib.gs_render_backward(
             C.byref(cam), P, ctx.D, _ptr(means3D), _ptr(shs if has_sh else None), _ptr(colors if has_col else None),
             _ptr(scales if has_sc else None), _ptr(rots if has_rot else None), _ptr(cov3Dp if has_cov else None),
-            _ptr(radii), _ptr(geom), _ptr(point_list), _ptr(image), _ptr(grad_color),
+            _ptr(radii), _ptr(geom), _ptr(point_list), _ptr(image), _ptr(grad_color), _ptr(grad_depth),
             _ptr(d_m2d), _ptr(d_m3d), _ptr(d_op), _ptr(d_col), _ptr(d_shs), _ptr(d_sc), _ptr(d_rot), _ptr(d_cov),
             _ptr(scratch), _stream(device)))
-        return d_m3d, d_m2d, d_shs, d_col, d_op, d_sc, d_rot, d_cov, None
+        return d_m3d, d_m2d, d_shs, d_col, d_op, d_sc, d_rot, d_cov, None, None
 
 
 def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                         raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                      cov3D_precomp, raster_settings)
+
+
+def render_rgbd(raster_settings, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+    """Single-pass RGB + depth + silhouette render -- an ADDITIONAL entry point, the
+    drop-in GaussianRasterizer is unchanged.
+
+    The reference rasterises every training iteration twice on identical geometry: once for RGB and once with
+    per-Gaussian "colours" [z_cam, 1, z_cam^2] (src/mapper/splatam/splatam.py:208,212 with
+    utils/slam_helpers.py:196-249).  With the settings' viewmatrix equal to the w2c used for z_cam (true at every
+    reference call site) those three channels are sum z*alpha*T, sum alpha*T and sum z^2*alpha*T of the SAME blend,
+    so one pass returns
+        color [3,H,W], radii [P], depth [1,H,W], silhouette [1,H,W], depth_sq [1,H,W]
+    with `color` AND `depth` differentiable (the mapping loss back-propagates through both; silhouette and
+    depth_sq are only used as masks / detached, splatam.py:213-231).  The depth gradient reaches means3D through
+    the per-Gaussian view depth exactly as in the two-pass formulation."""
+    if (shs is None) == (colors_precomp is None):
+        raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+            ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+    return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                     raster_settings, True)
 
 
 class GaussianRasterizer(nn.Module):

@@ -136,19 +136,23 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P,
 
 /* Stage 2: bin the instances by tile and depth-sort every tile list, then front-to-back alpha blend.
  * out_color [3,H,W], out_depth [1,H,W] (sum z*alpha*T), out_opacity [1,H,W] (1 - T_final).
- * point_list [D] receives the (tile, depth, index)-sorted Gaussian ids (kept for the backward). */
+ * point_list [D] receives the (tile, depth, index)-sorted Gaussian ids (kept for the backward).
+ * out_depth_sq [1,H,W] (nullable) additionally receives sum z^2*alpha*T: with out_depth and out_opacity these are
+ * the three channels of the reference's second, [z, 1, z^2] raster pass (slam_helpers.py:196-249), produced by
+ * the SAME pass as the colour. */
 int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_tile_instances,
                       void* geom_state, void* bin_state, uint32_t* point_list, void* image_state,
-                      float* out_color, float* out_depth, float* out_opacity, gs_stream_t stream);
+                      float* out_color, float* out_depth, float* out_opacity, float* out_depth_sq,
+                      gs_stream_t stream);
 
-/* Backward of `out_color` w.r.t. every input.  Any dL_d* output pointer may be NULL if that input
+/* Backward of `out_color` (and, when dL_ddepth [1,H,W] is non-NULL, of `out_depth`) w.r.t. every input.  Any dL_d* output pointer may be NULL if that input
  * was not given (shs vs colors_precomp, scales/rotations vs cov3D_precomp).
  * dL_dmeans2D [P,3] receives the NDC-scaled screen-space gradient (x*0.5W, y*0.5H, 0). */
 int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D,
                        const float* means3D, const float* shs, const float* colors_precomp,
                        const float* scales, const float* rotations, const float* cov3D_precomp,
                        const int32_t* radii, const void* geom_state, const uint32_t* point_list,
-                       const void* image_state, const float* dL_dcolor,
+                       const void* image_state, const float* dL_dcolor, const float* dL_ddepth,
                        float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities,
                        float* dL_dcolors_precomp, float* dL_dshs, float* dL_dscales,
                        float* dL_drotations, float* dL_dcov3D, void* scratch, gs_stream_t stream);

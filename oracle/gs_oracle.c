@@ -309,14 +309,15 @@ void gso_bin(const GsoCam *cam, const real *depth, const int32_t *rect, const ui
  * ---------------------------------------------------------------------------------------- */
 void gso_blend_forward(const GsoCam *cam, int NC, const real *bg, const uint32_t *ranges, const uint32_t *ids,
                        const real *xy, const real *depth, const real *conic_opacity, const real *feat,
-                       real *out_color, real *out_depth, real *out_opacity, real *final_T, uint32_t *n_contrib)
+                       real *out_color, real *out_depth, real *out_opacity, real *final_T, uint32_t *n_contrib,
+                       real *out_depth_sq /* nullable: sum z^2 alpha T (the reference's third depth/silhouette channel) */)
 {
     const int W = cam->W, H = cam->H, gx = (W + TILE - 1) / TILE;
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             const int t = (y / TILE) * gx + (x / TILE);
             const uint32_t s = ranges[2 * t], e = ranges[2 * t + 1];
-            real T = 1, C[16], Dp = 0;
+            real T = 1, C[16], Dp = 0, Dq = 0;
             for (int ch = 0; ch < NC; ch++) C[ch] = 0;
             uint32_t contributor = 0, last = 0;
             for (uint32_t j = s; j < e; j++) {
@@ -333,6 +334,7 @@ void gso_blend_forward(const GsoCam *cam, int NC, const real *bg, const uint32_t
                 const real w = alpha * T;
                 for (int ch = 0; ch < NC; ch++) C[ch] += feat[(size_t)NC * g + ch] * w;
                 Dp += depth[g] * w;
+                Dq += depth[g] * depth[g] * w;
                 T = test_T;
                 last = contributor;
             }
@@ -340,6 +342,7 @@ void gso_blend_forward(const GsoCam *cam, int NC, const real *bg, const uint32_t
             final_T[pix] = T; n_contrib[pix] = last;
             for (int ch = 0; ch < NC; ch++) out_color[(size_t)ch * H * W + pix] = C[ch] + T * bg[ch];
             out_depth[pix] = Dp; out_opacity[pix] = R(1) - T;
+            if (out_depth_sq) out_depth_sq[pix] = Dq;
         }
 }
 
@@ -351,11 +354,14 @@ void gso_blend_forward(const GsoCam *cam, int NC, const real *bg, const uint32_t
 void gso_blend_backward(const GsoCam *cam, int NC, const real *bg, const uint32_t *ranges, const uint32_t *ids,
                         const real *xy, const real *conic_opacity, const real *feat,
                         const real *final_T, const uint32_t *n_contrib, const real *dL_dpix,
-                        real *dL_dxy, real *dL_dconic, real *dL_dopacity, real *dL_dfeat)
+                        real *dL_dxy, real *dL_dconic, real *dL_dopacity, real *dL_dfeat,
+                        const real *depth /* per-Gaussian view z */, const real *dL_ddepth /* nullable [H*W] */,
+                        real *dL_dz /* nullable [P]: gradient w.r.t. the per-Gaussian view depth */)
 {
     const int W = cam->W, H = cam->H, P = cam->P, gx = (W + TILE - 1) / TILE;
     memset(dL_dxy, 0, sizeof(real) * 2 * (size_t)P); memset(dL_dconic, 0, sizeof(real) * 3 * (size_t)P);
     memset(dL_dopacity, 0, sizeof(real) * (size_t)P); memset(dL_dfeat, 0, sizeof(real) * (size_t)NC * P);
+    if (dL_dz) memset(dL_dz, 0, sizeof(real) * (size_t)P);
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             const int t = (y / TILE) * gx + (x / TILE);
@@ -364,6 +370,8 @@ void gso_blend_backward(const GsoCam *cam, int NC, const real *bg, const uint32_
             const real Tf = final_T[pix];
             const uint32_t last = n_contrib[pix];
             real T = Tf, dpx[16], accum[16], lastc[16], last_alpha = 0, bgdot = 0;
+            const real dd = dL_ddepth ? dL_ddepth[pix] : 0;
+            real accumz = 0, lastz = 0;
             for (int ch = 0; ch < NC; ch++) {
                 dpx[ch] = dL_dpix[(size_t)ch * H * W + pix]; accum[ch] = 0; lastc[ch] = 0; bgdot += bg[ch] * dpx[ch];
             }
@@ -385,6 +393,12 @@ void gso_blend_backward(const GsoCam *cam, int NC, const real *bg, const uint32_
                     lastc[ch] = c;
                     dL_dalpha += (c - accum[ch]) * dpx[ch];
                     dL_dfeat[(size_t)NC * g + ch] += w * dpx[ch];
+                }
+                if (dL_ddepth) {          /* the depth output is one more blended channel (background 0) */
+                    accumz = last_alpha * lastz + (R(1) - last_alpha) * accumz;
+                    lastz = depth[g];
+                    dL_dalpha += (depth[g] - accumz) * dd;
+                    dL_dz[g] += w * dd;
                 }
                 dL_dalpha *= T;
                 last_alpha = alpha;
@@ -412,7 +426,7 @@ void gso_blend_backward(const GsoCam *cam, int NC, const real *bg, const uint32_
  * ---------------------------------------------------------------------------------------- */
 void gso_preprocess_backward(const GsoCam *cam, const real *means3D, const real *shs, const real *scales,
                              const real *rots, const int32_t *radii, const real *cov3d, const uint8_t *clamped,
-                             const real *dL_dxy, const real *dL_dconic, const real *dL_drgb,
+                             const real *dL_dxy, const real *dL_dconic, const real *dL_drgb, const real *dL_dz /* nullable */,
                              real *dL_dmeans2D, real *dL_dmeans3D, real *dL_dscales, real *dL_drots,
                              real *dL_dcov3D, real *dL_dshs, real *dL_dcolors)
 {
@@ -498,6 +512,7 @@ void gso_preprocess_backward(const GsoCam *cam, const real *means3D, const real 
         const real dty = oky ? -fy * tz2 * dJ12 : 0;
         const real dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + R(2) * fx * cx_ * tz3 * dJ02 + R(2) * fy * cy_ * tz3 * dJ12;
         for (int c = 0; c < 3; c++) dmean[c] += dtx * Wm[0][c] + dty * Wm[1][c] + dtz * Wm[2][c];
+        if (dL_dz) for (int c = 0; c < 3; c++) dmean[c] += dL_dz[i] * Wm[2][c];       /* view depth z = W[2,:] p + t_z */
         /* ---- mean2D -> mean3D through the projective divide ---- */
         const real gxn = dL_dxy[2 * i] * R(0.5) * (real)W, gyn = dL_dxy[2 * i + 1] * R(0.5) * (real)H;
         dL_dmeans2D[3 * i] = gxn; dL_dmeans2D[3 * i + 1] = gyn;

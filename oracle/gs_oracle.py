@@ -106,23 +106,27 @@ class Oracle:
         bg = r(cam["bg"]).reshape(3)
         o.update(color=np.zeros((3, H, W), self.real), out_depth=np.zeros((1, H, W), self.real),
                  opacity=np.zeros((1, H, W), self.real), final_T=np.zeros((H, W), self.real),
-                 n_contrib=np.zeros((H, W), np.uint32))
+                 n_contrib=np.zeros((H, W), np.uint32), depth_sq=np.zeros((1, H, W), self.real))
         self.lib.gso_blend_forward(C.byref(c), 3, _ptr(bg), _ptr(o["ranges"]), _ptr(o["ids_sorted"]), _ptr(o["xy"]),
                                    _ptr(o["depth"]), _ptr(o["conic_opacity"]), _ptr(o["rgb"]), _ptr(o["color"]),
-                                   _ptr(o["out_depth"]), _ptr(o["opacity"]), _ptr(o["final_T"]), _ptr(o["n_contrib"]))
+                                   _ptr(o["out_depth"]), _ptr(o["opacity"]), _ptr(o["final_T"]), _ptr(o["n_contrib"]),
+                                   _ptr(o["depth_sq"]))
         o["_ctx"] = dict(c=c, means3D=means3D, shs=shs, scales=scales, rots=rots, bg=bg, colors=colors)
         return o
 
     # -- backward -------------------------------------------------------------------------
-    def backward(self, fwd: dict, dL_dcolor) -> dict:
+    def backward(self, fwd: dict, dL_dcolor, dL_ddepth=None) -> dict:
+        """dL_ddepth [1,H,W] (optional): gradient w.r.t. the `out_depth` output (fused RGB-D path)."""
         ctx = fwd["_ctx"]; c = ctx["c"]; P = c.P
         dpix = self._r(dL_dcolor).reshape(3, c.H, c.W)
+        ddep = None if dL_ddepth is None else self._r(dL_ddepth).reshape(c.H, c.W)
+        dz = None if dL_ddepth is None else np.zeros(P, self.real)
         dxy = np.zeros((P, 2), self.real); dconic = np.zeros((P, 3), self.real)
         dop = np.zeros(P, self.real); dfeat = np.zeros((P, 3), self.real)
         self.lib.gso_blend_backward(C.byref(c), 3, _ptr(ctx["bg"]), _ptr(fwd["ranges"]), _ptr(fwd["ids_sorted"]),
                                     _ptr(fwd["xy"]), _ptr(fwd["conic_opacity"]), _ptr(fwd["rgb"]),
                                     _ptr(fwd["final_T"]), _ptr(fwd["n_contrib"]), _ptr(dpix), _ptr(dxy),
-                                    _ptr(dconic), _ptr(dop), _ptr(dfeat))
+                                    _ptr(dconic), _ptr(dop), _ptr(dfeat), _ptr(fwd["depth"]), _ptr(ddep), _ptr(dz))
         M = c.sh_coeffs
         g = dict(means2D=np.zeros((P, 3), self.real), means3D=np.zeros((P, 3), self.real),
                  scales=np.zeros((P, 3), self.real), rotations=np.zeros((P, 4), self.real),
@@ -130,7 +134,7 @@ class Oracle:
                  colors_precomp=np.zeros((P, 3), self.real))
         self.lib.gso_preprocess_backward(C.byref(c), _ptr(ctx["means3D"]), _ptr(ctx["shs"]), _ptr(ctx["scales"]),
                                          _ptr(ctx["rots"]), _ptr(fwd["radii"]), _ptr(fwd["cov3d"]),
-                                         _ptr(fwd["clamped"]), _ptr(dxy), _ptr(dconic), _ptr(dfeat),
+                                         _ptr(fwd["clamped"]), _ptr(dxy), _ptr(dconic), _ptr(dfeat), _ptr(dz),
                                          _ptr(g["means2D"]), _ptr(g["means3D"]), _ptr(g["scales"]),
                                          _ptr(g["rotations"]), _ptr(g["cov3D_precomp"]), _ptr(g["shs"]),
                                          _ptr(g["colors_precomp"]))

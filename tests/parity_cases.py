@@ -126,3 +126,58 @@ def check_backward(rs, rv, oracle64, seed=0):
         rel = np.linalg.norm(g.astype(np.float64) - r) / np.linalg.norm(r)
         assert rel < 1e-3, (k, rel)
     return got, ref
+
+
+def check_fused_rgbd(rs, rv, oracle64, seed=0):
+    """rasterizer.render_rgbd (one pass) vs (a) the two reference-style passes of the same library and
+    (b) the fp64 oracle with a depth gradient."""
+    from activesplat_amd import rasterizer as R
+    H, W = int(rs.image_height), int(rs.image_width)
+    dev = rv["means3D"].device
+    g = torch.Generator().manual_seed(seed)
+    dLc = torch.randn(3, H, W, generator=g).to(dev)
+    dLd = torch.randn(1, H, W, generator=g).to(dev)
+    P = rv["means3D"].shape[0]
+
+    def leaves():
+        inp = {k: v.detach().clone().requires_grad_(True) for k, v in rv.items()}
+        return inp, torch.zeros(P, 3, device=dev, requires_grad=True)
+    # (1) fused
+    inp, m2d = leaves()
+    color, radii, depth, sil, dsq = R.render_rgbd(rs, means2D=m2d, **inp)
+    ((color * dLc).sum() + (depth * dLd).sum()).backward()
+    gf = {k: v.grad.detach().cpu().numpy() for k, v in inp.items()}
+    gf["means2D"] = m2d.grad.detach().cpu().numpy()
+    # (2) two passes, the second with colours [z_cam, 1, z_cam^2] built from means3D (viewmatrix row-vector convention)
+    inp2, m2a = leaves()
+    m2b = torch.zeros(P, 3, device=dev, requires_grad=True)
+    c1, r1, _, _ = R.GaussianRasterizer(raster_settings=rs)(means2D=m2a, **inp2)
+    V = rs.viewmatrix.reshape(4, 4).to(dev)
+    z = inp2["means3D"] @ V[:3, 2] + V[3, 2]
+    second = {k: v for k, v in inp2.items() if k not in ("colors_precomp", "shs")}
+    c2, _, _, _ = R.GaussianRasterizer(raster_settings=rs._replace(bg=torch.zeros(3, device=dev)))(
+        means2D=m2b, colors_precomp=torch.stack([z, torch.ones_like(z), z * z], 1), **second)
+    ((c1 * dLc).sum() + (c2[0:1] * dLd).sum()).backward()
+    n = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    assert np.array_equal(n(radii), n(r1))
+    np.testing.assert_array_equal(n(color), n(c1))
+    for a, b, name in ((depth[0], c2[0], "depth"), (sil[0], c2[1], "silhouette"), (dsq[0], c2[2], "depth_sq")):
+        sc = max(1.0, float(n(b).max()))
+        assert close_frac(n(a), n(b), 1e-5, 2e-6 * sc) > 0.9999, name
+    for k in gf:
+        two = n(inp2[k].grad) if k != "means2D" else n(m2a.grad) + n(m2b.grad)
+        rel = np.linalg.norm(gf[k].astype(np.float64) - two) / max(np.linalg.norm(two), 1e-30)
+        assert rel < 1e-4, (k, rel)
+    # (3) fp64 oracle
+    ref = util.run_oracle(oracle64, rs, rv)
+    go = oracle64.backward(ref, dLc.cpu().numpy(), dLd.cpu().numpy())
+    for k, gq in gf.items():
+        r = go[k].reshape(gq.shape)
+        rel = np.linalg.norm(gq.astype(np.float64) - r) / max(np.linalg.norm(r), 1e-30)
+        assert rel < 1e-3, (k, rel)
+    sc = max(1.0, float(ref["depth_sq"].max()))
+    assert close_frac(n(dsq), ref["depth_sq"], FWD_RTOL, FWD_ATOL * sc) >= 0.999
+
+
+def close_frac(a, b, rtol, atol):
+    return util.close_frac(a, b, rtol, atol)

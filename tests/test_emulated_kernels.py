@@ -52,3 +52,27 @@ def test_emulated_adam_matches_torch(emu):
         _lib.check(lib.gs_adam_step(n, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 1e-3, 0.9, 0.999, 1e-15,
                                     step, None))
         np.testing.assert_allclose(p.numpy(), ref.detach().numpy(), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", ["basic", "posed_white_bg", "ragged_image", "sh2", "dense_overdraw"])
+def test_emulated_fused_rgbd_matches_two_passes_and_oracle(emu, oracle64, case):
+    rs, rv = pc.build_case(case, emu)
+    pc.check_fused_rgbd(rs, rv, oracle64)
+
+
+def test_emulated_fused_loss_equals_two_pass_loss(emu):
+    """mapping.get_loss(fused=True) == the reference-style two-pass loss, value and parameter gradients."""
+    from activesplat_amd import mapping as M
+    from tests.test_parallel import _scene
+    out = []
+    for fused in (False, True):
+        params, kfs = _scene(n=500)
+        n = params["means3D"].shape[0]
+        variables = {k: torch.zeros(n) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+        loss, variables, _ = M.get_loss(params, kfs[1], variables, 1, dict(im=0.5, depth=1.0), fused=fused)
+        loss.backward()
+        out.append((float(loss), {k: v.grad.clone() for k, v in params.items() if v.grad is not None}))
+    assert abs(out[0][0] - out[1][0]) < 1e-6 * abs(out[0][0])
+    for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
+        a, b = out[0][1][k], out[1][1][k]
+        assert float((a - b).norm() / a.norm()) < 1e-4, k

@@ -167,3 +167,23 @@ def test_adam_matches_torch_optim_adam(oracle64):
         opt.step()
         pn, m, v = oracle64.adam(pn, g.numpy(), m, v, 2.5e-3, step)
         np.testing.assert_allclose(pn, ref.detach().numpy(), rtol=1e-12, atol=1e-14)
+
+
+def test_c_oracle_depth_gradient_equals_fp64_autograd(oracle64):
+    """The fused RGB-D backward: loss over colour AND the blended depth output."""
+    torch.manual_seed(1)
+    W, H, N = 48, 40, 300
+    rs, rv = util.scene(N, W, H, seed=5, w2c=util.pose(-0.15, (0.05, 0.02, 0.1)), bg=(0.2, 0.3, 0.1))
+    cd = util.cam_dict(rs)
+    inp = {k: v.double().clone().requires_grad_(True) for k, v in rv.items()}
+    m2d = torch.zeros(N, 3, dtype=torch.float64, requires_grad=True)
+    d = render_dense(cd, inp["means3D"], inp["opacities"], colors=inp["colors_precomp"], scales=inp["scales"],
+                     rotations=inp["rotations"], means2D=m2d)
+    dLc = torch.randn(3, H, W, dtype=torch.float64); dLd = torch.randn(1, H, W, dtype=torch.float64)
+    ((d["color"] * dLc).sum() + (d["depth"] * dLd).sum()).backward()
+    f = util.run_oracle(oracle64, rs, {k: v.detach() for k, v in inp.items()})
+    g = oracle64.backward(f, dLc.numpy(), dLd.numpy())
+    for k, t in inp.items():
+        a = t.grad.numpy()
+        np.testing.assert_allclose(g[k].reshape(a.shape), a, atol=1e-10 * max(1.0, np.abs(a).max()))
+    np.testing.assert_allclose(g["means2D"], m2d.grad.numpy(), atol=1e-10 * np.abs(m2d.grad.numpy()).max())
