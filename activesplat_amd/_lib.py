@@ -44,7 +44,7 @@ SORT_AUTO, SORT_TILE_LDS, SORT_RADIX = 0, 1, 2
 SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
            "gs_version", "gs_set_sort_path", "gs_preprocess_forward", "gs_render_forward", "gs_render_backward", "gs_adam_step",
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
-           "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows")
+           "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward")
 
 
 def _bind(lib):
@@ -68,6 +68,14 @@ def _bind(lib):
     lib.gs_profile_stage_name.restype = C.c_char_p
     lib.gs_profile_collect.argtypes = [vp, vp, i32]
     lib.gs_profile_collect.restype = C.c_int
+    lib.gs_activate_forward.argtypes = [i32, i32] + [vp] * 9 + [vp]
+    lib.gs_activate_forward.restype = C.c_int
+    lib.gs_activate_backward.argtypes = [i32, i32] + [vp] * 12 + [vp]
+    lib.gs_activate_backward.restype = C.c_int
+    lib.gs_mapping_loss_scratch_bytes.argtypes = [i32, i32]
+    lib.gs_mapping_loss_scratch_bytes.restype = C.c_uint64
+    lib.gs_mapping_loss.argtypes = [i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]
+    lib.gs_mapping_loss.restype = C.c_int
     lib.gs_compact_scratch_bytes.argtypes = [i64]
     lib.gs_compact_scratch_bytes.restype = C.c_uint64
     lib.gs_compact_index.argtypes = [i64, vp, vp, vp, vp, vp]

@@ -340,6 +340,51 @@ int gs_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, flo
     return GS_OK;
 }
 
+int gs_activate_forward(int32_t P, int32_t isotropic, const float* h_pose7, const float* means3D, const float* unnorm_rotations,
+                        const float* logit_opacities, const float* log_scales, float* out_means3D, float* out_rotations,
+                        float* out_opacities, float* out_scales, gs_stream_t stream)
+{
+    if (P < 0 || !h_pose7 || (P > 0 && (!means3D || !unnorm_rotations || !logit_opacities || !log_scales || !out_means3D ||
+                                        !out_rotations || !out_opacities || !out_scales)))
+        return fail(GS_EINVAL, "gs_activate_forward: bad argument");
+    hipError_t e = gs::launch_activate_forward(P, isotropic, h_pose7, means3D, unnorm_rotations, logit_opacities, log_scales,
+                                               out_means3D, out_rotations, out_opacities, out_scales, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_activate_forward: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_activate_backward(int32_t P, int32_t isotropic, const float* h_pose7, const float* unnorm_rotations, const float* out_opacities,
+                         const float* out_scales, const float* g_means3D, const float* g_rotations, const float* g_opacities,
+                         const float* g_scales, float* d_means3D, float* d_unnorm_rotations, float* d_logit_opacities,
+                         float* d_log_scales, gs_stream_t stream)
+{
+    if (P < 0 || !h_pose7 || (P > 0 && (!unnorm_rotations || !out_opacities || !out_scales || !d_means3D || !d_unnorm_rotations ||
+                                        !d_logit_opacities || !d_log_scales)))
+        return fail(GS_EINVAL, "gs_activate_backward: bad argument");
+    hipError_t e = gs::launch_activate_backward(P, isotropic, h_pose7, unnorm_rotations, out_opacities, out_scales, g_means3D, g_rotations,
+                                                g_opacities, g_scales, d_means3D, d_unnorm_rotations, d_logit_opacities, d_log_scales,
+                                                (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_activate_backward: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+uint64_t gs_mapping_loss_scratch_bytes(int32_t width, int32_t height)
+{
+    return align_up((uint64_t)(16 + 9 * (uint64_t)(width > 0 ? width : 1) * (uint64_t)(height > 0 ? height : 1)) * 4);
+}
+
+int gs_mapping_loss(int32_t width, int32_t height, const float* im, const float* gt_im, const float* depth,
+                    const float* depth_sq, const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
+                    float* dL_ddepth, void* scratch, gs_stream_t stream)
+{
+    if (width <= 0 || height <= 0 || !im || !gt_im || !depth || !gt_depth || !losses || !dL_dim || !dL_ddepth || !scratch)
+        return fail(GS_EINVAL, "gs_mapping_loss: bad argument");
+    hipError_t e = gs::launch_mapping_loss(width, height, im, gt_im, depth, depth_sq, gt_depth, w_im, w_depth, losses, dL_dim,
+                                           dL_ddepth, (float*)scratch, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_mapping_loss: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
 uint64_t gs_compact_scratch_bytes(int64_t n) { return align_up(gs::compact_scratch_bytes(n > 0 ? n : 1)); }
 
 int gs_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32_t* d_count, void* scratch, gs_stream_t stream)

@@ -136,6 +136,14 @@ hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint
 hipError_t launch_adam(int64_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2,
                        double eps, int step, hipStream_t st);
 
+hipError_t launch_activate_forward(int P, int iso, const float* pose7, const float* means3D, const float* rots, const float* logit_op,
+                                   const float* log_scales, float* o_means, float* o_rots, float* o_op, float* o_scales, hipStream_t st);
+hipError_t launch_activate_backward(int P, int iso, const float* pose7, const float* rots, const float* o_op, const float* o_scales,
+                                    const float* g_means, const float* g_rots, const float* g_op, const float* g_scales, float* d_means,
+                                    float* d_rots, float* d_logit, float* d_logs, hipStream_t st);
+hipError_t launch_mapping_loss(int W, int H, const float* im, const float* gt, const float* depth, const float* depth_sq,
+                               const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
+                               float* dL_ddepth, float* scratch, hipStream_t st);
 uint64_t compact_scratch_bytes(int64_t n);
 hipError_t launch_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32_t* d_count, void* scratch, hipStream_t st);
 hipError_t launch_gather_rows(int64_t n_out, int row_floats, const uint32_t* src_index, const float* src, float* dst, hipStream_t st);

@@ -39,7 +39,10 @@ from .keyframes import keyframe_selection_overlap
 DEFAULT_CONFIG = dict(
     seed=0, gaussian_distribution="anisotropic", scene_radius_depth_ratio=3, mean_sq_dist_method="projective",
     map_every=5, keyframe_every=5, mapping_window_size=12, mapping_iters=2, step_num=1000,
-    fused_render=False,      # True: one raster pass per iteration (rasterizer.render_rgbd) instead of the reference's two
+    # False = the reference's call pattern; True = the fused HIP paths of this build (same loss, see mapping.get_loss)
+    fused_render=False,      # one raster pass per iteration (rasterizer.render_rgbd) instead of two
+    fused_loss=False,        # masked-L1 + L1 + SSIM value and gradients by gs_mapping_loss
+    fused_inputs=False,      # transform_to_frame + activations by gs_activate_*
     mapping=dict(
         loss_weights=dict(im=0.5, depth=1.0), sil_thres=0.98, use_sil_for_loss=False, use_l1=True,
         ignore_outlier_depth_loss=False, add_new_gaussians=True, prune_gaussians=False,
@@ -133,7 +136,8 @@ class SplatMapper:
                 it_id, it_color, it_depth = kf["id"], kf["color"], kf["depth"]
             loss, self.variables, losses = M.get_loss(self.params, self._data(it_color, it_depth, it_id), self.variables, it_id,
                                                       mc["loss_weights"], mc["use_sil_for_loss"], mc["sil_thres"], mc["use_l1"],
-                                                      mc["ignore_outlier_depth_loss"], fused=cfg["fused_render"])
+                                                      mc["ignore_outlier_depth_loss"], fused=cfg["fused_render"], fused_loss=cfg["fused_loss"],
+                                                      fused_inputs=cfg["fused_inputs"])
             loss.backward()
             with torch.no_grad():
                 if mc["prune_gaussians"]:

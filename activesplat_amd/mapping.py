@@ -157,26 +157,132 @@ def calc_ssim(img1, img2):
     return (((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s11 + s22 + c2))).mean()
 
 
+class _FusedRendervars(torch.autograd.Function):
+    """gs_activate_forward / gs_activate_backward (csrc/activate.hip): transform_to_frame +
+    transformed_params2rendervar in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, means3D, unnorm_rotations, logit_opacities, log_scales, pose7):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.get()
+        dev = means3D.device
+        P = int(means3D.shape[0])
+        iso = 1 if log_scales.shape[1] == 1 else 0
+        c = lambda t: t.detach().contiguous().float()  # noqa: E731
+        m, r, o, s = c(means3D), c(unnorm_rotations), c(logit_opacities), c(log_scales)
+        om, orr = torch.empty(P, 3, device=dev), torch.empty(P, 4, device=dev)
+        oo, os_ = torch.empty(P, 1, device=dev), torch.empty(P, 3, device=dev)
+        pose = (C.c_float * 7)(*[float(v) for v in pose7])
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        _lib.check(lib.gs_activate_forward(P, iso, pose, p(m), p(r), p(o), p(s), p(om), p(orr), p(oo), p(os_), st))
+        ctx.save_for_backward(r, oo, os_)
+        ctx.pose, ctx.iso, ctx.st = pose, iso, st
+        return om, orr, oo, os_
+
+    @staticmethod
+    def backward(ctx, gm, gr, go, gs_):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.get()
+        r, oo, os_ = ctx.saved_tensors
+        P, dev = int(r.shape[0]), r.device
+        c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
+        gm, gr, go, gs_ = c(gm), c(gr), c(go), c(gs_)
+        dm, dr = torch.empty(P, 3, device=dev), torch.empty(P, 4, device=dev)
+        dl, ds = torch.empty(P, 1, device=dev), torch.empty(P, 1 if ctx.iso else 3, device=dev)
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        _lib.check(lib.gs_activate_backward(P, ctx.iso, ctx.pose, p(r), p(oo), p(os_), p(gm), p(gr), p(go), p(gs_), p(dm), p(dr),
+                                            p(dl), p(ds), st))
+        return dm, dr, dl, ds, None
+
+
+def fused_rendervar(params, time_idx, pose7=None):
+    """rendervar dict of transform_to_frame(gaussians_grad=True, camera_grad=False) +
+    transformed_params2rendervar, built by ONE HIP launch (and one more in the backward).  pose7 = host
+    (qw,qx,qy,qz,tx,ty,tz) of the frame's relative w2c; read from params['cam_*'] (one small D2H) if omitted."""
+    if pose7 is None:
+        q = F.normalize(params["cam_unnorm_rots"][..., time_idx].detach()).reshape(4)
+        pose7 = torch.cat([q, params["cam_trans"][..., time_idx].detach().reshape(3)]).cpu().tolist()
+    m, r, o, s = _FusedRendervars.apply(params["means3D"], params["unnorm_rotations"], params["logit_opacities"],
+                                        params["log_scales"], pose7)
+    return {"means3D": m, "colors_precomp": params["rgb_colors"], "rotations": r, "opacities": o, "scales": s,
+            "means2D": torch.zeros_like(params["means3D"], requires_grad=True) + 0}
+
+
+class _FusedMappingLoss(torch.autograd.Function):
+    """gs_mapping_loss: value and gradients in two HIP launches (csrc/loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, im, depth, depth_sq, gt_im, gt_depth, w_im, w_depth):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.get()
+        H, W = int(im.shape[1]), int(im.shape[2])
+        dev = im.device
+        c = lambda t: None if t is None else t.detach().contiguous().float()  # noqa: E731
+        im_, depth_, dsq_, gt_, gtd_ = c(im), c(depth), c(depth_sq), c(gt_im), c(gt_depth)
+        losses = torch.empty(3, dtype=torch.float32, device=dev)
+        d_im, d_depth = torch.empty_like(im_), torch.empty_like(depth_)
+        scratch = torch.empty(int(lib.gs_mapping_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        _lib.check(lib.gs_mapping_loss(W, H, p(im_), p(gt_), p(depth_), p(dsq_), p(gtd_), float(w_im), float(w_depth), p(losses),
+                                       p(d_im), p(d_depth), p(scratch), st))
+        ctx.save_for_backward(d_im, d_depth)
+        ctx.mark_non_differentiable(losses)
+        return losses[0].clone(), losses
+
+    @staticmethod
+    def backward(ctx, g, _gl):
+        d_im, d_depth = ctx.saved_tensors
+        return g * d_im, g * d_depth, None, None, None, None, None
+
+
+def fused_mapping_loss(im, depth, depth_sq, gt_im, gt_depth, loss_weights):
+    """(loss, {'im','depth','loss'}) with the reference's mapping-loss semantics, computed by the HIP library."""
+    loss, parts = _FusedMappingLoss.apply(im, depth, depth_sq, gt_im, gt_depth, loss_weights["im"], loss_weights["depth"])
+    return loss, {"im": parts[1], "depth": parts[2], "loss": loss}
+
+
 def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_for_loss=True, sil_thres=0.99,
-             use_l1=True, ignore_outlier_depth_loss=False, do_ba=False, fused=False):
+             use_l1=True, ignore_outlier_depth_loss=False, do_ba=False, fused=False, fused_loss=False, fused_inputs=False,
+             pose7=None):
     """Mapping loss: masked depth L1 + 0.8 L1 + 0.2 (1 - SSIM) on colour; updates
     variables['means2D'|'seen'|'max_2D_radius'].
     fused=False: the reference's two raster passes on the same geometry (RGB, then [z,1,z^2]).
     fused=True : ONE pass (rasterizer.render_rgbd) -- valid because curr_data['w2c'] is the settings' view
                  matrix at every reference call site; means2D.grad then also carries the depth term (the
-                 reference's densifier sees the colour pass only)."""
-    tg = transform_to_frame(params, iter_time_idx, gaussians_grad=True, camera_grad=do_ba)
-    rendervar = transformed_params2rendervar(params, tg)
+                 reference's densifier sees the colour pass only).
+    fused_loss : the masked-L1 + L1 + SSIM loss and its gradients come from gs_mapping_loss (csrc/loss.hip) instead
+                 of ~40 torch kernels.
+    fused_inputs : transform_to_frame + activations by gs_activate_* (csrc/activate.hip)."""
+    if fused_inputs and not do_ba:
+        tg = None
+        rendervar = fused_rendervar(params, iter_time_idx, pose7)
+    else:
+        tg = transform_to_frame(params, iter_time_idx, gaussians_grad=True, camera_grad=do_ba)
+        rendervar = transformed_params2rendervar(params, tg)
     rendervar["means2D"].retain_grad()
     if fused:
         im, radius, depth, _sil, depth_sq = render_rgbd(curr_data["cam"], **rendervar)
     else:
+        if tg is None:
+            tg = transform_to_frame(params, iter_time_idx, gaussians_grad=True, camera_grad=do_ba)
         depth_sil_rendervar = transformed_params2depthplussilhouette(params, curr_data["w2c"], tg)
         im, radius, _, _ = Renderer(raster_settings=curr_data["cam"])(**rendervar)
         depth_sil, _, _, _ = Renderer(raster_settings=curr_data["cam"])(**depth_sil_rendervar)
         depth = depth_sil[0].unsqueeze(0)
         depth_sq = depth_sil[2].unsqueeze(0)
     variables["means2D"] = rendervar["means2D"]          # densification reads the colour pass' gradient only
+    if fused_loss and use_l1 and not ignore_outlier_depth_loss:
+        loss, weighted = fused_mapping_loss(im, depth, depth_sq, curr_data["im"], curr_data["depth"], loss_weights)
+        seen = radius > 0
+        variables["max_2D_radius"] = torch.maximum(variables["max_2D_radius"], radius.to(variables["max_2D_radius"].dtype))
+        variables["seen"] = seen
+        return loss, variables, weighted
     uncertainty = (depth_sq - depth ** 2).detach()
     mask = curr_data["depth"] > 0
     if ignore_outlier_depth_loss:

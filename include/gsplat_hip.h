@@ -165,6 +165,28 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D,
 int gs_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                  double lr, double beta1, double beta2, double eps, int32_t step, gs_stream_t stream);
 
+/* Fused frame transform + activations (replaces transform_to_frame + transformed_params2rendervar,
+ * src/mapper/splatam/utils/slam_helpers.py:252-304,124-139).  h_pose7 is a HOST array {qw,qx,qy,qz,tx,ty,tz}: the
+ * normalised camera quaternion and translation of the relative w2c.  isotropic != 0: log_scales is [P,1] (tiled to 3,
+ * rotations only normalised).  The backward takes the gradients w.r.t. the four outputs (any may be NULL = zero). */
+int gs_activate_forward(int32_t P, int32_t isotropic, const float* h_pose7, const float* means3D, const float* unnorm_rotations,
+                        const float* logit_opacities, const float* log_scales, float* out_means3D, float* out_rotations,
+                        float* out_opacities, float* out_scales, gs_stream_t stream);
+int gs_activate_backward(int32_t P, int32_t isotropic, const float* h_pose7, const float* unnorm_rotations,
+                         const float* out_opacities, const float* out_scales, const float* g_means3D, const float* g_rotations,
+                         const float* g_opacities, const float* g_scales, float* d_means3D, float* d_unnorm_rotations,
+                         float* d_logit_opacities, float* d_log_scales, gs_stream_t stream);
+
+/* Fused mapping loss, forward AND backward (replaces src/mapper/splatam/splatam.py:213-249 + the SSIM of
+ * utils/slam_external.py:54-97 and their autograd):
+ *   loss = w_depth * mean_{gt_depth>0, finite} |gt_depth - depth| + w_im * (0.8 * mean|im - gt_im| + 0.2 * (1 - SSIM))
+ * im, gt_im [3,H,W]; depth, gt_depth [1,H,W]; depth_sq [1,H,W] nullable (only its NaN-ness enters the mask).
+ * Writes losses[3] = {loss, weighted image term, weighted depth term} (device), dL_dim [3,H,W], dL_ddepth [1,H,W]. */
+uint64_t gs_mapping_loss_scratch_bytes(int32_t width, int32_t height);
+int gs_mapping_loss(int32_t width, int32_t height, const float* im, const float* gt_im, const float* depth,
+                    const float* depth_sq, const float* gt_depth, float w_im, float w_depth, float* losses,
+                    float* dL_dim, float* dL_ddepth, void* scratch, gs_stream_t stream);
+
 /* Stream compaction for prune / densify surgery (replaces the boolean-mask gathers of
  * src/mapper/splatam/utils/slam_external.py:143-164 remove_points and the torch.cat appends of
  * :126-140): gs_compact_index turns a keep mask [n] (uint8) into the ascending list of kept row indices

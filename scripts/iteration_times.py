@@ -15,7 +15,7 @@ dev = torch.device("cuda")
 N, W, H = int(os.environ.get("N", 500_000)), int(os.environ.get("W", 640)), int(os.environ.get("H", 480))
 p = syn.make_params(N, W, H, seed=0)
 lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
-for fused in (False, True):
+for fused, floss, finp in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
     params = {k: torch.nn.Parameter(v.to(dev)) for k, v in p.items()}
     params["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([[1.0, 0, 0, 0]], device=dev).T.reshape(1, 4, 1).contiguous())
     params["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 1, device=dev))
@@ -26,7 +26,8 @@ for fused in (False, True):
     opt = O.initialize_optimizer(params, lrs)
 
     def it():
-        loss, _, _ = M.get_loss(params, data, variables, 0, dict(im=0.5, depth=1.0), fused=fused)
+        loss, _, _ = M.get_loss(params, data, variables, 0, dict(im=0.5, depth=1.0), fused=fused, fused_loss=floss, fused_inputs=finp,
+                                pose7=[1.0, 0, 0, 0, 0, 0, 0] if finp else None)
         loss.backward()
         with torch.no_grad():
             opt.step()
@@ -38,4 +39,4 @@ for fused in (False, True):
     for _ in range(30):
         it()
     torch.cuda.synchronize()
-    print(f"N={N} {W}x{H} fused={fused}: {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms per mapping iteration")
+    print(f"N={N} {W}x{H} fused_render={fused} fused_loss={floss} fused_inputs={finp}: {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms per mapping iteration")

@@ -25,6 +25,7 @@
 #include <vector>
 
 #define __global__
+#define __constant__
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))

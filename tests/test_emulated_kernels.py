@@ -65,14 +65,18 @@ def test_emulated_fused_loss_equals_two_pass_loss(emu):
     from activesplat_amd import mapping as M
     from tests.test_parallel import _scene
     out = []
-    for fused in (False, True):
+    for fused, floss, finp in ((False, False, False), (True, False, False), (True, True, True)):
         params, kfs = _scene(n=500)
         n = params["means3D"].shape[0]
         variables = {k: torch.zeros(n) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
-        loss, variables, _ = M.get_loss(params, kfs[1], variables, 1, dict(im=0.5, depth=1.0), fused=fused)
+        loss, variables, _ = M.get_loss(params, kfs[1], variables, 1, dict(im=0.5, depth=1.0), fused=fused, fused_loss=floss,
+                                        fused_inputs=finp)
         loss.backward()
-        out.append((float(loss), {k: v.grad.clone() for k, v in params.items() if v.grad is not None}))
-    assert abs(out[0][0] - out[1][0]) < 1e-6 * abs(out[0][0])
-    for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
-        a, b = out[0][1][k], out[1][1][k]
-        assert float((a - b).norm() / a.norm()) < 1e-4, k
+        out.append((float(loss.detach()), {k: v.grad.clone() for k, v in params.items() if v.grad is not None},
+                    variables["max_2D_radius"].clone(), variables["seen"].clone()))
+    for o in out[1:]:
+        assert abs(out[0][0] - o[0]) < 2e-6 * abs(out[0][0])
+        assert torch.equal(out[0][2], o[2]) and torch.equal(out[0][3], o[3])
+        for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
+            a, b = out[0][1][k], o[1][k]
+            assert float((a - b).norm() / a.norm()) < 2e-4, k

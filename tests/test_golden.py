@@ -270,3 +270,62 @@ def test_keyframe_selection_matches_reference():
     kfs = [{"id": i, "est_w2c": T(w)} for i, w in enumerate(d["kf_w2c"])]
     sel = keyframe_selection_overlap(T(d["gt_depth"]), T(d["w2c"]), T(d["K"]), kfs, 4, pixels=200, sampled=T(d["sampled"]), shuffle=False)
     assert [int(s) for s in sel] == [int(s) for s in d["selected"]]
+
+
+def test_fused_loss_kernel_matches_reference_loss(emu):
+    """gs_mapping_loss (csrc/loss.hip) reproduces the reference's get_loss value, split and gradients w.r.t. the
+    rendered colour and depth on the golden render/target pair."""
+    from activesplat_amd import mapping as M
+    d = load("loss.npz")
+    im_r, ds_r = T(d["im_r"]).requires_grad_(True), T(d["ds_r"])
+    depth = ds_r[0:1].clone().requires_grad_(True)
+    loss, parts = M.fused_mapping_loss(im_r, depth, ds_r[2:3], T(d["gt_im"]), T(d["gt_depth"]), dict(im=0.5, depth=1.0))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), d["loss"], rtol=5e-6)
+    np.testing.assert_allclose(parts["im"].item(), d["loss_im"], rtol=5e-6)
+    np.testing.assert_allclose(parts["depth"].item(), d["loss_depth"], rtol=5e-6)
+    np.testing.assert_allclose(im_r.grad.numpy(), d["d_im"], atol=2e-9, rtol=2e-3)
+    np.testing.assert_allclose(depth.grad.numpy()[0], d["d_ds"][0], atol=1e-9, rtol=1e-5)
+
+
+def test_fused_loss_ragged_image_and_torch_mirror(emu):
+    """Non-multiple-of-16 image, NaN / zero-depth pixels: fused kernel == the torch mirror of the reference loss."""
+    from activesplat_amd import mapping as M
+    g = torch.Generator().manual_seed(3)
+    H, W = 37, 50
+    im = torch.rand(3, H, W, generator=g).requires_grad_(True)
+    depth = (torch.rand(1, H, W, generator=g) * 3).requires_grad_(True)
+    gt_im = torch.rand(3, H, W, generator=g); gt_d = torch.rand(1, H, W, generator=g) * 3
+    gt_d[0, :3, :9] = 0.0
+    loss, parts = M.fused_mapping_loss(im, depth, depth.detach() ** 2 + 0.1, gt_im, gt_d, dict(im=0.5, depth=1.0))
+    loss.backward()
+    im2, d2 = im.detach().clone().requires_grad_(True), depth.detach().clone().requires_grad_(True)
+    mask = gt_d > 0
+    ref = 1.0 * (gt_d - d2).abs()[mask].mean() + 0.5 * (0.8 * M.l1_loss_v1(im2, gt_im) + 0.2 * (1.0 - M.calc_ssim(im2, gt_im)))
+    ref.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=5e-6)
+    np.testing.assert_allclose(im.grad.numpy(), im2.grad.numpy(), atol=2e-9, rtol=2e-3)
+    np.testing.assert_allclose(depth.grad.numpy(), d2.grad.numpy(), atol=1e-10, rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["aniso", "iso"])
+def test_fused_rendervar_kernel_matches_reference_transform(emu, tag):
+    """gs_activate_* == transform_to_frame + transformed_params2rendervar of the reference (golden), forward;
+    backward == autograd of the torch mirror."""
+    from activesplat_amd import mapping as M
+    d = load("transform.npz")
+    keys = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales", "cam_unnorm_rots", "cam_trans")
+    params = {k: T(d[f"{tag}_{k}"]).clone().requires_grad_(True) for k in keys}
+    rv = M.fused_rendervar(params, 3)
+    for k in ("means3D", "rotations", "opacities", "scales"):
+        np.testing.assert_allclose(rv[k].detach().numpy(), d[f"{tag}_rv_{k}"], atol=3e-6, rtol=2e-6, err_msg=k)
+    g = torch.Generator().manual_seed(0)
+    w = {k: torch.randn(rv[k].shape, generator=g) for k in ("means3D", "rotations", "opacities", "scales")}
+    sum((rv[k] * w[k]).sum() for k in w).backward()
+    got = {k: params[k].grad.clone() for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales")}
+    p2 = {k: T(d[f"{tag}_{k}"]).clone().requires_grad_(True) for k in keys}
+    tg = M.transform_to_frame(p2, 3, gaussians_grad=True, camera_grad=False)
+    rv2 = M.transformed_params2rendervar(p2, tg)
+    sum((rv2[k] * w[k]).sum() for k in w).backward()
+    for k in got:
+        np.testing.assert_allclose(got[k].numpy(), p2[k].grad.numpy(), atol=2e-6 * float(p2[k].grad.abs().max()), rtol=1e-4, err_msg=k)
