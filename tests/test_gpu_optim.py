@@ -110,3 +110,44 @@ def test_mapper_harness_gpu(hip):
         assert util.psnr(im[:, seen].cpu().numpy(), fr["color"][:, seen].cpu().numpy()) > 18.0
         err = ((depth / opacity.clamp_min(1e-6))[0][seen] - fr["depth"][0][seen]).abs().median()
         assert float(err) < 0.1
+
+
+def test_fused_loss_and_inputs_on_gpu(hip):
+    """gs_mapping_loss / gs_activate_* on the GPU == the torch mirrors of the reference functions, and the fully fused
+    get_loss == the reference-style two-pass get_loss (value, gradients, seen, max_2D_radius)."""
+    from activesplat_amd import mapping as M
+    from activesplat_amd import setup_camera, synthetic as syn
+    g = torch.Generator().manual_seed(0)
+    H, W = 150, 120
+    im = torch.rand(3, H, W, generator=g).to(hip).requires_grad_(True)
+    depth = (torch.rand(1, H, W, generator=g) * 3).to(hip).requires_grad_(True)
+    gt_im = torch.rand(3, H, W, generator=g).to(hip); gt_d = (torch.rand(1, H, W, generator=g) * 3).to(hip)
+    gt_d[0, :7, :11] = 0.0
+    loss, parts = M.fused_mapping_loss(im, depth, depth.detach() ** 2 + 0.1, gt_im, gt_d, dict(im=0.5, depth=1.0))
+    loss.backward()
+    im2, d2 = im.detach().clone().requires_grad_(True), depth.detach().clone().requires_grad_(True)
+    ref = 1.0 * (gt_d - d2).abs()[gt_d > 0].mean() + 0.5 * (0.8 * M.l1_loss_v1(im2, gt_im) + 0.2 * (1.0 - M.calc_ssim(im2, gt_im)))
+    ref.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
+    np.testing.assert_allclose(im.grad.cpu().numpy(), im2.grad.cpu().numpy(), atol=3e-9, rtol=3e-3)
+    np.testing.assert_allclose(depth.grad.cpu().numpy(), d2.grad.cpu().numpy(), atol=1e-10, rtol=1e-5)
+    # full iteration loss: all fused vs none
+    N, W, H = 40_000, 256, 192
+    p = syn.make_params(N, W, H, seed=1)
+    out = []
+    for flags in (dict(), dict(fused=True, fused_loss=True, fused_inputs=True)):
+        params = {k: torch.nn.Parameter(v.to(hip)) for k, v in p.items()}
+        params["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([0.98, 0.02, 0.15, -0.03], device=hip).reshape(1, 4, 1).repeat(1, 1, 2))
+        params["cam_trans"] = torch.nn.Parameter(torch.tensor([0.05, -0.02, 0.1], device=hip).reshape(1, 3, 1).repeat(1, 1, 2))
+        variables = {k: torch.zeros(N, device=hip) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+        tim, tdepth = syn.make_targets(W, H)
+        data = dict(cam=setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=hip), im=tim.to(hip), depth=tdepth.to(hip), id=1,
+                    w2c=torch.eye(4, device=hip))
+        loss, variables, _ = M.get_loss(params, data, variables, 1, dict(im=0.5, depth=1.0), **flags)
+        loss.backward()
+        out.append((float(loss.detach()), {k: v.grad.clone() for k, v in params.items() if v.grad is not None}, variables))
+    assert abs(out[0][0] - out[1][0]) < 1e-5 * abs(out[0][0])
+    assert torch.equal(out[0][2]["seen"], out[1][2]["seen"]) and torch.equal(out[0][2]["max_2D_radius"], out[1][2]["max_2D_radius"])
+    for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
+        a, b = out[0][1][k], out[1][1][k]
+        assert float((a - b).norm() / a.norm()) < 1e-3, k
