@@ -150,8 +150,21 @@ def main():
         dom = max((k for k in stages if k in sb), key=lambda k: stages[k]["avg_us"])
         ach = sb[dom] / (stages[dom]["avg_us"] * 1e-6)
         frame_bytes = N * 292 + D * 160 + W * H * 48
+        # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process; the most recent
+        # separate-pass collection (scripts/gpu_round_end.sh -> profiles/*_pmc_summary.json) is reported if present
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+            if files and N == 500_000 and (W, H) == (640, 480):
+                kern = {"blend_backward": "blend_backward_kernel", "blend_forward": "blend_forward_kernel"}.get(dom)
+                pm = json.load(open(files[-1]))
+                if kern in pm and "traffic_bytes" in pm[kern]:
+                    traffic, traffic_src = int(pm[kern]["traffic_bytes"]), os.path.basename(files[-1])
+        except Exception:
+            pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9,
-                           "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": None,
+                           "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": traffic, "traffic_source": traffic_src,
                            "alg_bytes_per_launch": sb[dom], "avg_us": stages[dom]["avg_us"],
                            "frame_alg_bytes": frame_bytes,
                            "frame_frac": round(frame_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 5),
@@ -170,6 +183,38 @@ def main():
                                              f"by oracle/gs_oracle.c (fp32, gcc -O2), {tc:.1f} s; host has {os.cpu_count()} cores"}
         except Exception as e:      # the baseline is a report, never a reason to lose the measurement
             out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- informational leg: one full ActiveSplat mapping iteration (get_loss + backward + Adam) on the same scene,
+        # with the reference's call pattern (two raster passes, torch loss, torch activations) vs this build's fused paths
+        try:
+            from activesplat_amd import mapping as M, optim as O
+            its = {}
+            for name, flags in (("reference_call_pattern", {}), ("fused", dict(fused=True, fused_loss=True, fused_inputs=True))):
+                prm = {k: torch.nn.Parameter(v.to(dev)) for k, v in params.items()}
+                prm["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([1.0, 0, 0, 0], device=dev).reshape(1, 4, 1))
+                prm["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 1, device=dev))
+                var = {k: torch.zeros(N, device=dev) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+                tim, tdepth = syn.make_targets(W, H)
+                data = dict(cam=cam, im=tim.to(dev), depth=tdepth.to(dev), id=0, w2c=torch.eye(4, device=dev))
+                opt = O.initialize_optimizer(prm, dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05,
+                                                       log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0))
+
+                def it():
+                    loss, _, _ = M.get_loss(prm, data, var, 0, dict(im=0.5, depth=1.0), pose7=[1.0, 0, 0, 0, 0, 0, 0] if flags else None, **flags)
+                    loss.backward()
+                    with torch.no_grad():
+                        opt.step(); opt.zero_grad(set_to_none=True)
+                for _ in range(5):
+                    it()
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for _ in range(20):
+                    it()
+                torch.cuda.synchronize()
+                its[name + "_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
+            out["mapping_iteration"] = dict(its, note="get_loss (RGB + depth/silhouette render, L1+SSIM+depth loss) + backward + Adam on the "
+                                            "bench scene; reference_call_pattern = splatam.py:172-301 op for op on this rasteriser")
+        except Exception as e:
+            out["mapping_iteration"] = {"error": str(e)}
     if rank == 0:
         print(json.dumps(out))
     if dist_on:
