@@ -26,6 +26,10 @@ constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTmin = 0.0001f;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr uint32_t kNoId = 0xffffffffu;
+#ifndef GS_FWD_UNROLL
+#define GS_FWD_UNROLL 2
+#endif
+constexpr int kFwdUnroll = GS_FWD_UNROLL;   // hit records evaluated per LDS wait in the forward blend
 
 struct TileCtx {
     int tile, tx, ty, px, py;
@@ -127,40 +131,31 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
                 if (m == 0ull) continue;
                 stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
                 __builtin_amdgcn_wave_barrier();
-                // two hit records per LDS wait; the blend itself is branch-free (predicated weights)
+                // kFwdUnroll hit records per LDS wait; the blend itself is branch-free (predicated weights)
                 while (m) {
-                    const int j1 = pop_low(m);
-                    const bool two = m != 0ull;
-                    const int j2 = two ? pop_low(m) : j1;
-                    const float4 a0 = s0[j1], a1 = s1[j1], a2 = s2[j1];
-                    const float4 b0 = s0[j2], b1 = s1[j2], b2 = s2[j2];
-                    {
-                        const float dx = a0.x - pxf, dy = a0.y - pyf;
-                        const float p = (a0.z * dx + a0.w * dy) * dx + (a1.x * dy) * dy;
-                        const float alpha = fminf(0.99f, a1.y * __builtin_amdgcn_exp2f(p));
-                        const float test_T = T * (1.0f - alpha);
-                        const bool vis = !done && p <= 0.0f && alpha >= kAlphaMin;
-                        const bool ok = vis && test_T >= kTmin;
-                        done = done || (vis && !ok);
-                        const float w = ok ? alpha * T : 0.0f;
-                        C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w; Dp += a2.y * w;
-                        if (DEPTH_SQ) Dq += a2.y * a2.y * w;
-                        T = ok ? test_T : T;
-                        last = ok ? base + (uint32_t)j1 + 1u : last;
+                    int jj[kFwdUnroll];
+                    bool vv[kFwdUnroll];
+                    float4 a0[kFwdUnroll], a1[kFwdUnroll], a2[kFwdUnroll];
+#pragma unroll
+                    for (int u = 0; u < kFwdUnroll; u++) {
+                        vv[u] = m != 0ull;
+                        jj[u] = pop_low(m);
+                        a0[u] = s0[jj[u]]; a1[u] = s1[jj[u]]; a2[u] = s2[jj[u]];
                     }
-                    {
-                        const float dx = b0.x - pxf, dy = b0.y - pyf;
-                        const float p = (b0.z * dx + b0.w * dy) * dx + (b1.x * dy) * dy;
-                        const float alpha = fminf(0.99f, b1.y * __builtin_amdgcn_exp2f(p));
+#pragma unroll
+                    for (int u = 0; u < kFwdUnroll; u++) {
+                        const float dx = a0[u].x - pxf, dy = a0[u].y - pyf;
+                        const float p = (a0[u].z * dx + a0[u].w * dy) * dx + (a1[u].x * dy) * dy;
+                        const float alpha = fminf(0.99f, a1[u].y * __builtin_amdgcn_exp2f(p));
                         const float test_T = T * (1.0f - alpha);
-                        const bool vis = two && !done && p <= 0.0f && alpha >= kAlphaMin;
+                        const bool vis = vv[u] && !done && p <= 0.0f && alpha >= kAlphaMin;
                         const bool ok = vis && test_T >= kTmin;
                         done = done || (vis && !ok);
                         const float w = ok ? alpha * T : 0.0f;
-                        C0 += b1.z * w; C1 += b1.w * w; C2 += b2.x * w; Dp += b2.y * w;
-                        if (DEPTH_SQ) Dq += b2.y * b2.y * w;
+                        C0 += a1[u].z * w; C1 += a1[u].w * w; C2 += a2[u].x * w; Dp += a2[u].y * w;
+                        if (DEPTH_SQ) Dq += a2[u].y * a2[u].y * w;
                         T = ok ? test_T : T;
-                        last = ok ? base + (uint32_t)j2 + 1u : last;
+                        last = ok ? base + (uint32_t)jj[u] + 1u : last;
                     }
                 }
             }
