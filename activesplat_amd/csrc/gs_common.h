@@ -14,7 +14,8 @@ constexpr int kWave = 64;           // CDNA wavefront
 constexpr int kQuad = 8;            // each wavefront owns one 8x8 pixel quadrant of the tile
 constexpr int kBinChunk = 2048;     // Gaussians per tile-binning workgroup (LDS-private histogram)
 constexpr int kMaxLdsTiles = 8192;  // tile-binning path needs the tile histogram in LDS (32 KiB)
-constexpr int kSortCapMax = 8192;   // largest per-tile list the LDS sort takes; beyond -> device radix sort
+constexpr int kSortChunk = 2048;    // keys one workgroup bitonic-sorts in LDS
+constexpr int kSortCapMax = 16384;  // largest per-tile list whose sorted chunks are rank-merged in LDS (128 KiB); beyond -> device radix sort
 
 // By-value kernel argument; matrices stay in device memory exactly where the caller's settings
 // tensors put them (uniform loads -> scalar cache).

@@ -232,6 +232,8 @@ __device__ __forceinline__ void tile_sort_impl(const uint2 range, uint32_t n, un
     }
 }
 
+// grid = (tiles, chunks): block (t, c) sorts keys [c*CAP, min(n, (c+1)*CAP)) of tile t in place and writes their ids.
+// A tile with n <= CAP is finished by this kernel alone; longer lists are completed by tile_merge_kernel.
 template <int CAP, int THREADS>
 __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restrict__ ranges,
                                                              unsigned long long* __restrict__ pairs,
@@ -240,13 +242,50 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restr
     __shared__ unsigned long long s_a[CAP];
     __shared__ unsigned long long s_b[CAP];
     const int tid = threadIdx.x;
-    const uint2 range = ranges[blockIdx.x];
-    const uint32_t n = range.y - range.x;
-    if (n == 0) return;                                       // uniform
+    uint2 range = ranges[blockIdx.x];
+    const uint32_t start = blockIdx.y * (uint32_t)CAP;
+    if (range.y - range.x <= start) return;                    // uniform (also n == 0)
+    range.x += start;
+    const uint32_t n = min(range.y - range.x, (uint32_t)CAP);
     constexpr int EMAX = CAP / THREADS;                       // 8
     if (n <= (uint32_t)THREADS * (EMAX / 4)) tile_sort_impl<EMAX / 4, THREADS>(range, n, pairs, point_list, s_a, s_b, tid);
     else if (n <= (uint32_t)THREADS * (EMAX / 2)) tile_sort_impl<EMAX / 2, THREADS>(range, n, pairs, point_list, s_a, s_b, tid);
     else tile_sort_impl<EMAX, THREADS>(range, n, pairs, point_list, s_a, s_b, tid);
+}
+
+// Tiles with CHUNK < n <= CAP: the CHUNK-sized sorted runs left by tile_sort_kernel are merged by RANK: the whole
+// list sits in LDS, every key adds to its index inside its own run the number of smaller keys in each other run
+// (binary search in LDS; keys are unique) and is written straight to its final position.
+template <int CAP, int CHUNK, int THREADS>
+__global__ __launch_bounds__(THREADS) void tile_merge_kernel(const uint2* __restrict__ ranges,
+                                                              unsigned long long* __restrict__ pairs,
+                                                              uint32_t* __restrict__ point_list)
+{
+    __shared__ unsigned long long s_k[CAP];
+    const int tid = threadIdx.x;
+    const uint2 range = ranges[blockIdx.x];
+    const uint32_t n = range.y - range.x;
+    if (n <= (uint32_t)CHUNK) return;                          // uniform: already final
+    for (uint32_t i = tid; i < n; i += THREADS) s_k[i] = pairs[range.x + i];
+    __syncthreads();
+    const uint32_t nruns = (n + CHUNK - 1) / CHUNK;
+    for (uint32_t i = tid; i < n; i += THREADS) {
+        const unsigned long long key = s_k[i];
+        const uint32_t own = i / CHUNK;
+        uint32_t rank = i - own * CHUNK;
+        for (uint32_t r = 0; r < nruns; r++) {
+            if (r == own) continue;
+            const uint32_t b0 = r * CHUNK, len = min((uint32_t)CHUNK, n - b0);
+            uint32_t lo = 0, hi = len;                          // first position with s_k[b0 + pos] > key
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_k[b0 + mid] < key) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        pairs[range.x + rank] = key;
+        point_list[range.x + rank] = (uint32_t)key;
+    }
 }
 
 // development knob: GS_BIN_VARIANT = threads*10000 + chunk (e.g. 10244096); default 1024 threads x 4096 Gaussians
@@ -287,10 +326,14 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
     const int nb = (P + chunk - 1) / chunk;
     if (nb > 0) launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs);
     if (getenv("GS_SKIP_TILE_SORT")) return hipGetLastError();     // development: time the scatter alone
-    if (max_tile_instances <= 2048)
-        hipLaunchKernelGGL((tile_sort_kernel<2048, 256>), dim3(tiles), dim3(256), 0, st, ranges, pairs, point_list);
-    else
-        hipLaunchKernelGGL((tile_sort_kernel<kSortCapMax, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list);
+    const unsigned chunks = (max_tile_instances + kSortChunk - 1) / kSortChunk;
+    hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, chunks ? chunks : 1), dim3(256), 0, st, ranges, pairs, point_list);
+    if (max_tile_instances > (uint32_t)kSortChunk) {
+        if (max_tile_instances <= 8192)
+            hipLaunchKernelGGL((tile_merge_kernel<8192, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list);
+        else
+            hipLaunchKernelGGL((tile_merge_kernel<kSortCapMax, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list);
+    }
     return hipGetLastError();
 }
 

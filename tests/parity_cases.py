@@ -37,6 +37,17 @@ def build_case(name, device):
     elif name == "dense_overdraw":          # early termination (T < 1e-4) everywhere
         W, H, N = 48, 48, 6000
         mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.5 + 0.5)  # noqa: E731
+    elif name == "merge_tiles":             # ~5k instances per tile: chunk sort + LDS rank-merge (8192 variant)
+        W, H, N = 48, 48, 20000
+        mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.05)  # noqa: E731
+    elif name == "merge_tiles_large":       # ~12k instances per tile: 16384 variant
+        W, H, N = 48, 48, 48000
+        mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.02)  # noqa: E731
+    elif name == "radix_fallback":          # > 16384 instances per tile: device radix sort chosen automatically
+        W, H, N = 32, 32, 40000
+        mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.02)  # noqa: E731
+    elif name == "many_tiles":              # 2064x1104 px = 129 x 69 = 8901 tiles > 8192: no LDS tile histogram -> radix path
+        W, H, N = 2064, 1104, 3000
     elif name == "low_opacity":             # many Gaussians below the 1/255 threshold
         mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.02)  # noqa: E731
     elif name == "one_gaussian":
@@ -61,6 +72,7 @@ def build_case(name, device):
     return rs, rv
 
 
+BIG_TILE_CASES = ["merge_tiles", "merge_tiles_large", "radix_fallback"]
 CASES = ["basic", "ragged_image", "tiny_lookaround", "posed_white_bg", "scale_modifier", "behind_camera", "all_culled",
          "huge_gaussians", "dense_overdraw", "low_opacity", "one_gaussian", "not_multiple_of_block", "sh0", "sh1", "sh2",
          "sh3", "cov3d_precomp"]

@@ -19,6 +19,14 @@ def test_emulated_forward_matches_oracle(emu, oracle32, case):
     assert util.artefacts()["path"] == 1        # tile-binning + LDS sort path
 
 
+@pytest.mark.parametrize("case,path", [("merge_tiles", 1), ("radix_fallback", 2)])
+def test_emulated_big_tile_lists(emu, oracle32, case, path):
+    """tile lists beyond one sort chunk: sorted chunks + LDS rank-merge; beyond the LDS capacity: radix path."""
+    rs, rv = pc.build_case(case, emu)
+    pc.check_forward(rs, rv, oracle32)
+    assert util.artefacts()["path"] == path
+
+
 @pytest.mark.parametrize("case", ["basic", "ragged_image", "all_culled", "huge_gaussians", "dense_overdraw", "one_gaussian"])
 def test_emulated_forward_radix_path_matches_oracle(emu, oracle32, case):
     rs, rv = pc.build_case(case, emu)

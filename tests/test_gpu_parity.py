@@ -124,3 +124,29 @@ def test_reference_call_pattern_two_passes(hip, oracle32):
 def test_fused_rgbd_matches_two_passes_and_oracle(hip, oracle64, case):
     rs, rv = pc.build_case(case, hip)
     pc.check_fused_rgbd(rs, rv, oracle64)
+
+
+@pytest.mark.parametrize("case,path", [("merge_tiles", 1), ("merge_tiles_large", 1), ("radix_fallback", 2)])
+def test_big_tile_lists(hip, oracle32, oracle64, case, path):
+    rs, rv = pc.build_case(case, hip)
+    pc.check_forward(rs, rv, oracle32)
+    assert util.artefacts()["path"] == path
+    pc.check_backward(rs, rv, oracle64)
+
+
+def test_more_tiles_than_the_lds_histogram_holds(hip, oracle32, oracle64):
+    rs, rv = pc.build_case("many_tiles", hip)
+    pc.check_forward(rs, rv, oracle32)
+    assert util.artefacts()["path"] == 2
+    pc.check_backward(rs, rv, oracle64)
+
+
+def test_zero_gaussians(hip):
+    from activesplat_amd import GaussianRasterizer
+    rs, _ = util.scene(4, 70, 50, device=hip, bg=(0.2, 0.4, 0.6))
+    e = lambda *s: torch.zeros(*s, device=hip, requires_grad=True)  # noqa: E731
+    color, radii, depth, opacity = GaussianRasterizer(raster_settings=rs)(means3D=e(0, 3), means2D=e(0, 3), opacities=e(0, 1),
+                                                                          colors_precomp=e(0, 3), scales=e(0, 3), rotations=e(0, 4))
+    assert radii.numel() == 0 and float(opacity.abs().max()) == 0 and float(depth.abs().max()) == 0
+    assert torch.allclose(color, torch.tensor([0.2, 0.4, 0.6], device=hip).view(3, 1, 1).expand(3, 50, 70))
+    color.sum().backward()
