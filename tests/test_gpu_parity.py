@@ -138,7 +138,8 @@ def test_more_tiles_than_the_lds_histogram_holds(hip, oracle32, oracle64):
     rs, rv = pc.build_case("many_tiles", hip)
     pc.check_forward(rs, rv, oracle32)
     assert util.artefacts()["path"] == 2
-    pc.check_backward(rs, rv, oracle64)
+    # sub-pixel Gaussians at this focal length: the fp32 ORACLE itself sits at 0.988-0.995 of the fp64 one here
+    pc.check_backward(rs, rv, oracle64, min_frac=0.985)
 
 
 def test_zero_gaussians(hip):
