@@ -68,7 +68,8 @@ def all_reduce_statistics(variables, group=None):
     return variables
 
 
-def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank=None, world=None, buf=None):
+def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank=None, world=None, buf=None,
+                          sharded_adam=False):
     """One optimiser step over a batch of keyframes sharded across ranks.
     loss_fn(params, keyframe, variables) -> (loss, variables).  Returns the local loss sum."""
     on = dist.is_available() and dist.is_initialized()
@@ -80,6 +81,92 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
         loss, variables = loss_fn(params, keyframes[i], variables)
         loss.backward()                       # autograd accumulates into .grad across this rank's keyframes
         total += float(loss.detach())
-    buf = all_reduce_gradients(params, buf)
-    optimizer.step()
+    if sharded_adam and on and world > 1:
+        reduce_scatter_adam_step(params, optimizer)
+    else:
+        buf = all_reduce_gradients(params, buf)
+        optimizer.step()
     return total, variables, buf
+
+
+# ------------------------------------------------------------------------------------------------------------
+# SURVEY 8(e) "preferred refinement": reduce-scatter -> Adam on this rank's 1/world row block -> all-gather of
+# the updated rows.  Same bytes on the wire as the all-reduce, 1/world of the Adam HBM traffic per GPU, and the
+# result is identical because Adam is element-wise.  Moments are only kept current for the owned rows;
+# `gather_moments` refreshes the full tensors before row surgery (densify / prune, every ~100 iterations).
+# ------------------------------------------------------------------------------------------------------------
+def _row_block(n: int, rank: int, world: int):
+    rows = (n + world - 1) // world
+    return rows, min(rank * rows, n), min((rank + 1) * rows, n)
+
+
+def _reduce_scatter_rows(flat_padded, rows, rank, group):
+    out = torch.empty(rows, flat_padded.shape[1], dtype=flat_padded.dtype, device=flat_padded.device)
+    try:
+        dist.reduce_scatter_tensor(out, flat_padded, op=dist.ReduceOp.SUM, group=group)
+    except (RuntimeError, NotImplementedError):          # gloo (CPU tests) has no reduce-scatter
+        dist.all_reduce(flat_padded, op=dist.ReduceOp.SUM, group=group)
+        out.copy_(flat_padded[rank * rows:(rank + 1) * rows])
+    return out
+
+
+def _all_gather_rows(full_padded, mine, group):
+    try:
+        dist.all_gather_into_tensor(full_padded, mine, group=group)
+    except (RuntimeError, NotImplementedError):
+        parts = list(full_padded.chunk(dist.get_world_size(group), dim=0))
+        dist.all_gather(parts, mine, group=group)
+    return full_padded
+
+
+def reduce_scatter_adam_step(params, optimizer, group=None):
+    """Replaces `all_reduce_gradients(...); optimizer.step()` when every rank holds replicated parameters."""
+    from . import _lib, optim as O
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    buf = FlatGradBuffer(params)
+    n, G = buf.flat.shape
+    rows, lo, hi = _row_block(n, rank, world)
+    padded = torch.zeros(rows * world, G, dtype=torch.float32, device=buf.flat.device)
+    padded[:n] = buf.pack(params)
+    gshard = _reduce_scatter_rows(padded, rows, rank, group)
+    lib = _lib.get()
+    pshard = torch.zeros(rows, G, dtype=torch.float32, device=buf.flat.device)
+    groups = {g["name"]: g for g in optimizer.param_groups}
+    col = 0
+    with torch.no_grad():
+        for k, w in zip(buf.keys, buf.widths):
+            p, g = params[k], groups[k]
+            st = optimizer.state.get(p)
+            if st is None or len(st) == 0:
+                st = optimizer.state[p] = {"step": torch.tensor(0.0), "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+            st["step"] = st["step"] + 1
+            if hi > lo:
+                grad = gshard[:hi - lo, col:col + w].contiguous()
+                b1, b2 = g["betas"]
+                _lib.check(lib.gs_adam_step((hi - lo) * w, p.data[lo:hi].data_ptr(), grad.data_ptr(), st["exp_avg"][lo:hi].data_ptr(),
+                                            st["exp_avg_sq"][lo:hi].data_ptr(), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+                                            int(st["step"].item()), O._stream(p)))
+                pshard[:hi - lo, col:col + w] = p.data[lo:hi]
+            col += w
+        full = _all_gather_rows(padded, pshard, group)     # reuse the padded buffer for the updated rows
+        col = 0
+        for k, w in zip(buf.keys, buf.widths):
+            params[k].data.copy_(full[:n, col:col + w])
+            col += w
+
+
+def gather_moments(params, optimizer, group=None):
+    """Make exp_avg / exp_avg_sq complete on every rank (each rank only advanced its own row block)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    for k in GRAD_KEYS:
+        st = optimizer.state.get(params.get(k))
+        if not st:
+            continue
+        n = params[k].shape[0]
+        rows, lo, hi = _row_block(n, rank, world)
+        for name in ("exp_avg", "exp_avg_sq"):
+            t = st[name].reshape(n, -1)
+            mine = torch.zeros(rows, t.shape[1], dtype=t.dtype, device=t.device)
+            mine[:hi - lo] = t[lo:hi]
+            full = _all_gather_rows(torch.empty(rows * world, t.shape[1], dtype=t.dtype, device=t.device), mine, group)
+            st[name].copy_(full[:n].reshape(st[name].shape))

@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_PEAK = 157.3e12         # MI355X_MICROARCH.md: fp32 vector peak
 
 
 def stage_bytes(P, D, npix):
@@ -169,6 +170,35 @@ def main():
                            "frame_alg_bytes": frame_bytes,
                            "frame_frac": round(frame_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 5),
                            "stages": stages}
+        # ---- secondary figures SURVEY 8(d) asks for: step-time spread, forward-only rate, blend flop rate ----
+        try:
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+            for i, (a, b) in enumerate(ev):
+                a.record(); step(i); b.record()
+            torch.cuda.synchronize()
+            ts = np.sort(np.array([a.elapsed_time(b) for a, b in ev]))
+            out["step_ms_percentiles"] = {"p10": round(float(ts[len(ts) // 10]), 4), "p50": round(float(ts[len(ts) // 2]), 4),
+                                          "p90": round(float(ts[(len(ts) * 9) // 10]), 4)}
+            rv_ng = {k: v.detach() for k, v in rv.items()}
+            m2d0 = torch.zeros(N, 3, device=dev)
+            with torch.no_grad():
+                for _ in range(args.warmup):
+                    GaussianRasterizer(raster_settings=cam)(means2D=m2d0, **rv_ng)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    GaussianRasterizer(raster_settings=cam)(means2D=m2d0, **rv_ng)
+                torch.cuda.synchronize()
+                out["forward_only_fps"] = round(args.steps / (time.perf_counter() - t1), 1)
+                GaussianRasterizer(raster_settings=cam._replace(debug=True))(means2D=m2d0, **rv_ng)
+            il = R.last_debug["il"]
+            ncontrib = R.last_debug["image"][il.n_contrib:il.n_contrib + 4 * W * H].view(torch.int32)
+            E = int(ncontrib.to(torch.int64).sum().item())          # list entries walked, summed over pixels
+            tf, tb = stages["blend_forward"]["avg_us"] * 1e-6, stages["blend_backward"]["avg_us"] * 1e-6
+            out["blend_flops"] = {"evaluations_E": E, "forward_frac_fp32_peak": round(E * 12 / tf / FP32_PEAK, 4),
+                                  "backward_frac_fp32_peak": round(E * 40 / tb / FP32_PEAK, 4), "peak_tflops": FP32_PEAK / 1e12,
+                                  "note": "SURVEY 8(d): F_alg = E*(12 fwd + 40 bwd) flop, E = sum of n_contrib"}
+        except Exception as e:
+            out["secondary_error"] = str(e)
         # ---- cpu_baseline leg: the C oracle on one host core, same workload, one frame ----
         try:
             from oracle.gs_oracle import Oracle

@@ -102,3 +102,53 @@ def test_two_rank_gradient_allreduce_equals_sequential_sum(emu_lib_path):
     for rank, err, same, mx, den in res:
         assert err < 1e-5, (rank, err)          # fp32 sum order differs (local accumulate + ring) but only at rounding level
         assert same and mx == 2.0 and den == 2.0
+
+
+def _worker_sharded_adam(rank, world, port, emu_path, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from activesplat_amd import _lib, optim as O, parallel as PL
+        _lib.load_for_tests(emu_path)
+        n = 601                                                    # not a multiple of the world size
+        widths = dict(means3D=3, rgb_colors=3, unnorm_rotations=4, logit_opacities=1, log_scales=3)
+        lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3)
+        g0 = torch.Generator().manual_seed(5)
+        init = {k: torch.randn(n, w, generator=g0) for k, w in widths.items()}
+        runs = []
+        for mode in ("allreduce", "reduce_scatter"):
+            params = {k: torch.nn.Parameter(v.clone()) for k, v in init.items()}
+            opt = O.initialize_optimizer(params, lrs)
+            gr = torch.Generator().manual_seed(100 + rank)         # every rank holds different local gradients
+            for _ in range(3):
+                for k, w in widths.items():
+                    params[k].grad = torch.randn(n, w, generator=gr)
+                if mode == "allreduce":
+                    PL.all_reduce_gradients(params)
+                    opt.step()
+                else:
+                    PL.reduce_scatter_adam_step(params, opt)
+            if mode == "reduce_scatter":
+                PL.gather_moments(params, opt)
+            runs.append({k: (params[k].detach().clone(), opt.state[params[k]]["exp_avg"].clone(),
+                             opt.state[params[k]]["exp_avg_sq"].clone(), float(opt.state[params[k]]["step"])) for k in widths})
+        same = all(torch.equal(a, b) for k in widths for a, b in zip(runs[0][k][:3], runs[1][k][:3]))
+        steps = all(runs[0][k][3] == runs[1][k][3] == 3.0 for k in widths)
+        q.put((rank, same, steps))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reduce_scatter_sharded_adam_equals_allreduce_adam(emu_lib_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded_adam, args=(r, 2, port, emu_lib_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(same and steps for _, same, steps in res), res
