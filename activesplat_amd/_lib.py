@@ -32,6 +32,12 @@ class GsImageLayout(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "ranges", "final_T", "n_contrib")]
 
 
+class GsAdamTensor(C.Structure):
+    _fields_ = [("n", C.c_int64), ("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class GsBinLayout(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "path", "pairs", "keys_unsorted", "vals_unsorted", "keys_sorted",
                                           "sort_temp")]
@@ -42,7 +48,7 @@ SORT_AUTO, SORT_TILE_LDS, SORT_RADIX = 0, 1, 2
 
 # every symbol include/gsplat_hip.h declares (tests check the library exports all of them)
 SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
-           "gs_version", "gs_set_sort_path", "gs_preprocess_forward", "gs_render_forward", "gs_render_backward", "gs_adam_step",
+           "gs_version", "gs_set_sort_path", "gs_preprocess_forward", "gs_render_forward", "gs_render_backward", "gs_adam_step", "gs_adam_step_multi",
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
            "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward")
 
@@ -62,6 +68,7 @@ def _bind(lib):
     lib.gs_render_forward.argtypes = [C.POINTER(GsCamera), i32, i64, C.c_uint32] + [vp] * 8 + [vp]
     lib.gs_render_backward.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 6 + [vp] * 6 + [vp] * 8 + [vp, vp]
     lib.gs_adam_step.argtypes = [i64, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, i32, vp]
+    lib.gs_adam_step_multi.argtypes = [i32, C.POINTER(GsAdamTensor), vp]
     lib.gs_profile_enable.argtypes = [i32]
     lib.gs_profile_stage_count.restype = i32
     lib.gs_profile_stage_name.argtypes = [i32]

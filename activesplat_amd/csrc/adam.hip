@@ -59,4 +59,69 @@ hipError_t launch_adam(int64_t n, float* p, const float* g, float* m, float* v, 
     return hipGetLastError();
 }
 
+// ---- multi-tensor variant: all parameter groups of the mapper in ONE launch ------------------------------------
+// The five per-Gaussian groups (means3D, rgb, rotations, opacities, scales) are 0.5-2 M elements each: separately
+// they are five ~8 us launches that cannot fill the chip; together one launch with a workgroup range per tensor.
+struct AdamSlot {
+    float* p; const float* g; float* m; float* v;
+    int64_t n;
+    float one_m_b1, b2, one_m_b2, step_size, inv_bc2s, eps;
+    unsigned block_begin;            // first workgroup of this tensor
+    unsigned blocks;                 // workgroups assigned to it
+};
+struct AdamBatch { AdamSlot s[kAdamMaxTensors]; int count; };
+
+__global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamBatch b)
+{
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < kAdamMaxTensors; ++i)
+        if (i < b.count && blockIdx.x >= b.s[i].block_begin) t = i;
+    const AdamSlot& a = b.s[t];
+    const unsigned lb = blockIdx.x - a.block_begin;
+    const int64_t n4 = a.n >> 2;
+    const int64_t stride = (int64_t)a.blocks * kBlock;
+    float4* p4 = reinterpret_cast<float4*>(a.p);
+    const float4* g4 = reinterpret_cast<const float4*>(a.g);
+    float4* m4 = reinterpret_cast<float4*>(a.m);
+    float4* v4 = reinterpret_cast<float4*>(a.v);
+    for (int64_t i = (int64_t)lb * kBlock + threadIdx.x; i < n4; i += stride) {
+        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        adam_elem(pp.x, gg.x, mm.x, vv.x, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
+        adam_elem(pp.y, gg.y, mm.y, vv.y, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
+        adam_elem(pp.z, gg.z, mm.z, vv.z, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
+        adam_elem(pp.w, gg.w, mm.w, vv.w, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    const int64_t tl = (n4 << 2) + threadIdx.x;
+    if (lb == 0 && tl < a.n) adam_elem(a.p[tl], a.g[tl], a.m[tl], a.v[tl], a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
+}
+
+hipError_t launch_adam_multi(int count, const GsAdamTensor* t, hipStream_t st)
+{
+    for (int base = 0; base < count; base += kAdamMaxTensors) {
+        AdamBatch b{};
+        unsigned next = 0;
+        for (int i = base; i < count && i < base + kAdamMaxTensors; ++i) {
+            if (t[i].n <= 0) continue;
+            AdamSlot& a = b.s[b.count++];
+            a.p = t[i].param; a.g = t[i].grad; a.m = t[i].exp_avg; a.v = t[i].exp_avg_sq; a.n = t[i].n;
+            const double bc1 = 1.0 - pow(t[i].beta1, (double)t[i].step);
+            const double bc2 = 1.0 - pow(t[i].beta2, (double)t[i].step);
+            a.one_m_b1 = (float)(1.0 - t[i].beta1); a.b2 = (float)t[i].beta2; a.one_m_b2 = (float)(1.0 - t[i].beta2);
+            a.step_size = (float)(t[i].lr / bc1); a.inv_bc2s = (float)(1.0 / sqrt(bc2)); a.eps = (float)t[i].eps;
+            int64_t nb = ((t[i].n >> 2) + kBlock - 1) / kBlock;
+            if (nb < 1) nb = 1;
+            if (nb > 256 * 8) nb = 256 * 8;
+            a.block_begin = next; a.blocks = (unsigned)nb;
+            next += (unsigned)nb;
+        }
+        if (b.count == 0) continue;
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(next), dim3(kBlock), 0, st, b);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 }  // namespace gs

@@ -340,6 +340,23 @@ int gs_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, flo
     return GS_OK;
 }
 
+int gs_adam_step_multi(int32_t count, const GsAdamTensor* tensors, gs_stream_t stream)
+{
+    if (count < 0 || (count > 0 && !tensors)) return fail(GS_EINVAL, "gs_adam_step_multi: bad count/tensors");
+    for (int i = 0; i < count; ++i) {
+        const GsAdamTensor& t = tensors[i];
+        if (t.n < 0 || t.step < 1) return fail(GS_EINVAL, "gs_adam_step_multi: a tensor has bad n/step");
+        if (t.n > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq)) return fail(GS_EINVAL, "gs_adam_step_multi: a tensor has a null pointer");
+    }
+    hipError_t e;
+    {
+        ScopedStage sc(ST_ADAM, (hipStream_t)stream);
+        e = gs::launch_adam_multi(count, tensors, (hipStream_t)stream);
+    }
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_adam_step_multi: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
 int gs_activate_forward(int32_t P, int32_t isotropic, const float* h_pose7, const float* means3D, const float* unnorm_rotations,
                         const float* logit_opacities, const float* log_scales, float* out_means3D, float* out_rotations,
                         float* out_opacities, float* out_scales, gs_stream_t stream)

@@ -134,6 +134,7 @@ hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint3
 hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  const float* dL_ddepth, float* grad2d, hipStream_t st);
+hipError_t launch_adam_multi(int count, const GsAdamTensor* tensors, hipStream_t st);
 hipError_t launch_adam(int64_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2,
                        double eps, int step, hipStream_t st);
 
@@ -154,6 +155,7 @@ size_t sort_temp_bytes(int64_t D, int end_bit);
 hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
                       const uint32_t* vals_in, uint32_t* vals_out, int64_t D, int end_bit, hipStream_t st);
 
+constexpr int kAdamMaxTensors = 8; // parameter tensors per multi-tensor Adam launch
 constexpr int kGradStride = 16;   // floats per Gaussian in the 2-D gradient record (64 B = one cache line, so an
                                   // atomic flush of the 9 components is ONE memory-side read-modify-write):
                                   // raw moments, see blend.hip: 0..4 geometry, 5 opacity, 6..8 colour, 9 view depth

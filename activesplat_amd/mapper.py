@@ -73,7 +73,7 @@ class SplatMapper:
         self.first_frame_w2c = torch.eye(4, device=self.device)
         self.cam = setup_camera(self.W, self.H, np.asarray(intrinsics), np.eye(4), device=self.device)
         self.params = self.variables = self.optimizer = None
-        self.keyframe_list, self.selected_keyframes = [], []
+        self.keyframe_list, self.selected_keyframes, self.gt_w2c_all_frames = [], [], []
         self.rng = np.random.RandomState(self.cfg["seed"])
         self.stats = dict(iters=0, iter_time=0.0, frames=0, frame_time=0.0)
         self.last_losses = None
@@ -155,7 +155,28 @@ class SplatMapper:
         if fid == 0 or (fid + 1) % cfg["keyframe_every"] == 0 or fid == cfg["step_num"] - 2:
             with torch.no_grad():
                 self.keyframe_list.append({"id": fid, "est_w2c": self._w2c(fid), "color": color, "depth": depth})
+        with torch.no_grad():
+            self.gt_w2c_all_frames.append(self._w2c(fid))
         return self.params
+
+    # -- hand-off (reference: q_main2vis.put(GaussianPacket(...)) __init__.py:536-542; post_processing :544-578) ----
+    def packet(self, c2w=None):
+        from .io import GaussianPacket
+        return GaussianPacket(self.params, c2w)
+
+    def post_processing(self, output_dir):
+        """Writes params.npz with the reference's 14 keys (cam_* trimmed to the mapped frames)."""
+        from . import io as IO
+        kf_ids = [int(k["id"]) for k in self.keyframe_list]
+        out = IO.finalize_params(self.params, self.variables, self.intrinsics, self.first_frame_w2c, self.W, self.H,
+                                 self.gt_w2c_all_frames, kf_ids)
+        return IO.save_params(out, output_dir)
+
+    @torch.no_grad()
+    def look_around(self, view_c2w, scale_modifier=1.0, fused=True):
+        """360-degree opacity / RGB / depth panorama of the planner (lookaround.py)."""
+        from . import lookaround as LA
+        return LA.look_around(self.params, view_c2w, scale_modifier, fused)
 
     # -- no-grad consumers (reference: render_rgbd / get_*_invisibility, __init__.py:604-838) ----------------
     @torch.no_grad()

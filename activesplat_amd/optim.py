@@ -61,7 +61,9 @@ class GaussianAdam:
 
     @torch.no_grad()
     def step(self):
+        """All parameter tensors that hold a gradient advance in ONE kernel launch (gs_adam_step_multi)."""
         lib = _lib.get()
+        batch, keep, stream = [], [], None
         for g in self.param_groups:
             b1, b2 = g["betas"]
             for p in g["params"]:
@@ -75,9 +77,14 @@ class GaussianAdam:
                                           "exp_avg_sq": torch.zeros_like(p)}
                 st["step"] = st["step"] + 1
                 grad = p.grad.contiguous().float()
-                _lib.check(lib.gs_adam_step(p.numel(), p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(),
-                                            st["exp_avg_sq"].data_ptr(), float(g["lr"]), float(b1), float(b2),
-                                            float(g["eps"]), int(st["step"].item()), _stream(p)))
+                keep.append(grad)
+                stream = _stream(p) if stream is None else stream
+                batch.append(_lib.GsAdamTensor(p.numel(), p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                               st["exp_avg_sq"].data_ptr(), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+                                               int(st["step"].item()), 0))
+        if batch:
+            arr = (_lib.GsAdamTensor * len(batch))(*batch)
+            _lib.check(lib.gs_adam_step_multi(len(batch), arr, stream))
 
 
 def initialize_optimizer(params, lrs_dict, tracking=False):

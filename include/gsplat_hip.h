@@ -165,6 +165,20 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D,
 int gs_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                  double lr, double beta1, double beta2, double eps, int32_t step, gs_stream_t stream);
 
+/* The same step for several parameter tensors in one launch (the mapper's five per-Gaussian groups; each keeps its
+ * own lr and step counter exactly like torch's per-group state).  `tensors` is a HOST array. */
+typedef struct GsAdamTensor {
+    int64_t n;
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    double lr, beta1, beta2, eps;
+    int32_t step;
+    int32_t reserved;
+} GsAdamTensor;
+int gs_adam_step_multi(int32_t count, const GsAdamTensor* tensors, gs_stream_t stream);
+
 /* Fused frame transform + activations (replaces transform_to_frame + transformed_params2rendervar,
  * src/mapper/splatam/utils/slam_helpers.py:252-304,124-139).  h_pose7 is a HOST array {qw,qx,qy,qz,tx,ty,tz}: the
  * normalised camera quaternion and translation of the relative w2c.  isotropic != 0: log_scales is [P,1] (tiled to 3,

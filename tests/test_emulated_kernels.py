@@ -62,6 +62,29 @@ def test_emulated_adam_matches_torch(emu):
         np.testing.assert_allclose(p.numpy(), ref.detach().numpy(), rtol=2e-6, atol=1e-7)
 
 
+def test_emulated_multi_tensor_adam_equals_per_tensor_launches(emu):
+    """11 tensors of ragged sizes (two launches of <= 8) must be bit-identical to 11 single-tensor steps."""
+    from activesplat_amd import _lib
+    lib = _lib.get()
+    g0 = torch.Generator().manual_seed(4)
+    sizes = [1, 3, 4, 5, 1003, 4096, 0, 777, 2, 64, 1501]
+    one = [[torch.randn(n, generator=g0) for _ in range(4)] for n in sizes]          # p, g, m, v
+    for t in one:
+        t[3].abs_()
+    many = [[x.clone() for x in t] for t in one]
+    for i, (p, g, m, v) in enumerate(one):
+        _lib.check(lib.gs_adam_step(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 1e-3 * (i + 1), 0.9, 0.999,
+                                    1e-15, i + 1, None))
+    arr = (_lib.GsAdamTensor * len(sizes))(*[_lib.GsAdamTensor(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                                               1e-3 * (i + 1), 0.9, 0.999, 1e-15, i + 1, 0)
+                                             for i, (p, g, m, v) in enumerate(many)])
+    _lib.check(lib.gs_adam_step_multi(len(sizes), arr, None))
+    for a, b in zip(one, many):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert lib.gs_adam_step_multi(1, (_lib.GsAdamTensor * 1)(_lib.GsAdamTensor(4, None, None, None, None, 1e-3, 0.9, 0.999, 1e-15, 1, 0)), None) != 0
+
+
 @pytest.mark.parametrize("case", ["basic", "posed_white_bg", "ragged_image", "sh2", "dense_overdraw"])
 def test_emulated_fused_rgbd_matches_two_passes_and_oracle(emu, oracle64, case):
     rs, rv = pc.build_case(case, emu)

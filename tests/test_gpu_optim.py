@@ -151,3 +151,26 @@ def test_fused_loss_and_inputs_on_gpu(hip):
     for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
         a, b = out[0][1][k], out[1][1][k]
         assert float((a - b).norm() / a.norm()) < 1e-3, k
+
+
+def test_look_around_fused_equals_reference_pattern_on_gpu(hip):
+    import numpy as np
+    from activesplat_amd import lookaround as LA, synthetic as syn
+    params = {k: v.to(hip) for k, v in syn.shell_scene(200_000, seed=2, W=LA.LOOK_W, H=LA.LOOK_H).items()}
+    c2w = np.eye(4); c2w[:3, 3] = [0.1, 0.0, -0.2]
+    a, b = LA.look_around(params, c2w, fused=True), LA.look_around(params, c2w, fused=False)
+    assert a["opacity"].shape == (150, 360) and a["rgb"].dtype == torch.uint8
+    assert torch.allclose(a["opacity"], b["opacity"], atol=1e-4)
+    assert float((a["depth"] - b["depth"]).abs().max()) <= 1e-3 * float(b["depth"].abs().max())
+    assert float(((a["rgb"].int() - b["rgb"].int()).abs() > 1).float().mean()) < 1e-3
+    assert abs(LA.local_invisibility(params, c2w) - float((1 - b["opacity"]).sum())) <= 1e-3 * 150 * 360
+
+
+def test_height_cut_on_gpu(hip):
+    from activesplat_amd import io as IO, synthetic as syn
+    p = {k: v.to(hip) for k, v in syn.make_params(100_000, 640, 480, seed=2).items()}
+    ref = {k: v.clone() for k, v in p.items()}
+    cond = torch.logical_or(-ref["means3D"][:, 1] < -0.3, -ref["means3D"][:, 1] > 0.4)
+    got = IO.cut_gaussian_by_height(p, -0.3, 0.4)
+    for k in IO.GAUSSIAN_ROW_KEYS:
+        assert torch.equal(got[k], ref[k][~cond]), k

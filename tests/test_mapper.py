@@ -45,3 +45,16 @@ def test_mapper_schedule_and_rerender(emu):
     inv = mp.invisibility(seq[0]["w2c"])
     assert inv.shape == (1, 150, 120) and float(inv.min()) >= 0.0 and float(inv.max()) <= 1.0
     assert all(np.isfinite(v) for v in mp.last_losses.values())
+    # hand-off artefacts: packet for the visualiser queue, params.npz for the offline tools, look-around panorama
+    import tempfile
+    from activesplat_amd import io as IO
+    pk = mp.packet(c2w=np.eye(4))
+    assert pk.has_gaussians and pk.params is mp.params
+    with tempfile.TemporaryDirectory() as d:
+        z = np.load(mp.post_processing(d))
+        assert set(z.files) == set(IO.FILE_KEYS)
+        assert z["cam_trans"].shape[-1] == len(seq) == z["gt_w2c_all_frames"].shape[0]
+        assert list(z["keyframe_time_indices"]) == [0, 4, 9]
+        assert z["means3D"].shape[0] == mp.params["means3D"].shape[0] == z["timestep"].shape[0]
+    pano = mp.look_around(np.eye(4))
+    assert pano["opacity"].shape == (150, 360) and float(pano["opacity"].max()) > 0.5
