@@ -421,4 +421,36 @@ int gs_gather_rows(int64_t n_out, int32_t row_floats, const uint32_t* src_index,
     return GS_OK;
 }
 
+uint64_t gs_grow_scratch_bytes(int32_t width, int32_t height)
+{
+    return align_up(gs::grow_scratch_bytes((int64_t)(width > 0 ? width : 1) * (height > 0 ? height : 1)));
+}
+
+int gs_grow_gaussians(int32_t width, int32_t height, const float* render_depth, const float* silhouette, const float* gt_depth,
+                      const float* color, const float* h_intrinsics4, const float* h_c2w12, float sil_thres, int32_t isotropic,
+                      float* out_means3D, float* out_rgb_colors, float* out_unnorm_rotations, float* out_logit_opacities,
+                      float* out_log_scales, uint32_t* d_counts, void* scratch, gs_stream_t stream)
+{
+    if (width <= 0 || height <= 0 || !render_depth || !silhouette || !gt_depth || !color || !h_intrinsics4 || !h_c2w12 ||
+        !out_means3D || !out_rgb_colors || !out_unnorm_rotations || !out_logit_opacities || !out_log_scales || !d_counts || !scratch)
+        return fail(GS_EINVAL, "gs_grow_gaussians: bad argument");
+    hipError_t e = gs::launch_grow(width, height, render_depth, silhouette, gt_depth, color, h_intrinsics4, h_c2w12, sil_thres,
+                                   isotropic != 0, out_means3D, out_rgb_colors, out_unnorm_rotations, out_logit_opacities,
+                                   out_log_scales, d_counts, scratch, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_grow_gaussians: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_keyframe_overlap(int32_t n_pts, const float* pts_world, int32_t n_keyframes, const float* w2c, const float* h_intrinsics9,
+                        int32_t width, int32_t height, int32_t edge, uint32_t* counts, gs_stream_t stream)
+{
+    if (n_pts < 0 || n_keyframes < 0 || width <= 0 || height <= 0 || !h_intrinsics9 ||
+        (n_keyframes > 0 && (!w2c || !counts)) || (n_pts > 0 && !pts_world))
+        return fail(GS_EINVAL, "gs_keyframe_overlap: bad argument");
+    hipError_t e = gs::launch_keyframe_overlap(n_pts, pts_world, n_keyframes, w2c, h_intrinsics9, width, height, edge, counts,
+                                               (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_keyframe_overlap: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
 }  // extern "C"

@@ -146,6 +146,12 @@ hipError_t launch_activate_backward(int P, int iso, const float* pose7, const fl
 hipError_t launch_mapping_loss(int W, int H, const float* im, const float* gt, const float* depth, const float* depth_sq,
                                const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
                                float* dL_ddepth, float* scratch, hipStream_t st);
+uint64_t grow_scratch_bytes(int64_t npix);
+hipError_t launch_grow(int W, int H, const float* rd, const float* sil, const float* gt, const float* color, const float* k4,
+                       const float* c2w12, float sil_thres, int isotropic, float* means3D, float* rgb, float* rot, float* logit,
+                       float* log_scales, uint32_t* d_counts, void* scratch, hipStream_t st);
+hipError_t launch_keyframe_overlap(int n_pts, const float* pts, int n_kf, const float* w2c, const float* k9, int W, int H, int edge,
+                                   uint32_t* counts, hipStream_t st);
 uint64_t compact_scratch_bytes(int64_t n);
 hipError_t launch_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32_t* d_count, void* scratch, hipStream_t st);
 hipError_t launch_gather_rows(int64_t n_out, int row_floats, const uint32_t* src_index, const float* src, float* dst, hipStream_t st);

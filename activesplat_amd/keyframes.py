@@ -29,8 +29,29 @@ def _backproject(depth, intrinsics, w2c, sampled_indices):
     return pts[~invalid]
 
 
+def overlap_counts(pts, keyframe_list, intrinsics, width, height, edge=20):
+    """gs_keyframe_overlap (csrc/grow.hip): how many of the world points land inside each keyframe's image (shrunk by
+    `edge` px, positive depth) -- one launch and one copy back for ALL keyframes."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.get()
+    dev = pts.device
+    n_kf = len(keyframe_list)
+    if n_kf == 0:
+        return []
+    w2c = torch.stack([kf["est_w2c"].detach().to(dev).float() for kf in keyframe_list]).contiguous()
+    p = pts.detach().contiguous().float()
+    counts = torch.zeros(n_kf, dtype=torch.int32, device=dev)
+    K = np.asarray(intrinsics.detach().cpu() if torch.is_tensor(intrinsics) else intrinsics, dtype=np.float64).reshape(-1)
+    k9 = (C.c_float * 9)(*[float(v) for v in K])
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+    _lib.check(lib.gs_keyframe_overlap(int(p.shape[0]), C.c_void_p(p.data_ptr()), n_kf, C.c_void_p(w2c.data_ptr()), k9, int(width),
+                                       int(height), int(edge), C.c_void_p(counts.data_ptr()), st))
+    return counts.cpu().tolist()
+
+
 def keyframe_selection_overlap(gt_depth, w2c, intrinsics, keyframe_list, k, pixels=1600, sampled=None, shuffle=True,
-                               return_percent=False):
+                               return_percent=False, fused=False):
     width, height = gt_depth.shape[2], gt_depth.shape[1]
     valid = torch.stack(torch.where(gt_depth[0] > 0), dim=1)
     if sampled is None:
@@ -38,7 +59,11 @@ def keyframe_selection_overlap(gt_depth, w2c, intrinsics, keyframe_list, k, pixe
     pts = _backproject(gt_depth, intrinsics, w2c, valid[sampled.to(valid.device)])
     ranked = []
     edge = 20
-    for kid, kf in enumerate(keyframe_list):
+    if fused:
+        n = max(int(pts.shape[0]), 1)
+        ranked = [{"id": kid, "percent_inside": torch.tensor(c / n)} for kid, c in
+                  enumerate(overlap_counts(pts, keyframe_list, intrinsics, width, height, edge))]
+    for kid, kf in enumerate([] if fused else keyframe_list):
         est = kf["est_w2c"]
         tp = pts @ est[:3, :3].T + est[:3, 3]
         p2 = tp @ intrinsics.T

@@ -43,6 +43,8 @@ DEFAULT_CONFIG = dict(
     fused_render=False,      # one raster pass per iteration (rasterizer.render_rgbd) instead of two
     fused_loss=False,        # masked-L1 + L1 + SSIM value and gradients by gs_mapping_loss
     fused_inputs=False,      # transform_to_frame + activations by gs_activate_*
+    fused_growth=False,      # add_new_gaussians: one forward + gs_grow_gaussians
+    fused_keyframes=False,   # keyframe overlap scores by gs_keyframe_overlap (one launch for all keyframes)
     mapping=dict(
         loss_weights=dict(im=0.5, depth=1.0), sil_thres=0.98, use_sil_for_loss=False, use_l1=True,
         ignore_outlier_depth_loss=False, add_new_gaussians=True, prune_gaussians=False,
@@ -116,10 +118,13 @@ class SplatMapper:
         if fid == 0 or (fid + 1) % map_every == 0:
             if mc["add_new_gaussians"] and fid > 0:
                 self.params, self.variables = M.add_new_gaussians(self.params, self.variables, self._data(color, depth, fid),
-                                                                  mc["sil_thres"], fid, cfg["gaussian_distribution"])
+                                                                  mc["sil_thres"], fid, cfg["gaussian_distribution"],
+                                                                  fused=cfg.get("fused_growth", False),
+                                                                  pose7=[float(v) for v in F.normalize(quat.view(1, 4)).view(4).tolist()]
+                                                                  + [float(v) for v in pos.tolist()] if cfg.get("fused_growth", False) else None)
             with torch.no_grad():
                 sel = keyframe_selection_overlap(depth, self._w2c(fid), self.intrinsics, self.keyframe_list[:-1],
-                                                 cfg["mapping_window_size"] - 2)
+                                                 cfg["mapping_window_size"] - 2, fused=cfg.get("fused_keyframes", False))
                 self.selected_keyframes = [int(s) for s in sel]
                 if len(self.keyframe_list) > 0:
                     self.selected_keyframes.append(len(self.keyframe_list) - 1)

@@ -359,7 +359,78 @@ def initialize_new_params(new_pt_cld, mean3_sq_dist, gaussian_distribution):
     return _as_params(_new_gaussians(new_pt_cld, mean3_sq_dist, gaussian_distribution))
 
 
-def add_new_gaussians(params, variables, curr_data, sil_thres, time_idx, gaussian_distribution):
+def _pose7(params, time_idx):
+    q = F.normalize(params["cam_unnorm_rots"][..., time_idx].detach()).reshape(4)
+    return torch.cat([q, params["cam_trans"][..., time_idx].detach().reshape(3)]).cpu().tolist()
+
+
+def _c2w_from_pose7(pose7):
+    """Host-side inverse of the frame's w2c = [R(q) | t] (double precision; R as build_rotation defines it)."""
+    w, x, y, z = [float(v) for v in pose7[:4]]
+    R = np.array([[1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * w * z, 2 * x * z + 2 * w * y],
+                  [2 * x * y + 2 * w * z, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * w * x],
+                  [2 * x * z - 2 * w * y, 2 * y * z + 2 * w * x, 1 - 2 * x * x - 2 * y * y]])
+    w2c = np.eye(4)
+    w2c[:3, :3], w2c[:3, 3] = R, [float(v) for v in pose7[4:7]]
+    return np.linalg.inv(w2c)
+
+
+def grow_rows(render_depth, silhouette, gt_depth, color, intrinsics, c2w, sil_thres, gaussian_distribution):
+    """gs_grow_gaussians (csrc/grow.hip): -> (dict of new per-Gaussian rows, number of non-presence pixels before the
+    valid-depth mask).  render_depth / silhouette / gt_depth: [H,W] or [1,H,W]; color [3,H,W]."""
+    import ctypes as C
+    from . import _lib
+    if gaussian_distribution not in ("isotropic", "anisotropic"):
+        raise ValueError(f"Unknown gaussian_distribution {gaussian_distribution}")
+    lib = _lib.get()
+    dev = gt_depth.device
+    H, W = int(color.shape[1]), int(color.shape[2])
+    c = lambda t: t.detach().contiguous().float()  # noqa: E731
+    rd, sil, gt, col = c(render_depth), c(silhouette), c(gt_depth), c(color)
+    n = H * W
+    iso = gaussian_distribution == "isotropic"
+    out = {"means3D": torch.empty(n, 3, device=dev), "rgb_colors": torch.empty(n, 3, device=dev),
+           "unnorm_rotations": torch.empty(n, 4, device=dev), "logit_opacities": torch.empty(n, 1, device=dev),
+           "log_scales": torch.empty(n, 1 if iso else 3, device=dev)}
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    scratch = torch.empty(int(lib.gs_grow_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
+    K = np.asarray(intrinsics.detach().cpu() if torch.is_tensor(intrinsics) else intrinsics, dtype=np.float64)
+    k4 = (C.c_float * 4)(K[0][0], K[1][1], K[0][2], K[1][2])
+    c2w = np.asarray(c2w.detach().cpu() if torch.is_tensor(c2w) else c2w, dtype=np.float64)
+    m12 = (C.c_float * 12)(*[float(v) for v in c2w[:3, :4].reshape(-1)])
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    _lib.check(lib.gs_grow_gaussians(W, H, p(rd), p(sil), p(gt), p(col), k4, m12, float(sil_thres), 1 if iso else 0, p(out["means3D"]),
+                                     p(out["rgb_colors"]), p(out["unnorm_rotations"]), p(out["logit_opacities"]), p(out["log_scales"]),
+                                     p(counts), p(scratch), st))
+    n_cand, n_new = [int(v) for v in counts.cpu().tolist()]              # the one host sync of the growth step
+    return {k: v[:n_new] for k, v in out.items()}, n_cand
+
+
+def add_new_gaussians(params, variables, curr_data, sil_thres, time_idx, gaussian_distribution, fused=False, pose7=None):
+    """Silhouette / depth-error driven growth (splatam.py:332-379).
+
+    fused=False: the reference op for op (second-pass style [z,1,z^2] render, torch masks, median, boolean gathers).
+    fused=True : ONE standard forward (its built-in depth / opacity outputs ARE the depth and silhouette channels,
+                 SURVEY 8c-iii) on the fused activations, then gs_grow_gaussians; pose7 = host (qw,qx,qy,qz,tx,ty,tz) of
+                 the frame (read from params with one small D2H when omitted)."""
+    if fused:
+        pose7 = _pose7(params, time_idx) if pose7 is None else pose7
+        with torch.no_grad():
+            rv = fused_rendervar(params, time_idx, pose7)
+            rv["means2D"] = torch.zeros_like(rv["means3D"])
+            _, _, render_depth, sil = Renderer(raster_settings=curr_data["cam"])(**rv)
+            rows, n_cand = grow_rows(render_depth, sil, curr_data["depth"], curr_data["im"], curr_data["intrinsics"],
+                                     _c2w_from_pose7(pose7), sil_thres, gaussian_distribution)
+        if n_cand > 0:
+            dev = curr_data["depth"].device
+            for k, v in rows.items():
+                params[k] = torch.nn.Parameter(torch.cat((params[k].detach(), v), dim=0).requires_grad_(True))
+            n = params["means3D"].shape[0]
+            for k in ("means2D_gradient_accum", "denom", "max_2D_radius"):
+                variables[k] = torch.zeros(n, device=dev)
+            variables["timestep"] = torch.cat((variables["timestep"], time_idx * torch.ones(rows["means3D"].shape[0], device=dev)), dim=0)
+        return params, variables
     """Silhouette / depth-error driven growth (splatam.py:332-379)."""
     tg = transform_to_frame(params, time_idx, gaussians_grad=False, camera_grad=False)
     dsv = transformed_params2depthplussilhouette(params, curr_data["w2c"], tg)

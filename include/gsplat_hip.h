@@ -213,6 +213,26 @@ int gs_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32
 int gs_gather_rows(int64_t n_out, int32_t row_floats, const uint32_t* src_index, const float* src, float* dst,
                    gs_stream_t stream);
 
+/* Map growth (replaces add_new_gaussians, src/mapper/splatam/splatam.py:332-379, with get_pointcloud :25-75 and
+ * initialize_new_params :304-329).  render_depth / silhouette / gt_depth are [H*W] device images, color is [3,H*W];
+ * h_intrinsics4 = HOST {fx,fy,cx,cy}; h_c2w12 = HOST row-major 3x4 camera-to-world of the frame.  Outputs must hold H*W
+ * rows (the worst case); d_counts[0] = pixels flagged non-present BEFORE the valid-depth mask (the reference enters its
+ * append branch, which also resets the densification statistics, iff this is > 0), d_counts[1] = rows written, in
+ * row-major pixel order.  log_scales is [rows,1] when isotropic != 0, else [rows,3]. */
+uint64_t gs_grow_scratch_bytes(int32_t width, int32_t height);
+int gs_grow_gaussians(int32_t width, int32_t height, const float* render_depth, const float* silhouette,
+                      const float* gt_depth, const float* color, const float* h_intrinsics4, const float* h_c2w12,
+                      float sil_thres, int32_t isotropic, float* out_means3D, float* out_rgb_colors,
+                      float* out_unnorm_rotations, float* out_logit_opacities, float* out_log_scales,
+                      uint32_t* d_counts, void* scratch, gs_stream_t stream);
+
+/* Keyframe overlap scores (the loop of keyframe_selection_overlap, src/mapper/splatam/utils/keyframe_selection.py:62-86):
+ * counts[k] = number of the n_pts world points [n_pts,3] that project into keyframe k (row-major 4x4 w2c at
+ * w2c[16k]) inside the image shrunk by `edge` pixels, with positive depth.  h_intrinsics9 = HOST row-major 3x3. */
+int gs_keyframe_overlap(int32_t n_pts, const float* pts_world, int32_t n_keyframes, const float* w2c,
+                        const float* h_intrinsics9, int32_t width, int32_t height, int32_t edge, uint32_t* counts,
+                        gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

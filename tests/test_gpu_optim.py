@@ -174,3 +174,52 @@ def test_height_cut_on_gpu(hip):
     got = IO.cut_gaussian_by_height(p, -0.3, 0.4)
     for k in IO.GAUSSIAN_ROW_KEYS:
         assert torch.equal(got[k], ref[k][~cond]), k
+
+
+def test_growth_kernel_equals_torch_growth_on_gpu(hip):
+    """640x480 frame: gs_grow_gaussians vs the reference-pattern torch masks / median / gathers on the same render."""
+    import numpy as np
+    from activesplat_amd import mapping as M, synthetic as syn
+    W, H = 640, 480
+    g = torch.Generator().manual_seed(3)
+    gt = (torch.rand(1, H, W, generator=g) * 3.5 + 0.5)
+    gt[0, :40] = 0.0                                                    # invalid-depth band
+    rd = gt[0] + torch.randn(H, W, generator=g) * 0.05
+    sil = torch.rand(H, W, generator=g)
+    color = torch.rand(3, H, W, generator=g)
+    K = torch.tensor(syn.intrinsics(W, H), dtype=torch.float32)
+    pose7 = [0.98, 0.05, -0.17, 0.02, 0.3, -0.1, 0.2]
+    n = float(np.linalg.norm(pose7[:4])); pose7 = [v / n for v in pose7[:4]] + pose7[4:]
+    c2w = M._c2w_from_pose7(pose7)
+    gt_d, rd_d, sil_d, col_d = gt.to(hip), rd.to(hip), sil.to(hip), color.to(hip)
+    rows, n_cand = M.grow_rows(rd_d, sil_d, gt_d, col_d, K, c2w, 0.5, "anisotropic")
+    # torch restatement of splatam.py:340-364 on the same images
+    err = (gt_d[0] - rd_d).abs() * (gt_d[0] > 0)
+    non = (sil_d < 0.5) | ((rd_d > gt_d[0]) & (err > 2 * err.median()) & (sil_d > 0.5) & (gt_d[0] < 5))
+    assert n_cand == int(non.sum())
+    mask = (non & (gt_d[0] > 0)).reshape(-1)
+    w2c = torch.tensor(np.linalg.inv(c2w), dtype=torch.float32, device=hip)
+    cld, msd = M.get_pointcloud(col_d, gt_d, K.to(hip), w2c, mask=mask, compute_mean_sq_dist=True)
+    ref = M._new_gaussians(cld, msd, "anisotropic")
+    assert rows["means3D"].shape[0] == int(mask.sum()) > 1000
+    for k in ref:
+        assert torch.allclose(rows[k], ref[k], atol=5e-6, rtol=1e-5), k
+
+
+def test_keyframe_overlap_kernel_equals_torch_on_gpu(hip):
+    import numpy as np
+    from activesplat_amd import synthetic as syn
+    from activesplat_amd.keyframes import keyframe_selection_overlap
+    W, H = 256, 256
+    g = torch.Generator().manual_seed(5)
+    depth = (torch.rand(1, H, W, generator=g) * 3 + 0.5).to(hip)
+    K = torch.tensor(syn.intrinsics(W, H), dtype=torch.float32, device=hip)
+    kfs = [{"id": i, "est_w2c": torch.tensor(syn.keyframe_w2c(i, 24), dtype=torch.float32, device=hip)} for i in range(24)]
+    sampled = torch.randint(H * W, (1600,), generator=g)
+    args = (depth, torch.eye(4, device=hip), K, kfs, 8)
+    a, ra = keyframe_selection_overlap(*args, sampled=sampled, shuffle=False, fused=True, return_percent=True)
+    b, rb = keyframe_selection_overlap(*args, sampled=sampled, shuffle=False, return_percent=True)
+    pa = {r["id"]: float(r["percent_inside"]) for r in ra}
+    pb = {r["id"]: float(r["percent_inside"]) for r in rb}
+    assert max(abs(pa[i] - pb[i]) for i in pa) <= 2 / 1600            # at most a borderline point or two per keyframe
+    assert len(a) == len(b) == 8

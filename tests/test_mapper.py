@@ -58,3 +58,29 @@ def test_mapper_schedule_and_rerender(emu):
         assert z["means3D"].shape[0] == mp.params["means3D"].shape[0] == z["timestep"].shape[0]
     pano = mp.look_around(np.eye(4))
     assert pano["opacity"].shape == (150, 360) and float(pano["opacity"].max()) > 0.5
+
+
+def test_fused_growth_and_keyframe_scoring_build_the_same_map(emu):
+    """Harness with the HIP growth / keyframe-overlap kernels vs the reference-pattern torch code: same schedule, same
+    keyframes, the same number of Gaussians up to threshold flips of single pixels."""
+    ref, seq, log_ref = run_harness(emu, n_gt=3000, frames=6)
+    fus, _, log_fus = run_harness(emu, n_gt=3000, frames=6, cfg=dict(fused_growth=True, fused_keyframes=True))
+    assert [e["keyframes"] for e in log_ref] == [e["keyframes"] for e in log_fus]
+    n_ref, n_fus = ref.params["means3D"].shape[0], fus.params["means3D"].shape[0]
+    assert abs(n_ref - n_fus) <= max(3, 0.005 * n_ref), (n_ref, n_fus)
+    grew = [e["grew"] for e in log_fus]
+    assert grew[4] > 0
+    # every appended Gaussian sits (up to the two Adam steps it has since taken, lr 1e-4) on the sensor ray of a valid
+    # pixel of frame 4 at its measured depth
+    n0 = n_fus - grew[4] if grew[5] == 0 else None
+    if n0 is not None:
+        fr = seq[4]
+        new = fus.params["means3D"].detach()[n0:]
+        w2c = torch.as_tensor(np.asarray(fr["w2c"]), dtype=torch.float32, device=new.device)
+        cam = new @ w2c[:3, :3].T + w2c[:3, 3]
+        K = fus.intrinsics
+        u = cam[:, 0] / cam[:, 2] * K[0, 0] + K[0, 2]
+        v = cam[:, 1] / cam[:, 2] * K[1, 1] + K[1, 2]
+        assert float((u - u.round()).abs().max()) < 0.05 and float((v - v.round()).abs().max()) < 0.05
+        z = fr["depth"].to(new.device)[0, v.round().long(), u.round().long()]
+        assert torch.allclose(z, cam[:, 2], rtol=2e-3, atol=2e-3) and bool((z > 0).all())
