@@ -18,15 +18,20 @@ def setup_camera(w, h, k, w2c, near=0.01, far=100, scale_modifier=1.0, bg=(0.0, 
     if device is None:
         device = "cuda" if torch.cuda.is_available() else "cpu"
     fx, fy, cx, cy = float(k[0][0]), float(k[1][1]), float(k[0][2]), float(k[1][2])
+    # Host poses (the usual case: numpy / CPU tensors) are processed on the host in fp32 with the same torch ops and only
+    # the three small results are copied over: on the device the 4x4 inverse and the 4x4 product would drag in rocSOLVER /
+    # rocBLAS (hundreds of ms of one-time initialisation, ~100 us per call) for 2 x 64 flops.
+    work = torch.device(device) if (torch.is_tensor(w2c) and w2c.device.type != "cpu") else torch.device("cpu")
     w2c_t = torch.as_tensor(np.asarray(w2c, dtype=np.float64) if not torch.is_tensor(w2c) else w2c).to(
-        device=device, dtype=torch.float32)
+        device=work, dtype=torch.float32)
     cam_center = torch.inverse(w2c_t)[:3, 3]
     view = w2c_t.unsqueeze(0).transpose(1, 2)
     opengl_proj = torch.tensor([[2 * fx / w, 0.0, -(w - 2 * cx) / w, 0.0],
                                 [0.0, 2 * fy / h, -(h - 2 * cy) / h, 0.0],
                                 [0.0, 0.0, far / (far - near), -(far * near) / (far - near)],
-                                [0.0, 0.0, 1.0, 0.0]], dtype=torch.float32, device=device).unsqueeze(0).transpose(1, 2)
+                                [0.0, 0.0, 1.0, 0.0]], dtype=torch.float32, device=work).unsqueeze(0).transpose(1, 2)
     full_proj = view.bmm(opengl_proj)
+    view, full_proj, cam_center = view.to(device), full_proj.to(device), cam_center.to(device)
     return GaussianRasterizationSettings(
         image_height=int(h), image_width=int(w), tanfovx=w / (2 * fx), tanfovy=h / (2 * fy),
         bg=torch.tensor(list(bg), dtype=torch.float32, device=device), scale_modifier=scale_modifier,

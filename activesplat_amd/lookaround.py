@@ -63,12 +63,11 @@ def look_around(params, view_c2w, scale_modifier=1.0, fused=True, views=None):
     cfg = dict(viz_w=LOOK_W, viz_h=LOOK_H, viz_near=VIZ_NEAR, viz_far=VIZ_FAR)
     device = params["means3D"].device
     rv = _world_rendervar(params) if fused else None
-    white = torch.ones(3, dtype=torch.float32, device=device)
     ops, rgbs, deps = [], [], []
     for i in range(views):
         w2c = np.linalg.inv(rot_axis(np.asarray(view_c2w, dtype=np.float64), "y", np.deg2rad(LOOK_HFOV_DEG * i)))
         if fused:
-            cam = setup_camera(LOOK_W, LOOK_H, k, w2c, VIZ_NEAR, VIZ_FAR, scale_modifier=scale_modifier, device=device, bg=white)
+            cam = setup_camera(LOOK_W, LOOK_H, k, w2c, VIZ_NEAR, VIZ_FAR, scale_modifier=scale_modifier, device=device, bg=(1.0, 1.0, 1.0))
             im, _, depth, opacity = GaussianRasterizer(raster_settings=cam)(**rv)
         else:
             scene, scene_depth = M.get_rendervars(params, torch.tensor(w2c, dtype=torch.float32, device=device))

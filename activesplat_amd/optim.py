@@ -97,13 +97,15 @@ def inverse_sigmoid(x):
 
 
 def accumulate_mean2d_gradient(variables):
+    """slam_external.py:100-108: accum[seen] += ||means2D.grad[seen, :2]||, denom[seen] += 1 -- written as masked
+    element-wise updates (identical values; no boolean-index gathers, no host sync on `seen.sum()`)."""
     g = variables["means2D"].grad
     if g is None or g.shape[0] != variables["means2D"].shape[0] or g.shape[1] < 2:
         return variables
     seen = variables["seen"]
-    if seen.sum() > 0:
-        variables["means2D_gradient_accum"][seen] += torch.norm(g[seen, :2], dim=-1)
-        variables["denom"][seen] += 1
+    norm = torch.norm(g[:, :2], dim=-1)
+    variables["means2D_gradient_accum"] += torch.where(seen, norm, torch.zeros_like(norm))
+    variables["denom"] += seen.to(variables["denom"].dtype)
     return variables
 
 
@@ -239,7 +241,9 @@ def densify(params, variables, optimizer, iter, densify_dict, samples=None):
         if samples is None:
             samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
         rots = build_rotation_from(new_params["unnorm_rotations"])
-        new_params["means3D"] = new_params["means3D"] + torch.bmm(rots, samples.to(dev).unsqueeze(-1)).squeeze(-1)
+        # R * sample as an element-wise product-sum: a [n,3,3] x [n,3,1] bmm would pull in rocBLAS (hundreds of ms of
+        # one-time library initialisation at the first densify event) for 9 multiply-adds per row
+        new_params["means3D"] = new_params["means3D"] + (rots * samples.to(dev).unsqueeze(1)).sum(dim=-1)
         new_params["log_scales"] = torch.log(torch.exp(new_params["log_scales"]) / (0.8 * n))
         if ts is not None:
             ts = torch.cat((ts, gather_rows(ts, split_idx)))
