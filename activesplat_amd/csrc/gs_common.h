@@ -110,6 +110,51 @@ __device__ __forceinline__ void sh_rows_from_lds(const float* lds, float* __rest
     }
 }
 
+// Wavefront-private variants: one wave moves `nrows` (<= kShHalf) rows between global memory and ITS OWN padded slab,
+// 16 B per lane per step, no workgroup barrier -- the four waves of a workgroup overlap their load / compute / store
+// phases instead of taking turns.  row0 * K * 4 bytes is 16-byte aligned because row0 is a multiple of 32.
+constexpr int kShHalf = 32;
+__device__ __forceinline__ void sh_wave_rows_to_lds(float* slab, const float* __restrict__ src, int row0, int nrows, int K, int lane)
+{
+    const int stride = sh_row_stride(K), total = nrows * K, total4 = total >> 2;
+    const float* s = src + (size_t)row0 * K;
+    const float4* s4 = reinterpret_cast<const float4*>(s);
+    for (int q = lane; q < total4; q += kWave) {
+        const float4 v = s4[q];
+        int e = q << 2, r = e / K, c = e - r * K;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            slab[r * stride + c] = vv[t];
+            if (++c == K) { c = 0; ++r; }
+        }
+    }
+    for (int e = (total4 << 2) + lane; e < total; e += kWave) {
+        const int r = e / K;
+        slab[r * stride + (e - r * K)] = s[e];
+    }
+}
+__device__ __forceinline__ void sh_wave_rows_from_lds(const float* slab, float* __restrict__ dst, int row0, int nrows, int K, int lane)
+{
+    const int stride = sh_row_stride(K), total = nrows * K, total4 = total >> 2;
+    float* d = dst + (size_t)row0 * K;
+    float4* d4 = reinterpret_cast<float4*>(d);
+    for (int q = lane; q < total4; q += kWave) {
+        int e = q << 2, r = e / K, c = e - r * K;
+        float vv[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            vv[t] = slab[r * stride + c];
+            if (++c == K) { c = 0; ++r; }
+        }
+        d4[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+    for (int e = (total4 << 2) + lane; e < total; e += kWave) {
+        const int r = e / K;
+        d[e] = slab[r * stride + (e - r * K)];
+    }
+}
+
 // ---- launchers implemented in the individual translation units -------------------------------------
 hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D, const float* shs,
                                      const float* colors, const float* opac, const float* scales,

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     __shared__ __attribute__((aligned(16))) float s_col[kBlock * 3];
     __shared__ __attribute__((aligned(16))) float s_cov[kBlock * 6];
     __shared__ uint32_t s_wsum[kBlock / kWave];
-    __shared__ float s_sh[HAS_SH ? kWave * kShPad : 1];
+    __shared__ __attribute__((aligned(16))) float s_sh[HAS_SH ? (kBlock / kWave) * kShHalf * kShPad : 1];   // per-wave slabs
 
     const int tid = threadIdx.x;
     const int base = blockIdx.x * kBlock;
@@ -73,25 +73,27 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     if (!HAS_SH) stage_rows<3>(s_col, colors, base, nrows, tid);
     __syncthreads();
 
-    // SH -> RGB for every Gaussian of the workgroup, one wavefront's 64 coefficient rows per LDS pass
-    // (coalesced global reads by all 256 threads; lane = row reads at an odd stride are conflict-free)
+    // SH -> RGB for every Gaussian: each wavefront streams its own 64 coefficient rows through a private padded LDS slab,
+    // 32 rows at a time (coalesced 16 B/lane global reads; lane = row reads at an odd stride are conflict-free)
     float sh_rgb[3] = {0.f, 0.f, 0.f};
     uint32_t sh_clamp = 0;
     if (HAS_SH) {
         const int M = cam.sh_coeffs, K = M * 3, nbasis = (cam.sh_degree + 1) * (cam.sh_degree + 1);
         const int stride = sh_row_stride(K);
-        for (int w = 0; w < kBlock / kWave; w++) {
-            const int row0 = base + w * kWave;
-            if (row0 >= P) break;                                  // uniform
-            __syncthreads();
-            sh_rows_to_lds(s_sh, shs, row0, min(kWave, P - row0), K, tid);
-            __syncthreads();
-            if ((tid >> 6) == w && base + tid < P) {
+        const int lane = tid & 63, wave = tid >> 6;
+        float* slab = s_sh + wave * kShHalf * kShPad;
+        for (int h = 0; h < kWave / kShHalf; h++) {
+            const int row0 = base + wave * kWave + h * kShHalf;
+            if (row0 >= P) break;                                  // wave-uniform
+            __builtin_amdgcn_wave_barrier();
+            sh_wave_rows_to_lds(slab, shs, row0, min(kShHalf, P - row0), K, lane);
+            __builtin_amdgcn_wave_barrier();
+            if ((lane >> 5) == h && base + tid < P) {
                 const float dx = s_mean[tid * 3] - cam.campos[0], dy = s_mean[tid * 3 + 1] - cam.campos[1], dz = s_mean[tid * 3 + 2] - cam.campos[2];
                 const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
                 float b[16];
                 sh_basis(cam.sh_degree, dx * inv, dy * inv, dz * inv, b);
-                const float* sh = s_sh + (tid & 63) * stride;
+                const float* sh = slab + (lane & 31) * stride;
                 float acc[3] = {0.f, 0.f, 0.f};
                 for (int k = 0; k < nbasis; k++) {
                     acc[0] += b[k] * sh[3 * k]; acc[1] += b[k] * sh[3 * k + 1]; acc[2] += b[k] * sh[3 * k + 2];

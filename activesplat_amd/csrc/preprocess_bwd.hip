@@ -56,8 +56,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     float* __restrict__ dcolors, float* __restrict__ dshs, float* __restrict__ dscales,
     float* __restrict__ drots, float* __restrict__ dcov3D)
 {
-    __shared__ float s_sh[HAS_SH ? kWave * kShPad : 1];       // coefficient rows of one wavefront's Gaussians
-    __shared__ float s_dsh[HAS_SH ? kWave * kShPad : 1];      // their gradients
+    // per-wave slabs: 32 coefficient rows in, their gradients written back IN PLACE (each element is read before it is overwritten)
+    __shared__ __attribute__((aligned(16))) float s_sh[HAS_SH ? (kBlock / kWave) * kShHalf * kShPad : 1];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kBlock + tid;
     const bool in_range = i < P;
@@ -77,15 +77,17 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     if (HAS_SH) {
         const int deg = cam.sh_degree, nb = (deg + 1) * (deg + 1), M = cam.sh_coeffs, K = M * 3;
         const int stride = sh_row_stride(K);
-        for (int w = 0; w < kBlock / kWave; w++) {
-            const int row0 = blockIdx.x * kBlock + w * kWave;
-            if (row0 >= P) break;                                  // uniform
-            const int nrows = min(kWave, P - row0);
-            __syncthreads();
-            sh_rows_to_lds(s_sh, shs, row0, nrows, K, tid);
-            __syncthreads();
-            if ((tid >> 6) == w && in_range) {
-                float* dsh = s_dsh + (tid & 63) * stride;
+        const int lane = tid & 63, wave = tid >> 6;
+        float* slab = s_sh + wave * kShHalf * kShPad;
+        for (int h = 0; h < kWave / kShHalf; h++) {
+            const int row0 = blockIdx.x * kBlock + wave * kWave + h * kShHalf;
+            if (row0 >= P) break;                                  // wave-uniform
+            const int nrows = min(kShHalf, P - row0);
+            __builtin_amdgcn_wave_barrier();
+            sh_wave_rows_to_lds(slab, shs, row0, nrows, K, lane);
+            __builtin_amdgcn_wave_barrier();
+            if ((lane >> 5) == h && in_range) {
+                float* dsh = slab + (lane & 31) * stride;
                 if (live) {
                     const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
                     const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
@@ -94,11 +96,10 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
                     sh_basis_and_grad(deg, ux, uy, uz, b, bx, by, bz);
                     const uint32_t cl = clamped[i];
                     float du[3] = {0.f, 0.f, 0.f};
-                    const float* sh = s_sh + (tid & 63) * stride;
                     for (int ch = 0; ch < 3; ch++) {
                         const float g = ((cl >> (8 * ch)) & 1u) ? 0.f : drgb[ch];
                         for (int k = 0; k < nb; k++) {
-                            const float coef = sh[3 * k + ch];
+                            const float coef = dsh[3 * k + ch];
                             dsh[3 * k + ch] = g * b[k];
                             du[0] += g * coef * bx[k]; du[1] += g * coef * by[k]; du[2] += g * coef * bz[k];
                         }
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
                     for (int k = 0; k < K; k++) dsh[k] = 0.f;
                 }
             }
-            __syncthreads();
-            sh_rows_from_lds(s_dsh, dshs, row0, nrows, K, tid);
+            __builtin_amdgcn_wave_barrier();
+            sh_wave_rows_from_lds(slab, dshs, row0, nrows, K, lane);
         }
         if (!in_range) return;
     }
