@@ -53,13 +53,19 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales,
     const float* __restrict__ rots, const float* __restrict__ cov3Dp, int32_t* __restrict__ radii, GeomPtrs gp)
 {
+    // LDS: means | one pool that holds, in turn, the per-wave SH slabs (HAS_SH, first phase) and the staged
+    // scale+rotation (or covariance) rows and colours (second phase)
+    constexpr int kGeoFloats = kBlock * 7, kColFloats = HAS_SH ? 0 : kBlock * 3;
+    constexpr int kSlabFloats = HAS_SH ? (kBlock / kWave) * kShHalf * kShPad : 0;
+    constexpr int kPoolFloats = (kGeoFloats + kColFloats) > kSlabFloats ? (kGeoFloats + kColFloats) : kSlabFloats;
     __shared__ __attribute__((aligned(16))) float s_mean[kBlock * 3];
-    __shared__ __attribute__((aligned(16))) float s_scale[kBlock * 3];
-    __shared__ __attribute__((aligned(16))) float s_rot[kBlock * 4];
-    __shared__ __attribute__((aligned(16))) float s_col[kBlock * 3];
-    __shared__ __attribute__((aligned(16))) float s_cov[kBlock * 6];
+    __shared__ __attribute__((aligned(16))) float s_pool[kPoolFloats];
     __shared__ uint32_t s_wsum[kBlock / kWave];
-    __shared__ __attribute__((aligned(16))) float s_sh[HAS_SH ? (kBlock / kWave) * kShHalf * kShPad : 1];   // per-wave slabs
+    float* const s_scale = s_pool;                       // [kBlock*3]  (scales + rotations) ...
+    float* const s_rot = s_pool + kBlock * 3;            // [kBlock*4]
+    float* const s_cov = s_pool;                         // [kBlock*6]  ... or the precomputed covariance
+    float* const s_col = s_pool + kGeoFloats;            // [kBlock*3]  colours (no-SH instantiation only)
+    float* const s_sh = s_pool;
 
     const int tid = threadIdx.x;
     const int base = blockIdx.x * kBlock;
@@ -68,9 +74,11 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     if (base + tid < cam.gx * cam.gy) gp.tile_total[base + tid] = 0u;
     const int i = base + tid;
     stage_rows<3>(s_mean, means3D, base, nrows, tid);
-    if (cov3Dp) stage_rows<6>(s_cov, cov3Dp, base, nrows, tid);
-    else { stage_rows<3>(s_scale, scales, base, nrows, tid); stage_rows<4>(s_rot, rots, base, nrows, tid); }
-    if (!HAS_SH) stage_rows<3>(s_col, colors, base, nrows, tid);
+    if (!HAS_SH) {
+        if (cov3Dp) stage_rows<6>(s_cov, cov3Dp, base, nrows, tid);
+        else { stage_rows<3>(s_scale, scales, base, nrows, tid); stage_rows<4>(s_rot, rots, base, nrows, tid); }
+        stage_rows<3>(s_col, colors, base, nrows, tid);
+    }
     __syncthreads();
 
     // SH -> RGB for every Gaussian: each wavefront streams its own 64 coefficient rows through a private padded LDS slab,
@@ -105,6 +113,12 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
         }
     }
 
+    if (HAS_SH) {                                        // the slabs are done: reuse the pool for the geometry rows
+        __syncthreads();
+        if (cov3Dp) stage_rows<6>(s_cov, cov3Dp, base, nrows, tid);
+        else { stage_rows<3>(s_scale, scales, base, nrows, tid); stage_rows<4>(s_rot, rots, base, nrows, tid); }
+        __syncthreads();
+    }
     uint32_t ntiles = 0;
     if (i < P) {
         const float* m = cam.view;
