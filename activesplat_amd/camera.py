@@ -31,7 +31,9 @@ def setup_camera(w, h, k, w2c, near=0.01, far=100, scale_modifier=1.0, bg=(0.0, 
                                 [0.0, 0.0, far / (far - near), -(far * near) / (far - near)],
                                 [0.0, 0.0, 1.0, 0.0]], dtype=torch.float32, device=work).unsqueeze(0).transpose(1, 2)
     full_proj = view.bmm(opengl_proj)
-    view, full_proj, cam_center = view.to(device), full_proj.to(device), cam_center.to(device)
+    # values as the reference builds them; stored contiguous and 16-byte aligned so that the rasteriser passes the
+    # pointers through instead of re-packing a transposed view / an offset slice on every call
+    view, full_proj, cam_center = view.contiguous().to(device), full_proj.contiguous().to(device), cam_center.clone().to(device)
     return GaussianRasterizationSettings(
         image_height=int(h), image_width=int(w), tanfovx=w / (2 * fx), tanfovy=h / (2 * fy),
         bg=torch.tensor(list(bg), dtype=torch.float32, device=device), scale_modifier=scale_modifier,

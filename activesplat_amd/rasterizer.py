@@ -134,7 +134,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         _lib.check(lib.gs_render_forward(C.byref(cam), P, D, max_tile, _ptr(geom), _ptr(binning), _ptr(point_list), _ptr(image),
                                          _ptr(color), _ptr(depth), _ptr(opacity), _ptr(depth_sq), st))
         last_stats["num_rendered"], last_stats["P"], last_stats["max_tile_instances"] = D, P, max_tile
-        ctx.rs, ctx.D, ctx.keep, ctx.fused = rs, D, keep, fused
+        ctx.rs, ctx.D, ctx.keep, ctx.fused, ctx.cam = rs, D, keep, fused, cam      # the backward reuses the camera block
         ctx.has = (shs is not None, colors_precomp is not None, scales is not None, rotations is not None,
                    cov3D_precomp is not None)
         if rs.debug:
@@ -159,7 +159,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         device = means3D.device
         P = int(means3D.shape[0])
         M = int(shs.shape[1]) if has_sh else 0
-        cam, keep = _camera(ctx.rs, device, M)
+        cam = ctx.cam                                    # its device pointers are kept alive by ctx.keep
         if grad_color is None:
             grad_color = torch.zeros(3, int(ctx.rs.image_height), int(ctx.rs.image_width), device=device)
         grad_color = _f32(grad_color, device)
