@@ -248,7 +248,7 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_ti
         if (D > 0) {          // ranges were written by gs_preprocess_forward
             ScopedStage ps(ST_TILE_SCATTER_SORT, st);
             e = gs::launch_tile_scatter_sort(k, P, gp, gp.tile_base, ranges, max_tile_instances,
-                                             (unsigned long long*)(bb + BL.pairs), point_list, st);
+                                             (unsigned long long*)(bb + BL.pairs), point_list, (uint32_t)D, st);
             if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: tile scatter/sort %s", hipGetErrorString(e));
         }
     } else {
@@ -279,7 +279,8 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_ti
     {
         ScopedStage ps(ST_BLEND_FWD, st);
         e = gs::launch_blend_forward(k, ranges, point_list, gp.geom, out_color, out_depth, out_opacity,
-                                     (float*)(ib + IL.final_T), (uint32_t*)(ib + IL.n_contrib), out_depth_sq, st);
+                                     (float*)(ib + IL.final_T), (uint32_t*)(ib + IL.n_contrib), out_depth_sq,
+                                     BL.path == GS_SORT_TILE_LDS ? (uint32_t)D : 0xffffffffu, st);
     }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: blend %s", hipGetErrorString(e));
     return GS_OK;

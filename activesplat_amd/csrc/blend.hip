@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ out_depth_sq)
+    float* __restrict__ out_depth_sq, uint32_t cap)
 {
     __shared__ float4 s_rec[kBlock / kWave][3][kWave];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -102,7 +102,8 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     const bool inside = c.inside;
     const float pxf = c.pxf, pyf = c.pyf;
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
-    const uint2 range = ranges[c.tile];
+    uint2 range = ranges[c.tile];
+    range.x = min(range.x, cap); range.y = min(range.y, cap);   // workspace capacity: an optimistic launch never reads past it
     const uint32_t n = range.y - range.x;
     const uint32_t* list = point_list + range.x;
 
@@ -340,15 +341,15 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
 
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
-                                uint32_t* n_contrib, float* out_depth_sq, hipStream_t st)
+                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, hipStream_t st)
 {
     const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
     if (out_depth_sq)
         hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
-                           out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq);
+                           out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap);
     else
         hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
-                           out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq);
+                           out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap);
     return hipGetLastError();
 }
 

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(THREADS) void tile_bin_kernel(Cam cam, int P, GeomP
                                                           uint32_t* __restrict__ tile_total,
                                                           uint32_t* __restrict__ tile_base,
                                                           const uint2* __restrict__ ranges,
-                                                          unsigned long long* __restrict__ pairs)
+                                                          unsigned long long* __restrict__ pairs, uint32_t cap)
 {
     __shared__ uint32_t s_hist[kMaxLdsTiles];      // count pass: histogram; scatter pass: cursors
     __shared__ uint32_t s_incl[THREADS];
@@ -86,7 +86,9 @@ __global__ __launch_bounds__(THREADS) void tile_bin_kernel(Cam cam, int P, GeomP
         expand_wave(s_incl + wave * kWave, s_x0w, s_y0, wave, lane, total, cam.gx, [&](uint32_t tile, int j) {
             if (SCATTER) {
                 const uint32_t slot = atomicAdd(&s_hist[tile], 1u);
-                pairs[slot] = ((unsigned long long)s_depth[j] << 32) | (uint32_t)(gbase + j);
+                // cap = capacity of `pairs`: an optimistic launch (workspace sized from the previous frame, true D still in
+                // flight) must never write past it -- the host discards and repeats such a frame
+                if (slot < cap) pairs[slot] = ((unsigned long long)s_depth[j] << 32) | (uint32_t)(gbase + j);
             } else {
                 atomicAdd(&s_hist[tile], 1u);
             }
@@ -237,12 +239,13 @@ __device__ __forceinline__ void tile_sort_impl(const uint2 range, uint32_t n, un
 template <int CAP, int THREADS>
 __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restrict__ ranges,
                                                              unsigned long long* __restrict__ pairs,
-                                                             uint32_t* __restrict__ point_list)
+                                                             uint32_t* __restrict__ point_list, uint32_t cap)
 {
     __shared__ unsigned long long s_a[CAP];
     __shared__ unsigned long long s_b[CAP];
     const int tid = threadIdx.x;
     uint2 range = ranges[blockIdx.x];
+    range.x = min(range.x, cap); range.y = min(range.y, cap);   // workspace capacity (see tile_bin_kernel)
     const uint32_t start = blockIdx.y * (uint32_t)CAP;
     if (range.y - range.x <= start) return;                    // uniform (also n == 0)
     range.x += start;
@@ -259,13 +262,14 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restr
 template <int CAP, int CHUNK, int THREADS>
 __global__ __launch_bounds__(THREADS) void tile_merge_kernel(const uint2* __restrict__ ranges,
                                                               unsigned long long* __restrict__ pairs,
-                                                              uint32_t* __restrict__ point_list)
+                                                              uint32_t* __restrict__ point_list, uint32_t cap)
 {
     __shared__ unsigned long long s_k[CAP];
     const int tid = threadIdx.x;
-    const uint2 range = ranges[blockIdx.x];
+    uint2 range = ranges[blockIdx.x];
+    range.x = min(range.x, cap); range.y = min(range.y, cap);
     const uint32_t n = range.y - range.x;
-    if (n <= (uint32_t)CHUNK) return;                          // uniform: already final
+    if (n <= (uint32_t)CHUNK || n > (uint32_t)CAP) return;     // uniform: already final / longer than the caller assumed
     for (uint32_t i = tid; i < n; i += THREADS) s_k[i] = pairs[range.x + i];
     __syncthreads();
     const uint32_t nruns = (n + CHUNK - 1) / CHUNK;
@@ -299,11 +303,11 @@ static void bin_config(int& threads, int& chunk)
 
 template <bool SCATTER>
 static void launch_bin(int threads, int nb, hipStream_t st, Cam cam, int P, GeomPtrs gp, int tiles, int chunk,
-                       uint32_t* tile_total, uint32_t* tile_base, const uint2* ranges, unsigned long long* pairs)
+                       uint32_t* tile_total, uint32_t* tile_base, const uint2* ranges, unsigned long long* pairs, uint32_t cap)
 {
-    if (threads == 256) hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 256>), dim3(nb), dim3(256), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs);
-    else if (threads == 512) hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 512>), dim3(nb), dim3(512), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs);
-    else hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 1024>), dim3(nb), dim3(1024), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs);
+    if (threads == 256) hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 256>), dim3(nb), dim3(256), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs, cap);
+    else if (threads == 512) hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 512>), dim3(nb), dim3(512), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs, cap);
+    else hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 1024>), dim3(nb), dim3(1024), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs, cap);
 }
 
 hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,
@@ -312,27 +316,27 @@ hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_
     const int tiles = cam.gx * cam.gy;       // tile_total was zeroed by the preprocess stage
     int threads, chunk; bin_config(threads, chunk);
     const int nb = (P + chunk - 1) / chunk;
-    if (nb > 0) launch_bin<false>(threads, nb, st, cam, P, gp, tiles, chunk, tile_total, tile_base, nullptr, nullptr);
+    if (nb > 0) launch_bin<false>(threads, nb, st, cam, P, gp, tiles, chunk, tile_total, tile_base, nullptr, nullptr, 0u);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_total, tiles, ranges, d_counts);
     return hipGetLastError();
 }
 
 hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_base, const uint2* ranges,
                                     uint32_t max_tile_instances, unsigned long long* pairs, uint32_t* point_list,
-                                    hipStream_t st)
+                                    uint32_t cap, hipStream_t st)
 {
     const int tiles = cam.gx * cam.gy;
     int threads, chunk; bin_config(threads, chunk);
     const int nb = (P + chunk - 1) / chunk;
-    if (nb > 0) launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs);
+    if (nb > 0) launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
     if (getenv("GS_SKIP_TILE_SORT")) return hipGetLastError();     // development: time the scatter alone
     const unsigned chunks = (max_tile_instances + kSortChunk - 1) / kSortChunk;
-    hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, chunks ? chunks : 1), dim3(256), 0, st, ranges, pairs, point_list);
+    hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, chunks ? chunks : 1), dim3(256), 0, st, ranges, pairs, point_list, cap);
     if (max_tile_instances > (uint32_t)kSortChunk) {
         if (max_tile_instances <= 8192)
-            hipLaunchKernelGGL((tile_merge_kernel<8192, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list);
+            hipLaunchKernelGGL((tile_merge_kernel<8192, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
         else
-            hipLaunchKernelGGL((tile_merge_kernel<kSortCapMax, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list);
+            hipLaunchKernelGGL((tile_merge_kernel<kSortCapMax, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
     }
     return hipGetLastError();
 }

@@ -50,6 +50,10 @@ last_stats = {"num_rendered": 0, "P": 0}
 #: with raster_settings.debug=True the state buffers of the most recent forward are kept here so
 #: that tests can check the integer artefacts (layouts: include/gsplat_hip.h)
 last_debug = {}
+#: per (P, W, H, device): (pair capacity, tile-list capacity) guessed for the next frame's optimistic launch
+_capacity = {}
+#: set False to always size the binning workspace from the exact counts (one mid-pipeline host sync per forward)
+optimistic = True
 
 _pinned = {}
 
@@ -120,19 +124,47 @@ class _RasterizeGaussians(torch.autograd.Function):
         _lib.check(lib.gs_preprocess_forward(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
                                              _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
                                              _ptr(radii), _ptr(geom), _ptr(image), _ptr(d_num), _ptr(h_num), st))
-        if device.type == "cuda":
-            torch.cuda.current_stream(device).synchronize()      # the one host sync: D sizes the binning buffers
-        D = int(h_num[0].item()) & 0xFFFFFFFF
-        max_tile = int(h_num[1].item()) & 0xFFFFFFFF
-        bl = _lib.GsBinLayout(); _lib.check(lib.gs_bin_layout(D, max_tile, W, H, C.byref(bl)))
-        binning = torch.empty(bl.total_bytes, dtype=torch.uint8, device=device)
-        point_list = torch.empty(max(D, 1), dtype=torch.int32, device=device)
         color = torch.empty(3, H, W, dtype=torch.float32, device=device)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=device)
         opacity = torch.empty(1, H, W, dtype=torch.float32, device=device)
         depth_sq = torch.empty(1, H, W, dtype=torch.float32, device=device) if fused else None
-        _lib.check(lib.gs_render_forward(C.byref(cam), P, D, max_tile, _ptr(geom), _ptr(binning), _ptr(point_list), _ptr(image),
-                                         _ptr(color), _ptr(depth), _ptr(opacity), _ptr(depth_sq), st))
+
+        def render(cap_d, cap_tile):
+            bl_ = _lib.GsBinLayout(); _lib.check(lib.gs_bin_layout(cap_d, cap_tile, W, H, C.byref(bl_)))
+            binning_ = torch.empty(bl_.total_bytes, dtype=torch.uint8, device=device)
+            plist_ = torch.empty(max(cap_d, 1), dtype=torch.int32, device=device)
+            _lib.check(lib.gs_render_forward(C.byref(cam), P, cap_d, cap_tile, _ptr(geom), _ptr(binning_), _ptr(plist_), _ptr(image),
+                                             _ptr(color), _ptr(depth), _ptr(opacity), _ptr(depth_sq), st))
+            return bl_, binning_, plist_
+
+        # Optimistic launch: the binning workspace is sized from the previous frame of this (P, W, H) stream (+25 %), the
+        # whole render is enqueued BEHIND the counting kernels, and only then does the host wait for the two counters --
+        # the GPU keeps working through what used to be an idle gap (host wake-up + allocation + launch).  A frame whose
+        # true counts exceed the guess is re-launched with exact sizes (gs_render_forward is capacity-safe and idempotent).
+        done = None
+        key = (P, W, H, device.index)
+        guess = _capacity.get(key) if optimistic else None
+        if guess is not None:
+            if device.type == "cuda":
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(device))
+            bl_g = _lib.GsBinLayout(); _lib.check(lib.gs_bin_layout(guess[0], guess[1], W, H, C.byref(bl_g)))
+            if bl_g.path == 1:
+                done = render(*guess)
+            if device.type == "cuda":
+                ev.synchronize()                                # counters are on the host; the render is still in flight
+        elif device.type == "cuda":
+            torch.cuda.current_stream(device).synchronize()      # first frame of a stream: D sizes the binning buffers
+        D = int(h_num[0].item()) & 0xFFFFFFFF
+        max_tile = int(h_num[1].item()) & 0xFFFFFFFF
+        if done is not None and D <= guess[0] and max_tile <= guess[1]:
+            bl, binning, point_list = done
+            last_stats["optimistic_hits"] = last_stats.get("optimistic_hits", 0) + 1
+        else:
+            bl, binning, point_list = render(D, max_tile)
+            last_stats["optimistic_misses"] = last_stats.get("optimistic_misses", 0) + (1 if guess is not None else 0)
+        old = _capacity.get(key, (0, 0))                        # monotone: views that alternate settle on the largest
+        _capacity[key] = (max(old[0], int(D * 1.25) + 4096), max(old[1], int(max_tile * 1.25) + 64))
         last_stats["num_rendered"], last_stats["P"], last_stats["max_tile_instances"] = D, P, max_tile
         ctx.rs, ctx.D, ctx.keep, ctx.fused, ctx.cam = rs, D, keep, fused, cam      # the backward reuses the camera block
         ctx.has = (shs is not None, colors_precomp is not None, scales is not None, rotations is not None,

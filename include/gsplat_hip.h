@@ -139,7 +139,12 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P,
  * point_list [D] receives the (tile, depth, index)-sorted Gaussian ids (kept for the backward).
  * out_depth_sq [1,H,W] (nullable) additionally receives sum z^2*alpha*T: with out_depth and out_opacity these are
  * the three channels of the reference's second, [z, 1, z^2] raster pass (slam_helpers.py:196-249), produced by
- * the SAME pass as the colour. */
+ * the SAME pass as the colour.
+ * D and max_tile_instances may be UPPER BOUNDS (the capacity the caller sized bin_state / point_list for) as long as
+ * gs_bin_layout reports GS_SORT_TILE_LDS for them: no kernel reads or writes past D, so a host may enqueue this call
+ * right behind gs_preprocess_forward with bounds from the previous frame, read h_counts afterwards, and simply call it
+ * again with the exact counts in the rare frame where they exceed the bounds (the call is idempotent; a frame whose
+ * true counts exceed the bounds it was launched with has unspecified outputs). */
 int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_tile_instances,
                       void* geom_state, void* bin_state, uint32_t* point_list, void* image_state,
                       float* out_color, float* out_depth, float* out_opacity, float* out_depth_sq,

@@ -195,3 +195,47 @@ def check_fused_rgbd(rs, rv, oracle64, seed=0):
 
 def close_frac(a, b, rtol, atol):
     return util.close_frac(a, b, rtol, atol)
+
+
+def check_optimistic_launch(device):
+    """The binning workspace of frame k is sized from frame k-1 and the render enqueued before the counters are read:
+    a hit (same view again) and a miss (a view with 10x the instances, re-launched with exact sizes after the
+    capacity-clamped first attempt) must both reproduce the exactly-sized launch bit for bit."""
+    from activesplat_amd import GaussianRasterizer, rasterizer as R
+    N = 20000
+    rs_far, rv = util.scene(N, 96, 80, seed=11, device=device, w2c=util.pose(0.0, (0.0, 0.0, -3.3)))     # most of the scene behind the camera
+    rs_near, _ = util.scene(N, 96, 80, seed=11, device=device)
+    m2d = torch.zeros(N, 3, device=device)
+    run = lambda rs: [t.clone() for t in GaussianRasterizer(raster_settings=rs)(means2D=m2d, **rv)]  # noqa: E731
+    R.optimistic = False
+    try:
+        exact_far, exact_near = run(rs_far), run(rs_near)
+        d_far = R.last_stats["num_rendered"]
+    finally:
+        R.optimistic = True
+    R._capacity.clear()
+    R.last_stats.pop("optimistic_hits", None); R.last_stats.pop("optimistic_misses", None)
+    a = run(rs_far)                       # no guess yet: exact
+    b = run(rs_far)                       # hit
+    assert R.last_stats.get("optimistic_hits", 0) == 1 and R.last_stats.get("optimistic_misses", 0) == 0
+    d_near_guess = R._capacity[(N, 96, 80, torch.device(device).index)][0]
+    c = run(rs_near)                      # miss: D grows far beyond 1.25 x
+    assert R.last_stats["num_rendered"] > d_near_guess and R.last_stats["optimistic_misses"] == 1
+    d = run(rs_near)                      # hit at the grown capacity
+    e = run(rs_far)                       # hit with a much larger capacity than needed
+    assert R.last_stats["optimistic_hits"] == 3
+    for got, ref in ((a, exact_far), (b, exact_far), (c, exact_near), (d, exact_near), (e, exact_far)):
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y)
+    # gradients through an optimistic hit
+    rv_g = {k: v.clone().requires_grad_(True) for k, v in rv.items()}
+    GaussianRasterizer(raster_settings=rs_near)(means2D=m2d, **rv_g)[0].sum().backward()
+    R.optimistic = False
+    try:
+        rv_h = {k: v.clone().requires_grad_(True) for k, v in rv.items()}
+        GaussianRasterizer(raster_settings=rs_near)(means2D=m2d, **rv_h)[0].sum().backward()
+    finally:
+        R.optimistic = True
+    for k in rv_g:
+        if rv_g[k].grad is not None:
+            assert torch.allclose(rv_g[k].grad, rv_h[k].grad, rtol=1e-5, atol=1e-7), k

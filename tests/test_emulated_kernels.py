@@ -111,3 +111,7 @@ def test_emulated_fused_loss_equals_two_pass_loss(emu):
         for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
             a, b = out[0][1][k], o[1][k]
             assert float((a - b).norm() / a.norm()) < 2e-4, k
+
+
+def test_emulated_optimistic_launch_hit_and_miss_equal_exact_launch(emu):
+    pc.check_optimistic_launch(emu)

@@ -151,3 +151,7 @@ def test_zero_gaussians(hip):
     assert radii.numel() == 0 and float(opacity.abs().max()) == 0 and float(depth.abs().max()) == 0
     assert torch.allclose(color, torch.tensor([0.2, 0.4, 0.6], device=hip).view(3, 1, 1).expand(3, 50, 70))
     color.sum().backward()
+
+
+def test_optimistic_launch_hit_and_miss_equal_exact_launch(hip):
+    pc.check_optimistic_launch(hip)
