@@ -218,7 +218,7 @@ def check_optimistic_launch(device):
     a = run(rs_far)                       # no guess yet: exact
     b = run(rs_far)                       # hit
     assert R.last_stats.get("optimistic_hits", 0) == 1 and R.last_stats.get("optimistic_misses", 0) == 0
-    d_near_guess = R._capacity[(N, 96, 80, torch.device(device).index)][0]
+    d_near_guess = R._capacity[(N, 96, 80, rv["means3D"].device.index)][0]
     c = run(rs_near)                      # miss: D grows far beyond 1.25 x
     assert R.last_stats["num_rendered"] > d_near_guess and R.last_stats["optimistic_misses"] == 1
     d = run(rs_near)                      # hit at the grown capacity
