@@ -164,6 +164,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             bl, binning, point_list = render(D, max_tile)
             last_stats["optimistic_misses"] = last_stats.get("optimistic_misses", 0) + (1 if guess is not None else 0)
         old = _capacity.get(key, (0, 0))                        # monotone: views that alternate settle on the largest
+        if len(_capacity) >= 64 and key not in _capacity:       # P changes with every densify / growth step: keep the table small
+            _capacity.pop(next(iter(_capacity)))
         _capacity[key] = (max(old[0], int(D * 1.25) + 4096), max(old[1], int(max_tile * 1.25) + 64))
         last_stats["num_rendered"], last_stats["P"], last_stats["max_tile_instances"] = D, P, max_tile
         ctx.rs, ctx.D, ctx.keep, ctx.fused, ctx.cam = rs, D, keep, fused, cam      # the backward reuses the camera block
