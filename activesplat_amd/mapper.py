@@ -34,6 +34,7 @@ import torch.nn.functional as F
 from . import mapping as M
 from . import optim as O
 from .camera import setup_camera
+from . import frames as FR
 from .keyframes import keyframe_selection_overlap
 
 DEFAULT_CONFIG = dict(
@@ -74,6 +75,8 @@ class SplatMapper:
         self.intrinsics = torch.as_tensor(np.asarray(intrinsics), dtype=torch.float32, device=self.device)
         self.first_frame_w2c = torch.eye(4, device=self.device)
         self.cam = setup_camera(self.W, self.H, np.asarray(intrinsics), np.eye(4), device=self.device)
+        self.densify_cam, self.densify_intrinsics = self.cam, self.intrinsics      # replaced when frames carry a densify copy
+        self.first_abs_pose = None
         self.params = self.variables = self.optimizer = None
         self.keyframe_list, self.selected_keyframes, self.gt_w2c_all_frames = [], [], []
         self.rng = np.random.RandomState(self.cfg["seed"])
@@ -100,14 +103,22 @@ class SplatMapper:
         depth = frame["depth"].to(self.device).float()
         quat = torch.as_tensor(frame["quat"], dtype=torch.float32, device=self.device)
         pos = torch.as_tensor(frame["position"], dtype=torch.float32, device=self.device)
+        # densification-resolution copy of the frame (reference :362-376); defaults to the mapping resolution
+        d_color = frame["densify_color"].to(self.device).float() if "densify_color" in frame else color
+        d_depth = frame["densify_depth"].to(self.device).float() if "densify_depth" in frame else depth
+        if fid == 0 and d_color.shape[1:] != color.shape[1:]:
+            fac = color.shape[2] / d_color.shape[2]
+            self.densify_intrinsics = FR.densify_intrinsics(self.intrinsics.cpu(), fac).to(self.device)
+            self.densify_cam = setup_camera(d_color.shape[2], d_color.shape[1], self.densify_intrinsics.cpu().numpy(), np.eye(4),
+                                            device=self.device)
         if fid == 0:
             init_w2c = torch.eye(4, device=self.device)
             init_w2c[:3, :3] = M.build_rotation(quat.view(1, 4))
             init_w2c[:3, 3] = pos
-            mask = (depth > 0).reshape(-1)
-            cld, msd = M.get_pointcloud(color, depth, self.intrinsics, init_w2c, mask=mask, compute_mean_sq_dist=True)
+            mask = (d_depth > 0).reshape(-1)
+            cld, msd = M.get_pointcloud(d_color, d_depth, self.densify_intrinsics, init_w2c, mask=mask, compute_mean_sq_dist=True)
             self.params, self.variables = M.initialize_params(cld, cfg["step_num"], msd, cfg["gaussian_distribution"])
-            self.variables["scene_radius"] = torch.max(depth) / cfg["scene_radius_depth_ratio"]
+            self.variables["scene_radius"] = torch.max(d_depth) / cfg["scene_radius_depth_ratio"]
         map_every = cfg["map_every"]
         iter_per_frame = int(cfg["mapping_iters"] // map_every)
         if iter_per_frame == 0 and fid % map_every == 0:
@@ -117,7 +128,9 @@ class SplatMapper:
             self.params["cam_trans"][..., fid] = pos
         if fid == 0 or (fid + 1) % map_every == 0:
             if mc["add_new_gaussians"] and fid > 0:
-                self.params, self.variables = M.add_new_gaussians(self.params, self.variables, self._data(color, depth, fid),
+                d_data = {"cam": self.densify_cam, "im": d_color, "depth": d_depth, "id": fid, "intrinsics": self.densify_intrinsics,
+                          "w2c": self.first_frame_w2c}
+                self.params, self.variables = M.add_new_gaussians(self.params, self.variables, d_data,
                                                                   mc["sil_thres"], fid, cfg["gaussian_distribution"],
                                                                   fused=cfg.get("fused_growth", False),
                                                                   pose7=[float(v) for v in F.normalize(quat.view(1, 4)).view(4).tolist()]
@@ -163,6 +176,20 @@ class SplatMapper:
         with torch.no_grad():
             self.gt_w2c_all_frames.append(self._w2c(fid))
         return self.params
+
+    def run_raw(self, image, depth, X_WV, frame_id, quat, position):
+        """Sensor frame in (uint8 [h,w,3] image, [h,w] metric depth, 4x4 pose X_WV): pre-processing of :332-378 (pose to the
+        relative OpenGL-convention w2c, resize to the mapping resolution and to the densification resolution), then run().
+        quat (w,x,y,z) / position are the tracker's camera parameters for this frame (the reference skips tracking and
+        writes the simulator's, :400-405)."""
+        gt_w2c, self.first_abs_pose = FR.gt_w2c_from_pose(X_WV, self.first_abs_pose)
+        color, d = FR.to_mapping_tensors(image, depth, self.W, self.H, self.device)
+        fac = float(self.cfg.get("densify_downscale_factor", 1))
+        frame = {"id": frame_id, "color": color, "depth": d, "quat": quat, "position": position, "gt_w2c": gt_w2c}
+        if fac != 1:
+            frame["densify_color"], frame["densify_depth"] = FR.to_mapping_tensors(image, depth, int(self.W / fac), int(self.H / fac),
+                                                                                   self.device)
+        return self.run(frame)
 
     # -- hand-off (reference: q_main2vis.put(GaussianPacket(...)) __init__.py:536-542; post_processing :544-578) ----
     def packet(self, c2w=None):

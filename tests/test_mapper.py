@@ -84,3 +84,27 @@ def test_fused_growth_and_keyframe_scoring_build_the_same_map(emu):
         assert float((u - u.round()).abs().max()) < 0.05 and float((v - v.round()).abs().max()) < 0.05
         z = fr["depth"].to(new.device)[0, v.round().long(), u.round().long()]
         assert torch.allclose(z, cam[:, 2], rtol=2e-3, atol=2e-3) and bool((z > 0).all())
+
+
+def test_raw_frames_with_densification_resolution(emu):
+    """run_raw: uint8 image + metric depth + pose in, resized mapping / densification copies out; the map is seeded and
+    grown at the (half) densification resolution while the loss runs at the mapping resolution."""
+    from activesplat_amd import synthetic as syn
+    from activesplat_amd.mapper import SplatMapper
+    W, H, frames = 64, 48, 6
+    gt = syn.shell_scene(3000, seed=2, W=W, H=H)
+    gt["logit_opacities"] = gt["logit_opacities"] + 3.0
+    seq = list(syn.orbit_sequence(gt, frames, W, H, emu))
+    mp = SplatMapper(syn.intrinsics(W, H), W, H, config=dict(step_num=frames, densify_downscale_factor=2), device=emu)
+    for fr in seq:
+        image = (fr["color"].permute(1, 2, 0).clamp(0, 1) * 255).round().to(torch.uint8).cpu().numpy()
+        depth = fr["depth"][0].cpu().numpy()
+        mp.run_raw(image, depth, np.linalg.inv(np.asarray(fr["w2c"], dtype=np.float64)), fr["id"], fr["quat"], fr["position"])
+    assert (mp.densify_cam.image_width, mp.densify_cam.image_height) == (32, 24)
+    assert float(mp.densify_intrinsics[0, 0]) == float(mp.intrinsics[0, 0]) / 2
+    valid0 = int((torch.as_tensor(seq[0]["depth"])[0, ::2, ::2] > 0).sum())
+    assert mp.params["means3D"].shape[0] >= valid0                  # seeded from the 32x24 copy of frame 0, then grown
+    assert mp.params["means3D"].shape[0] < 32 * 24 * 3
+    im, depth, opacity = mp.render_rgbd(seq[0]["w2c"])
+    assert im.shape == (3, H, W) and float(opacity.mean()) > 0.3
+    assert len(mp.gt_w2c_all_frames) == frames
