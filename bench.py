@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4   # wave64 VALU instructions/s (MI355X_MICROARCH.md: 256 CUs, 4 SIMDs, 2.4 GHz)
 FP32_PEAK = 157.3e12         # MI355X_MICROARCH.md: fp32 vector peak
 
 
@@ -153,7 +154,7 @@ def main():
         frame_bytes = N * 292 + D * 160 + W * H * 48
         # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process; the most recent
         # separate-pass collection (scripts/gpu_round_end.sh -> profiles/*_pmc_summary.json) is reported if present
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu = None, None, None
         try:
             import glob
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
@@ -162,12 +163,19 @@ def main():
                 pm = json.load(open(files[-1]))
                 if kern in pm and "traffic_bytes" in pm[kern]:
                     traffic, traffic_src = int(pm[kern]["traffic_bytes"]), os.path.basename(files[-1])
+                if kern in pm and "SQ_INSTS_VALU" in pm[kern]:
+                    # the bound that actually limits the blend kernels: vector-ALU issue slots (one wave64 instruction per
+                    # SIMD per 4 cycles; 256 CUs x 4 SIMDs x 2.4 GHz / 4 = 614 G wave-instructions/s)
+                    vi = float(pm[kern]["SQ_INSTS_VALU"])
+                    valu = {"wave_insts_per_launch": int(vi), "achieved_ginst_s": round(vi / (stages[dom]["avg_us"] * 1e-6) / 1e9, 1),
+                            "peak_ginst_s": VALU_ISSUE_PEAK / 1e9, "frac": round(vi / (stages[dom]["avg_us"] * 1e-6) / VALU_ISSUE_PEAK, 4),
+                            "source": os.path.basename(files[-1])}
         except Exception:
             pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9,
                            "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "traffic": traffic, "traffic_source": traffic_src,
                            "alg_bytes_per_launch": sb[dom], "avg_us": stages[dom]["avg_us"],
-                           "frame_alg_bytes": frame_bytes,
+                           "valu_issue": valu, "frame_alg_bytes": frame_bytes,
                            "frame_frac": round(frame_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 5),
                            "stages": stages}
         # ---- secondary figures SURVEY 8(d) asks for: step-time spread, forward-only rate, blend flop rate ----
