@@ -73,18 +73,29 @@ __device__ __forceinline__ bool subblock_hit(const float4& q0, const float4& q2,
     return ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) && (q0.y - ey <= y0 + 3.0f);
 }
 
-// pop the lowest / highest set bit of a wave-uniform mask; returns its index (0 when the mask is empty)
+// pop the lowest / highest set bit of a wave-uniform mask; returns its index -- or kWave, the SENTINEL slot of the
+// staging arrays, when the mask is empty: that slot holds a record with opacity 0, whose alpha fails the 1/255 test
+// for every pixel, so a stream that has run dry needs no validity flag in the inner loop
 __device__ __forceinline__ int pop_low(unsigned long long& m)
 {
-    const int j = m ? __ffsll(m) - 1 : 0;
+    const int j = m ? __ffsll(m) - 1 : kWave;
     m &= m - 1;
     return j;
 }
 __device__ __forceinline__ int pop_high(unsigned long long& m)
 {
-    const int j = m ? 63 - __clzll(m) : 0;
-    m &= ~(1ull << j);
+    const int j = m ? 63 - __clzll(m) : kWave;
+    m &= ~(1ull << (j & 63));
     return j;
+}
+__device__ __forceinline__ void write_sentinel(float4* s0, float4* s1, float4* s2, int lane)
+{
+    if (lane == 0) {
+        s0[kWave] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s1[kWave] = make_float4(0.f, 0.f, 0.f, 0.f);       // .y = opacity 0
+        s2[kWave] = make_float4(0.f, 0.f, __uint_as_float(0u), 0.f);
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 template <bool DEPTH_SQ>     // also accumulate sum z^2 alpha T (third channel of the reference's depth/silhouette pass)
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     float* __restrict__ out_opacity, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     float* __restrict__ out_depth_sq, uint32_t cap)
 {
-    __shared__ float4 s_rec[kBlock / kWave][3][kWave];
+    __shared__ float4 s_rec[kBlock / kWave][3][kWave + 1];           // + the sentinel slot
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
     if (!tile_ctx(cam, wave, lane, c)) return;
@@ -102,6 +113,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     const bool inside = c.inside;
     const float pxf = c.pxf, pyf = c.pyf;
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
+    write_sentinel(s0, s1, s2, lane);
     uint2 range = ranges[c.tile];
     range.x = min(range.x, cap); range.y = min(range.y, cap);   // workspace capacity: an optimistic launch never reads past it
     const uint32_t n = range.y - range.x;
@@ -135,11 +147,9 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
                 // kFwdUnroll hit records per LDS wait; the blend itself is branch-free (predicated weights)
                 while (m) {
                     int jj[kFwdUnroll];
-                    bool vv[kFwdUnroll];
                     float4 a0[kFwdUnroll], a1[kFwdUnroll], a2[kFwdUnroll];
 #pragma unroll
                     for (int u = 0; u < kFwdUnroll; u++) {
-                        vv[u] = m != 0ull;
                         jj[u] = pop_low(m);
                         a0[u] = s0[jj[u]]; a1[u] = s1[jj[u]]; a2[u] = s2[jj[u]];
                     }
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
                         const float p = (a0[u].z * dx + a0[u].w * dy) * dx + (a1[u].x * dy) * dy;
                         const float alpha = fminf(0.99f, a1[u].y * __builtin_amdgcn_exp2f(p));
                         const float test_T = T * (1.0f - alpha);
-                        const bool vis = vv[u] && !done && p <= 0.0f && alpha >= kAlphaMin;
+                        const bool vis = !done && p <= 0.0f && alpha >= kAlphaMin;     // sentinel: alpha = 0
                         const bool ok = vis && test_T >= kTmin;
                         done = done || (vis && !ok);
                         const float w = ok ? alpha * T : 0.0f;
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const float4* __restrict__ geom, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, float* __restrict__ grad2d)
 {
-    __shared__ float4 s_rec[kBlock / kWave][3][kWave];
+    __shared__ float4 s_rec[kBlock / kWave][3][kWave + 1];           // + the sentinel slot
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
     if (!tile_ctx(cam, wave, lane, c)) return;
@@ -247,6 +257,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const bool inside = px < cam.W && py < cam.H;
     const float pxf = (float)px, pyf = (float)py;
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
+    write_sentinel(s0, s1, s2, lane);
     const uint2 range = ranges[c.tile];
     const uint32_t* list = point_list + range.x;
     const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
@@ -292,20 +303,18 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
         __builtin_amdgcn_wave_barrier();
         while ((m0 | m1 | m2 | m3) != 0ull) {
-            // scalar side: each row pops the deepest remaining record of ITS mask; the four indices and
-            // valid bits travel to the lanes packed in two scalar registers (one v_bfe each)
-            const uint32_t vbits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
+            // scalar side: each row pops the deepest remaining record of ITS mask (the sentinel once it has run dry); the
+            // four indices travel to the lanes packed in one scalar register (one v_bfe)
             const uint32_t jpack = (uint32_t)pop_high(m0) | ((uint32_t)pop_high(m1) << 8) | ((uint32_t)pop_high(m2) << 16) |
                                    ((uint32_t)pop_high(m3) << 24);
             const int j = (int)((jpack >> row8) & 0xffu);
-            const bool valid = ((vbits >> row) & 1u) != 0u;
             const uint32_t pos = (uint32_t)ch * kWave + (uint32_t)j;          // 0-based position in the tile list
             const float4 a0 = s0[j], a1 = s1[j], a2 = s2[j];
             const float dx = a0.x - pxf, dy = a0.y - pyf;
             const float p = (a0.z * dx + a0.w * dy) * dx + (a1.x * dy) * dy;
             const float G = __builtin_amdgcn_exp2f(p);
             const float alpha = fminf(0.99f, a1.y * G);
-            const bool ok = valid && pos < last && p <= 0.0f && alpha >= kAlphaMin;
+            const bool ok = pos < last && p <= 0.0f && alpha >= kAlphaMin;
             const unsigned long long okm = __ballot(ok);
             if (okm == 0ull) continue;
             // branch-free replay step.  `acc` is the colour composited BEHIND the current record; after the
