@@ -51,7 +51,7 @@ SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_sc
            "gs_version", "gs_set_sort_path", "gs_preprocess_forward", "gs_render_forward", "gs_render_backward", "gs_adam_step", "gs_adam_step_multi",
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
            "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward",
-           "gs_grow_scratch_bytes", "gs_grow_gaussians", "gs_keyframe_overlap")
+           "gs_grow_scratch_bytes", "gs_grow_gaussians", "gs_keyframe_overlap", "gs_visibility_stats", "gs_accumulate_grad2d")
 
 
 def _bind(lib):
@@ -96,6 +96,10 @@ def _bind(lib):
     lib.gs_grow_gaussians.restype = C.c_int
     lib.gs_keyframe_overlap.argtypes = [i32, vp, i32, vp, vp, i32, i32, i32, vp, vp]
     lib.gs_keyframe_overlap.restype = C.c_int
+    lib.gs_visibility_stats.argtypes = [i32, vp, vp, vp, vp]
+    lib.gs_visibility_stats.restype = C.c_int
+    lib.gs_accumulate_grad2d.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.gs_accumulate_grad2d.restype = C.c_int
     lib.gs_adam_step_multi.restype = C.c_int
     for n in ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_preprocess_forward", "gs_render_forward",
               "gs_render_backward", "gs_adam_step"):

@@ -422,6 +422,22 @@ int gs_gather_rows(int64_t n_out, int32_t row_floats, const uint32_t* src_index,
     return GS_OK;
 }
 
+int gs_visibility_stats(int32_t P, const int32_t* radii, uint8_t* seen, float* max_2D_radius, gs_stream_t stream)
+{
+    if (P < 0 || (P > 0 && !radii)) return fail(GS_EINVAL, "gs_visibility_stats: bad argument");
+    hipError_t e = gs::launch_visibility_stats(P, radii, seen, max_2D_radius, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_visibility_stats: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_accumulate_grad2d(int32_t P, const float* means2D_grad, const uint8_t* seen, float* grad_accum, float* denom, gs_stream_t stream)
+{
+    if (P < 0 || (P > 0 && (!means2D_grad || !seen || !grad_accum || !denom))) return fail(GS_EINVAL, "gs_accumulate_grad2d: bad argument");
+    hipError_t e = gs::launch_accumulate_grad2d(P, means2D_grad, seen, grad_accum, denom, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_accumulate_grad2d: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
 uint64_t gs_grow_scratch_bytes(int32_t width, int32_t height)
 {
     return align_up(gs::grow_scratch_bytes((int64_t)(width > 0 ? width : 1) * (height > 0 ? height : 1)));

@@ -279,9 +279,8 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
     variables["means2D"] = rendervar["means2D"]          # densification reads the colour pass' gradient only
     if fused_loss and use_l1 and not ignore_outlier_depth_loss:
         loss, weighted = fused_mapping_loss(im, depth, depth_sq, curr_data["im"], curr_data["depth"], loss_weights)
-        seen = radius > 0
-        variables["max_2D_radius"] = torch.maximum(variables["max_2D_radius"], radius.to(variables["max_2D_radius"].dtype))
-        variables["seen"] = seen
+        from . import optim as O
+        variables["seen"] = O.visibility_stats(radius, variables["max_2D_radius"])      # one launch: seen + max radius in place
         return loss, variables, weighted
     uncertainty = (depth_sq - depth ** 2).detach()
     mask = curr_data["depth"] > 0

@@ -96,16 +96,35 @@ def inverse_sigmoid(x):
     return torch.log(x / (1 - x))
 
 
+def visibility_stats(radius: torch.Tensor, max_2D_radius: torch.Tensor) -> torch.Tensor:
+    """seen = radius > 0 (returned, bool) and max_2D_radius = max(max_2D_radius, radius) IN PLACE -- splatam.py:296-298 in one
+    launch (gs_visibility_stats).  Falls back to torch ops for tensors the kernel does not take (dtype / layout)."""
+    P = int(radius.shape[0])
+    if radius.dtype == torch.int32 and radius.is_contiguous() and max_2D_radius.dtype == torch.float32 and max_2D_radius.is_contiguous() \
+            and max_2D_radius.shape == (P,):
+        seen = torch.empty(P, dtype=torch.bool, device=radius.device)
+        _lib.check(_lib.get().gs_visibility_stats(P, radius.data_ptr(), seen.data_ptr(), max_2D_radius.data_ptr(), _stream(radius)))
+        return seen
+    seen = radius > 0
+    max_2D_radius.copy_(torch.maximum(max_2D_radius, radius.to(max_2D_radius.dtype)))
+    return seen
+
+
 def accumulate_mean2d_gradient(variables):
-    """slam_external.py:100-108: accum[seen] += ||means2D.grad[seen, :2]||, denom[seen] += 1 -- written as masked
-    element-wise updates (identical values; no boolean-index gathers, no host sync on `seen.sum()`)."""
+    """slam_external.py:100-108: accum[seen] += ||means2D.grad[seen, :2]||, denom[seen] += 1 -- one launch
+    (gs_accumulate_grad2d) instead of boolean-index gathers and a host sync on `seen.sum()`; identical values."""
     g = variables["means2D"].grad
     if g is None or g.shape[0] != variables["means2D"].shape[0] or g.shape[1] < 2:
         return variables
-    seen = variables["seen"]
+    seen, accum, denom = variables["seen"], variables["means2D_gradient_accum"], variables["denom"]
+    P = int(g.shape[0])
+    if g.dtype == torch.float32 and g.is_contiguous() and g.shape[1] == 3 and seen.dtype == torch.bool and seen.is_contiguous() \
+            and accum.dtype == torch.float32 and accum.is_contiguous() and denom.dtype == torch.float32 and denom.is_contiguous():
+        _lib.check(_lib.get().gs_accumulate_grad2d(P, g.data_ptr(), seen.data_ptr(), accum.data_ptr(), denom.data_ptr(), _stream(g)))
+        return variables
     norm = torch.norm(g[:, :2], dim=-1)
-    variables["means2D_gradient_accum"] += torch.where(seen, norm, torch.zeros_like(norm))
-    variables["denom"] += seen.to(variables["denom"].dtype)
+    accum += torch.where(seen, norm, torch.zeros_like(norm))
+    denom += seen.to(denom.dtype)
     return variables
 
 

@@ -218,6 +218,15 @@ int gs_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32
 int gs_gather_rows(int64_t n_out, int32_t row_floats, const uint32_t* src_index, const float* src, float* dst,
                    gs_stream_t stream);
 
+/* Densification statistics, one launch each.
+ * gs_visibility_stats : seen[i] = radii[i] > 0 (uint8, nullable); max_2D_radius[i] = max(max_2D_radius[i], radii[i]) (nullable)
+ *                       -- src/mapper/splatam/splatam.py:296-298.
+ * gs_accumulate_grad2d: for seen rows, grad_accum += ||means2D_grad[i,:2]||, denom += 1; means2D_grad is [P,3]
+ *                       -- src/mapper/splatam/utils/slam_external.py:100-108. */
+int gs_visibility_stats(int32_t P, const int32_t* radii, uint8_t* seen, float* max_2D_radius, gs_stream_t stream);
+int gs_accumulate_grad2d(int32_t P, const float* means2D_grad, const uint8_t* seen, float* grad_accum, float* denom,
+                         gs_stream_t stream);
+
 /* Map growth (replaces add_new_gaussians, src/mapper/splatam/splatam.py:332-379, with get_pointcloud :25-75 and
  * initialize_new_params :304-329).  render_depth / silhouette / gt_depth are [H*W] device images, color is [3,H*W];
  * h_intrinsics4 = HOST {fx,fy,cx,cy}; h_c2w12 = HOST row-major 3x4 camera-to-world of the frame.  Outputs must hold H*W

@@ -115,3 +115,27 @@ def test_emulated_fused_loss_equals_two_pass_loss(emu):
 
 def test_emulated_optimistic_launch_hit_and_miss_equal_exact_launch(emu):
     pc.check_optimistic_launch(emu)
+
+
+def test_emulated_densification_statistics_kernels(emu):
+    from activesplat_amd import optim as O
+    g0 = torch.Generator().manual_seed(8)
+    P = 1003
+    radius = torch.randint(0, 9, (P,), generator=g0, dtype=torch.int32)
+    radius[::3] = 0
+    mx = torch.rand(P, generator=g0) * 6
+    ref_seen = radius > 0
+    ref_mx = torch.maximum(mx, radius.float())
+    seen = O.visibility_stats(radius, mx)
+    assert seen.dtype == torch.bool and torch.equal(seen, ref_seen) and torch.equal(mx, ref_mx)
+    m2d = torch.zeros(P, 3, requires_grad=True)
+    m2d.grad = torch.randn(P, 3, generator=g0)
+    accum, denom = torch.rand(P, generator=g0), torch.randint(0, 5, (P,), generator=g0).float()
+    ref_acc, ref_den = accum.clone(), denom.clone()
+    ref_acc[ref_seen] += torch.norm(m2d.grad[ref_seen, :2], dim=-1)
+    ref_den[ref_seen] += 1
+    O.accumulate_mean2d_gradient({"means2D": m2d, "seen": seen, "means2D_gradient_accum": accum, "denom": denom})
+    assert torch.allclose(accum, ref_acc, rtol=1e-6, atol=0) and torch.equal(denom, ref_den)
+    # dtype the kernel does not take: same result through the torch fallback
+    mx64 = torch.zeros(P, dtype=torch.float64)
+    assert torch.equal(O.visibility_stats(radius, mx64), ref_seen) and torch.equal(mx64, radius.double())
