@@ -80,8 +80,15 @@ __global__ __launch_bounds__(kBlock) void grow_mask_kernel(int64_t n, const floa
         take = cand && (g > 0.0f);
         keep[i] = take ? 1 : 0;
     }
+    // candidate count: 64 accumulator lines (thousands of same-address device atomics would serialise for ~70 us)
     const unsigned long long m = __ballot(cand);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(d_candidates, (uint32_t)__popcll(m));
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(d_candidates + (blockIdx.x & 63) * 16, (uint32_t)__popcll(m));
+}
+
+__global__ __launch_bounds__(kWave) void grow_sum_slots_kernel(const uint32_t* __restrict__ slots, uint32_t* __restrict__ out)
+{
+    const uint32_t v = wave_sum_u32(slots[threadIdx.x * 16]);
+    if (threadIdx.x == 0) *out = v;
 }
 
 struct GrowCam { float fx, fy, cx, cy; float c2w[12]; int W; int isotropic; };
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void grow_rows_kernel(GrowCam c, int64_t np
 
 uint64_t grow_scratch_bytes(int64_t npix)
 {   // keep mask | index list | median | compaction block sums
-    return (uint64_t)((npix + 255) / 256 * 256) + (uint64_t)npix * 4 + 256 + compact_scratch_bytes(npix) + 256;
+    return (uint64_t)((npix + 255) / 256 * 256) + (uint64_t)npix * 4 + 256 + 64 * 64 + compact_scratch_bytes(npix) + 256;
 }
 
 hipError_t launch_grow(int W, int H, const float* rd, const float* sil, const float* gt, const float* color, const float* k4,
@@ -128,12 +135,14 @@ hipError_t launch_grow(int W, int H, const float* rd, const float* sil, const fl
     uint8_t* keep = (uint8_t*)scratch;
     uint32_t* index = (uint32_t*)(keep + (n + 255) / 256 * 256);
     float* med = (float*)(index + n);
-    void* cscr = (void*)(med + 64);
-    hipError_t e = hipMemsetAsync(d_counts, 0, 8, st);
+    uint32_t* slots = (uint32_t*)(med + 64);                 // 64 lines of candidate counters
+    void* cscr = (void*)(slots + 64 * 16);
+    hipError_t e = hipMemsetAsync(slots, 0, 64 * 64, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(grow_median_kernel, dim3(1), dim3(kSelectThreads), 0, st, n, gt, rd, med);
     const int nb = (int)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(grow_mask_kernel, dim3(nb), dim3(kBlock), 0, st, n, gt, rd, sil, (const float*)med, sil_thres, keep, d_counts);
+    hipLaunchKernelGGL(grow_mask_kernel, dim3(nb), dim3(kBlock), 0, st, n, gt, rd, sil, (const float*)med, sil_thres, keep, slots);
+    hipLaunchKernelGGL(grow_sum_slots_kernel, dim3(1), dim3(kWave), 0, st, (const uint32_t*)slots, d_counts);
     e = launch_compact_index(n, keep, index, d_counts + 1, cscr, st);
     if (e != hipSuccess) return e;
     GrowCam c;

@@ -36,7 +36,20 @@ __device__ __forceinline__ float block_sum(float v, float* s_red, int tid)
     return s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
-// acc[0] = sum SSIM, acc[1] = sum |im - gt|, acc[2] = sum masked |gt_depth - depth|, acc[3] = mask count
+// Accumulators: kAccSlots copies of {sum SSIM, sum |im - gt|, sum masked |gt_depth - depth|, mask count}, one 64-byte line
+// each; a block adds to slot (block index mod kAccSlots).  With a single copy the 4 x 1200 same-line device atomics of a
+// 640x480 frame serialise at the memory side and cost ~70 us -- more than all the arithmetic of the loss.
+constexpr int kAccSlots = 64;
+constexpr int kAccFloats = kAccSlots * 16;
+__device__ __forceinline__ void acc_totals(const float* __restrict__ acc, float* s_tot, int tid)
+{
+    if (tid < kWave) {
+        const float4 v = *reinterpret_cast<const float4*>(acc + tid * 16);
+        const float a = wave_sum(v.x), b = wave_sum(v.y), c = wave_sum(v.z), d = wave_sum(v.w);
+        if (tid == 0) { s_tot[0] = a; s_tot[1] = b; s_tot[2] = c; s_tot[3] = d; }
+    }
+    __syncthreads();
+}
 __global__ __launch_bounds__(kBlock) void loss_stats_kernel(int W, int H, const float* __restrict__ im,
                                                             const float* __restrict__ gt, const float* __restrict__ depth,
                                                             const float* __restrict__ depth_sq,
@@ -107,7 +120,10 @@ __global__ __launch_bounds__(kBlock) void loss_stats_kernel(int W, int H, const 
     sum_l1 = block_sum(sum_l1, s_red, tid);
     sum_d = block_sum(sum_d, s_red, tid);
     cnt = block_sum(cnt, s_red, tid);
-    if (tid == 0) { atomicAdd(acc, sum_ssim); atomicAdd(acc + 1, sum_l1); atomicAdd(acc + 2, sum_d); atomicAdd(acc + 3, cnt); }
+    if (tid == 0) {
+        float* a = acc + ((blockIdx.y * gridDim.x + blockIdx.x) & (kAccSlots - 1)) * 16;
+        atomicAdd(a, sum_ssim); atomicAdd(a + 1, sum_l1); atomicAdd(a + 2, sum_d); atomicAdd(a + 3, cnt);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void loss_grad_kernel(int W, int H, const float* __restrict__ im,
@@ -120,7 +136,9 @@ __global__ __launch_bounds__(kBlock) void loss_grad_kernel(int W, int H, const f
 {
     __shared__ float s_p[3][kLP][kLP + 1];
     __shared__ float s_h[3][kLP][kLT + 1];
+    __shared__ float s_tot[4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    acc_totals(acc, s_tot, tid);
     const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
     const int px = x0 + tx, py = y0 + ty;
     const bool inside = px < W && py < H;
@@ -164,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void loss_grad_kernel(int W, int H, const f
             dL_dim[o] = k_ssim * (g1 + 2.f * x * g2 + y * g3) + k_l1 * sgn;
         }
     }
-    const float cnt = acc[3];
+    const float cnt = s_tot[3];
     if (inside) {
         const size_t o = (size_t)py * W + px;
         const float d = depth[o], g = gt_depth[o];
@@ -175,8 +193,8 @@ __global__ __launch_bounds__(kBlock) void loss_grad_kernel(int W, int H, const f
         dL_ddepth[o] = m ? w_depth * sgn / cnt : 0.f;
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-        const float l_im = w_im * (0.8f * acc[1] / n3 + 0.2f * (1.0f - acc[0] / n3));
-        const float l_depth = w_depth * acc[2] / cnt;
+        const float l_im = w_im * (0.8f * s_tot[1] / n3 + 0.2f * (1.0f - s_tot[0] / n3));
+        const float l_depth = w_depth * s_tot[2] / cnt;
         losses[0] = l_im + l_depth; losses[1] = l_im; losses[2] = l_depth;
     }
 }
@@ -185,9 +203,9 @@ hipError_t launch_mapping_loss(int W, int H, const float* im, const float* gt, c
                                const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
                                float* dL_ddepth, float* scratch, hipStream_t st)
 {
-    float* acc = scratch;                         // 4 accumulators (64-byte slot), then 9 partial maps
-    float* partials = scratch + 16;
-    hipError_t e = hipMemsetAsync(acc, 0, 16 * sizeof(float), st);
+    float* acc = scratch;                         // kAccSlots x 4 accumulators (one 64-byte line each), then 9 partial maps
+    float* partials = scratch + kAccFloats;
+    hipError_t e = hipMemsetAsync(acc, 0, kAccFloats * sizeof(float), st);
     if (e != hipSuccess) return e;
     const dim3 grid((W + kLT - 1) / kLT, (H + kLT - 1) / kLT);
     hipLaunchKernelGGL(loss_stats_kernel, grid, dim3(kBlock), 0, st, W, H, im, gt, depth, depth_sq, gt_depth, partials, acc);

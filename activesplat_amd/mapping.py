@@ -208,8 +208,10 @@ def fused_rendervar(params, time_idx, pose7=None):
         pose7 = torch.cat([q, params["cam_trans"][..., time_idx].detach().reshape(3)]).cpu().tolist()
     m, r, o, s = _FusedRendervars.apply(params["means3D"], params["unnorm_rotations"], params["logit_opacities"],
                                         params["log_scales"], pose7)
+    # means2D only exists to receive the screen-space gradient: a fresh LEAF (autograd hands it the rasteriser's gradient
+    # tensor as .grad without a copy; the reference's `zeros + 0` non-leaf costs an add and a retain_grad clone)
     return {"means3D": m, "colors_precomp": params["rgb_colors"], "rotations": r, "opacities": o, "scales": s,
-            "means2D": torch.zeros_like(params["means3D"], requires_grad=True) + 0}
+            "means2D": torch.zeros_like(params["means3D"], requires_grad=True)}
 
 
 class _FusedMappingLoss(torch.autograd.Function):

@@ -15,7 +15,10 @@ dev = torch.device("cuda")
 N, W, H = int(os.environ.get("N", 500_000)), int(os.environ.get("W", 640)), int(os.environ.get("H", 480))
 p = syn.make_params(N, W, H, seed=0)
 lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
-for fused, floss, finp in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
+MODES = ((False, False, False), (True, False, False), (True, True, False), (True, True, True))
+if os.environ.get("ONLY_FUSED"):
+    MODES = MODES[-1:]
+for fused, floss, finp in MODES:
     params = {k: torch.nn.Parameter(v.to(dev)) for k, v in p.items()}
     params["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([[1.0, 0, 0, 0]], device=dev).T.reshape(1, 4, 1).contiguous())
     params["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 1, device=dev))
