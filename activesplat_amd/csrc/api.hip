@@ -209,9 +209,14 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, 
                                           cov3D_precomp, radii, gp, d_counts, st);
     }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: %s", hipGetErrorString(e));
+    bool mirrored = false;
     if (tiles <= gs::kMaxLdsTiles) {          // tile counting: ranges, D and the largest tile list
+        // if h_counts is mapped pinned host memory the scan kernel stores the counters there itself (no copy engine hop)
+        uint32_t* host_dev = nullptr;
+        if (h_counts && hipHostGetDevicePointer((void**)&host_dev, h_counts, 0) != hipSuccess) { host_dev = nullptr; (void)hipGetLastError(); }
+        mirrored = host_dev != nullptr;
         ScopedStage ps(ST_TILE_COUNT, st);
-        e = gs::launch_tile_count(k, P, gp, gp.tile_total, gp.tile_base, ranges, d_counts, st);
+        e = gs::launch_tile_count(k, P, gp, gp.tile_total, gp.tile_base, ranges, d_counts, host_dev, st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: tile count %s", hipGetErrorString(e));
     } else {                                   // too many tiles for the LDS histogram: radix path, counts = {D, 2^32-1}
         e = gs::launch_scan_block_sums(P, gp, d_counts, st);
@@ -219,7 +224,7 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, 
         e = hipMemsetAsync(d_counts + 1, 0xff, sizeof(uint32_t), st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: memset %s", hipGetErrorString(e));
     }
-    if (h_counts) {
+    if (h_counts && !mirrored) {
         e = hipMemcpyAsync(h_counts, d_counts, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: D2H %s", hipGetErrorString(e));
     }

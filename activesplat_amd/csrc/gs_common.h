@@ -167,7 +167,7 @@ hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3
                                       float* dmeans2D, float* dmeans3D, float* dopac, float* dcolors, float* dshs,
                                       float* dscales, float* drots, float* dcov3D, hipStream_t st);
 hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,
-                             uint2* ranges, uint32_t* d_counts, hipStream_t st);
+                             uint2* ranges, uint32_t* d_counts, uint32_t* host_counts, hipStream_t st);
 hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_base, const uint2* ranges,
                                     uint32_t max_tile_instances, unsigned long long* pairs, uint32_t* point_list,
                                     uint32_t cap, hipStream_t st);

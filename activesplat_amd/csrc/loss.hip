@@ -196,6 +196,7 @@ __global__ __launch_bounds__(kBlock) void loss_grad_kernel(int W, int H, const f
         const float l_im = w_im * (0.8f * s_tot[1] / n3 + 0.2f * (1.0f - s_tot[0] / n3));
         const float l_depth = w_depth * s_tot[2] / cnt;
         losses[0] = l_im + l_depth; losses[1] = l_im; losses[2] = l_depth;
+        losses[3] = l_im + l_depth;      // second copy: the host side hands out [0..2] as the report and [3] as the loss value
     }
 }
 

@@ -106,7 +106,8 @@ __global__ __launch_bounds__(THREADS) void tile_bin_kernel(Cam cam, int P, GeomP
 
 // exclusive scan of the per-tile totals: ranges[t] = [start, start+count); counts[0] = D, counts[1] = max
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ tile_total, int tiles,
-                                                         uint2* __restrict__ ranges, uint32_t* __restrict__ counts)
+                                                         uint2* __restrict__ ranges, uint32_t* __restrict__ counts,
+                                                         uint32_t* __restrict__ host_counts)
 {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_m[16];
@@ -139,6 +140,8 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restr
         uint32_t mx = 0;
         for (int w = 0; w < 16; w++) mx = max(mx, s_m[w]);
         counts[0] = s_carry; counts[1] = mx;
+        // mapped pinned host memory: the two counters land on the host without a separate D2H copy in the stream
+        if (host_counts) { host_counts[0] = s_carry; host_counts[1] = mx; }
     }
 }
 
@@ -311,13 +314,13 @@ static void launch_bin(int threads, int nb, hipStream_t st, Cam cam, int P, Geom
 }
 
 hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,
-                             uint2* ranges, uint32_t* d_counts, hipStream_t st)
+                             uint2* ranges, uint32_t* d_counts, uint32_t* host_counts, hipStream_t st)
 {
     const int tiles = cam.gx * cam.gy;       // tile_total was zeroed by the preprocess stage
     int threads, chunk; bin_config(threads, chunk);
     const int nb = (P + chunk - 1) / chunk;
     if (nb > 0) launch_bin<false>(threads, nb, st, cam, P, gp, tiles, chunk, tile_total, tile_base, nullptr, nullptr, 0u);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_total, tiles, ranges, d_counts);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_total, tiles, ranges, d_counts, host_counts);
     return hipGetLastError();
 }
 

@@ -77,6 +77,7 @@ class SplatMapper:
         self.cam = setup_camera(self.W, self.H, np.asarray(intrinsics), np.eye(4), device=self.device)
         self.densify_cam, self.densify_intrinsics = self.cam, self.intrinsics      # replaced when frames carry a densify copy
         self.first_abs_pose = None
+        self._one = torch.ones((), dtype=torch.float32, device=self.device)
         self.params = self.variables = self.optimizer = None
         self.keyframe_list, self.selected_keyframes, self.gt_w2c_all_frames = [], [], []
         self.rng = np.random.RandomState(self.cfg["seed"])
@@ -156,7 +157,7 @@ class SplatMapper:
                                                       mc["loss_weights"], mc["use_sil_for_loss"], mc["sil_thres"], mc["use_l1"],
                                                       mc["ignore_outlier_depth_loss"], fused=cfg["fused_render"], fused_loss=cfg["fused_loss"],
                                                       fused_inputs=cfg["fused_inputs"])
-            loss.backward()
+            loss.backward(gradient=self._one)           # cached dL/dloss = 1: saves autograd's ones_like launch per iteration
             with torch.no_grad():
                 if mc["prune_gaussians"]:
                     self.params, self.variables = O.prune_gaussians(self.params, self.variables, self.optimizer, it, mc["pruning_dict"])

@@ -226,21 +226,27 @@ class _FusedMappingLoss(torch.autograd.Function):
         dev = im.device
         c = lambda t: None if t is None else t.detach().contiguous().float()  # noqa: E731
         im_, depth_, dsq_, gt_, gtd_ = c(im), c(depth), c(depth_sq), c(gt_im), c(gt_depth)
-        losses = torch.empty(3, dtype=torch.float32, device=dev)
-        d_im, d_depth = torch.empty_like(im_), torch.empty_like(depth_)
+        buf = torch.empty(4, dtype=torch.float32, device=dev)            # {loss, im term, depth term, loss}
+        grads = torch.empty(4, H, W, dtype=torch.float32, device=dev)    # dL/dim [3,H,W] and dL/ddepth [1,H,W] in ONE buffer
+        d_im, d_depth = grads[:3], grads[3:]
         scratch = torch.empty(int(lib.gs_mapping_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-        _lib.check(lib.gs_mapping_loss(W, H, p(im_), p(gt_), p(depth_), p(dsq_), p(gtd_), float(w_im), float(w_depth), p(losses),
+        _lib.check(lib.gs_mapping_loss(W, H, p(im_), p(gt_), p(depth_), p(dsq_), p(gtd_), float(w_im), float(w_depth), p(buf),
                                        p(d_im), p(d_depth), p(scratch), st))
-        ctx.save_for_backward(d_im, d_depth)
+        ctx.save_for_backward(grads)
+        ctx.set_materialize_grads(False)
+        losses, loss = buf[:3], buf[3]          # two views of one small buffer: no clone kernel for the scalar
         ctx.mark_non_differentiable(losses)
-        return losses[0].clone(), losses
+        return loss, losses
 
     @staticmethod
-    def backward(ctx, g, _gl):
-        d_im, d_depth = ctx.saved_tensors
-        return g * d_im, g * d_depth, None, None, None, None, None
+    def backward(ctx, g, _gl=None):
+        (grads,) = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None, None, None, None
+        gd = g * grads                           # one launch for both gradients
+        return gd[:3], gd[3:], None, None, None, None, None
 
 
 def fused_mapping_loss(im, depth, depth_sq, gt_im, gt_depth, loss_weights):

@@ -124,8 +124,9 @@ int gs_profile_collect(float* ms_sum, int32_t* calls, int32_t n_stages);
 /* Stage 1: per-Gaussian preprocess (view/projective transform, near cull, 3-D -> 2-D covariance, conic,
  * radius, tile rect, SH -> RGB), tile counting and the tile-range scan.  Writes radii[P] (0 = culled),
  * the geom state and the tile ranges (image state); d_counts[0] = D (number of tile instances),
- * d_counts[1] = largest per-tile instance count; if h_counts != NULL both are copied there
- * asynchronously (read them after synchronising `stream`). Exactly one of shs/colors_precomp and
+ * d_counts[1] = largest per-tile instance count; if h_counts != NULL both also reach that host buffer
+ * asynchronously -- stored by the scan kernel itself when h_counts is mapped pinned memory (hipHostMalloc), by an
+ * async copy otherwise (read them after synchronising `stream` or an event recorded behind this call). Exactly one of shs/colors_precomp and
  * exactly one of (scales,rotations)/cov3D_precomp must be given. */
 int gs_preprocess_forward(const GsCamera* cam, int32_t P,
                           const float* means3D, const float* shs, const float* colors_precomp,
@@ -200,7 +201,8 @@ int gs_activate_backward(int32_t P, int32_t isotropic, const float* h_pose7, con
  * utils/slam_external.py:54-97 and their autograd):
  *   loss = w_depth * mean_{gt_depth>0, finite} |gt_depth - depth| + w_im * (0.8 * mean|im - gt_im| + 0.2 * (1 - SSIM))
  * im, gt_im [3,H,W]; depth, gt_depth [1,H,W]; depth_sq [1,H,W] nullable (only its NaN-ness enters the mask).
- * Writes losses[3] = {loss, weighted image term, weighted depth term} (device), dL_dim [3,H,W], dL_ddepth [1,H,W]. */
+ * Writes losses[4] = {loss, weighted image term, weighted depth term, loss again} (device), dL_dim [3,H,W],
+ * dL_ddepth [1,H,W]. */
 uint64_t gs_mapping_loss_scratch_bytes(int32_t width, int32_t height);
 int gs_mapping_loss(int32_t width, int32_t height, const float* im, const float* gt_im, const float* depth,
                     const float* depth_sq, const float* gt_depth, float w_im, float w_depth, float* losses,

@@ -296,6 +296,7 @@ static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 // ---- runtime API subset --------------------------------------------------------------------------
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memmove(d, s, n); return 0; }
+static inline hipError_t hipHostGetDevicePointer(void** dp, void* hp, unsigned) { *dp = hp; return 0; }   // host memory IS device memory here
 typedef void* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
