@@ -238,4 +238,5 @@ def check_optimistic_launch(device):
         R.optimistic = True
     for k in rv_g:
         if rv_g[k].grad is not None:
-            assert torch.allclose(rv_g[k].grad, rv_h[k].grad, rtol=1e-5, atol=1e-7), k
+            a, b = rv_g[k].grad.double(), rv_h[k].grad.double()     # two runs of the atomics: sums in a different order
+            assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 1e-5, k
