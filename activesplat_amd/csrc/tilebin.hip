@@ -141,7 +141,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restr
         for (int w = 0; w < 16; w++) mx = max(mx, s_m[w]);
         counts[0] = s_carry; counts[1] = mx;
         // mapped pinned host memory: the two counters land on the host without a separate D2H copy in the stream
-        if (host_counts) { host_counts[0] = s_carry; host_counts[1] = mx; }
+        if (host_counts) { host_counts[0] = s_carry; host_counts[1] = mx; __threadfence_system(); }
     }
 }
 

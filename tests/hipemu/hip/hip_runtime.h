@@ -292,6 +292,7 @@ static inline int atomicMax(int* p, int v) { int o = __atomic_load_n(p, __ATOMIC
 static inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 // ---- runtime API subset --------------------------------------------------------------------------
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return 0; }
