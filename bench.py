@@ -222,6 +222,38 @@ def main():
         except Exception as e:      # the baseline is a report, never a reason to lose the measurement
             out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0 and world == 1 and not args.no_extras:
+        # ---- the north-star's target configuration: forward+backward render of 2 M Gaussians at 640x480 (SH degree 0 and 3),
+        # as frames/s and as fraction of the HBM roofline with SURVEY 8(d)'s algorithmic bytes (b_g = 292 / 832 B)
+        try:
+            ns = {}
+            for name, deg, bg_bytes in (("sh0", None, 292), ("sh3", 3, 832)):
+                N2 = 2_000_000
+                p2 = syn.make_params(N2, W, H, seed=0, sh_degree=deg)
+                rv2 = {k: v.to(dev).requires_grad_(True) for k, v in syn.activate(p2).items()}
+                cam2 = setup_camera(W, H, K, np.eye(4), device=dev, sh_degree=deg or 0)
+                keys2 = list(rv2.keys())
+
+                def step2():
+                    m2 = torch.zeros(N2, 3, device=dev, requires_grad=True)
+                    col = GaussianRasterizer(raster_settings=cam2)(means2D=m2, **rv2)[0]
+                    return torch.autograd.grad(col, [rv2[k] for k in keys2] + [m2], dL)
+                for _ in range(5):
+                    step2()
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for _ in range(30):
+                    step2()
+                torch.cuda.synchronize()
+                t = (time.perf_counter() - t1) / 30
+                D2 = int(R.last_stats["num_rendered"])
+                fb = N2 * bg_bytes + D2 * 160 + W * H * 48
+                ns[name] = {"frames_per_s": round(1.0 / t, 1), "ms_per_frame": round(t * 1e3, 4), "tile_instances_D": D2,
+                            "frame_alg_bytes": fb, "frame_frac_hbm": round(fb / t / HBM_PEAK, 4)}
+                del rv2, p2
+            out["north_star_2M"] = ns
+        except Exception as e:
+            out["north_star_2M"] = {"error": str(e)}
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_extras:
         # ---- informational leg: one full ActiveSplat mapping iteration (get_loss + backward + Adam) on the same scene,
         # with the reference's call pattern (two raster passes, torch loss, torch activations) vs this build's fused paths
         try:
