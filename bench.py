@@ -216,6 +216,20 @@ def main():
             t1 = time.perf_counter()
             f = util.run_oracle(o, cam, rv_cpu, dL.cpu())
             tc = time.perf_counter() - t1
+            try:
+                # "PSNR vs ref" half of the metric: this device's render and gradients against the oracle's, same inputs
+                with torch.no_grad():
+                    col_gpu = GaussianRasterizer(raster_settings=cam)(means2D=torch.zeros(N, 3, device=dev), **{k: v.detach() for k, v in rv.items()})[0]
+                mse = float(((col_gpu.cpu().double() - torch.from_numpy(np.asarray(f["color"])).double()) ** 2).mean())
+                g_gpu = step(0)
+                rel = {}
+                for k, g in zip(keys, g_gpu[:5]):
+                    ref = torch.from_numpy(np.asarray(f["grads"][k])).double().reshape(g.shape)
+                    rel[k] = float((g.cpu().double() - ref).norm() / ref.norm().clamp_min(1e-30))
+                out["parity_vs_oracle"] = {"psnr_color_db": round(10 * np.log10(1.0 / max(mse, 1e-30)), 1),
+                                           "grad_rel_l2_max": float(f"{max(rel.values()):.3g}"), "oracle": "oracle/gs_oracle.c fp32 build, same inputs"}
+            except Exception as e:
+                out["parity_vs_oracle"] = {"error": str(e)}
             out["cpu_baseline"] = {"value": round(1.0 / tc, 5), "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": f"1 frame forward+backward of the same workload (N={N}, {W}x{H}, D={f['D']}) "
                                              f"by oracle/gs_oracle.c (fp32, gcc -O2), {tc:.1f} s; host has {os.cpu_count()} cores"}

@@ -23,6 +23,10 @@ def build_case(name, device):
         W, H, N = 50, 37, 800
     elif name == "tiny_lookaround":         # the reference's 120x150 visibility views
         W, H, N = 120, 150, 1500
+    elif name == "lookaround_intrinsics":   # the planner's 120 x 150 view: hfov 120, vfov 150 -> fx = 34.6, fy = 20.1, cx = 59, cy = 74
+        from activesplat_amd.lookaround import look_around_k
+        W, H, N = 120, 150, 4000
+        kw = dict(K=look_around_k(), w2c=util.pose(0.4, (0.05, -0.02, 0.2)), bg=(1.0, 1.0, 1.0))
     elif name == "posed_white_bg":
         kw = dict(w2c=util.pose(0.25, (0.1, -0.05, 0.3)), bg=(1.0, 1.0, 1.0))
     elif name == "scale_modifier":
@@ -75,7 +79,7 @@ def build_case(name, device):
 
 
 BIG_TILE_CASES = ["merge_tiles", "merge_tiles_large", "radix_fallback"]
-CASES = ["basic", "ragged_image", "tiny_lookaround", "posed_white_bg", "scale_modifier", "behind_camera", "all_culled",
+CASES = ["basic", "ragged_image", "tiny_lookaround", "lookaround_intrinsics", "posed_white_bg", "scale_modifier", "behind_camera", "all_culled",
          "huge_gaussians", "dense_overdraw", "low_opacity", "one_gaussian", "not_multiple_of_block", "sh0", "sh1", "sh2",
          "sh3", "sh2_ragged", "cov3d_precomp"]
 

@@ -25,8 +25,8 @@ def pose(yaw=0.0, t=(0.0, 0.0, 0.0)):
     return w2c
 
 
-def scene(N, W, H, seed=0, device="cpu", w2c=None, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degree=None, **kw):
-    K = syn.intrinsics(W, H)
+def scene(N, W, H, seed=0, device="cpu", w2c=None, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degree=None, K=None, **kw):
+    K = syn.intrinsics(W, H) if K is None else K
     rs = setup_camera(W, H, K, np.eye(4) if w2c is None else w2c, device=device, bg=bg, scale_modifier=scale_modifier,
                       sh_degree=0 if sh_degree is None else sh_degree)
     rs = rs._replace(debug=True)
