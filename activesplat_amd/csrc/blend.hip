@@ -22,6 +22,8 @@
 
 namespace gs {
 
+constexpr int kFwdStreamsDefault = 4;
+
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTmin = 0.0001f;
 constexpr float kLog2e = 1.4426950408889634f;
@@ -188,6 +190,122 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Forward, multi-stream variant: the quadrant's 64 lanes form NS streams of 64/NS lanes (NS = 4: 4x4 pixel blocks,
+// NS = 8: 4x2 blocks), every stream walks ITS OWN list of the staged records whose alpha-visible box overlaps its
+// block.  With sigma ~ 1 px splats a record touches 2.2 of the 4 (3.0 of the 8) blocks of a quadrant, so the loop
+// makes 0.66x (0.59x) the trips of the one-record-per-wave walk (simulated on BASELINE configs[1]).
+// The per-stream lists live in LDS: while staging a chunk, each lane whose record hits stream s writes its lane
+// index at position mbcnt(ballot_s) of list s (lists pre-filled with the sentinel slot); in the loop a lane reads
+// two list entries with ONE 16-bit LDS read -- no scalar pop sequences, which is what made a four-stream forward
+// lose before (four s_ff1/s_andn2/s_cselect chains per trip for ~22 VALU of blending).
+// ---------------------------------------------------------------------------------------------------
+template <bool DEPTH_SQ, int NS>
+__global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
+    Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
+    float* __restrict__ out_opacity, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+    float* __restrict__ out_depth_sq, uint32_t cap)
+{
+    constexpr int LS = kWave / NS;          // lanes per stream
+    constexpr int BH = LS / 4;              // block = 4 x BH pixels
+    __shared__ float4 s_rec[kBlock / kWave][3][kWave + 1];           // + the sentinel slot
+    __shared__ __attribute__((aligned(16))) uint8_t s_list[kBlock / kWave][NS][kWave];   // pair reads end at byte 63 (t even, t < 64)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    TileCtx c;
+    if (!tile_ctx(cam, wave, lane, c)) return;
+    // lane -> pixel: stream sid owns block (sid & 1, sid >> 1) of the quadrant
+    const int sid = lane / LS, l = lane % LS;
+    const int px = (int)c.qx0 + (sid & 1) * 4 + (l & 3), py = (int)c.qy0 + (sid >> 1) * BH + (l >> 2);
+    const bool inside = px < cam.W && py < cam.H;
+    const float pxf = (float)px, pyf = (float)py;
+    float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
+    write_sentinel(s0, s1, s2, lane);
+    uint8_t* my_list = s_list[wave][sid];
+    uint2 range = ranges[c.tile];
+    range.x = min(range.x, cap); range.y = min(range.y, cap);
+    const uint32_t n = range.y - range.x;
+    const uint32_t* list = point_list + range.x;
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Dq = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    if (!__all(done)) {
+        uint32_t id_next = (uint32_t)lane < n ? list[lane] : kNoId;
+        uint32_t id_next2 = (uint32_t)lane + 64u < n ? list[lane + 64] : kNoId;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
+        if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
+        for (uint32_t base = 0; base < n; base += kWave) {
+            const float4 q0 = r0, q1 = r1, q2 = r2;
+            const uint32_t id_cur = id_next;
+            id_next = id_next2;
+            id_next2 = base + 128u + (uint32_t)lane < n ? list[base + 128u + lane] : kNoId;
+            r2 = make_float4(0.f, 0.f, -1.f, -1.f);
+            if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
+
+            const bool live = id_cur != kNoId;
+            if (!__any(live && quadrant_hit(q0, q2, c.qx0, c.qy0))) continue;
+            stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
+            // per-stream lists: sentinel fill (one store per lane covers NS x 64 bytes), then every hit lane drops its index
+            {
+                uint32_t* fill = reinterpret_cast<uint32_t*>(&s_list[wave][0][0]);
+                constexpr int kWords = NS * kWave / 4;
+                for (int w = lane; w < kWords; w += kWave) fill[w] = 0x40404040u;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int ntrips = 0;
+            const float ex = q2.z, ey = q2.w;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const float x0 = c.qx0 + (float)((s & 1) * 4), y0 = c.qy0 + (float)((s >> 1) * BH);
+                const bool hit = live && ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) &&
+                                 (q0.y - ey <= y0 + (float)(BH - 1));
+                const unsigned long long m = __ballot(hit);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (hit) s_list[wave][s][rank] = (uint8_t)lane;
+                ntrips = max(ntrips, (int)__popcll(m));
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int t = 0; t < ntrips; t += 2) {
+                const uint32_t jj2 = *reinterpret_cast<const uint16_t*>(my_list + t);     // two list entries
+                const int jj[2] = {(int)(jj2 & 0xffu), (int)(jj2 >> 8)};
+                float4 a0[2], a1[2], a2[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) { a0[u] = s0[jj[u]]; a1[u] = s1[jj[u]]; a2[u] = s2[jj[u]]; }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const float dx = a0[u].x - pxf, dy = a0[u].y - pyf;
+                    const float p = (a0[u].z * dx + a0[u].w * dy) * dx + (a1[u].x * dy) * dy;
+                    const float alpha = fminf(0.99f, a1[u].y * __builtin_amdgcn_exp2f(p));
+                    const float test_T = T * (1.0f - alpha);
+                    const bool vis = !done && p <= 0.0f && alpha >= kAlphaMin;     // sentinel: alpha = 0
+                    const bool ok = vis && test_T >= kTmin;
+                    done = done || (vis && !ok);
+                    const float w = ok ? alpha * T : 0.0f;
+                    C0 += a1[u].z * w; C1 += a1[u].w * w; C2 += a2[u].x * w; Dp += a2[u].y * w;
+                    if (DEPTH_SQ) Dq += a2[u].y * a2[u].y * w;
+                    T = ok ? test_T : T;
+                    last = ok ? base + (uint32_t)jj[u] + 1u : last;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (__all(done)) break;
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = C0 + T * cam.bg[0];
+        out_color[HW + pix] = C1 + T * cam.bg[1];
+        out_color[2 * HW + pix] = C2 + T * cam.bg[2];
+        out_depth[pix] = Dp;
+        out_opacity[pix] = 1.0f - T;
+        if (DEPTH_SQ) out_depth_sq[pix] = Dq;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Backward: back-to-front replay.  Same independent-quadrant walk as the forward, but each wavefront
 // runs FOUR record streams at once, one per 16-lane DPP row:
 //   row r of the wave = the 4x4 pixel sub-block r of the quadrant (lane -> pixel mapping below);
@@ -248,6 +366,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, float* __restrict__ grad2d)
 {
     __shared__ float4 s_rec[kBlock / kWave][3][kWave + 1];           // + the sentinel slot
+    __shared__ __attribute__((aligned(16))) uint8_t s_list[kBlock / kWave][4][kWave];       // per-row record lists of the staged chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
     if (!tile_ctx(cam, wave, lane, c)) return;
@@ -258,6 +377,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const float pxf = (float)px, pyf = (float)py;
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
     write_sentinel(s0, s1, s2, lane);
+    const uint8_t* my_list = s_list[wave][row];
     const uint2 range = ranges[c.tile];
     const uint32_t* list = point_list + range.x;
     const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
@@ -276,7 +396,6 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor(wmax, m));
     if (wmax == 0) return;
 
-    const uint32_t row8 = (uint32_t)row * 8u;
     const bool b8 = (l16 & 8) != 0, b4 = (l16 & 4) != 0, b2 = (l16 & 2) != 0, b1 = (l16 & 1) != 0;
     const int my_comp = row_comp(l16, DEPTH_GRAD);
     const int cmax = (int)((wmax - 1) / kWave);
@@ -294,20 +413,27 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
 
         const bool live = id_cur != kNoId;
-        unsigned long long m0 = __ballot(live && subblock_hit(q0, q2, c.qx0, c.qy0));
-        unsigned long long m1 = __ballot(live && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0));
-        unsigned long long m2 = __ballot(live && subblock_hit(q0, q2, c.qx0, c.qy0 + 4.0f));
-        unsigned long long m3 = __ballot(live && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0 + 4.0f));
-        const unsigned long long hit_any = m0 | m1 | m2 | m3;
-        if (hit_any == 0ull) continue;
+        const bool h0 = live && subblock_hit(q0, q2, c.qx0, c.qy0), h1 = live && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0);
+        const bool h2 = live && subblock_hit(q0, q2, c.qx0, c.qy0 + 4.0f), h3 = live && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0 + 4.0f);
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+        if ((m0 | m1 | m2 | m3) == 0ull) continue;
         stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
+        // per-row lists in LDS, DEEPEST record first: sentinel fill (one store per lane = 4 x 64 bytes), then every lane
+        // whose record hits row r drops its index at position (#hits of row r above this lane)
+        reinterpret_cast<uint32_t*>(&s_list[wave][0][0])[lane] = 0x40404040u;
         __builtin_amdgcn_wave_barrier();
-        while ((m0 | m1 | m2 | m3) != 0ull) {
-            // scalar side: each row pops the deepest remaining record of ITS mask (the sentinel once it has run dry); the
-            // four indices travel to the lanes packed in one scalar register (one v_bfe)
-            const uint32_t jpack = (uint32_t)pop_high(m0) | ((uint32_t)pop_high(m1) << 8) | ((uint32_t)pop_high(m2) << 16) |
-                                   ((uint32_t)pop_high(m3) << 24);
-            const int j = (int)((jpack >> row8) & 0xffu);
+        const int n0 = (int)__popcll(m0), n1 = (int)__popcll(m1), n2 = (int)__popcll(m2), n3 = (int)__popcll(m3);
+#define GS_RANK(m) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u)))
+        if (h0) s_list[wave][0][n0 - 1 - GS_RANK(m0)] = (uint8_t)lane;
+        if (h1) s_list[wave][1][n1 - 1 - GS_RANK(m1)] = (uint8_t)lane;
+        if (h2) s_list[wave][2][n2 - 1 - GS_RANK(m2)] = (uint8_t)lane;
+        if (h3) s_list[wave][3][n3 - 1 - GS_RANK(m3)] = (uint8_t)lane;
+#undef GS_RANK
+        const int ntrips = max(max(n0, n1), max(n2, n3));
+        __builtin_amdgcn_wave_barrier();
+        for (int t = 0; t < ntrips; t++) {
+            // each row walks ITS list; rows that have run dry read the sentinel (alpha = 0)
+            const int j = (int)my_list[t];
             const uint32_t pos = (uint32_t)ch * kWave + (uint32_t)j;          // 0-based position in the tile list
             const float4 a0 = s0[j], a1 = s1[j], a2 = s2[j];
             const float dx = a0.x - pxf, dy = a0.y - pyf;
@@ -348,17 +474,24 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     }
 }
 
+static int fwd_streams()
+{
+    const char* e = getenv("GS_FWD_STREAMS");      // development knob: 0 (one record per wave) | 4 | 8
+    return e ? atoi(e) : kFwdStreamsDefault;
+}
+
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
                                 uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, hipStream_t st)
 {
     const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
-    if (out_depth_sq)
-        hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
-                           out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap);
-    else
-        hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
-                           out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap);
+    const int ns = fwd_streams();
+#define GS_LAUNCH_FWD(K) hipLaunchKernelGGL(K, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom, out_color, out_depth, \
+                                            out_opacity, final_T, n_contrib, out_depth_sq, cap)
+    if (ns == 4) { if (out_depth_sq) GS_LAUNCH_FWD((blend_forward_streams_kernel<true, 4>)); else GS_LAUNCH_FWD((blend_forward_streams_kernel<false, 4>)); }
+    else if (ns == 8) { if (out_depth_sq) GS_LAUNCH_FWD((blend_forward_streams_kernel<true, 8>)); else GS_LAUNCH_FWD((blend_forward_streams_kernel<false, 8>)); }
+    else { if (out_depth_sq) GS_LAUNCH_FWD(blend_forward_kernel<true>); else GS_LAUNCH_FWD(blend_forward_kernel<false>); }
+#undef GS_LAUNCH_FWD
     return hipGetLastError();
 }
 

@@ -195,7 +195,18 @@ static inline void hipemu_wave_barrier() { hipemu::wave_exchange(0ull, 12, nullp
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
-#define __builtin_amdgcn_mbcnt_lo(a, b) 0
+static inline unsigned hipemu_mbcnt_lo(unsigned mask, unsigned base)
+{
+    const unsigned l = hipemu::lane_id();
+    return base + (unsigned)__builtin_popcount(mask & (l >= 32 ? 0xffffffffu : ((1u << l) - 1u)));
+}
+static inline unsigned hipemu_mbcnt_hi(unsigned mask, unsigned base)
+{
+    const unsigned l = hipemu::lane_id();
+    return base + (unsigned)__builtin_popcount(l <= 32 ? 0u : (mask & ((1u << (l - 32)) - 1u)));
+}
+#define __builtin_amdgcn_mbcnt_lo(a, b) hipemu_mbcnt_lo(a, b)
+#define __builtin_amdgcn_mbcnt_hi(a, b) hipemu_mbcnt_hi(a, b)
 #define __lane_id() (hipemu::lane_id())
 
 // DPP emulation (the subset of controls the kernels use); semantics of v_mov_b32_dpp with
