@@ -209,7 +209,8 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
     constexpr int LS = kWave / NS;          // lanes per stream
     constexpr int BH = LS / 4;              // block = 4 x BH pixels
     __shared__ float4 s_rec[kBlock / kWave][3][kWave + 1];           // + the sentinel slot
-    __shared__ __attribute__((aligned(16))) uint8_t s_list[kBlock / kWave][NS][kWave];   // pair reads end at byte 63 (t even, t < 64)
+    // NS rows of 64 entries per wave (+16 bytes so that the look-ahead read behind the last row stays inside the wave's slab)
+    __shared__ __attribute__((aligned(16))) uint8_t s_list[kBlock / kWave][NS * kWave + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
     if (!tile_ctx(cam, wave, lane, c)) return;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
     const float pxf = (float)px, pyf = (float)py;
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
     write_sentinel(s0, s1, s2, lane);
-    uint8_t* my_list = s_list[wave][sid];
+    uint8_t* my_list = s_list[wave] + sid * kWave;
     uint2 range = ranges[c.tile];
     range.x = min(range.x, cap); range.y = min(range.y, cap);
     const uint32_t n = range.y - range.x;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
             stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
             // per-stream lists: sentinel fill (one store per lane covers NS x 64 bytes), then every hit lane drops its index
             {
-                uint32_t* fill = reinterpret_cast<uint32_t*>(&s_list[wave][0][0]);
+                uint32_t* fill = reinterpret_cast<uint32_t*>(s_list[wave]);
                 constexpr int kWords = NS * kWave / 4;
                 for (int w = lane; w < kWords; w += kWave) fill[w] = 0x40404040u;
             }
@@ -262,12 +263,14 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
                                  (q0.y - ey <= y0 + (float)(BH - 1));
                 const unsigned long long m = __ballot(hit);
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (hit) s_list[wave][s][rank] = (uint8_t)lane;
+                if (hit) s_list[wave][s * kWave + rank] = (uint8_t)lane;
                 ntrips = max(ntrips, (int)__popcll(m));
             }
             __builtin_amdgcn_wave_barrier();
+            uint32_t jj2_next = *reinterpret_cast<const uint16_t*>(my_list);                // two list entries per read
             for (int t = 0; t < ntrips; t += 2) {
-                const uint32_t jj2 = *reinterpret_cast<const uint16_t*>(my_list + t);     // two list entries
+                const uint32_t jj2 = jj2_next;
+                jj2_next = *reinterpret_cast<const uint16_t*>(my_list + t + 2);           // next pair: off the critical path
                 const int jj[2] = {(int)(jj2 & 0xffu), (int)(jj2 >> 8)};
                 float4 a0[2], a1[2], a2[2];
 #pragma unroll
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, float* __restrict__ grad2d)
 {
     __shared__ float4 s_rec[kBlock / kWave][3][kWave + 1];           // + the sentinel slot
-    __shared__ __attribute__((aligned(16))) uint8_t s_list[kBlock / kWave][4][kWave];       // per-row record lists of the staged chunk
+    __shared__ __attribute__((aligned(16))) uint8_t s_list[kBlock / kWave][4 * kWave + 16];  // per-row record lists of the staged chunk (+ look-ahead pad)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
     if (!tile_ctx(cam, wave, lane, c)) return;
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const float pxf = (float)px, pyf = (float)py;
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
     write_sentinel(s0, s1, s2, lane);
-    const uint8_t* my_list = s_list[wave][row];
+    const uint8_t* my_list = s_list[wave] + row * kWave;
     const uint2 range = ranges[c.tile];
     const uint32_t* list = point_list + range.x;
     const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
@@ -420,20 +423,22 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
         // per-row lists in LDS, DEEPEST record first: sentinel fill (one store per lane = 4 x 64 bytes), then every lane
         // whose record hits row r drops its index at position (#hits of row r above this lane)
-        reinterpret_cast<uint32_t*>(&s_list[wave][0][0])[lane] = 0x40404040u;
+        reinterpret_cast<uint32_t*>(s_list[wave])[lane] = 0x40404040u;
         __builtin_amdgcn_wave_barrier();
         const int n0 = (int)__popcll(m0), n1 = (int)__popcll(m1), n2 = (int)__popcll(m2), n3 = (int)__popcll(m3);
 #define GS_RANK(m) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u)))
-        if (h0) s_list[wave][0][n0 - 1 - GS_RANK(m0)] = (uint8_t)lane;
-        if (h1) s_list[wave][1][n1 - 1 - GS_RANK(m1)] = (uint8_t)lane;
-        if (h2) s_list[wave][2][n2 - 1 - GS_RANK(m2)] = (uint8_t)lane;
-        if (h3) s_list[wave][3][n3 - 1 - GS_RANK(m3)] = (uint8_t)lane;
+        if (h0) s_list[wave][0 * kWave + n0 - 1 - GS_RANK(m0)] = (uint8_t)lane;
+        if (h1) s_list[wave][1 * kWave + n1 - 1 - GS_RANK(m1)] = (uint8_t)lane;
+        if (h2) s_list[wave][2 * kWave + n2 - 1 - GS_RANK(m2)] = (uint8_t)lane;
+        if (h3) s_list[wave][3 * kWave + n3 - 1 - GS_RANK(m3)] = (uint8_t)lane;
 #undef GS_RANK
         const int ntrips = max(max(n0, n1), max(n2, n3));
         __builtin_amdgcn_wave_barrier();
+        int j_next = (int)my_list[0];
         for (int t = 0; t < ntrips; t++) {
             // each row walks ITS list; rows that have run dry read the sentinel (alpha = 0)
-            const int j = (int)my_list[t];
+            const int j = j_next;
+            j_next = (int)my_list[t + 1];                                    // next entry: off the critical path
             const uint32_t pos = (uint32_t)ch * kWave + (uint32_t)j;          // 0-based position in the tile list
             const float4 a0 = s0[j], a1 = s1[j], a2 = s2[j];
             const float dx = a0.x - pxf, dy = a0.y - pyf;
