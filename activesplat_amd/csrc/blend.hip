@@ -434,46 +434,63 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
 #undef GS_RANK
         const int ntrips = max(max(n0, n1), max(n2, n3));
         __builtin_amdgcn_wave_barrier();
-        int j_next = (int)my_list[0];
-        for (int t = 0; t < ntrips; t++) {
-            // each row walks ITS list; rows that have run dry read the sentinel (alpha = 0)
-            const int j = j_next;
-            j_next = (int)my_list[t + 1];                                    // next entry: off the critical path
-            const uint32_t pos = (uint32_t)ch * kWave + (uint32_t)j;          // 0-based position in the tile list
-            const float4 a0 = s0[j], a1 = s1[j], a2 = s2[j];
-            const float dx = a0.x - pxf, dy = a0.y - pyf;
-            const float p = (a0.z * dx + a0.w * dy) * dx + (a1.x * dy) * dy;
-            const float G = __builtin_amdgcn_exp2f(p);
-            const float alpha = fminf(0.99f, a1.y * G);
-            const bool ok = pos < last && p <= 0.0f && alpha >= kAlphaMin;
-            const unsigned long long okm = __ballot(ok);
-            if (okm == 0ull) continue;
-            // branch-free replay step.  `acc` is the colour composited BEHIND the current record; after the
-            // record's gradient is taken it absorbs the record: acc += alpha (c - acc).  Lanes that do not
-            // contribute run with alpha = 0, G = 0 (T, acc unchanged, all partials zero).
-            const float a_eff = ok ? alpha : 0.0f;
-            const float G_eff = ok ? G : 0.0f;
-            const float rcp = __builtin_amdgcn_rcpf(1.0f - a_eff);
-            T = T * rcp;                                          // transmittance in front of this record
-            const float df0 = a1.z - acc0, df1 = a1.w - acc1, df2 = a2.x - acc2;
-            float dot = df0 * d0 + df1 * d1 + df2 * d2;
-            if (DEPTH_GRAD) {
-                const float dfz = a2.y - accz;
-                dot += dfz * dz_;
-                accz += a_eff * dfz;
+        // TWO list entries per iteration (one 16-bit LDS read, fetched one iteration ahead): the alpha evaluations and the two
+        // in-row reductions of a pair are independent instruction chains that the scheduler interleaves; only the short
+        // T / behind-colour update is serial.  An odd tail pairs the last record with the sentinel.
+        uint32_t jj2_next = *reinterpret_cast<const uint16_t*>(my_list);
+        for (int t = 0; t < ntrips; t += 2) {
+            const uint32_t jj2 = jj2_next;
+            jj2_next = *reinterpret_cast<const uint16_t*>(my_list + t + 2);
+            const int jj[2] = {(int)(jj2 & 0xffu), (int)(jj2 >> 8)};
+            float4 a0[2], a1[2], a2[2];
+            float dx[2], dy[2], G[2], alpha[2];
+            bool ok[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) { a0[u] = s0[jj[u]]; a1[u] = s1[jj[u]]; a2[u] = s2[jj[u]]; }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t pos = (uint32_t)ch * kWave + (uint32_t)jj[u];       // 0-based position in the tile list
+                dx[u] = a0[u].x - pxf; dy[u] = a0[u].y - pyf;
+                const float p = (a0[u].z * dx[u] + a0[u].w * dy[u]) * dx[u] + (a1[u].x * dy[u]) * dy[u];
+                G[u] = __builtin_amdgcn_exp2f(p);
+                alpha[u] = fminf(0.99f, a1[u].y * G[u]);
+                ok[u] = pos < last && p <= 0.0f && alpha[u] >= kAlphaMin;
             }
-            const float dL_dalpha = dot * T - tfbg * rcp;
-            const float w = a_eff * T;
-            acc0 += a_eff * df0; acc1 += a_eff * df1; acc2 += a_eff * df2;
-            const float GdA = G_eff * dL_dalpha;
-            const float Z = a1.y * GdA;                           // G dL/dG
-            const float zx = Z * dx, zy = Z * dy;
-            const float v[10] = {zx, zy, zx * dx, zx * dy, zy * dy, GdA, w * d0, w * d1, w * d2, DEPTH_GRAD ? w * dz_ : 0.0f};
-            const float x = row_reduce10(v, b8, b4, b2, b1);
+            const unsigned long long okm0 = __ballot(ok[0]), okm1 = __ballot(ok[1]);
+            if ((okm0 | okm1) == 0ull) continue;
+            // branch-free replay steps, deeper record first.  `acc` is the colour composited BEHIND the current record; after
+            // the record's gradient is taken it absorbs the record: acc += alpha (c - acc).  Lanes that do not contribute run
+            // with alpha = 0, G = 0 (T, acc unchanged, all partials zero).
+            float v[2][10];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const float a_eff = ok[u] ? alpha[u] : 0.0f;
+                const float G_eff = ok[u] ? G[u] : 0.0f;
+                const float rcp = __builtin_amdgcn_rcpf(1.0f - a_eff);
+                T = T * rcp;                                      // transmittance in front of this record
+                const float df0 = a1[u].z - acc0, df1 = a1[u].w - acc1, df2 = a2[u].x - acc2;
+                float dot = df0 * d0 + df1 * d1 + df2 * d2;
+                if (DEPTH_GRAD) {
+                    const float dfz = a2[u].y - accz;
+                    dot += dfz * dz_;
+                    accz += a_eff * dfz;
+                }
+                const float dL_dalpha = dot * T - tfbg * rcp;
+                const float w = a_eff * T;
+                acc0 += a_eff * df0; acc1 += a_eff * df1; acc2 += a_eff * df2;
+                const float GdA = G_eff * dL_dalpha;
+                const float Z = a1[u].y * GdA;                    // G dL/dG
+                const float zx = Z * dx[u], zy = Z * dy[u];
+                v[u][0] = zx; v[u][1] = zy; v[u][2] = zx * dx[u]; v[u][3] = zx * dy[u]; v[u][4] = zy * dy[u]; v[u][5] = GdA;
+                v[u][6] = w * d0; v[u][7] = w * d1; v[u][8] = w * d2; v[u][9] = DEPTH_GRAD ? w * dz_ : 0.0f;
+            }
+            const float x0 = row_reduce10(v[0], b8, b4, b2, b1);
+            const float x1 = row_reduce10(v[1], b8, b4, b2, b1);
             // every row that had a contributing pixel adds its 9 (10) components to ITS record: one hardware fp32 atomic
             // instruction, 9-10 lanes per row, each record's components inside one 64-byte line (kGradStride = 16)
-            const bool row_any = ((okm >> (row * 16)) & 0xffffull) != 0ull;
-            if (row_any && my_comp >= 0) atomicAdd(grad2d + (size_t)__float_as_uint(a2.z) * kGradStride + my_comp, x);
+            const bool any0 = ((okm0 >> (row * 16)) & 0xffffull) != 0ull, any1 = ((okm1 >> (row * 16)) & 0xffffull) != 0ull;
+            if (any0 && my_comp >= 0) atomicAdd(grad2d + (size_t)__float_as_uint(a2[0].z) * kGradStride + my_comp, x0);
+            if (any1 && my_comp >= 0) atomicAdd(grad2d + (size_t)__float_as_uint(a2[1].z) * kGradStride + my_comp, x1);
         }
         __builtin_amdgcn_wave_barrier();
     }
