@@ -90,17 +90,24 @@ def main():
     rv = {k: v.to(dev).requires_grad_(True) for k, v in syn.activate(params).items()}
     dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
     keys = ["means3D", "colors_precomp", "rotations", "opacities", "scales"]
-    flat = torch.zeros(N, 14, device=dev)                   # accumulated per-Gaussian gradient (3+3+4+1+3)
+    # N > 1: per-key gradient accumulators (contiguous adds), packed into ONE flat [N,14] buffer per all-reduce
+    acc = [torch.zeros_like(rv[k]) for k in keys] if dist_on else None
+
+    def reduce_gradients():
+        flat = torch.cat(acc, dim=1)                        # 3+3+4+1+3 columns: one collective instead of five
+        dist.all_reduce(flat)
+        for a in acc:
+            a.zero_()
+        return flat
 
     def step(i):
         m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
         color, radii, depth, opacity = GaussianRasterizer(raster_settings=cam)(means2D=m2d, **rv)
         grads = torch.autograd.grad(color, [rv[k] for k in keys] + [m2d], dL)
         if dist_on:
-            flat.add_(torch.cat(grads[:5], dim=1))
+            torch._foreach_add_(acc, list(grads[:5]))
             if (i + 1) % args.accum == 0:
-                dist.all_reduce(flat)
-                flat.zero_()
+                reduce_gradients()
         return grads
 
     def barrier():
@@ -116,7 +123,7 @@ def main():
     for i in range(args.steps):
         step(i)
     if dist_on and args.steps % args.accum:
-        dist.all_reduce(flat)
+        reduce_gradients()
     barrier()
     dt = time.perf_counter() - t0
     if dist_on:
