@@ -68,11 +68,16 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     dist_on = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # development knobs for exercising the N > 1 code path on a 1-GPU box: all ranks on device 0, gloo instead of RCCL
+    same_dev = bool(os.environ.get("BENCH_SAME_DEVICE"))
+    torch.cuda.set_device(0 if same_dev else local_rank)
+    dev = torch.device("cuda", 0 if same_dev else local_rank)
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        if os.environ.get("BENCH_BACKEND") == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
 
     from activesplat_amd import GaussianRasterizer, _lib, setup_camera
     from activesplat_amd import rasterizer as R
