@@ -9,11 +9,12 @@
 //     meets a workgroup barrier -- a quadrant that saturates (T < 1e-4) or whose contributors end early
 //     simply finishes.  Sharing a workgroup keeps the four walkers of a tile on one CU, so the 48-byte
 //     record gathers of three of them hit that CU's L1.
-//   * 64 records at a time: every lane gathers one record and tests ITS alpha>=1/255 bounding box
-//     against the wave's quadrant; one 64-bit __ballot gives the hit mask.  Hit records are staged into
-//     the wave's private LDS slice (3 KiB) and the wave then walks only the set bits with scalar
-//     find-first-set -- a wave-uniform loop, LDS broadcast reads, no divergence.  Skipped records can
-//     never pass the alpha>=1/255 test, so the result is identical to evaluating all of them.
+//   * 64 records at a time: every lane gathers one record, stages it in the wave's private LDS slice (3 KiB)
+//     and tests ITS alpha>=1/255 bounding box against the four 4x4-pixel blocks of the quadrant; per block
+//     a 64-bit __ballot plus an mbcnt rank turn the hits into a LIST of record slots in LDS.  The 16 lanes
+//     of a block (one DPP row) then walk only their own list -- four record streams per wavefront, no
+//     scalar bookkeeping in the loop.  Skipped records can never pass the alpha>=1/255 test, so the result
+//     is identical to evaluating all of them.
 //   * the loop is software-pipelined: ids two chunks ahead, records one chunk ahead.
 //   * blockIdx -> tile mapping is XCD-aware: the dispatcher places block b on XCD b%8, so XCD x is
 //     given the contiguous band of tiles [x*ceil(T/8), (x+1)*ceil(T/8)) and neighbouring tiles (which
@@ -22,16 +23,12 @@
 
 namespace gs {
 
-constexpr int kFwdStreamsDefault = 4;
+constexpr int kFwdStreams = 4;        // record streams per wavefront in the forward (8 streams of 4x2 pixels measured the same)
 
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTmin = 0.0001f;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr uint32_t kNoId = 0xffffffffu;
-#ifndef GS_FWD_UNROLL
-#define GS_FWD_UNROLL 2
-#endif
-constexpr int kFwdUnroll = GS_FWD_UNROLL;   // hit records evaluated per LDS wait in the forward blend
 
 struct TileCtx {
     int tile, tx, ty, px, py;
@@ -100,97 +97,8 @@ __device__ __forceinline__ void write_sentinel(float4* s0, float4* s1, float4* s
     __builtin_amdgcn_wave_barrier();
 }
 
-template <bool DEPTH_SQ>     // also accumulate sum z^2 alpha T (third channel of the reference's depth/silhouette pass)
-__global__ __launch_bounds__(kBlock) void blend_forward_kernel(
-    Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
-    float* __restrict__ out_opacity, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ out_depth_sq, uint32_t cap)
-{
-    __shared__ float4 s_rec[kBlock / kWave][3][kWave + 1];           // + the sentinel slot
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    TileCtx c;
-    if (!tile_ctx(cam, wave, lane, c)) return;
-    const int px = c.px, py = c.py;
-    const bool inside = c.inside;
-    const float pxf = c.pxf, pyf = c.pyf;
-    float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
-    write_sentinel(s0, s1, s2, lane);
-    uint2 range = ranges[c.tile];
-    range.x = min(range.x, cap); range.y = min(range.y, cap);   // workspace capacity: an optimistic launch never reads past it
-    const uint32_t n = range.y - range.x;
-    const uint32_t* list = point_list + range.x;
-
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Dq = 0.f;
-    uint32_t last = 0;
-    bool done = !inside;
-
-    if (!__all(done)) {
-        // pipeline prologue: ids of chunks 0 and 1, records of chunk 0
-        uint32_t id_next = (uint32_t)lane < n ? list[lane] : kNoId;
-        uint32_t id_next2 = (uint32_t)lane + 64u < n ? list[lane + 64] : kNoId;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
-        if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
-        for (uint32_t base = 0; base < n; base += kWave) {
-            const float4 q0 = r0, q1 = r1, q2 = r2;
-            const uint32_t id_cur = id_next;
-            // issue the next chunk's record gather and the ids two chunks ahead
-            id_next = id_next2;
-            id_next2 = base + 128u + (uint32_t)lane < n ? list[base + 128u + lane] : kNoId;
-            r2 = make_float4(0.f, 0.f, -1.f, -1.f);
-            if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
-
-            const bool live = id_cur != kNoId;
-            {
-                unsigned long long m = __ballot(live && quadrant_hit(q0, q2, c.qx0, c.qy0));
-                if (m == 0ull) continue;
-                stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
-                __builtin_amdgcn_wave_barrier();
-                // kFwdUnroll hit records per LDS wait; the blend itself is branch-free (predicated weights)
-                while (m) {
-                    int jj[kFwdUnroll];
-                    float4 a0[kFwdUnroll], a1[kFwdUnroll], a2[kFwdUnroll];
-#pragma unroll
-                    for (int u = 0; u < kFwdUnroll; u++) {
-                        jj[u] = pop_low(m);
-                        a0[u] = s0[jj[u]]; a1[u] = s1[jj[u]]; a2[u] = s2[jj[u]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < kFwdUnroll; u++) {
-                        const float dx = a0[u].x - pxf, dy = a0[u].y - pyf;
-                        const float p = (a0[u].z * dx + a0[u].w * dy) * dx + (a1[u].x * dy) * dy;
-                        const float alpha = fminf(0.99f, a1[u].y * __builtin_amdgcn_exp2f(p));
-                        const float test_T = T * (1.0f - alpha);
-                        const bool vis = !done && p <= 0.0f && alpha >= kAlphaMin;     // sentinel: alpha = 0
-                        const bool ok = vis && test_T >= kTmin;
-                        done = done || (vis && !ok);
-                        const float w = ok ? alpha * T : 0.0f;
-                        C0 += a1[u].z * w; C1 += a1[u].w * w; C2 += a2[u].x * w; Dp += a2[u].y * w;
-                        if (DEPTH_SQ) Dq += a2[u].y * a2[u].y * w;
-                        T = ok ? test_T : T;
-                        last = ok ? base + (uint32_t)jj[u] + 1u : last;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (__all(done)) break;
-        }
-    }
-    if (inside) {
-        const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
-        final_T[pix] = T;
-        n_contrib[pix] = last;
-        out_color[pix] = C0 + T * cam.bg[0];
-        out_color[HW + pix] = C1 + T * cam.bg[1];
-        out_color[2 * HW + pix] = C2 + T * cam.bg[2];
-        out_depth[pix] = Dp;
-        out_opacity[pix] = 1.0f - T;
-        if (DEPTH_SQ) out_depth_sq[pix] = Dq;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
-// Forward, multi-stream variant: the quadrant's 64 lanes form NS streams of 64/NS lanes (NS = 4: 4x4 pixel blocks,
+// Forward: the quadrant's 64 lanes form NS streams of 64/NS lanes (NS = 4: 4x4 pixel blocks,
 // NS = 8: 4x2 blocks), every stream walks ITS OWN list of the staged records whose alpha-visible box overlaps its
 // block.  With sigma ~ 1 px splats a record touches 2.2 of the 4 (3.0 of the 8) blocks of a quadrant, so the loop
 // makes 0.66x (0.59x) the trips of the one-record-per-wave walk (simulated on BASELINE configs[1]).
@@ -199,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
 // two list entries with ONE 16-bit LDS read -- no scalar pop sequences, which is what made a four-stream forward
 // lose before (four s_ff1/s_andn2/s_cselect chains per trip for ~22 VALU of blending).
 // ---------------------------------------------------------------------------------------------------
-template <bool DEPTH_SQ, int NS>
+template <bool DEPTH_SQ, int NS>     // DEPTH_SQ: also accumulate sum z^2 alpha T (third channel of the reference's depth/silhouette pass)
 __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -496,24 +404,17 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     }
 }
 
-static int fwd_streams()
-{
-    const char* e = getenv("GS_FWD_STREAMS");      // development knob: 0 (one record per wave) | 4 | 8
-    return e ? atoi(e) : kFwdStreamsDefault;
-}
-
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
                                 uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, hipStream_t st)
 {
     const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
-    const int ns = fwd_streams();
-#define GS_LAUNCH_FWD(K) hipLaunchKernelGGL(K, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom, out_color, out_depth, \
-                                            out_opacity, final_T, n_contrib, out_depth_sq, cap)
-    if (ns == 4) { if (out_depth_sq) GS_LAUNCH_FWD((blend_forward_streams_kernel<true, 4>)); else GS_LAUNCH_FWD((blend_forward_streams_kernel<false, 4>)); }
-    else if (ns == 8) { if (out_depth_sq) GS_LAUNCH_FWD((blend_forward_streams_kernel<true, 8>)); else GS_LAUNCH_FWD((blend_forward_streams_kernel<false, 8>)); }
-    else { if (out_depth_sq) GS_LAUNCH_FWD(blend_forward_kernel<true>); else GS_LAUNCH_FWD(blend_forward_kernel<false>); }
-#undef GS_LAUNCH_FWD
+    if (out_depth_sq)
+        hipLaunchKernelGGL((blend_forward_streams_kernel<true, kFwdStreams>), dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
+                           out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap);
+    else
+        hipLaunchKernelGGL((blend_forward_streams_kernel<false, kFwdStreams>), dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
+                           out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap);
     return hipGetLastError();
 }
 
