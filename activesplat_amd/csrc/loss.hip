@@ -66,8 +66,8 @@ __global__ __launch_bounds__(kBlock) void loss_stats_kernel(int W, int H, const 
     const bool inside = px < W && py < H;
     const size_t HW = (size_t)W * H;
     float sum_ssim = 0.f, sum_l1 = 0.f;
-    for (int ch = 0; ch < 3; ch++) {
-        __syncthreads();
+    const int ch = blockIdx.z;                  // one colour channel per workgroup: 3x the workgroups, a third of the serial chain
+    {
         for (int e = tid; e < kLP * kLP; e += kBlock) {
             const int r = e / kLP, c = e - r * kLP;
             const int gx = x0 + c - kLH, gy = y0 + r - kLH;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void loss_stats_kernel(int W, int H, const 
         }
     }
     float sum_d = 0.f, cnt = 0.f;
-    if (inside) {
+    if (inside && ch == 0) {                    // the depth term rides with the channel-0 workgroups
         const size_t o = (size_t)py * W + px;
         const float d = depth[o], g = gt_depth[o];
         const float unc = depth_sq ? depth_sq[o] - d * d : 0.f;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void loss_stats_kernel(int W, int H, const 
     sum_d = block_sum(sum_d, s_red, tid);
     cnt = block_sum(cnt, s_red, tid);
     if (tid == 0) {
-        float* a = acc + ((blockIdx.y * gridDim.x + blockIdx.x) & (kAccSlots - 1)) * 16;
+        float* a = acc + (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & (kAccSlots - 1)) * 16;
         atomicAdd(a, sum_ssim); atomicAdd(a + 1, sum_l1); atomicAdd(a + 2, sum_d); atomicAdd(a + 3, cnt);
     }
 }
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(kBlock) void loss_grad_kernel(int W, int H, const f
     const size_t HW = (size_t)W * H;
     const float n3 = 3.0f * (float)HW;
     const float k_ssim = -0.2f * w_im / n3, k_l1 = 0.8f * w_im / n3;
-    for (int ch = 0; ch < 3; ch++) {
-        __syncthreads();
+    const int ch = blockIdx.z;
+    {
         for (int e = tid; e < kLP * kLP; e += kBlock) {
             const int r = e / kLP, c = e - r * kLP;
             const int gx = x0 + c - kLH, gy = y0 + r - kLH;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void loss_grad_kernel(int W, int H, const f
         }
     }
     const float cnt = s_tot[3];
-    if (inside) {
+    if (inside && ch == 0) {
         const size_t o = (size_t)py * W + px;
         const float d = depth[o], g = gt_depth[o];
         const float unc = depth_sq ? depth_sq[o] - d * d : 0.f;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void loss_grad_kernel(int W, int H, const f
         const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
         dL_ddepth[o] = m ? w_depth * sgn / cnt : 0.f;
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
         const float l_im = w_im * (0.8f * s_tot[1] / n3 + 0.2f * (1.0f - s_tot[0] / n3));
         const float l_depth = w_depth * s_tot[2] / cnt;
         losses[0] = l_im + l_depth; losses[1] = l_im; losses[2] = l_depth;
@@ -208,7 +208,7 @@ hipError_t launch_mapping_loss(int W, int H, const float* im, const float* gt, c
     float* partials = scratch + kAccFloats;
     hipError_t e = hipMemsetAsync(acc, 0, kAccFloats * sizeof(float), st);
     if (e != hipSuccess) return e;
-    const dim3 grid((W + kLT - 1) / kLT, (H + kLT - 1) / kLT);
+    const dim3 grid((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, 3);
     hipLaunchKernelGGL(loss_stats_kernel, grid, dim3(kBlock), 0, st, W, H, im, gt, depth, depth_sq, gt_depth, partials, acc);
     hipLaunchKernelGGL(loss_grad_kernel, grid, dim3(kBlock), 0, st, W, H, im, gt, depth, depth_sq, gt_depth, partials, acc, w_im,
                        w_depth, dL_dim, dL_ddepth, losses);
