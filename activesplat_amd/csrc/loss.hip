@@ -77,60 +77,36 @@ __global__ __launch_bounds__(kBlock) void loss_stats_kernel(int W, int H, const 
             s_y[r][c] = in ? gt[o] : 0.f;
         }
         __syncthreads();
-        // horizontal pass, sliding window: thread (row r, group g) produces 4 adjacent outputs from 14 loaded values per map
-        // (7 LDS reads per output instead of 22)
-        if (tid < kLP * (kLT / 4)) {
-            const int r = tid >> 2, c0 = (tid & 3) * 4;
-            float xv[14], yv[14];
+        for (int e = tid; e < kLP * kLT; e += kBlock) {       // horizontal pass: 26 rows x 16 columns
+            const int r = e / kLT, c = e - r * kLT;
+            float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
 #pragma unroll
-            for (int i = 0; i < 14; i++) { xv[i] = s_x[r][c0 + i]; yv[i] = s_y[r][c0 + i]; }
-#pragma unroll
-            for (int o = 0; o < 4; o++) {
-                float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
-#pragma unroll
-                for (int k = 0; k < 11; k++) {
-                    const float w = kWin[k], x = xv[o + k], y = yv[o + k];
-                    a += w * x; b += w * y; aa += w * x * x; bb += w * y * y; ab += w * x * y;
-                }
-                s_h[0][r][c0 + o] = a; s_h[1][r][c0 + o] = b; s_h[2][r][c0 + o] = aa; s_h[3][r][c0 + o] = bb; s_h[4][r][c0 + o] = ab;
+            for (int k = 0; k < 11; k++) {
+                const float w = kWin[k], xv = s_x[r][c + k], yv = s_y[r][c + k];
+                a += w * xv; b += w * yv; aa += w * xv * xv; bb += w * yv * yv; ab += w * xv * yv;
             }
+            s_h[0][r][c] = a; s_h[1][r][c] = b; s_h[2][r][c] = aa; s_h[3][r][c] = bb; s_h[4][r][c] = ab;
         }
         __syncthreads();
-        // vertical pass + SSIM, sliding window again: thread (column tx4, group g) produces 4 vertically adjacent pixels
-        if (tid < kLT * (kLT / 4)) {
-            const int cx = tid & 15, r0 = (tid >> 4) * 4;
-            float res[5][4];
+        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
-            for (int m = 0; m < 5; m++) {
-                float col[14];
-#pragma unroll
-                for (int i = 0; i < 14; i++) col[i] = s_h[m][r0 + i][cx];
-#pragma unroll
-                for (int o = 0; o < 4; o++) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 11; k++) a += kWin[k] * col[o + k];
-                    res[m][o] = a;
-                }
-            }
-#pragma unroll
-            for (int o = 0; o < 4; o++) {
-                const int qx = x0 + cx, qy = y0 + r0 + o;
-                if (qx < W && qy < H) {
-                    const float m1 = res[0][o], m2 = res[1][o], e11 = res[2][o], e22 = res[3][o], e12 = res[4][o];
-                    const float c1 = 0.0001f, c2 = 0.0009f;
-                    const float A1 = 2.f * m1 * m2 + c1, A2 = 2.f * (e12 - m1 * m2) + c2;
-                    const float B1 = m1 * m1 + m2 * m2 + c1, B2 = (e11 - m1 * m1) + (e22 - m2 * m2) + c2;
-                    const float inv = 1.0f / (B1 * B2);
-                    const float S = A1 * A2 * inv;
-                    sum_ssim += S;
-                    const size_t q = ch * HW + (size_t)qy * W + qx;
-                    partials[q] = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * (1.0f / B1 - 1.0f / B2);   // dS/dmu1
-                    partials[3 * HW + q] = -S / B2;                                                      // dS/dE[x^2]
-                    partials[6 * HW + q] = 2.f * A1 * inv;                                               // dS/dE[xy]
-                    sum_l1 += fabsf(s_x[r0 + o + kLH][cx + kLH] - s_y[r0 + o + kLH][cx + kLH]);
-                }
-            }
+        for (int k = 0; k < 11; k++) {                         // vertical pass
+            const float w = kWin[k];
+            m1 += w * s_h[0][ty + k][tx]; m2 += w * s_h[1][ty + k][tx]; e11 += w * s_h[2][ty + k][tx];
+            e22 += w * s_h[3][ty + k][tx]; e12 += w * s_h[4][ty + k][tx];
+        }
+        if (inside) {
+            const float c1 = 0.0001f, c2 = 0.0009f;
+            const float A1 = 2.f * m1 * m2 + c1, A2 = 2.f * (e12 - m1 * m2) + c2;
+            const float B1 = m1 * m1 + m2 * m2 + c1, B2 = (e11 - m1 * m1) + (e22 - m2 * m2) + c2;
+            const float inv = 1.0f / (B1 * B2);
+            const float S = A1 * A2 * inv;
+            sum_ssim += S;
+            const size_t o = ch * HW + (size_t)py * W + px;
+            partials[o] = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * (1.0f / B1 - 1.0f / B2);   // dS/dmu1
+            partials[3 * HW + o] = -S / B2;                                                      // dS/dE[x^2]
+            partials[6 * HW + o] = 2.f * A1 * inv;                                               // dS/dE[xy]
+            sum_l1 += fabsf(s_x[ty + kLH][tx + kLH] - s_y[ty + kLH][tx + kLH]);
         }
     }
     float sum_d = 0.f, cnt = 0.f;
@@ -181,50 +157,29 @@ __global__ __launch_bounds__(kBlock) void loss_grad_kernel(int W, int H, const f
             s_p[2][r][c] = in ? partials[6 * HW + o] : 0.f;
         }
         __syncthreads();
-        if (tid < kLP * (kLT / 4)) {                          // horizontal pass, 4 outputs per thread (sliding window)
-            const int r = tid >> 2, c0 = (tid & 3) * 4;
+        for (int e = tid; e < kLP * kLT; e += kBlock) {
+            const int r = e / kLT, c = e - r * kLT;
+            float a = 0.f, b = 0.f, d = 0.f;
 #pragma unroll
-            for (int m = 0; m < 3; m++) {
-                float v[14];
-#pragma unroll
-                for (int i = 0; i < 14; i++) v[i] = s_p[m][r][c0 + i];
-#pragma unroll
-                for (int o = 0; o < 4; o++) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 11; k++) a += kWin[k] * v[o + k];
-                    s_h[m][r][c0 + o] = a;
-                }
+            for (int k = 0; k < 11; k++) {
+                const float w = kWin[k];
+                a += w * s_p[0][r][c + k]; b += w * s_p[1][r][c + k]; d += w * s_p[2][r][c + k];
             }
+            s_h[0][r][c] = a; s_h[1][r][c] = b; s_h[2][r][c] = d;
         }
         __syncthreads();
-        if (tid < kLT * (kLT / 4)) {                          // vertical pass, 4 pixels per thread
-            const int cx = tid & 15, r0 = (tid >> 4) * 4;
-            float g[3][4];
+        float g1 = 0.f, g2 = 0.f, g3 = 0.f;
 #pragma unroll
-            for (int m = 0; m < 3; m++) {
-                float col[14];
-#pragma unroll
-                for (int i = 0; i < 14; i++) col[i] = s_h[m][r0 + i][cx];
-#pragma unroll
-                for (int o = 0; o < 4; o++) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 11; k++) a += kWin[k] * col[o + k];
-                    g[m][o] = a;
-                }
-            }
-#pragma unroll
-            for (int o = 0; o < 4; o++) {
-                const int qx = x0 + cx, qy = y0 + r0 + o;
-                if (qx < W && qy < H) {
-                    const size_t q = ch * HW + (size_t)qy * W + qx;
-                    const float x = im[q], y = gt[q];
-                    const float diff = x - y;
-                    const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-                    dL_dim[q] = k_ssim * (g[0][o] + 2.f * x * g[1][o] + y * g[2][o]) + k_l1 * sgn;
-                }
-            }
+        for (int k = 0; k < 11; k++) {
+            const float w = kWin[k];
+            g1 += w * s_h[0][ty + k][tx]; g2 += w * s_h[1][ty + k][tx]; g3 += w * s_h[2][ty + k][tx];
+        }
+        if (inside) {
+            const size_t o = ch * HW + (size_t)py * W + px;
+            const float x = im[o], y = gt[o];
+            const float diff = x - y;
+            const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+            dL_dim[o] = k_ssim * (g1 + 2.f * x * g2 + y * g3) + k_l1 * sgn;
         }
     }
     const float cnt = s_tot[3];
