@@ -181,3 +181,11 @@ def test_full_size_config2_sh3_against_oracle_and_properties(hip, oracle32):
     for k in ("means3D", "shs", "opacities"):
         a, b = gp["grads"][k].astype(np.float64), g[k][perm.cpu().numpy()].astype(np.float64)
         assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-3, k
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scene_matches_oracle_on_gpu(hip, oracle32, oracle64, seed):
+    from tests.test_randomized import _draw
+    rs, rv = _draw(5000 + seed, hip)
+    pc.check_forward(rs, rv, oracle32)
+    pc.check_backward(rs, rv, oracle64, min_frac=0.99)
