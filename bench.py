@@ -171,7 +171,7 @@ def main():
             import glob
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
             if files and N == 500_000 and (W, H) == (640, 480):
-                kern = {"blend_backward": "blend_backward_kernel", "blend_forward": "blend_forward_kernel"}.get(dom)
+                kern = {"blend_backward": "blend_backward_kernel", "blend_forward": "blend_forward_streams_kernel"}.get(dom)
                 pm = json.load(open(files[-1]))
                 if kern in pm and "traffic_bytes" in pm[kern]:
                     traffic, traffic_src = int(pm[kern]["traffic_bytes"]), os.path.basename(files[-1])
