@@ -79,6 +79,17 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(int64_t total, int 
     }
 }
 
+// rows of a multiple of 4 floats (quaternions, SH coefficient rows and their Adam moments): 16 B per lane, 32-bit index math
+__global__ __launch_bounds__(kBlock) void gather_rows_vec4_kernel(uint32_t total4, uint32_t row4, const uint32_t* __restrict__ src_index,
+                                                                   const float4* __restrict__ src, float4* __restrict__ dst)
+{
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < total4; e += stride) {
+        const uint32_t r = e / row4, c = e - r * row4;
+        dst[e] = src[(size_t)src_index[r] * row4 + c];
+    }
+}
+
 uint64_t compact_scratch_bytes(int64_t n) { return (uint64_t)((n + kCompactBlock - 1) / kCompactBlock + 1) * 4; }
 
 hipError_t launch_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32_t* d_count, void* scratch, hipStream_t st)
@@ -95,6 +106,14 @@ hipError_t launch_gather_rows(int64_t n_out, int row_floats, const uint32_t* src
 {
     const int64_t total = n_out * row_floats;
     if (total <= 0) return hipSuccess;
+    if ((row_floats & 3) == 0 && (total >> 2) < ((int64_t)1 << 32) && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const uint32_t total4 = (uint32_t)(total >> 2);
+        uint32_t nb4 = (total4 + kBlock - 1) / kBlock;
+        if (nb4 > 256 * 16) nb4 = 256 * 16;
+        hipLaunchKernelGGL(gather_rows_vec4_kernel, dim3(nb4), dim3(kBlock), 0, st, total4, (uint32_t)(row_floats >> 2), src_index,
+                           reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst));
+        return hipGetLastError();
+    }
     int64_t nb = (total + kBlock - 1) / kBlock;
     if (nb > 256 * 16) nb = 256 * 16;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, total, row_floats, src_index, src, dst);
