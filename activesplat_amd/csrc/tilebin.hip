@@ -295,22 +295,17 @@ __global__ __launch_bounds__(THREADS) void tile_merge_kernel(const uint2* __rest
     }
 }
 
-// development knob: GS_BIN_VARIANT = threads*10000 + chunk (e.g. 10244096); default 1024 threads x 4096 Gaussians
+// 1024 threads x kBinChunk Gaussians per workgroup (measured best of 256/512/1024 threads x 1024..4096 Gaussians)
 static void bin_config(int& threads, int& chunk)
 {
     threads = 1024; chunk = kBinChunk;
-    const char* ev = getenv("GS_BIN_VARIANT");
-    if (ev) { const int v = atoi(ev); threads = v / 10000; chunk = v % 10000; }
-    if (chunk < 1024) chunk = 1024;
 }
 
 template <bool SCATTER>
 static void launch_bin(int threads, int nb, hipStream_t st, Cam cam, int P, GeomPtrs gp, int tiles, int chunk,
                        uint32_t* tile_total, uint32_t* tile_base, const uint2* ranges, unsigned long long* pairs, uint32_t cap)
 {
-    if (threads == 256) hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 256>), dim3(nb), dim3(256), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs, cap);
-    else if (threads == 512) hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 512>), dim3(nb), dim3(512), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs, cap);
-    else hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 1024>), dim3(nb), dim3(1024), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs, cap);
+    hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 1024>), dim3(nb), dim3(1024), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs, cap);
 }
 
 hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,
@@ -332,7 +327,6 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
     int threads, chunk; bin_config(threads, chunk);
     const int nb = (P + chunk - 1) / chunk;
     if (nb > 0) launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
-    if (getenv("GS_SKIP_TILE_SORT")) return hipGetLastError();     // development: time the scatter alone
     const unsigned chunks = (max_tile_instances + kSortChunk - 1) / kSortChunk;
     hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, chunks ? chunks : 1), dim3(256), 0, st, ranges, pairs, point_list, cap);
     if (max_tile_instances > (uint32_t)kSortChunk) {
