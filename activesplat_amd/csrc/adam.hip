@@ -10,6 +10,20 @@
 
 namespace gs {
 
+// streaming (non-temporal) 16-byte load: data that is read exactly once should not evict the L2's working set
+__device__ __forceinline__ float4 load_stream(const float4* p)
+{
+    typedef float v4f __attribute__((vector_size(16)));
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store_stream(float4* p, const float4& x)
+{
+    typedef float v4f __attribute__((vector_size(16)));
+    const v4f v = {x.x, x.y, x.z, x.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+}
+
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float one_m_b1, float b2, float one_m_b2,
                                           float step_size, float inv_bc2s, float eps)
 {
@@ -30,7 +44,7 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n, float* __restri
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
-        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];     // the gradient is read once: keep it out of L2
         adam_elem(pp.x, gg.x, mm.x, vv.x, one_m_b1, b2, one_m_b2, step_size, inv_bc2s, eps);
         adam_elem(pp.y, gg.y, mm.y, vv.y, one_m_b1, b2, one_m_b2, step_size, inv_bc2s, eps);
         adam_elem(pp.z, gg.z, mm.z, vv.z, one_m_b1, b2, one_m_b2, step_size, inv_bc2s, eps);
@@ -68,7 +82,9 @@ struct AdamSlot {
     float one_m_b1, b2, one_m_b2, step_size, inv_bc2s, eps;
     unsigned block_begin;            // first workgroup of this tensor
     unsigned blocks;                 // workgroups assigned to it
+    int stream;                      // tensor larger than the last-level cache: non-temporal loads / stores
 };
+constexpr int64_t kAdamStreamBytes = 256ll << 20;     // 256 MiB last-level (Infinity) cache: beyond it, re-use is impossible anyway
 struct AdamBatch { AdamSlot s[kAdamMaxTensors]; int count; };
 
 __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamBatch b)
@@ -85,13 +101,24 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamBatch b)
     const float4* g4 = reinterpret_cast<const float4*>(a.g);
     float4* m4 = reinterpret_cast<float4*>(a.m);
     float4* v4 = reinterpret_cast<float4*>(a.v);
-    for (int64_t i = (int64_t)lb * kBlock + threadIdx.x; i < n4; i += stride) {
-        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
-        adam_elem(pp.x, gg.x, mm.x, vv.x, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
-        adam_elem(pp.y, gg.y, mm.y, vv.y, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
-        adam_elem(pp.z, gg.z, mm.z, vv.z, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
-        adam_elem(pp.w, gg.w, mm.w, vv.w, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
-        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    if (a.stream) {
+        for (int64_t i = (int64_t)lb * kBlock + threadIdx.x; i < n4; i += stride) {
+            float4 pp = load_stream(&p4[i]), gg = load_stream(&g4[i]), mm = load_stream(&m4[i]), vv = load_stream(&v4[i]);
+            adam_elem(pp.x, gg.x, mm.x, vv.x, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
+            adam_elem(pp.y, gg.y, mm.y, vv.y, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
+            adam_elem(pp.z, gg.z, mm.z, vv.z, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
+            adam_elem(pp.w, gg.w, mm.w, vv.w, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
+            store_stream(&p4[i], pp); store_stream(&m4[i], mm); store_stream(&v4[i], vv);
+        }
+    } else {
+        for (int64_t i = (int64_t)lb * kBlock + threadIdx.x; i < n4; i += stride) {
+            float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+            adam_elem(pp.x, gg.x, mm.x, vv.x, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
+            adam_elem(pp.y, gg.y, mm.y, vv.y, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
+            adam_elem(pp.z, gg.z, mm.z, vv.z, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
+            adam_elem(pp.w, gg.w, mm.w, vv.w, a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
+            p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        }
     }
     const int64_t tl = (n4 << 2) + threadIdx.x;
     if (lb == 0 && tl < a.n) adam_elem(a.p[tl], a.g[tl], a.m[tl], a.v[tl], a.one_m_b1, a.b2, a.one_m_b2, a.step_size, a.inv_bc2s, a.eps);
@@ -114,6 +141,7 @@ hipError_t launch_adam_multi(int count, const GsAdamTensor* t, hipStream_t st)
             if (nb < 1) nb = 1;
             if (nb > 256 * 8) nb = 256 * 8;
             a.block_begin = next; a.blocks = (unsigned)nb;
+            a.stream = t[i].n * 28 > kAdamStreamBytes ? 1 : 0;
             next += (unsigned)nb;
         }
         if (b.count == 0) continue;

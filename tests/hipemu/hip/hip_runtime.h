@@ -193,6 +193,8 @@ static inline void hipemu_wave_barrier() { hipemu::wave_exchange(0ull, 12, nullp
 #define __builtin_amdgcn_readlane(v, l) hipemu_readlane(v, l)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 static inline unsigned hipemu_mbcnt_lo(unsigned mask, unsigned base)

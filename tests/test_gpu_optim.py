@@ -223,3 +223,20 @@ def test_keyframe_overlap_kernel_equals_torch_on_gpu(hip):
     pb = {r["id"]: float(r["percent_inside"]) for r in rb}
     assert max(abs(pa[i] - pb[i]) for i in pa) <= 2 / 1600            # at most a borderline point or two per keyframe
     assert len(a) == len(b) == 8
+
+
+def test_adam_streaming_path_for_tensors_beyond_the_last_level_cache(hip):
+    """> 256 MiB of Adam traffic per tensor switches the kernel to non-temporal loads / stores: same arithmetic."""
+    from activesplat_amd import optim as O
+    n = 10_000_003                                                  # 280 MB of traffic; odd tail
+    g0 = torch.Generator().manual_seed(1)
+    init = torch.randn(n, generator=g0)
+    a = torch.nn.Parameter(init.clone().to(hip)); b = torch.nn.Parameter(init.clone().to(hip))
+    oa = O.GaussianAdam([{"params": [a], "name": "x", "lr": 2e-3}], lr=0.0, eps=1e-15)
+    ob = torch.optim.Adam([{"params": [b], "lr": 2e-3}], lr=0.0, eps=1e-15)
+    for _ in range(3):
+        g = torch.randn(n, generator=g0).to(hip)
+        a.grad, b.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    assert torch.allclose(a, b, rtol=3e-6, atol=1e-7)
+    assert torch.allclose(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=3e-6, atol=1e-12)
