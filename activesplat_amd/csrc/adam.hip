@@ -10,20 +10,6 @@
 
 namespace gs {
 
-// streaming (non-temporal) 16-byte load: data that is read exactly once should not evict the L2's working set
-__device__ __forceinline__ float4 load_stream(const float4* p)
-{
-    typedef float v4f __attribute__((vector_size(16)));
-    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
-    return make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ void store_stream(float4* p, const float4& x)
-{
-    typedef float v4f __attribute__((vector_size(16)));
-    const v4f v = {x.x, x.y, x.z, x.w};
-    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
-}
-
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float one_m_b1, float b2, float one_m_b2,
                                           float step_size, float inv_bc2s, float eps)
 {

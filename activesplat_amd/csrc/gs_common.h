@@ -87,6 +87,20 @@ __device__ __forceinline__ void stage_rows(float* lds, const float* __restrict__
 // SH coefficient rows ([P][M][3] floats, M*3 = K floats per Gaussian, 192 B at degree 3) are moved between HBM
 // and a wave's threads through an LDS slab with an ODD row stride (conflict-free lane = row access): one
 // wavefront's 64 rows at a time, all 256 threads of the workgroup doing the coalesced global side.
+// streaming (non-temporal) 16-byte load: data that is read exactly once should not evict the L2's working set
+__device__ __forceinline__ float4 load_stream(const float4* p)
+{
+    typedef float v4f __attribute__((vector_size(16)));
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store_stream(float4* p, const float4& x)
+{
+    typedef float v4f __attribute__((vector_size(16)));
+    const v4f v = {x.x, x.y, x.z, x.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+}
+
 constexpr int kShPad = 49;          // LDS row stride for up to 48 floats (16 coefficients x RGB)
 __device__ __forceinline__ int sh_row_stride(int K) { return K | 1; }
 // global rows [row0, row0+nrows) -> LDS (padded); nrows <= 64
@@ -120,7 +134,7 @@ __device__ __forceinline__ void sh_wave_rows_to_lds(float* slab, const float* __
     const float* s = src + (size_t)row0 * K;
     const float4* s4 = reinterpret_cast<const float4*>(s);
     for (int q = lane; q < total4; q += kWave) {
-        const float4 v = s4[q];
+        const float4 v = load_stream(&s4[q]);              // coefficient rows are read once per pass
         int e = q << 2, r = e / K, c = e - r * K;
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -147,7 +161,7 @@ __device__ __forceinline__ void sh_wave_rows_from_lds(const float* slab, float* 
             vv[t] = slab[r * stride + c];
             if (++c == K) { c = 0; ++r; }
         }
-        d4[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        store_stream(&d4[q], make_float4(vv[0], vv[1], vv[2], vv[3]));
     }
     for (int e = (total4 << 2) + lane; e < total; e += kWave) {
         const int r = e / K;
