@@ -12,3 +12,8 @@ pmc write WRITE_SIZE
 pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
 pmc sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT
 cd $R; ls gpurun_out/final | head -40
+# secondary evidence: kernel tables of the fused mapping iteration and of the 2M north-star configuration, configs report
+bash scripts/profile_fused_iteration.sh > gpurun_out/final/fused_iteration.txt 2>&1; cp gpurun_out/prof/fiter_kernel_stats.csv gpurun_out/final/${TAG}_fused_iteration_kernel_stats.csv
+bash scripts/profile_2m.sh > gpurun_out/final/north_star_2m.txt 2>&1; cp gpurun_out/prof2m/n2m_kernel_stats.csv gpurun_out/final/${TAG}_2m_kernel_stats.csv
+python scripts/configs_report.py > gpurun_out/final/${TAG}_configs.json 2> gpurun_out/final/configs.err
+tail -3 gpurun_out/final/fused_iteration.txt; head -2 gpurun_out/final/north_star_2m.txt
