@@ -239,17 +239,28 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
 // the same register.  Partner maps: lane^8 (row_ror:8), mirror within 8 (row_half_mirror), lane^2 and
 // lane^1 (quad_perm).  Afterwards lane l of the row holds the row total of component row_comp(l).
 #define GS_DPP_ADD(keep, send, ctrl) ((keep) + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), ctrl, 0xf, 0xf, true)))
+// Merge of two registers at a level whose lane split coincides with DPP banks (4 consecutive lanes): the lanes of the banks in
+// mask M0 end with x0 + x0[partner], the others with x1 + x1[partner] -- two bank-masked v_add_f32_dpp, no select.  (The
+// generic form needs two v_cndmask and one DPP add.)  s_nop 1: the two wait states a DPP read needs after a VALU write.
+#ifndef GS_ROW_MERGE
+#define GS_ROW_MERGE(dst, x0, x1, CTRL_STR, CTRL, M0_STR, M1_STR, M0)                                                         \
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 " CTRL_STR " row_mask:0xf bank_mask:" M0_STR "\n\t"                              \
+        "v_add_f32_dpp %0, %2, %2 " CTRL_STR " row_mask:0xf bank_mask:" M1_STR                                                \
+        : "=&v"(dst) : "v"(x0), "v"(x1))
+#endif
 __device__ __forceinline__ float row_reduce10(const float (&v)[10], bool b8, bool b4, bool b2, bool b1)
 {
-    // level A: partner lane^8
-    const float a0 = GS_DPP_ADD(b8 ? v[1] : v[0], b8 ? v[0] : v[1], 0x128);     // row_ror:8
-    const float a1 = GS_DPP_ADD(b8 ? v[3] : v[2], b8 ? v[2] : v[3], 0x128);
-    const float a2 = GS_DPP_ADD(b8 ? v[5] : v[4], b8 ? v[4] : v[5], 0x128);
-    const float a3 = GS_DPP_ADD(b8 ? v[7] : v[6], b8 ? v[6] : v[7], 0x128);
-    const float a4 = GS_DPP_ADD(b8 ? v[9] : v[8], b8 ? v[8] : v[9], 0x128);
-    // level B: partner = mirror within the 8-lane half
-    const float c0 = GS_DPP_ADD(b4 ? a1 : a0, b4 ? a0 : a1, 0x141);             // row_half_mirror
-    const float c1 = GS_DPP_ADD(b4 ? a3 : a2, b4 ? a2 : a3, 0x141);
+    // level A: partner lane^8 (row_ror:8); lanes 0-7 = banks 0,1 keep the even register, lanes 8-15 the odd one
+    float a0, a1, a2, a3, a4;
+    GS_ROW_MERGE(a0, v[0], v[1], "row_ror:8", 0x128, "0x3", "0xc", 0x3);
+    GS_ROW_MERGE(a1, v[2], v[3], "row_ror:8", 0x128, "0x3", "0xc", 0x3);
+    GS_ROW_MERGE(a2, v[4], v[5], "row_ror:8", 0x128, "0x3", "0xc", 0x3);
+    GS_ROW_MERGE(a3, v[6], v[7], "row_ror:8", 0x128, "0x3", "0xc", 0x3);
+    GS_ROW_MERGE(a4, v[8], v[9], "row_ror:8", 0x128, "0x3", "0xc", 0x3);
+    // level B: partner = mirror within the 8-lane half (row_half_mirror); lanes with bit 2 clear = banks 0,2
+    float c0, c1;
+    GS_ROW_MERGE(c0, a0, a1, "row_half_mirror", 0x141, "0x5", "0xa", 0x5);
+    GS_ROW_MERGE(c1, a2, a3, "row_half_mirror", 0x141, "0x5", "0xa", 0x5);
     const float c2 = GS_DPP_ADD(a4, a4, 0x141);
     // level C: partner lane^2
     const float e0 = GS_DPP_ADD(b2 ? c1 : c0, b2 ? c0 : c1, 0x4E);              // quad_perm:[2,3,0,1]
