@@ -289,6 +289,11 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
 {
     __shared__ float4 s_rec[kBlock / kWave][3][kWave + 1];           // + the sentinel slot
     __shared__ __attribute__((aligned(16))) uint8_t s_list[kBlock / kWave][4 * kWave + 16];  // per-row record lists of the staged chunk (+ look-ahead pad)
+    // per-wave gradient accumulators of the staged chunk: slot j = record j, 16 floats like the global record.  The rows add
+    // their reduced moments here (LDS atomics) and the chunk is flushed ONCE per record with global atomics: the kernel is
+    // bound by the memory-side atomic units (38.5 M dword atomics per frame when every (row, record) pair went to HBM
+    // directly: 272 us, against 186 us with the atomics removed), and a record is seen by 2.2 of the 4 rows on average.
+    __shared__ __attribute__((aligned(16))) float s_acc[kBlock / kWave][kWave * kGradStride];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
     if (!tile_ctx(cam, wave, lane, c)) return;
@@ -300,6 +305,10 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
     write_sentinel(s0, s1, s2, lane);
     const uint8_t* my_list = s_list[wave] + row * kWave;
+    float* acc_lds = s_acc[wave];
+#pragma unroll
+    for (int k = 0; k < kGradStride; k++) acc_lds[k * kWave + lane] = 0.0f;          // zeroed once; the flush re-zeroes what it drains
+    const int fl_rec = lane / 10, fl_comp = lane - fl_rec * 10;                  // flush mapping: 6 records x 10 components per instruction
     const uint2 range = ranges[c.tile];
     const uint32_t* list = point_list + range.x;
     const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
@@ -408,8 +417,31 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             // every row that had a contributing pixel adds its 9 (10) components to ITS record: one hardware fp32 atomic
             // instruction, 9-10 lanes per row, each record's components inside one 64-byte line (kGradStride = 16)
             const bool any0 = ((okm0 >> (row * 16)) & 0xffffull) != 0ull, any1 = ((okm1 >> (row * 16)) & 0xffffull) != 0ull;
-            if (any0 && my_comp >= 0) atomicAdd(grad2d + (size_t)__float_as_uint(a2[0].z) * kGradStride + my_comp, x0);
-            if (any1 && my_comp >= 0) atomicAdd(grad2d + (size_t)__float_as_uint(a2[1].z) * kGradStride + my_comp, x1);
+            if (any0 && my_comp >= 0) atomicAdd(acc_lds + jj[0] * kGradStride + my_comp, x0);
+            if (any1 && my_comp >= 0) atomicAdd(acc_lds + jj[1] * kGradStride + my_comp, x1);
+        }
+        // flush: the records some row hit (union of the four ballots), 6 records x 10 components per global atomic instruction;
+        // components that received nothing stay out (a record none of whose pixels passed alpha >= 1/255 costs no request)
+        __builtin_amdgcn_wave_barrier();
+        {
+            const unsigned long long many = m0 | m1 | m2 | m3;
+            const int n_any = (int)__popcll(many);
+            uint8_t* ulist = s_list[wave];                     // the row lists are spent: reuse their space for the union list
+            if ((many >> lane) & 1ull)
+                ulist[(int)__builtin_amdgcn_mbcnt_hi((uint32_t)(many >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)many, 0u))] = (uint8_t)lane;
+            __builtin_amdgcn_wave_barrier();
+            for (int g = 0; g < n_any; g += 6) {
+                const int k = g + fl_rec;
+                if (lane < 60 && k < n_any) {
+                    const int slot = (int)ulist[k];
+                    float* a = acc_lds + slot * kGradStride + fl_comp;
+                    const float val = *a;
+                    if (val != 0.0f) {
+                        *a = 0.0f;
+                        atomicAdd(grad2d + (size_t)__float_as_uint(s2[slot].z) * kGradStride + fl_comp, val);
+                    }
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
