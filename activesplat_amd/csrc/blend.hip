@@ -420,8 +420,9 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             if (any0 && my_comp >= 0) atomicAdd(acc_lds + jj[0] * kGradStride + my_comp, x0);
             if (any1 && my_comp >= 0) atomicAdd(acc_lds + jj[1] * kGradStride + my_comp, x1);
         }
-        // flush: the records some row hit (union of the four ballots), 6 records x 10 components per global atomic instruction;
-        // components that received nothing stay out (a record none of whose pixels passed alpha >= 1/255 costs no request)
+        // flush: the records some row hit (union of the four ballots), 6 records x 10 components per global atomic instruction,
+        // software-pipelined (slot index two groups ahead, value and Gaussian id one group ahead).  Components that received
+        // nothing stay out, so a record none of whose pixels passed alpha >= 1/255 costs no request.
         __builtin_amdgcn_wave_barrier();
         {
             const unsigned long long many = m0 | m1 | m2 | m3;
@@ -430,17 +431,22 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             if ((many >> lane) & 1ull)
                 ulist[(int)__builtin_amdgcn_mbcnt_hi((uint32_t)(many >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)many, 0u))] = (uint8_t)lane;
             __builtin_amdgcn_wave_barrier();
+            const int krec = min(fl_rec, 5);                   // lanes 60..63 idle along with record 5's mapping (never valid)
+            int slot_c = (int)ulist[krec];                                          // group 0
+            int slot_n = (int)ulist[6 + krec];                                      // group 1 (entries beyond n_any are stale: masked below)
+            bool valid_c = lane < 60 && krec < n_any;
+            float val_c = valid_c ? acc_lds[slot_c * kGradStride + fl_comp] : 0.0f;
+            uint32_t id_c = valid_c ? __float_as_uint(s2[slot_c].z) : 0u;
             for (int g = 0; g < n_any; g += 6) {
-                const int k = g + fl_rec;
-                if (lane < 60 && k < n_any) {
-                    const int slot = (int)ulist[k];
-                    float* a = acc_lds + slot * kGradStride + fl_comp;
-                    const float val = *a;
-                    if (val != 0.0f) {
-                        *a = 0.0f;
-                        atomicAdd(grad2d + (size_t)__float_as_uint(s2[slot].z) * kGradStride + fl_comp, val);
-                    }
+                const bool valid_n = lane < 60 && g + 6 + krec < n_any;
+                const float val_n = valid_n ? acc_lds[slot_n * kGradStride + fl_comp] : 0.0f;
+                const uint32_t id_n = valid_n ? __float_as_uint(s2[slot_n].z) : 0u;
+                const int slot_nn = (int)ulist[min(g + 12 + krec, 4 * kWave + 15)];
+                if (val_c != 0.0f) {
+                    acc_lds[slot_c * kGradStride + fl_comp] = 0.0f;
+                    atomicAdd(grad2d + (size_t)id_c * kGradStride + fl_comp, val_c);
                 }
+                slot_c = slot_n; slot_n = slot_nn; val_c = val_n; id_c = id_n;
             }
         }
         __builtin_amdgcn_wave_barrier();
