@@ -417,8 +417,20 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             // every row that had a contributing pixel adds its 9 (10) components to ITS record: one hardware fp32 atomic
             // instruction, 9-10 lanes per row, each record's components inside one 64-byte line (kGradStride = 16)
             const bool any0 = ((okm0 >> (row * 16)) & 0xffffull) != 0ull, any1 = ((okm1 >> (row * 16)) & 0xffffull) != 0ull;
-            if (any0 && my_comp >= 0) atomicAdd(acc_lds + jj[0] * kGradStride + my_comp, x0);
-            if (any1 && my_comp >= 0) atomicAdd(acc_lds + jj[1] * kGradStride + my_comp, x1);
+            // LDS float atomics retire ~1 lane per clock: use them only when two rows hold the SAME record in this step (44 % of
+            // the steps); otherwise every row owns its slot and a plain read-add-write is enough (LDS ops of a wave stay in order)
+            const float xs[2] = {x0, x1};
+            const bool anys[2] = {any0, any1};
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int ja = __builtin_amdgcn_readlane(jj[u], 0), jb = __builtin_amdgcn_readlane(jj[u], 16);
+                const int jc = __builtin_amdgcn_readlane(jj[u], 32), jd = __builtin_amdgcn_readlane(jj[u], 48);
+                const bool clash = (ja != kWave && (ja == jb || ja == jc || ja == jd)) || (jb != kWave && (jb == jc || jb == jd)) ||
+                                   (jc != kWave && jc == jd);
+                float* a = acc_lds + jj[u] * kGradStride + my_comp;
+                if (clash) { if (anys[u] && my_comp >= 0) atomicAdd(a, xs[u]); }
+                else if (anys[u] && my_comp >= 0) *a = *a + xs[u];
+            }
         }
         // flush: the records some row hit (union of the four ballots), 6 records x 10 components per global atomic instruction,
         // software-pipelined (slot index two groups ahead, value and Gaussian id one group ahead).  Components that received
