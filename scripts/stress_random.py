@@ -1,0 +1,19 @@
+"""One-off robustness sweep on the device: many random scenes (tests/test_randomized._draw) against the oracle.
+usage (GPU box): python scripts/stress_random.py [first_seed] [count]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from oracle.gs_oracle import Oracle  # noqa: E402
+from tests import parity_cases as pc  # noqa: E402
+from tests.test_randomized import _draw  # noqa: E402
+first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 300
+o32, o64 = Oracle("f32"), Oracle("f64")
+bad = []
+for seed in range(first, first + count):
+    try:
+        rs, rv = _draw(seed, torch.device("cuda"))
+        pc.check_forward(rs, rv, o32)
+        pc.check_backward(rs, rv, o64, min_frac=0.99, oracle32=o32)
+    except AssertionError as e:
+        bad.append((seed, str(e)[:200]))
+print(f"{count - len(bad)}/{count} random scenes match the oracle; failures: {bad[:10]}")

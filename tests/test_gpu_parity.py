@@ -188,4 +188,4 @@ def test_random_scene_matches_oracle_on_gpu(hip, oracle32, oracle64, seed):
     from tests.test_randomized import _draw
     rs, rv = _draw(5000 + seed, hip)
     pc.check_forward(rs, rv, oracle32)
-    pc.check_backward(rs, rv, oracle64, min_frac=0.99)
+    pc.check_backward(rs, rv, oracle64, min_frac=0.99, oracle32=oracle32)
