@@ -430,6 +430,9 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                 float* a = acc_lds + jj[u] * kGradStride + my_comp;
                 if (clash) { if (anys[u] && my_comp >= 0) atomicAdd(a, xs[u]); }
                 else if (anys[u] && my_comp >= 0) *a = *a + xs[u];
+                // the next step's slot of another row may be THIS step's slot of this row: keep the LDS accesses of the two
+                // steps in program order (LDS executes a wave's operations in order)
+                __builtin_amdgcn_wave_barrier();
             }
         }
         // flush: the records some row hit (union of the four ballots), 6 records x 10 components per global atomic instruction,
