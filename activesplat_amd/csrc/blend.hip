@@ -362,6 +362,14 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
 #undef GS_RANK
         const int ntrips = max(max(n0, n1), max(n2, n3));
         __builtin_amdgcn_wave_barrier();
+        // list positions at which two rows hold the SAME record (lane t looks at position t of the four lists)
+        unsigned long long clash_mask;
+        {
+            const uint8_t* L = s_list[wave];
+            const int e0 = L[lane], e1 = L[kWave + lane], e2 = L[2 * kWave + lane], e3 = L[3 * kWave + lane];
+            clash_mask = __ballot((e0 != kWave && (e0 == e1 || e0 == e2 || e0 == e3)) || (e1 != kWave && (e1 == e2 || e1 == e3)) ||
+                                  (e2 != kWave && e2 == e3));
+        }
         // TWO list entries per iteration (one 16-bit LDS read, fetched one iteration ahead): the alpha evaluations and the two
         // in-row reductions of a pair are independent instruction chains that the scheduler interleaves; only the short
         // T / behind-colour update is serial.  An odd tail pairs the last record with the sentinel.
@@ -423,10 +431,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             const bool anys[2] = {any0, any1};
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const int ja = __builtin_amdgcn_readlane(jj[u], 0), jb = __builtin_amdgcn_readlane(jj[u], 16);
-                const int jc = __builtin_amdgcn_readlane(jj[u], 32), jd = __builtin_amdgcn_readlane(jj[u], 48);
-                const bool clash = (ja != kWave && (ja == jb || ja == jc || ja == jd)) || (jb != kWave && (jb == jc || jb == jd)) ||
-                                   (jc != kWave && jc == jd);
+                const bool clash = ((clash_mask >> (t + u)) & 1ull) != 0ull;
                 float* a = acc_lds + jj[u] * kGradStride + my_comp;
                 if (clash) { if (anys[u] && my_comp >= 0) atomicAdd(a, xs[u]); }
                 else if (anys[u] && my_comp >= 0) *a = *a + xs[u];
