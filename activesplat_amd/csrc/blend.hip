@@ -281,8 +281,10 @@ __device__ __forceinline__ int row_comp(int l16, bool with9)
 //   0: sum Z dx   1: sum Z dy   2: sum Z dx dx   3: sum Z dx dy   4: sum Z dy dy   5: sum G dL/dalpha   6..8: sum w dL/dC
 //   9: sum w dL/d(depth)   (DEPTH_GRAD: the depth output is one more blended channel whose per-Gaussian value
 //      is the view-space z; this is the fused replacement of the reference's second, [z,1,z^2] raster pass)
+// 1200 tile workgroups on 256 CUs = 4.7 resident waves per SIMD: the kernel must fit FIVE waves per SIMD (<= 96 VGPRs after the
+// allocation granularity); at 97 VGPRs the depth-gradient instantiation dropped to four and ran 277 us instead of ~215
 template <bool DEPTH_GRAD>
-__global__ __launch_bounds__(kBlock) void blend_backward_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void blend_backward_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, float* __restrict__ grad2d)

@@ -20,8 +20,17 @@ def run(N=500_000, W=640, H=480, steps=30, warmup=5, backward=True):
     dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
     lib = _lib.get()
 
+    rgbd = bool(os.environ.get("RGBD"))                     # fused single-pass RGB-D render with a depth gradient (DEPTH_GRAD kernels)
+    dLd = torch.randn(1, H, W, generator=torch.Generator().manual_seed(2)).to(dev)
+
     def step():
         m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
+        if rgbd:
+            from activesplat_amd.rasterizer import render_rgbd
+            color, _, depth, _, _ = render_rgbd(cam, means2D=m2d, **rv)
+            if backward:
+                torch.autograd.grad([color, depth], list(rv.values()) + [m2d], [dL, dLd])
+            return
         color, _, _, _ = GaussianRasterizer(raster_settings=cam)(means2D=m2d, **rv)
         if backward:
             torch.autograd.grad(color, list(rv.values()) + [m2d], dL)
