@@ -330,7 +330,12 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
     const unsigned chunks = (max_tile_instances + kSortChunk - 1) / kSortChunk;
     hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, chunks ? chunks : 1), dim3(256), 0, st, ranges, pairs, point_list, cap);
     if (max_tile_instances > (uint32_t)kSortChunk) {
-        if (max_tile_instances <= 8192)
+        // the list sits in LDS: the smallest capacity that holds the longest list keeps the most workgroups resident per CU
+        if (max_tile_instances <= 4096)
+            hipLaunchKernelGGL((tile_merge_kernel<4096, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
+        else if (max_tile_instances <= 6144)
+            hipLaunchKernelGGL((tile_merge_kernel<6144, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
+        else if (max_tile_instances <= 8192)
             hipLaunchKernelGGL((tile_merge_kernel<8192, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
         else
             hipLaunchKernelGGL((tile_merge_kernel<kSortCapMax, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
