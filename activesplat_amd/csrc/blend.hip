@@ -217,21 +217,22 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Backward: back-to-front replay.  Same independent-quadrant walk as the forward, but each wavefront
-// runs FOUR record streams at once, one per 16-lane DPP row:
-//   row r of the wave = the 4x4 pixel sub-block r of the quadrant (lane -> pixel mapping below);
-//   while staging 64 records every lane tests its record's alpha-visible box against the four
-//   sub-blocks -> four 64-bit ballots (scalar registers); each row walks ITS OWN hit mask (scalar
-//   find-first-set per row, lane picks its row's record index with v_cndmask), so one pass of the loop
-//   body evaluates up to four different records on 16 pixels each.  With sigma ~ 1 px splats a record
-//   touches 2.1 of the 4 sub-blocks of a quadrant on average: 0.65x the loop trips of one record per
-//   wave (measured on BASELINE configs[1]).
-//   The nine per-pixel partials are then reduced WITHIN each row only, by a transposed DPP butterfly
-//   (row_reduce9: 27 VALU, no cross-row traffic, the totals land one component per lane) and one
-//   hardware fp32 atomic instruction carries 4 rows x 9 components into the per-Gaussian gradient
-//   records.  The records are 64-byte aligned (kGradStride = 16 floats): device-scope atomics are
-//   read-modify-writes of whole lines at the memory side on this multi-XCD part, and a 48-byte stride
-//   that lets half the records straddle two lines cost +100 us per launch.
+// Backward: back-to-front replay.  Same independent-quadrant walk and the same four record streams as the forward (one
+// per 16-lane DPP row = 4x4 pixel block of the quadrant), lists built deepest-first, two list entries per iteration:
+//   * branch-free replay step per record (T divided back, behind-colour accumulator, dL/dalpha);
+//   * the ten per-pixel partials are reduced WITHIN each row by a transposed DPP butterfly (row_reduce10: 22-29 VALU, no
+//     cross-row traffic, the totals land one component per lane);
+//   * the row totals go to per-wave LDS accumulators (one 16-float slot per staged record): plain read-add-write when the
+//     four rows hold distinct records in that step, ds_add_f32 at the list positions where two rows hold the same record
+//     (found once per chunk: lane t compares position t of the four lists); after the chunk every record that received
+//     something is flushed with ONE global fp32 atomic request (6 records x 10 components per instruction).
+//   Why: adding every (row, record) total straight to HBM made the kernel atomic-bound -- the memory-side atomic units
+//   saturate near 140 G dword atomics/s (38.5 M per frame = 272 us against 186 us with the atomics removed); LDS float
+//   atomics retire ~1 lane per clock per CU, hence the plain path.  The global records are 64-byte aligned
+//   (kGradStride = 16 floats): device-scope atomics are read-modify-writes of whole lines at the memory side on this
+//   multi-XCD part, and a 48-byte stride that lets half the records straddle two lines cost +100 us per launch.
+//   Resources: 30 KB of LDS and <= 96 VGPRs per workgroup/wave -- FIVE workgroups per CU must stay resident (1200 tile
+//   workgroups / 256 CUs = 4.7); four cost 25 % (see amdgpu_waves_per_eu below).
 // ---------------------------------------------------------------------------------------------------
 // Transposed in-row butterfly: the 16-lane row sums of up to TEN values in 29 VALU (instead of 9 x 4 DPP adds
 // plus an 8-deep select chain).  At every level two registers are merged into one: each lane keeps the
