@@ -19,22 +19,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _scene(n=600, W=64, H=48, K=4):
+def _scene(n=600, W=64, H=48, K=4, device="cpu"):
     from activesplat_amd import synthetic as syn
     from activesplat_amd.camera import setup_camera
     p = syn.make_params(n, W, H, seed=3)
-    params = {k: torch.nn.Parameter(v.clone()) for k, v in p.items()}
-    params["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([[1.0, 0, 0, 0]]).T.repeat(1, 1, K).reshape(1, 4, K))
-    params["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, K))
+    params = {k: torch.nn.Parameter(v.clone().to(device)) for k, v in p.items()}
+    params["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([[1.0, 0, 0, 0]]).T.repeat(1, 1, K).reshape(1, 4, K).to(device))
+    params["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, K, device=device))
     with torch.no_grad():
         for i in range(K):                                  # keyframe i: small yaw + shift
             a = 0.03 * i
             params["cam_unnorm_rots"][0, :, i] = torch.tensor([np.cos(a / 2), 0.0, np.sin(a / 2), 0.0])
             params["cam_trans"][0, :, i] = torch.tensor([0.02 * i, 0.0, 0.01 * i])
-    cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device="cpu")
+    cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=device)
     g = torch.Generator().manual_seed(9)
-    kfs = [dict(cam=cam, id=i, im=torch.rand(3, H, W, generator=g), depth=torch.rand(1, H, W, generator=g) * 3 + 0.5,
-                w2c=torch.eye(4)) for i in range(K)]
+    kfs = [dict(cam=cam, id=i, im=torch.rand(3, H, W, generator=g).to(device), depth=(torch.rand(1, H, W, generator=g) * 3 + 0.5).to(device),
+                w2c=torch.eye(4, device=device)) for i in range(K)]
     return params, kfs
 
 
@@ -44,16 +44,17 @@ def _loss_fn(params, kf, variables):
     return loss, variables
 
 
-def _worker(rank, world, port, emu_path, q):
+def _worker(rank, world, port, emu_path, q, device="cpu"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from activesplat_amd import _lib, optim as O, parallel as PL
-        _lib.load_for_tests(emu_path)
-        params, kfs = _scene()
+        if device == "cpu":
+            _lib.load_for_tests(emu_path)
+        params, kfs = _scene(device=device) if device == "cpu" else _scene(n=20000, W=128, H=96, device=device)
         n = params["means3D"].shape[0]
-        variables = {k: torch.zeros(n) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+        variables = {k: torch.zeros(n, device=device) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
         lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
         # sequential reference on this rank: sum of all K keyframe gradients
         seq = {k: torch.zeros_like(params[k]) for k in PL.GRAD_KEYS}
@@ -75,7 +76,7 @@ def _worker(rank, world, port, emu_path, q):
         gathered = [torch.zeros_like(flat_p) for _ in range(world)]
         dist.all_gather(gathered, flat_p)
         same = all(torch.equal(gathered[0], t) for t in gathered)
-        stats = PL.all_reduce_statistics({"max_2D_radius": torch.full((4,), float(rank + 1)), "denom": torch.ones(4)})
+        stats = PL.all_reduce_statistics({"max_2D_radius": torch.full((4,), float(rank + 1), device=device), "denom": torch.ones(4, device=device)})
         q.put((rank, err, same, float(stats["max_2D_radius"][0]), float(stats["denom"][0])))
     finally:
         dist.destroy_process_group()
@@ -152,3 +153,22 @@ def test_reduce_scatter_sharded_adam_equals_allreduce_adam(emu_lib_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(same and steps for _, same, steps in res), res
+
+
+@pytest.mark.gpu
+def test_two_rank_keyframe_step_on_the_device(hip):
+    """The same two-rank check with the real HIP library: both ranks share the one GPU of the test box and exchange through
+    gloo (RCCL refuses two ranks on one device); the collective call sites are the ones bench.py / parallel.py use with RCCL."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, None, q, "cuda")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, err, same, mx, den in res:
+        assert err < 1e-4, (rank, err)          # two GPUs' worth of atomics + a different summation order
+        assert same and mx == 2.0 and den == 2.0
