@@ -69,18 +69,59 @@ def all_reduce_statistics(variables, group=None):
 
 
 def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank=None, world=None, buf=None,
-                          sharded_adam=False):
+                          sharded_adam=False, streams=1):
     """One optimiser step over a batch of keyframes sharded across ranks.
-    loss_fn(params, keyframe, variables) -> (loss, variables).  Returns the local loss sum."""
+    loss_fn(params, keyframe, variables) -> (loss, variables).  Returns the local loss sum.
+
+    streams > 1 (GPU only): this rank's keyframes are independent until the optimiser step, so they are rendered on
+    `streams` HIP streams in turn -- one frame's kernels fill the tails and the placement imbalance of the other's
+    (two streams: 2404 -> 3062 frames/s on BASELINE configs[1], `two_stream_fps` in the bench line).  Each keyframe's
+    gradients are taken with autograd.grad on its own stream and summed after the streams have joined."""
     on = dist.is_available() and dist.is_initialized()
     rank = (dist.get_rank() if on else 0) if rank is None else rank
     world = (dist.get_world_size() if on else 1) if world is None else world
     optimizer.zero_grad(set_to_none=True)
-    total = 0.0
-    for i in shard_keyframes(len(keyframes), rank, world):
-        loss, variables = loss_fn(params, keyframes[i], variables)
-        loss.backward()                       # autograd accumulates into .grad across this rank's keyframes
-        total += float(loss.detach())
+    mine = list(shard_keyframes(len(keyframes), rank, world))
+    dev = params[GRAD_KEYS[0]].device
+    if streams > 1 and dev.type == "cuda" and len(mine) > 1:
+        keys = [k for k in GRAD_KEYS if k in params]
+        main = torch.cuda.current_stream(dev)
+        pool = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+        for s in pool:
+            s.wait_stream(main)
+        partial = [None] * streams
+        losses = []
+        # per-stream copies of the one statistic get_loss updates in place (running max radius); merged below
+        vs = [dict(variables, max_2D_radius=variables["max_2D_radius"].clone()) if "max_2D_radius" in variables else dict(variables)
+              for _ in range(streams)]
+        for n, i in enumerate(mine):
+            with torch.cuda.stream(pool[n % streams]):
+                loss, vs[n % streams] = loss_fn(params, keyframes[i], vs[n % streams])
+                g = torch.autograd.grad(loss, [params[k] for k in keys], allow_unused=True)
+                g = [torch.zeros_like(params[k]) if x is None else x for k, x in zip(keys, g)]
+                if partial[n % streams] is None:
+                    partial[n % streams] = list(g)
+                else:
+                    torch._foreach_add_(partial[n % streams], list(g))
+                losses.append(loss.detach())
+        for s in pool:
+            main.wait_stream(s)
+        variables = vs[(len(mine) - 1) % streams]                  # `means2D` / `seen` of the last keyframe, as in the serial loop
+        if "max_2D_radius" in variables:
+            for v in vs:
+                variables["max_2D_radius"] = torch.maximum(variables["max_2D_radius"], v["max_2D_radius"])
+        live = [p for p in partial if p is not None]
+        for p in live[1:]:
+            torch._foreach_add_(live[0], p)
+        for k, g in zip(keys, live[0]):
+            params[k].grad = g
+        total = float(torch.stack(losses).sum())
+    else:
+        total = 0.0
+        for i in mine:
+            loss, variables = loss_fn(params, keyframes[i], variables)
+            loss.backward()                       # autograd accumulates into .grad across this rank's keyframes
+            total += float(loss.detach())
     if sharded_adam and on and world > 1:
         reduce_scatter_adam_step(params, optimizer)
     else:

@@ -200,6 +200,19 @@ def main():
             ts = np.sort(np.array([a.elapsed_time(b) for a, b in ev]))
             out["step_ms_percentiles"] = {"p10": round(float(ts[len(ts) // 10]), 4), "p50": round(float(ts[len(ts) // 2]), 4),
                                           "p90": round(float(ts[(len(ts) * 9) // 10]), 4)}
+            # independent keyframes of a batch (configs[3]: 8 per rank between Adam steps) need not be rendered one after the
+            # other: two streams let one frame's kernels fill the other's tails and placement imbalance
+            streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            torch.cuda.synchronize()
+            for i in range(args.warmup):
+                with torch.cuda.stream(streams[i % 2]):
+                    step(i)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for i in range(args.steps):
+                with torch.cuda.stream(streams[i % 2]):
+                    step(i)
+            torch.cuda.synchronize()
+            out["two_stream_fps"] = round(args.steps / (time.perf_counter() - t1), 1)
             rv_ng = {k: v.detach() for k, v in rv.items()}
             m2d0 = torch.zeros(N, 3, device=dev)
             with torch.no_grad():

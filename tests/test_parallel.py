@@ -172,3 +172,24 @@ def test_two_rank_keyframe_step_on_the_device(hip):
     for rank, err, same, mx, den in res:
         assert err < 1e-4, (rank, err)          # two GPUs' worth of atomics + a different summation order
         assert same and mx == 2.0 and den == 2.0
+
+
+@pytest.mark.gpu
+def test_two_stream_keyframe_batch_equals_serial_batch(hip):
+    """streams=2: the batch's keyframes rendered on two HIP streams give the serial batch's gradients and statistics."""
+    from activesplat_amd import optim as O, parallel as PL
+    lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
+    out = []
+    for streams in (1, 2):
+        params, kfs = _scene(n=50000, W=160, H=120, K=6, device=hip)
+        n = params["means3D"].shape[0]
+        variables = {k: torch.zeros(n, device=hip) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+        opt = O.initialize_optimizer(params, {k: 0.0 for k in lrs})            # lr 0: keep the gradients, leave the parameters
+        total, variables, _ = PL.sharded_keyframe_step(params, variables, kfs, opt, _loss_fn, rank=0, world=1, streams=streams)
+        torch.cuda.synchronize()
+        out.append((total, {k: params[k].grad.clone() for k in PL.GRAD_KEYS}, variables["max_2D_radius"].clone()))
+    (t1, g1, m1), (t2, g2, m2) = out
+    assert abs(t1 - t2) <= 1e-5 * abs(t1)
+    assert torch.equal(m1, m2)
+    for k in g1:
+        assert float((g1[k] - g2[k]).norm() / g1[k].norm()) < 1e-4, k
