@@ -64,16 +64,36 @@ def look_around(params, view_c2w, scale_modifier=1.0, fused=True, views=None):
     device = params["means3D"].device
     rv = _world_rendervar(params) if fused else None
     ops, rgbs, deps = [], [], []
+    # the views are independent: on the GPU the fused path issues them on separate HIP streams, so that one view's small
+    # kernels (a 120 x 150 image is 80 tiles) overlap the other views' instead of leaving most of the chip idle in turn
+    pool = None
+    if fused and device.type == "cuda" and views > 1:
+        main = torch.cuda.current_stream(device)
+        pool = [torch.cuda.Stream(device=device) for _ in range(views)]
+        for s in pool:
+            s.wait_stream(main)
     for i in range(views):
         w2c = np.linalg.inv(rot_axis(np.asarray(view_c2w, dtype=np.float64), "y", np.deg2rad(LOOK_HFOV_DEG * i)))
         if fused:
             cam = setup_camera(LOOK_W, LOOK_H, k, w2c, VIZ_NEAR, VIZ_FAR, scale_modifier=scale_modifier, device=device, bg=(1.0, 1.0, 1.0))
+            if pool is not None:
+                with torch.cuda.stream(pool[i]):
+                    im, _, depth, opacity = GaussianRasterizer(raster_settings=cam)(**rv)
+                    rgb = (torch.clamp(im, min=0, max=1.0) * 255).byte().permute(1, 2, 0)
+                    op, dep = opacity[0], depth.float().permute(1, 2, 0)
+                rgbs.append(rgb); ops.append(op); deps.append(dep)
+                continue
             im, _, depth, opacity = GaussianRasterizer(raster_settings=cam)(**rv)
         else:
             scene, scene_depth = M.get_rendervars(params, torch.tensor(w2c, dtype=torch.float32, device=device))
             im, depth, opacity, _ = M.render(w2c, k, scene, scene_depth, cfg, scale_modifier)
         rgbs.append((torch.clamp(im, min=0, max=1.0) * 255).byte().permute(1, 2, 0))
         ops.append(opacity[0]); deps.append(depth.float().permute(1, 2, 0))
+    if pool is not None:
+        for s in pool:
+            main.wait_stream(s)
+        for t in ops + rgbs + deps:
+            t.record_stream(main)
     return {"opacity": torch.cat(ops, dim=1), "rgb": torch.cat(rgbs, dim=1).contiguous(), "depth": torch.cat(deps, dim=1)}
 
 

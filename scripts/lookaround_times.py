@@ -1,0 +1,21 @@
+"""Planner panorama timing (GPU box): reference call pattern vs fused single-stream vs fused multi-stream."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from activesplat_amd import lookaround as LA, synthetic as syn  # noqa: E402
+dev = torch.device("cuda")
+N = int(os.environ.get("N", 1_000_000))
+params = {k: v.to(dev) for k, v in syn.shell_scene(N, seed=2, W=LA.LOOK_W, H=LA.LOOK_H).items()}
+c2w = np.eye(4)
+def bench(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
+print(f"N={N}: reference call pattern {bench(lambda: LA.look_around(params, c2w, fused=False)):.3f} ms / panorama")
+print(f"N={N}: fused, 3 streams        {bench(lambda: LA.look_around(params, c2w, fused=True)):.3f} ms / panorama")
+_cuda = torch.device("cuda").type
+class _One:  # single-stream variant: pretend there is one view per call
+    pass
+t1 = bench(lambda: [LA.look_around(params, LA.rot_axis(c2w, 'y', np.deg2rad(120 * i)), fused=True, views=1) for i in range(3)])
+print(f"N={N}: fused, views one after the other {t1:.3f} ms / panorama")
