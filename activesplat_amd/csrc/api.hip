@@ -22,6 +22,7 @@ enum Stage { ST_PREPROCESS = 0, ST_TILE_COUNT, ST_EMIT, ST_SORT, ST_RANGES, ST_T
 const char* kStageNames[ST_COUNT] = {"preprocess_forward+scan", "tile_count+scan", "emit", "sort", "ranges",
                                      "tile_scatter+sort", "blend_forward", "blend_backward", "preprocess_backward", "adam"};
 int g_sort_path = GS_SORT_AUTO;
+bool g_segments_enabled = true;
 
 int choose_path(int tiles, uint32_t max_tile_instances)
 {
@@ -126,6 +127,12 @@ int gs_set_sort_path(int32_t path)
     return GS_OK;
 }
 
+int gs_set_forward_segments(int32_t on)
+{
+    g_segments_enabled = on != 0;
+    return GS_OK;
+}
+
 int gs_geom_layout(int32_t P, int32_t width, int32_t height, GsGeomLayout* out)
 {
     if (!out || P < 0 || width <= 0 || height <= 0) return fail(GS_EINVAL, "gs_geom_layout: bad argument");
@@ -174,6 +181,16 @@ int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t
         out->vals_unsorted = o; o = align_up(o + n * 4);
         out->keys_sorted = o; o = align_up(o + n * 8);
         out->sort_temp = o; o = align_up(o + gs::sort_temp_bytes(D, 32 + tile_bits(tiles)));
+    }
+    // few tiles with very long lists (the planner's 120 x 150 views of a large map): cut every list into segments that are
+    // composited in parallel -- enough of them to fill the 5120 wavefront slots, each at least 1024 records long
+    out->segments = 1;
+    if (g_segments_enabled && tiles * 4 * 2 <= gs::kWaveSlots && max_tile_instances != 0xffffffffu && max_tile_instances >= 4096) {
+        uint64_t S = (uint64_t)gs::kWaveSlots / ((uint64_t)tiles * 4);
+        const uint64_t by_len = max_tile_instances / 1024;
+        if (S > by_len) S = by_len;
+        if (S > 32) S = 32;
+        if (S >= 2) { out->segments = S; out->seg_T = o; o = align_up(o + (uint64_t)tiles * S * gs::kBlock * 4); }
     }
     out->total_bytes = o;
     return GS_OK;
@@ -285,7 +302,8 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_ti
         ScopedStage ps(ST_BLEND_FWD, st);
         e = gs::launch_blend_forward(k, ranges, point_list, gp.geom, out_color, out_depth, out_opacity,
                                      (float*)(ib + IL.final_T), (uint32_t*)(ib + IL.n_contrib), out_depth_sq,
-                                     BL.path == GS_SORT_TILE_LDS ? (uint32_t)D : 0xffffffffu, st);
+                                     BL.path == GS_SORT_TILE_LDS ? (uint32_t)D : 0xffffffffu, (int)BL.segments,
+                                     BL.segments > 1 ? (float*)(bb + BL.seg_T) : nullptr, st);
     }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: blend %s", hipGetErrorString(e));
     return GS_OK;

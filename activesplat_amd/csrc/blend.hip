@@ -107,12 +107,21 @@ __device__ __forceinline__ void write_sentinel(float4* s0, float4* s1, float4* s
 // two list entries with ONE 16-bit LDS read -- no scalar pop sequences, which is what made a four-stream forward
 // lose before (four s_ff1/s_andn2/s_cselect chains per trip for ~22 VALU of blending).
 // ---------------------------------------------------------------------------------------------------
-template <bool DEPTH_SQ, int NS>     // DEPTH_SQ: also accumulate sum z^2 alpha T (third channel of the reference's depth/silhouette pass)
+// SEG (segmented compositing for images of a few tiles with very long lists -- the planner's 120 x 150 views over a million
+// Gaussians are 80 tiles of up to ~80 k records: 320 wavefronts on a 5120-wavefront machine).  Alpha compositing is
+// associative, so a tile's list is cut into gridDim.y segments that run in parallel:
+//   SEG = 1: every (tile, segment) workgroup multiplies up its segment's transmittance T_seg per pixel (alpha tests only);
+//   SEG = 2: it composites its segment starting from T_in = product of the earlier segments' T_seg, with the normal stop
+//            rule (a pixel has stopped before this segment  <=>  T_in < 1e-4, because up to the stop the running T IS that
+//            product) and adds its colour / depth sums to the zero-initialised images with atomics; the last segment of a
+//            pixel that is not yet stopped at entry writes final_T, opacity and T*bg; n_contrib is an atomic max.
+//   SEG = 0: the whole list in one workgroup (the normal path; its code is untouched by the other two).
+template <bool DEPTH_SQ, int NS, int SEG>     // DEPTH_SQ: also accumulate sum z^2 alpha T (third channel of the reference's depth/silhouette pass)
 __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ out_depth_sq, uint32_t cap)
+    float* __restrict__ out_depth_sq, uint32_t cap, float* __restrict__ seg_T)
 {
     constexpr int LS = kWave / NS;          // lanes per stream
     constexpr int BH = LS / 4;              // block = 4 x BH pixels
@@ -132,19 +141,36 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
     uint8_t* my_list = s_list[wave] + sid * kWave;
     uint2 range = ranges[c.tile];
     range.x = min(range.x, cap); range.y = min(range.y, cap);
-    const uint32_t n = range.y - range.x;
+    const uint32_t n_all = range.y - range.x;
     const uint32_t* list = point_list + range.x;
-
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Dq = 0.f;
+    // segment [first, n) of the list (SEG = 0: everything)
+    uint32_t first = 0, n = n_all;
+    float T = 1.0f;
+    bool next_stopped = true;                   // SEG = 2: the following segment finds this pixel stopped at its entry
+    float* my_seg_T = nullptr;
+    if (SEG != 0) {
+        const uint32_t S = gridDim.y, seg = blockIdx.y;
+        const uint32_t L = (((n_all + S - 1) / S + kWave - 1) / kWave) * kWave;       // chunk-aligned segment length
+        first = min(n_all, seg * L);
+        n = min(n_all, first + L);
+        float* tile_T = seg_T + ((size_t)c.tile * S) * kBlock + wave * kWave + lane;   // [tile][segment][quadrant][lane]
+        my_seg_T = tile_T + (size_t)seg * kBlock;
+        if (SEG == 2) {
+            for (uint32_t q = 0; q < seg; q++) T *= tile_T[(size_t)q * kBlock];
+            next_stopped = seg + 1 == S ? true : (T * my_seg_T[0] < kTmin);
+        }
+    }
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Dq = 0.f;
     uint32_t last = 0;
-    bool done = !inside;
+    const bool stopped_at_entry = SEG == 2 && T < kTmin;
+    bool done = !inside || stopped_at_entry;
 
-    if (!__all(done)) {
-        uint32_t id_next = (uint32_t)lane < n ? list[lane] : kNoId;
-        uint32_t id_next2 = (uint32_t)lane + 64u < n ? list[lane + 64] : kNoId;
+    if (SEG == 1 || !__all(done)) {
+        uint32_t id_next = first + (uint32_t)lane < n ? list[first + lane] : kNoId;
+        uint32_t id_next2 = first + (uint32_t)lane + 64u < n ? list[first + lane + 64] : kNoId;
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
         if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
-        for (uint32_t base = 0; base < n; base += kWave) {
+        for (uint32_t base = first; base < n; base += kWave) {
             const float4 q0 = r0, q1 = r1, q2 = r2;
             const uint32_t id_cur = id_next;
             id_next = id_next2;
@@ -188,6 +214,10 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
                     const float dx = a0[u].x - pxf, dy = a0[u].y - pyf;
                     const float p = (a0[u].z * dx + a0[u].w * dy) * dx + (a1[u].x * dy) * dy;
                     const float alpha = fminf(0.99f, a1[u].y * __builtin_amdgcn_exp2f(p));
+                    if (SEG == 1) {                                                  // transmittance of the segment only
+                        T = (p <= 0.0f && alpha >= kAlphaMin) ? T * (1.0f - alpha) : T;
+                        continue;
+                    }
                     const float test_T = T * (1.0f - alpha);
                     const bool vis = !done && p <= 0.0f && alpha >= kAlphaMin;     // sentinel: alpha = 0
                     const bool ok = vis && test_T >= kTmin;
@@ -200,8 +230,23 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (__all(done)) break;
+            if (SEG != 1 && __all(done)) break;
         }
+    }
+    if (SEG == 1) { my_seg_T[0] = T; return; }
+    if (SEG == 2) {
+        if (inside && !stopped_at_entry) {
+            const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
+            const float tb = next_stopped ? T : 0.0f;            // exactly one segment per pixel owns final_T and the background
+            atomicAdd(out_color + pix, C0 + tb * cam.bg[0]);
+            atomicAdd(out_color + HW + pix, C1 + tb * cam.bg[1]);
+            atomicAdd(out_color + 2 * HW + pix, C2 + tb * cam.bg[2]);
+            atomicAdd(out_depth + pix, Dp);
+            if (DEPTH_SQ) atomicAdd(out_depth_sq + pix, Dq);
+            if (last) atomicMax(n_contrib + pix, last);
+            if (next_stopped) { final_T[pix] = T; out_opacity[pix] = 1.0f - T; }
+        }
+        return;
     }
     if (inside) {
         const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
@@ -478,15 +523,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
 
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
-                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, hipStream_t st)
+                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, hipStream_t st)
 {
     const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
-    if (out_depth_sq)
-        hipLaunchKernelGGL((blend_forward_streams_kernel<true, kFwdStreams>), dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
-                           out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap);
-    else
-        hipLaunchKernelGGL((blend_forward_streams_kernel<false, kFwdStreams>), dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
-                           out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap);
+#define GS_FWD(DSQ, SEG, GRID)                                                                                                     \
+    hipLaunchKernelGGL((blend_forward_streams_kernel<DSQ, kFwdStreams, SEG>), GRID, dim3(kBlock), 0, st, cam, ranges, point_list, geom, \
+                       out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap, seg_T)
+    if (segments > 1 && seg_T) {
+        // segmented compositing: the sums are added with atomics, so the images start from zero
+        const size_t HW = (size_t)cam.W * cam.H;
+        hipError_t e = hipMemsetAsync(out_color, 0, 3 * HW * sizeof(float), st);
+        if (e == hipSuccess) e = hipMemsetAsync(out_depth, 0, HW * sizeof(float), st);
+        if (e == hipSuccess && out_depth_sq) e = hipMemsetAsync(out_depth_sq, 0, HW * sizeof(float), st);
+        if (e == hipSuccess) e = hipMemsetAsync(n_contrib, 0, HW * sizeof(uint32_t), st);
+        if (e != hipSuccess) return e;
+        const dim3 grid(nb, segments);
+        if (out_depth_sq) { GS_FWD(true, 1, grid); GS_FWD(true, 2, grid); }
+        else { GS_FWD(false, 1, grid); GS_FWD(false, 2, grid); }
+    } else if (out_depth_sq) GS_FWD(true, 0, dim3(nb));
+    else GS_FWD(false, 0, dim3(nb));
+#undef GS_FWD
     return hipGetLastError();
 }
 

@@ -189,7 +189,7 @@ hipError_t launch_emit(const Cam& cam, int P, GeomPtrs gp, uint64_t* keys, uint3
 hipError_t launch_ranges(int64_t D, const uint64_t* keys_sorted, uint2* ranges, hipStream_t st);
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
-                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, hipStream_t st);
+                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, hipStream_t st);
 hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  const float* dL_ddepth, float* grad2d, hipStream_t st);
@@ -222,6 +222,7 @@ size_t sort_temp_bytes(int64_t D, int end_bit);
 hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
                       const uint32_t* vals_in, uint32_t* vals_out, int64_t D, int end_bit, hipStream_t st);
 
+constexpr int kWaveSlots = 256 * 4 * 5;   // CUs x SIMDs x the five wavefronts per SIMD the blend kernels are sized for
 constexpr int kAdamMaxTensors = 8; // parameter tensors per multi-tensor Adam launch
 constexpr int kGradStride = 16;   // floats per Gaussian in the 2-D gradient record (64 B = one cache line, so an
                                   // atomic flush of the 9 components is ONE memory-side read-modify-write):

@@ -99,6 +99,8 @@ typedef struct GsBinLayout {
     uint64_t vals_unsorted; /* RADIX: uint32 [D] : Gaussian index */
     uint64_t keys_sorted;   /* RADIX: uint64 [D] */
     uint64_t sort_temp;     /* RADIX: scratch of the sort */
+    uint64_t segments;      /* > 1: gs_render_forward composites every tile list in this many parallel segments (few tiles, long lists) */
+    uint64_t seg_T;         /* float [tiles][segments][256]: per-segment transmittance of the segmented forward */
 } GsBinLayout;
 
 int gs_geom_layout(int32_t P, int32_t width, int32_t height, GsGeomLayout* out);
@@ -106,6 +108,9 @@ int gs_image_layout(int32_t width, int32_t height, GsImageLayout* out);
 int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t height, GsBinLayout* out);
 /* Force a binning path (GS_SORT_*; default GS_SORT_AUTO picks TILE_LDS when every tile list fits LDS). */
 int gs_set_sort_path(int32_t path);
+/* Segmented compositing of long tile lists in images of few tiles (GsBinLayout.segments > 1): on by default; 0 switches it
+ * off (every list is then walked by one workgroup, bit-reproducible forward). */
+int gs_set_forward_segments(int32_t on);
 /* bytes of the scratch gs_render_backward needs (per-Gaussian 2-D gradient records) */
 uint64_t gs_backward_scratch_bytes(int32_t P);
 

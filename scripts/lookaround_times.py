@@ -19,3 +19,9 @@ class _One:  # single-stream variant: pretend there is one view per call
     pass
 t1 = bench(lambda: [LA.look_around(params, LA.rot_axis(c2w, 'y', np.deg2rad(120 * i)), fused=True, views=1) for i in range(3)])
 print(f"N={N}: fused, views one after the other {t1:.3f} ms / panorama")
+from activesplat_amd import _lib, rasterizer as R
+lib = _lib.get(); lib.gs_profile_enable(1)
+for _ in range(10):
+    LA.look_around(params, c2w, fused=True, views=1)
+torch.cuda.synchronize()
+print({k: round(ms / c * 1e3, 1) for k, (ms, c) in _lib.profile_collect().items() if c}, R.last_stats)

@@ -261,3 +261,37 @@ def check_optimistic_launch(device):
         if rv_g[k].grad is not None:
             a, b = rv_g[k].grad.double(), rv_h[k].grad.double()     # two runs of the atomics: sums in a different order
             assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 1e-5, k
+
+
+def check_segmented_forward(device, oracle32):
+    """Few tiles, long lists: the tile lists are composited in parallel segments (GsBinLayout.segments > 1).  Against the
+    oracle like every other case, and against the one-workgroup-per-tile walk of the same library."""
+    from activesplat_amd import _lib, rasterizer as R
+    lib = _lib.get()
+    rs, rv = build_case("merge_tiles", device)                       # 48 x 48: 9 tiles of ~5 k records
+    got, ref = check_forward(rs, rv, oracle32)
+    assert int(R.last_debug["bl"].segments) > 1
+    seg = util.artefacts()
+    _lib.check(lib.gs_set_forward_segments(0))
+    try:
+        one = util.run_product(rs, rv)
+        assert int(R.last_debug["bl"].segments) == 1
+        art = util.artefacts()
+    finally:
+        _lib.check(lib.gs_set_forward_segments(1))
+    for k in ("color", "depth", "opacity"):
+        assert np.abs(got[k] - one[k]).max() <= 2e-5 * max(1.0, float(np.abs(one[k]).max())), k
+    assert np.mean(seg["n_contrib"] == art["n_contrib"]) >= 0.999
+    assert np.abs(seg["final_T"] - art["final_T"]).max() <= 1e-6
+    # the backward consumes the segmented forward's final_T / n_contrib
+    dL = torch.randn(3, int(rs.image_height), int(rs.image_width), generator=torch.Generator().manual_seed(0))
+    a = util.run_product(rs, rv, dL)["grads"]
+    _lib.check(lib.gs_set_forward_segments(0))
+    try:
+        b = util.run_product(rs, rv, dL)["grads"]
+    finally:
+        _lib.check(lib.gs_set_forward_segments(1))
+    for k in a:
+        den = np.linalg.norm(b[k])
+        if den > 0:
+            assert np.linalg.norm(a[k] - b[k]) / den < 1e-4, k

@@ -139,3 +139,7 @@ def test_emulated_densification_statistics_kernels(emu):
     # dtype the kernel does not take: same result through the torch fallback
     mx64 = torch.zeros(P, dtype=torch.float64)
     assert torch.equal(O.visibility_stats(radius, mx64), ref_seen) and torch.equal(mx64, radius.double())
+
+
+def test_emulated_segmented_forward(emu, oracle32):
+    pc.check_segmented_forward(emu, oracle32)

@@ -189,3 +189,7 @@ def test_random_scene_matches_oracle_on_gpu(hip, oracle32, oracle64, seed):
     rs, rv = _draw(5000 + seed, hip)
     pc.check_forward(rs, rv, oracle32)
     pc.check_backward(rs, rv, oracle64, min_frac=0.99, oracle32=oracle32)
+
+
+def test_segmented_forward(hip, oracle32):
+    pc.check_segmented_forward(hip, oracle32)
