@@ -186,7 +186,7 @@ int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t
     // composited in parallel -- enough of them to fill the 5120 wavefront slots, each at least 1024 records long
     out->segments = 1;
     if (g_segments_enabled && tiles * 4 * 2 <= gs::kWaveSlots && max_tile_instances != 0xffffffffu && max_tile_instances >= 4096) {
-        uint64_t S = (uint64_t)gs::kWaveSlots / ((uint64_t)tiles * 4);
+        uint64_t S = 2 * (uint64_t)gs::kWaveSlots / ((uint64_t)tiles * 4);      // 2x oversubscribed: segments differ in work (early stop)
         const uint64_t by_len = max_tile_instances / 1024;
         if (S > by_len) S = by_len;
         if (S > 32) S = 32;

@@ -64,14 +64,7 @@ def look_around(params, view_c2w, scale_modifier=1.0, fused=True, views=None):
     device = params["means3D"].device
     rv = _world_rendervar(params) if fused else None
     ops, rgbs, deps = [], [], []
-    # the views are independent: on the GPU the fused path issues them on separate HIP streams, so that one view's small
-    # kernels (a 120 x 150 image is 80 tiles) overlap the other views' instead of leaving most of the chip idle in turn
-    pool = None
-    if fused and device.type == "cuda" and views > 1:
-        main = torch.cuda.current_stream(device)
-        pool = [torch.cuda.Stream(device=device) for _ in range(views)]
-        for s in pool:
-            s.wait_stream(main)
+    pool = None        # (views on separate HIP streams were tried: with segmented compositing every view fills the chip on its own)
     for i in range(views):
         w2c = np.linalg.inv(rot_axis(np.asarray(view_c2w, dtype=np.float64), "y", np.deg2rad(LOOK_HFOV_DEG * i)))
         if fused:

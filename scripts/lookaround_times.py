@@ -13,12 +13,12 @@ def bench(fn, n=20):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
 print(f"N={N}: reference call pattern {bench(lambda: LA.look_around(params, c2w, fused=False)):.3f} ms / panorama")
-print(f"N={N}: fused, 3 streams        {bench(lambda: LA.look_around(params, c2w, fused=True)):.3f} ms / panorama")
+print(f"N={N}: fused                   {bench(lambda: LA.look_around(params, c2w, fused=True)):.3f} ms / panorama")
 _cuda = torch.device("cuda").type
 class _One:  # single-stream variant: pretend there is one view per call
     pass
 t1 = bench(lambda: [LA.look_around(params, LA.rot_axis(c2w, 'y', np.deg2rad(120 * i)), fused=True, views=1) for i in range(3)])
-print(f"N={N}: fused, views one after the other {t1:.3f} ms / panorama")
+print(f"N={N}: fused, three single-view calls {t1:.3f} ms / panorama")
 from activesplat_amd import _lib, rasterizer as R
 lib = _lib.get(); lib.gs_profile_enable(1)
 for _ in range(10):
