@@ -268,7 +268,7 @@ def check_segmented_forward(device, oracle32):
     oracle like every other case, and against the one-workgroup-per-tile walk of the same library."""
     from activesplat_amd import _lib, rasterizer as R
     lib = _lib.get()
-    rs, rv = build_case("merge_tiles", device)                       # 48 x 48: 9 tiles of ~5 k records
+    rs, rv = build_case("merge_tiles_large", device)                 # 48 x 48: 9 tiles of ~12 k records
     got, ref = check_forward(rs, rv, oracle32)
     assert int(R.last_debug["bl"].segments) > 1
     seg = util.artefacts()
