@@ -338,6 +338,19 @@ def main():
                 fb = N2 * bg_bytes + D2 * 160 + W * H * 48
                 ns[name] = {"frames_per_s": round(1.0 / t, 1), "ms_per_frame": round(t * 1e3, 4), "tile_instances_D": D2,
                             "frame_alg_bytes": fb, "frame_frac_hbm": round(fb / t / HBM_PEAK, 4)}
+                # the same frames as a keyframe batch on two streams (what `value` does for configs[1])
+                pool2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+                torch.cuda.synchronize()
+                for i in range(4):
+                    with torch.cuda.stream(pool2[i % 2]):
+                        step2()
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for i in range(30):
+                    with torch.cuda.stream(pool2[i % 2]):
+                        step2()
+                torch.cuda.synchronize()
+                t2 = (time.perf_counter() - t1) / 30
+                ns[name].update(two_stream_frames_per_s=round(1.0 / t2, 1), two_stream_frame_frac_hbm=round(fb / t2 / HBM_PEAK, 4))
                 del rv2, p2
             out["north_star_2M"] = ns
         except Exception as e:
