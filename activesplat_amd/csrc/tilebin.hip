@@ -327,6 +327,15 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
     int threads, chunk; bin_config(threads, chunk);
     const int nb = (P + chunk - 1) / chunk;
     if (nb > 0) launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
+    if (max_tile_instances > 8192) {
+        // very long lists (256 x 256 frames over a million Gaussians: ~10 k per tile): 4096-key runs halve the number of runs the
+        // rank merge has to search (3 instead of 6 for 11 k keys)
+        constexpr int kBigChunk = 2 * kSortChunk;
+        const unsigned chunks = (max_tile_instances + kBigChunk - 1) / kBigChunk;
+        hipLaunchKernelGGL((tile_sort_kernel<kBigChunk, 512>), dim3(tiles, chunks), dim3(512), 0, st, ranges, pairs, point_list, cap);
+        hipLaunchKernelGGL((tile_merge_kernel<kSortCapMax, kBigChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
+        return hipGetLastError();
+    }
     const unsigned chunks = (max_tile_instances + kSortChunk - 1) / kSortChunk;
     hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, chunks ? chunks : 1), dim3(256), 0, st, ranges, pairs, point_list, cap);
     if (max_tile_instances > (uint32_t)kSortChunk) {
@@ -335,10 +344,8 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
             hipLaunchKernelGGL((tile_merge_kernel<4096, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
         else if (max_tile_instances <= 6144)
             hipLaunchKernelGGL((tile_merge_kernel<6144, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
-        else if (max_tile_instances <= 8192)
-            hipLaunchKernelGGL((tile_merge_kernel<8192, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
         else
-            hipLaunchKernelGGL((tile_merge_kernel<kSortCapMax, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
+            hipLaunchKernelGGL((tile_merge_kernel<8192, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
     }
     return hipGetLastError();
 }
