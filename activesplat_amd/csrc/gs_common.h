@@ -128,14 +128,18 @@ __device__ __forceinline__ void sh_rows_from_lds(const float* lds, float* __rest
 // 16 B per lane per step, no workgroup barrier -- the four waves of a workgroup overlap their load / compute / store
 // phases instead of taking turns.  row0 * K * 4 bytes is 16-byte aligned because row0 is a multiple of 32.
 constexpr int kShHalf = 32;
-__device__ __forceinline__ void sh_wave_rows_to_lds(float* slab, const float* __restrict__ src, int row0, int nrows, int K, int lane)
+// row_mask: bit r set = row r is needed (rows of culled Gaussians are not fetched; their slab contents stay undefined)
+__device__ __forceinline__ void sh_wave_rows_to_lds(float* slab, const float* __restrict__ src, int row0, int nrows, int K, int lane,
+                                                    uint32_t row_mask = 0xffffffffu)
 {
     const int stride = sh_row_stride(K), total = nrows * K, total4 = total >> 2;
     const float* s = src + (size_t)row0 * K;
     const float4* s4 = reinterpret_cast<const float4*>(s);
     for (int q = lane; q < total4; q += kWave) {
-        const float4 v = load_stream(&s4[q]);              // coefficient rows are read once per pass
         int e = q << 2, r = e / K, c = e - r * K;
+        const int r_last = (e + 3) / K;                    // a 16-byte piece may straddle two rows
+        if (!(((row_mask >> r) | (row_mask >> min(r_last, 31))) & 1u)) continue;
+        const float4 v = load_stream(&s4[q]);              // coefficient rows are read once per pass
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int t = 0; t < 4; t++) {
@@ -145,7 +149,7 @@ __device__ __forceinline__ void sh_wave_rows_to_lds(float* slab, const float* __
     }
     for (int e = (total4 << 2) + lane; e < total; e += kWave) {
         const int r = e / K;
-        slab[r * stride + (e - r * K)] = s[e];
+        if ((row_mask >> r) & 1u) slab[r * stride + (e - r * K)] = s[e];
     }
 }
 __device__ __forceinline__ void sh_wave_rows_from_lds(const float* slab, float* __restrict__ dst, int row0, int nrows, int K, int lane)

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
             if (row0 >= P) break;                                  // wave-uniform
             const int nrows = min(kShHalf, P - row0);
             __builtin_amdgcn_wave_barrier();
-            sh_wave_rows_to_lds(slab, shs, row0, nrows, K, lane);
+            // only live Gaussians read their coefficients (a culled one's gradient row is all zeros)
+            const uint32_t live_rows = (uint32_t)(__ballot(live) >> (h * kShHalf));
+            sh_wave_rows_to_lds(slab, shs, row0, nrows, K, lane, live_rows);
             __builtin_amdgcn_wave_barrier();
             if ((lane >> 5) == h && in_range) {
                 float* dsh = slab + (lane & 31) * stride;

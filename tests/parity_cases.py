@@ -60,6 +60,8 @@ def build_case(name, device):
         N = 257
     elif name in ("sh0", "sh1", "sh2", "sh3"):
         kw = dict(sh_degree=int(name[2]), w2c=util.pose(-0.15, (0.05, 0.0, 0.1)))
+    elif name == "sh3_half_culled":         # half of the Gaussians near-culled: their SH rows are not fetched in the backward
+        N, kw = 1500, dict(sh_degree=3, w2c=util.pose(0.0, (0.0, 0.0, -2.0)))
     elif name == "sh2_ragged":              # 1003 = 31*32 + 11 rows of 27 floats: partial slab, scalar tail of the 16 B copies
         N, kw = 1003, dict(sh_degree=2, w2c=util.pose(0.1, (0.0, 0.05, 0.1)))
     elif name == "cov3d_precomp":
@@ -81,7 +83,7 @@ def build_case(name, device):
 BIG_TILE_CASES = ["merge_tiles", "merge_tiles_large", "radix_fallback"]
 CASES = ["basic", "ragged_image", "tiny_lookaround", "lookaround_intrinsics", "posed_white_bg", "scale_modifier", "behind_camera", "all_culled",
          "huge_gaussians", "dense_overdraw", "low_opacity", "one_gaussian", "not_multiple_of_block", "sh0", "sh1", "sh2",
-         "sh3", "sh2_ragged", "cov3d_precomp"]
+         "sh3", "sh2_ragged", "sh3_half_culled", "cov3d_precomp"]
 
 
 def set_sort_path(path):
