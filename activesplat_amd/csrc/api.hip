@@ -305,7 +305,7 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_ti
         e = gs::launch_blend_forward(k, ranges, point_list, gp.geom, out_color, out_depth, out_opacity,
                                      (float*)(ib + IL.final_T), (uint32_t*)(ib + IL.n_contrib), out_depth_sq,
                                      BL.path == GS_SORT_TILE_LDS ? (uint32_t)D : 0xffffffffu, (int)BL.segments,
-                                     BL.segments > 1 ? (float*)(bb + BL.seg_T) : nullptr, st);
+                                     BL.segments > 1 ? (float*)(bb + BL.seg_T) : nullptr, (uint32_t)P, st);
     }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: blend %s", hipGetErrorString(e));
     return GS_OK;

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ out_depth_sq, uint32_t cap, float* __restrict__ seg_T)
+    float* __restrict__ out_depth_sq, uint32_t cap, float* __restrict__ seg_T, uint32_t P)
 {
     constexpr int LS = kWave / NS;          // lanes per stream
     constexpr int BH = LS / 4;              // block = 4 x BH pixels
@@ -166,8 +166,13 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
     bool done = !inside || stopped_at_entry;
 
     if (SEG == 1 || !__all(done)) {
+        // An optimistic launch (rasterizer.py) may run with a tile-list capacity below the true list length: the sort then
+        // leaves the tail of point_list unwritten (uninitialised memory).  Such a frame is discarded and re-rendered, but it
+        // must not fault: an id that is not a Gaussian index is treated as "no record" (ids >= P; kNoId is one of them).
         uint32_t id_next = first + (uint32_t)lane < n ? list[first + lane] : kNoId;
         uint32_t id_next2 = first + (uint32_t)lane + 64u < n ? list[first + lane + 64] : kNoId;
+        if (id_next >= P) id_next = kNoId;
+        if (id_next2 >= P) id_next2 = kNoId;
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
         if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
         for (uint32_t base = first; base < n; base += kWave) {
@@ -175,6 +180,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
             const uint32_t id_cur = id_next;
             id_next = id_next2;
             id_next2 = base + 128u + (uint32_t)lane < n ? list[base + 128u + lane] : kNoId;
+            if (id_next2 >= P) id_next2 = kNoId;
             r2 = make_float4(0.f, 0.f, -1.f, -1.f);
             if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
 
@@ -523,12 +529,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
 
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
-                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, hipStream_t st)
+                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, uint32_t P, hipStream_t st)
 {
     const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
 #define GS_FWD(DSQ, SEG, GRID)                                                                                                     \
     hipLaunchKernelGGL((blend_forward_streams_kernel<DSQ, kFwdStreams, SEG>), GRID, dim3(kBlock), 0, st, cam, ranges, point_list, geom, \
-                       out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap, seg_T)
+                       out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap, seg_T, P)
     if (segments > 1 && seg_T) {
         // segmented compositing: the sums are added with atomics, so the images start from zero
         const size_t HW = (size_t)cam.W * cam.H;

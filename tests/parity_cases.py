@@ -265,6 +265,40 @@ def check_optimistic_launch(device):
             assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 1e-5, k
 
 
+def check_optimistic_tile_list_growth(device):
+    """An optimistic launch whose TILE-LIST capacity is too small: frame 1 has lists under one sort chunk (2048), frame 2 --
+    same (P, W, H) key -- lists of several thousand, so the optimistic attempt sorts only the first chunk(s) of every tile
+    and leaves the tail of point_list unwritten.  The attempt must neither fault (garbage ids are not Gaussian indices)
+    nor leak into the result: the exact re-launch reproduces the exactly-sized render bit for bit."""
+    from activesplat_amd import GaussianRasterizer, rasterizer as R
+    N, W, H = 20000, 48, 48
+    rs_far, rv = util.scene(N, W, H, seed=5, device=device, w2c=util.pose(0.0, (0.0, 0.0, -3.4)))
+    rs_near, _ = util.scene(N, W, H, seed=5, device=device)
+    rv["opacities"] = rv["opacities"] * 0.05
+    m2d = torch.zeros(N, 3, device=device)
+    run = lambda rs: [t.clone() for t in GaussianRasterizer(raster_settings=rs)(means2D=m2d, **rv)]  # noqa: E731
+    R.optimistic = False
+    try:
+        exact_far = run(rs_far); far_tile = R.last_stats["max_tile_instances"]
+        exact_near = run(rs_near); near_tile = R.last_stats["max_tile_instances"]
+    finally:
+        R.optimistic = True
+    assert 0 < far_tile < 1500 and near_tile > 2 * 2048, (far_tile, near_tile)
+    R._capacity.clear()
+    R.last_stats.pop("optimistic_hits", None); R.last_stats.pop("optimistic_misses", None)
+    a = run(rs_far)
+    # what the caching allocator hands to the optimistic attempt's point_list: make it look like anything but Gaussian ids
+    junk = torch.full((int(R.last_stats["num_rendered"] * 16 + 65536),), 0x7F7F7F7F, dtype=torch.int32, device=device)
+    del junk
+    b = run(rs_near)
+    assert R.last_stats.get("optimistic_misses", 0) == 1
+    c = run(rs_near)
+    assert R.last_stats.get("optimistic_hits", 0) == 1
+    for got, ref in ((a, exact_far), (b, exact_near), (c, exact_near)):
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y)
+
+
 def check_segmented_forward(device, oracle32):
     """Few tiles, long lists: the tile lists are composited in parallel segments (GsBinLayout.segments > 1).  Against the
     oracle like every other case, and against the one-workgroup-per-tile walk of the same library."""

@@ -115,6 +115,7 @@ def test_emulated_fused_loss_equals_two_pass_loss(emu):
 
 def test_emulated_optimistic_launch_hit_and_miss_equal_exact_launch(emu):
     pc.check_optimistic_launch(emu)
+    pc.check_optimistic_tile_list_growth(emu)
 
 
 def test_emulated_densification_statistics_kernels(emu):

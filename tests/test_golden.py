@@ -14,8 +14,21 @@ def load(name):
     return np.load(os.path.join(G, name), allow_pickle=False)
 
 
+_DEV = ["cpu"]
+
+
 def T(a):
-    return torch.tensor(np.asarray(a))
+    return torch.tensor(np.asarray(a), device=_DEV[0])
+
+
+@pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request):
+    """Every kernel-backed golden test runs twice: on the host-emulated kernel build (CPU suite) and -- ONE hop,
+    reference fixture vs HIP kernel -- on the real library on cuda:0 (`-m gpu`)."""
+    dev = request.getfixturevalue(request.param)
+    _DEV[0] = dev
+    yield dev
+    _DEV[0] = "cpu"
 
 
 def test_setup_camera_matches_reference():
@@ -27,19 +40,19 @@ def test_setup_camera_matches_reference():
         cam = setup_camera(W, H, d[f"c{i}_K"], d[f"c{i}_w2c"], near, far, scale_modifier=float(d[f"c{i}_mod"]), device="cpu")
         assert (cam.image_width, cam.image_height) == (W, H) and cam.sh_degree == 0
         assert not cam.prefiltered and not cam.debug
-        np.testing.assert_allclose(cam.viewmatrix.numpy(), d[f"c{i}_view"], rtol=0, atol=1e-7)
-        np.testing.assert_allclose(cam.projmatrix.numpy(), d[f"c{i}_proj"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(cam.viewmatrix.cpu().numpy(), d[f"c{i}_view"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(cam.projmatrix.cpu().numpy(), d[f"c{i}_proj"], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose([cam.tanfovx, cam.tanfovy], d[f"c{i}_tanfov"], rtol=1e-6)
-        np.testing.assert_allclose(cam.campos.numpy(), d[f"c{i}_campos"], atol=1e-5)
-        np.testing.assert_array_equal(cam.bg.numpy(), d[f"c{i}_bg"])
+        np.testing.assert_allclose(cam.campos.cpu().numpy(), d[f"c{i}_campos"], atol=1e-5)
+        np.testing.assert_array_equal(cam.bg.cpu().numpy(), d[f"c{i}_bg"])
     assert abs(float(d["c0_tanfov"][0]) - 1.0) < 1e-7 and abs(float(d["c0_tanfov"][1]) - 0.75) < 1e-7
 
 
 def test_rotations_match_reference():
     from activesplat_amd import mapping as M
     d = load("rot.npz")
-    np.testing.assert_allclose(M.build_rotation(T(d["q1"])).numpy(), d["build_rotation"], atol=1e-6)
-    np.testing.assert_allclose(M.quat_mult(T(d["q1"]), T(d["q2"])).numpy(), d["quat_mult"], atol=1e-6)
+    np.testing.assert_allclose(M.build_rotation(T(d["q1"])).cpu().numpy(), d["build_rotation"], atol=1e-6)
+    np.testing.assert_allclose(M.quat_mult(T(d["q1"]), T(d["q2"])).cpu().numpy(), d["quat_mult"], atol=1e-6)
 
 
 @pytest.mark.parametrize("tag", ["aniso", "iso"])
@@ -49,18 +62,18 @@ def test_transform_and_rendervars_match_reference(tag):
     keys = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales", "cam_unnorm_rots", "cam_trans")
     params = {k: T(d[f"{tag}_{k}"]) for k in keys}
     tg = M.transform_to_frame(params, 3, gaussians_grad=True, camera_grad=False)
-    np.testing.assert_allclose(tg["means3D"].numpy(), d[f"{tag}_tg_means3D"], atol=2e-6)
-    np.testing.assert_allclose(tg["unnorm_rotations"].numpy(), d[f"{tag}_tg_rots"], atol=2e-6)
+    np.testing.assert_allclose(tg["means3D"].cpu().numpy(), d[f"{tag}_tg_means3D"], atol=2e-6)
+    np.testing.assert_allclose(tg["unnorm_rotations"].cpu().numpy(), d[f"{tag}_tg_rots"], atol=2e-6)
     rv = M.transformed_params2rendervar(params, tg)
     for k in ("means3D", "colors_precomp", "rotations", "opacities", "scales", "means2D"):
-        np.testing.assert_allclose(rv[k].detach().numpy(), d[f"{tag}_rv_{k}"], atol=2e-6, rtol=1e-6)
+        np.testing.assert_allclose(rv[k].detach().cpu().numpy(), d[f"{tag}_rv_{k}"], atol=2e-6, rtol=1e-6)
     assert rv["means2D"].requires_grad and rv["scales"].shape[1] == 3
     dv = M.transformed_params2depthplussilhouette(params, T(d[f"{tag}_w2c"]), tg)
-    np.testing.assert_allclose(dv["colors_precomp"].numpy(), d[f"{tag}_dv_colors"], atol=3e-6, rtol=1e-6)
+    np.testing.assert_allclose(dv["colors_precomp"].cpu().numpy(), d[f"{tag}_dv_colors"], atol=3e-6, rtol=1e-6)
     rv2, dv2 = M.get_rendervars(params, d[f"{tag}_w2c"])
-    np.testing.assert_allclose(rv2["scales"].numpy(), d[f"{tag}_grv_scales"], rtol=1e-6)
-    np.testing.assert_allclose(rv2["rotations"].numpy(), d[f"{tag}_grv_rot"], atol=1e-6)
-    np.testing.assert_allclose(dv2["colors_precomp"].numpy(), d[f"{tag}_grv_dcolors"], atol=3e-6, rtol=1e-6)
+    np.testing.assert_allclose(rv2["scales"].cpu().numpy(), d[f"{tag}_grv_scales"], rtol=1e-6)
+    np.testing.assert_allclose(rv2["rotations"].cpu().numpy(), d[f"{tag}_grv_rot"], atol=1e-6)
+    np.testing.assert_allclose(dv2["colors_precomp"].cpu().numpy(), d[f"{tag}_grv_dcolors"], atol=3e-6, rtol=1e-6)
 
 
 def test_loss_matches_reference(monkeypatch):
@@ -91,10 +104,10 @@ def test_loss_matches_reference(monkeypatch):
     np.testing.assert_allclose(loss.item(), d["loss"], rtol=2e-6)
     np.testing.assert_allclose(wl["im"].item(), d["loss_im"], rtol=2e-6)
     np.testing.assert_allclose(wl["depth"].item(), d["loss_depth"], rtol=2e-6)
-    np.testing.assert_allclose(im_r.grad.numpy(), d["d_im"], atol=1e-9, rtol=2e-4)
-    np.testing.assert_allclose(ds_r.grad.numpy(), d["d_ds"], atol=1e-9, rtol=1e-5)
-    np.testing.assert_array_equal(variables["seen"].numpy(), d["seen"])
-    np.testing.assert_allclose(variables["max_2D_radius"].numpy(), d["max2d_after"])
+    np.testing.assert_allclose(im_r.grad.cpu().numpy(), d["d_im"], atol=1e-9, rtol=2e-4)
+    np.testing.assert_allclose(ds_r.grad.cpu().numpy(), d["d_ds"], atol=1e-9, rtol=1e-5)
+    np.testing.assert_array_equal(variables["seen"].cpu().numpy(), d["seen"])
+    np.testing.assert_allclose(variables["max_2D_radius"].cpu().numpy(), d["max2d_after"])
 
 
 KEYS = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales", "cam_unnorm_rots", "cam_trans")
@@ -108,7 +121,7 @@ def _optimizer_from(d, prefix, emu_unused=None):
     return params, O.initialize_optimizer(params, lrs, tracking=False)
 
 
-def test_fused_adam_matches_reference_optimizer(emu):
+def test_fused_adam_matches_reference_optimizer(backend):
     """3 steps of the mapper's Adam groups (camera groups have no grad and must be skipped entirely)."""
     d = load("adam.npz")
     params, opt = _optimizer_from(d, "")
@@ -119,13 +132,13 @@ def test_fused_adam_matches_reference_optimizer(emu):
             p.grad = None if k.startswith("cam_") else T(d[f"g{s}_{k}"])
         opt.step()
         for k, p in params.items():
-            np.testing.assert_allclose(p.detach().numpy(), d[f"p{s}_{k}"], rtol=3e-6, atol=1e-7, err_msg=f"{k} step {s}")
+            np.testing.assert_allclose(p.detach().cpu().numpy(), d[f"p{s}_{k}"], rtol=3e-6, atol=1e-7, err_msg=f"{k} step {s}")
             if k.startswith("cam_"):
                 assert p not in opt.state or not opt.state[p]
             else:
                 st = opt.state[p]
-                np.testing.assert_allclose(st["exp_avg"].numpy(), d[f"m{s}_{k}"], rtol=2e-6, atol=1e-9)
-                np.testing.assert_allclose(st["exp_avg_sq"].numpy(), d[f"v{s}_{k}"], rtol=2e-6, atol=1e-12)
+                np.testing.assert_allclose(st["exp_avg"].cpu().numpy(), d[f"m{s}_{k}"], rtol=2e-6, atol=1e-9)
+                np.testing.assert_allclose(st["exp_avg_sq"].cpu().numpy(), d[f"v{s}_{k}"], rtol=2e-6, atol=1e-12)
                 assert float(st["step"]) == float(d[f"t{s}_{k}"]) == s
         opt.zero_grad(set_to_none=True)
         assert all(p.grad is None for p in params.values())
@@ -134,11 +147,11 @@ def test_fused_adam_matches_reference_optimizer(emu):
 def _seed_state(opt, params, d, prefix, tag):
     for k, p in params.items():
         if f"{prefix}{tag}_{k}".replace("_p0", "") and f"{prefix}m0_{k}" in d:
-            opt.state[p] = {"step": torch.tensor(1.0), "exp_avg": T(d[f"{prefix}m0_{k}"]).clone(), "exp_avg_sq": T(d[f"{prefix}v0_{k}"]).clone()}
+            opt.state[p] = {"step": torch.tensor(1.0, device=_DEV[0]), "exp_avg": T(d[f"{prefix}m0_{k}"]).clone(), "exp_avg_sq": T(d[f"{prefix}v0_{k}"]).clone()}
 
 
 @pytest.mark.parametrize("tag", ["aniso", "iso"])
-def test_prune_cat_reset_match_reference(emu, tag):
+def test_prune_cat_reset_match_reference(backend, tag):
     from activesplat_amd import optim as O
     d = load("prune.npz")
     params, opt = _optimizer_from(d, f"{tag}_")
@@ -149,30 +162,30 @@ def test_prune_cat_reset_match_reference(emu, tag):
     params, variables = O.prune_gaussians(params, variables, opt, 0, pdict)
     assert params["means3D"].shape[0] == d[f"{tag}_p1_means3D"].shape[0] < d[f"{tag}_p0_means3D"].shape[0]
     for k in KEYS:
-        np.testing.assert_array_equal(params[k].detach().numpy(), d[f"{tag}_p1_{k}"])
+        np.testing.assert_array_equal(params[k].detach().cpu().numpy(), d[f"{tag}_p1_{k}"])
         if not k.startswith("cam_"):
             st = opt.state[params[k]]
-            np.testing.assert_array_equal(st["exp_avg"].numpy(), d[f"{tag}_m1_{k}"])
-            np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), d[f"{tag}_v1_{k}"])
+            np.testing.assert_array_equal(st["exp_avg"].cpu().numpy(), d[f"{tag}_m1_{k}"])
+            np.testing.assert_array_equal(st["exp_avg_sq"].cpu().numpy(), d[f"{tag}_v1_{k}"])
             assert float(st["step"]) == float(d[f"{tag}_t1_{k}"])
     for k in ("means2D_gradient_accum", "denom", "max_2D_radius", "timestep"):
-        np.testing.assert_array_equal(variables[k].numpy(), d[f"{tag}_var1_{k}"])
+        np.testing.assert_array_equal(variables[k].cpu().numpy(), d[f"{tag}_var1_{k}"])
     newp = {k: T(d[f"{tag}_new_{k}"]) for k in KEYS[:5]}
     params = O.cat_params_to_optimizer(newp, params, opt)
     for k in KEYS[:5]:
-        np.testing.assert_array_equal(params[k].detach().numpy(), d[f"{tag}_p2_{k}"])
+        np.testing.assert_array_equal(params[k].detach().cpu().numpy(), d[f"{tag}_p2_{k}"])
         st = opt.state[params[k]]
-        np.testing.assert_array_equal(st["exp_avg"].numpy(), d[f"{tag}_m2_{k}"])
-        np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), d[f"{tag}_v2_{k}"])
+        np.testing.assert_array_equal(st["exp_avg"].cpu().numpy(), d[f"{tag}_m2_{k}"])
+        np.testing.assert_array_equal(st["exp_avg_sq"].cpu().numpy(), d[f"{tag}_v2_{k}"])
         assert float(st["step"]) == float(d[f"{tag}_t2_{k}"])
     newo = {"logit_opacities": O.inverse_sigmoid(torch.ones_like(params["logit_opacities"]) * 0.01)}
     params = O.update_params_and_optimizer(newo, params, opt)
-    np.testing.assert_allclose(params["logit_opacities"].detach().numpy(), d[f"{tag}_p3_logit_opacities"], rtol=1e-6)
+    np.testing.assert_allclose(params["logit_opacities"].detach().cpu().numpy(), d[f"{tag}_p3_logit_opacities"], rtol=1e-6)
     st = opt.state[params["logit_opacities"]]
     assert float(st["exp_avg"].abs().sum()) == 0 and float(st["step"]) == float(d[f"{tag}_t3_logit_opacities"])
 
 
-def test_densify_matches_reference_isotropic(emu):
+def test_densify_matches_reference_isotropic(backend):
     """The one variant of the reference's densify that runs as shipped (isotropic, no timestep), with the
     recorded normal samples injected."""
     from activesplat_amd import optim as O
@@ -180,26 +193,26 @@ def test_densify_matches_reference_isotropic(emu):
     params, opt = _optimizer_from(d, "den_")
     _seed_state(opt, params, d, "den_", "p0")
     N = params["means3D"].shape[0]
-    m2d = torch.zeros(N, 2, requires_grad=True)
+    m2d = torch.zeros(N, 2, requires_grad=True, device=backend)
     m2d.grad = T(d["den_m2d_grad"])
     variables = dict(means2D=m2d, seen=T(d["den_seen"]), means2D_gradient_accum=T(d["den_accum0"]).clone(), denom=T(d["den_denom0"]).clone(),
-                     max_2D_radius=torch.zeros(N), scene_radius=T(d["den_scene_radius"]))
+                     max_2D_radius=torch.zeros(N, device=backend), scene_radius=T(d["den_scene_radius"]))
     ddict = {k: d[f"den_ddict_{k}"].item() for k in ("start_after", "remove_big_after", "stop_after", "densify_every", "grad_thresh", "num_to_split_into",
                                                     "removal_opacity_threshold", "final_removal_opacity_threshold", "reset_opacities", "reset_opacities_every")}
     params, variables = O.densify(params, variables, opt, 10, ddict, samples=T(d["den_samples"]))
     assert params["means3D"].shape[0] == d["den_p1_means3D"].shape[0] != N
     for k in KEYS:
-        np.testing.assert_allclose(params[k].detach().numpy(), d[f"den_p1_{k}"], rtol=1e-6, atol=1e-7, err_msg=k)
+        np.testing.assert_allclose(params[k].detach().cpu().numpy(), d[f"den_p1_{k}"], rtol=1e-6, atol=1e-7, err_msg=k)
         if not k.startswith("cam_"):
             st = opt.state[params[k]]
-            np.testing.assert_array_equal(st["exp_avg"].numpy(), d[f"den_m1_{k}"])
-            np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), d[f"den_v1_{k}"])
+            np.testing.assert_array_equal(st["exp_avg"].cpu().numpy(), d[f"den_m1_{k}"])
+            np.testing.assert_array_equal(st["exp_avg_sq"].cpu().numpy(), d[f"den_v1_{k}"])
             assert float(st["step"]) == float(d[f"den_t1_{k}"])
     for k, g in (("means2D_gradient_accum", "den_accum1"), ("denom", "den_denom1"), ("max_2D_radius", "den_max2d1")):
-        np.testing.assert_array_equal(variables[k].numpy(), d[g])
+        np.testing.assert_array_equal(variables[k].cpu().numpy(), d[g])
 
 
-def test_densify_anisotropic_with_timestep_runs(emu):
+def test_densify_anisotropic_with_timestep_runs(backend):
     """The cases the reference cannot execute: per-axis split noise, timestep inherited."""
     from activesplat_amd import optim as O
     g = torch.Generator().manual_seed(0)
@@ -208,15 +221,17 @@ def test_densify_anisotropic_with_timestep_runs(emu):
         means3D=torch.randn(N, 3, generator=g), rgb_colors=torch.rand(N, 3, generator=g), unnorm_rotations=torch.randn(N, 4, generator=g),
         logit_opacities=torch.randn(N, 1, generator=g) * 2, log_scales=torch.randn(N, 3, generator=g) * 0.7 - 4.0,
         cam_unnorm_rots=torch.randn(1, 4, 2, generator=g), cam_trans=torch.randn(1, 3, 2, generator=g)).items()}
+    params = {k: torch.nn.Parameter(p.detach().to(backend)) for k, p in params.items()}
     lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
     opt = O.initialize_optimizer(params, lrs)
     for k, p in params.items():
-        p.grad = None if k.startswith("cam_") else torch.randn(p.shape, generator=g)
+        p.grad = None if k.startswith("cam_") else torch.randn(p.shape, generator=g).to(backend)
     opt.step()
-    m2d = torch.zeros(N, 3, requires_grad=True); m2d.grad = torch.randn(N, 3, generator=g) * 3e-4
+    m2d = torch.zeros(N, 3, requires_grad=True, device=backend); m2d.grad = (torch.randn(N, 3, generator=g) * 3e-4).to(backend)
     variables = dict(means2D=m2d, seen=torch.rand(N, generator=g) > 0.3, means2D_gradient_accum=torch.rand(N, generator=g) * 4e-4,
                      denom=(torch.rand(N, generator=g) * 3).floor(), max_2D_radius=torch.zeros(N), timestep=torch.arange(N).float(),
                      scene_radius=torch.tensor(2.0))
+    variables = {k: (v if k == "means2D" else v.to(backend)) for k, v in variables.items()}
     ddict = dict(start_after=0, remove_big_after=0, stop_after=100, densify_every=10, grad_thresh=0.0002, num_to_split_into=2,
                  removal_opacity_threshold=0.005, final_removal_opacity_threshold=0.005, reset_opacities=False, reset_opacities_every=3000)
     params, variables = O.densify(params, variables, opt, 10, ddict)
@@ -232,15 +247,15 @@ def test_pointcloud_and_growth_match_reference(monkeypatch):
     d = load("pointcloud.npz")
     color, depth, K, w2c, mask = T(d["color"]), T(d["depth"]), T(d["K"]), T(d["w2c"]), T(d["mask"])
     pc, msd = M.get_pointcloud(color, depth, K, w2c, mask=mask, compute_mean_sq_dist=True)
-    np.testing.assert_allclose(pc.numpy(), d["pc"], atol=2e-6, rtol=1e-6)
-    np.testing.assert_allclose(msd.numpy(), d["msd"], rtol=1e-6)
+    np.testing.assert_allclose(pc.cpu().numpy(), d["pc"], atol=2e-6, rtol=1e-6)
+    np.testing.assert_allclose(msd.cpu().numpy(), d["msd"], rtol=1e-6)
     for tag in ("anisotropic", "isotropic"):
         p, v = M.initialize_params(pc, 3, msd, tag)
         for k in KEYS:
-            np.testing.assert_allclose(p[k].detach().numpy(), d[f"init_{tag}_{k}"], atol=2e-6, rtol=1e-6)
+            np.testing.assert_allclose(p[k].detach().cpu().numpy(), d[f"init_{tag}_{k}"], atol=2e-6, rtol=1e-6)
             assert isinstance(p[k], torch.nn.Parameter)
         for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep"):
-            np.testing.assert_array_equal(v[k].numpy(), d[f"initvar_{tag}_{k}"])
+            np.testing.assert_array_equal(v[k].cpu().numpy(), d[f"initvar_{tag}_{k}"])
     # add_new_gaussians with the recorded silhouette render
     p = {k: torch.nn.Parameter(T(d[f"add_p0_{k}"]).clone()) for k in KEYS}
     n0 = p["means3D"].shape[0]
@@ -257,11 +272,11 @@ def test_pointcloud_and_growth_match_reference(monkeypatch):
     monkeypatch.setattr(M, "Renderer", Stub)
     curr = dict(cam=None, im=color, depth=depth, intrinsics=K, w2c=torch.eye(4))
     p2, v2 = M.add_new_gaussians(p, v, curr, 0.5, 1, "anisotropic")
-    np.testing.assert_allclose(calls[0]["colors_precomp"].numpy(), d["add_call_colors"], atol=3e-6, rtol=1e-6)
+    np.testing.assert_allclose(calls[0]["colors_precomp"].cpu().numpy(), d["add_call_colors"], atol=3e-6, rtol=1e-6)
     for k in KEYS:
-        np.testing.assert_allclose(p2[k].detach().numpy(), d[f"add_p1_{k}"], atol=3e-6, rtol=1e-6, err_msg=k)
+        np.testing.assert_allclose(p2[k].detach().cpu().numpy(), d[f"add_p1_{k}"], atol=3e-6, rtol=1e-6, err_msg=k)
     for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep"):
-        np.testing.assert_array_equal(v2[k].numpy(), d[f"add_var1_{k}"])
+        np.testing.assert_array_equal(v2[k].cpu().numpy(), d[f"add_var1_{k}"])
 
 
 def test_keyframe_selection_matches_reference():
@@ -272,7 +287,7 @@ def test_keyframe_selection_matches_reference():
     assert [int(s) for s in sel] == [int(s) for s in d["selected"]]
 
 
-def test_keyframe_overlap_kernel_matches_reference(emu):
+def test_keyframe_overlap_kernel_matches_reference(backend):
     from activesplat_amd.keyframes import keyframe_selection_overlap
     d = load("keyframe.npz")
     kfs = [{"id": i, "est_w2c": T(w)} for i, w in enumerate(d["kf_w2c"])]
@@ -285,7 +300,7 @@ def test_keyframe_overlap_kernel_matches_reference(emu):
     assert keyframe_selection_overlap(*args[:3], [], 4, pixels=200, sampled=T(d["sampled"]), shuffle=False, fused=True) == []
 
 
-def test_growth_kernel_matches_reference_add_new_gaussians(emu):
+def test_growth_kernel_matches_reference_add_new_gaussians(backend):
     """gs_grow_gaussians on the recorded silhouette render == the rows the reference's add_new_gaussians appended."""
     from activesplat_amd import mapping as M
     d = load("pointcloud.npz")
@@ -300,9 +315,9 @@ def test_growth_kernel_matches_reference_add_new_gaussians(emu):
         n_new = d["add_p1_means3D"].shape[0] - n0
         assert n_cand >= n_new > 0 and rows["means3D"].shape[0] == n_new
         for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities"):
-            np.testing.assert_allclose(rows[k].numpy(), d[f"add_p1_{k}"][n0:], atol=3e-6, rtol=1e-6, err_msg=k)
+            np.testing.assert_allclose(rows[k].cpu().numpy(), d[f"add_p1_{k}"][n0:], atol=3e-6, rtol=1e-6, err_msg=k)
         ls = d["add_p1_log_scales"][n0:]
-        np.testing.assert_allclose(rows["log_scales"].numpy(), ls if tag == "anisotropic" else ls[:, :1], atol=3e-6, rtol=1e-6)
+        np.testing.assert_allclose(rows["log_scales"].cpu().numpy(), ls if tag == "anisotropic" else ls[:, :1], atol=3e-6, rtol=1e-6)
     # nothing to add: full silhouette, exact depth
     full = torch.ones_like(ds[1])
     rows, n_cand = M.grow_rows(depth[0], full, depth, color, K, np.eye(4), 0.5, "anisotropic")
@@ -311,7 +326,7 @@ def test_growth_kernel_matches_reference_add_new_gaussians(emu):
         M.grow_rows(ds[0], ds[1], depth, color, K, np.eye(4), 0.5, "spherical")
 
 
-def test_fused_loss_kernel_matches_reference_loss(emu):
+def test_fused_loss_kernel_matches_reference_loss(backend):
     """gs_mapping_loss (csrc/loss.hip) reproduces the reference's get_loss value, split and gradients w.r.t. the
     rendered colour and depth on the golden render/target pair."""
     from activesplat_amd import mapping as M
@@ -323,18 +338,18 @@ def test_fused_loss_kernel_matches_reference_loss(emu):
     np.testing.assert_allclose(loss.item(), d["loss"], rtol=5e-6)
     np.testing.assert_allclose(parts["im"].item(), d["loss_im"], rtol=5e-6)
     np.testing.assert_allclose(parts["depth"].item(), d["loss_depth"], rtol=5e-6)
-    np.testing.assert_allclose(im_r.grad.numpy(), d["d_im"], atol=2e-9, rtol=2e-3)
-    np.testing.assert_allclose(depth.grad.numpy()[0], d["d_ds"][0], atol=1e-9, rtol=1e-5)
+    np.testing.assert_allclose(im_r.grad.cpu().numpy(), d["d_im"], atol=2e-9, rtol=2e-3)
+    np.testing.assert_allclose(depth.grad.cpu().numpy()[0], d["d_ds"][0], atol=1e-9, rtol=1e-5)
 
 
-def test_fused_loss_ragged_image_and_torch_mirror(emu):
+def test_fused_loss_ragged_image_and_torch_mirror(backend):
     """Non-multiple-of-16 image, NaN / zero-depth pixels: fused kernel == the torch mirror of the reference loss."""
     from activesplat_amd import mapping as M
     g = torch.Generator().manual_seed(3)
     H, W = 37, 50
-    im = torch.rand(3, H, W, generator=g).requires_grad_(True)
-    depth = (torch.rand(1, H, W, generator=g) * 3).requires_grad_(True)
-    gt_im = torch.rand(3, H, W, generator=g); gt_d = torch.rand(1, H, W, generator=g) * 3
+    im = torch.rand(3, H, W, generator=g).to(backend).requires_grad_(True)
+    depth = (torch.rand(1, H, W, generator=g) * 3).to(backend).requires_grad_(True)
+    gt_im = torch.rand(3, H, W, generator=g).to(backend); gt_d = (torch.rand(1, H, W, generator=g) * 3).to(backend)
     gt_d[0, :3, :9] = 0.0
     loss, parts = M.fused_mapping_loss(im, depth, depth.detach() ** 2 + 0.1, gt_im, gt_d, dict(im=0.5, depth=1.0))
     loss.backward()
@@ -343,12 +358,12 @@ def test_fused_loss_ragged_image_and_torch_mirror(emu):
     ref = 1.0 * (gt_d - d2).abs()[mask].mean() + 0.5 * (0.8 * M.l1_loss_v1(im2, gt_im) + 0.2 * (1.0 - M.calc_ssim(im2, gt_im)))
     ref.backward()
     np.testing.assert_allclose(loss.item(), ref.item(), rtol=5e-6)
-    np.testing.assert_allclose(im.grad.numpy(), im2.grad.numpy(), atol=2e-9, rtol=2e-3)
-    np.testing.assert_allclose(depth.grad.numpy(), d2.grad.numpy(), atol=1e-10, rtol=1e-5)
+    np.testing.assert_allclose(im.grad.cpu().numpy(), im2.grad.cpu().numpy(), atol=2e-9, rtol=2e-3)
+    np.testing.assert_allclose(depth.grad.cpu().numpy(), d2.grad.cpu().numpy(), atol=1e-10, rtol=1e-5)
 
 
 @pytest.mark.parametrize("tag", ["aniso", "iso"])
-def test_fused_rendervar_kernel_matches_reference_transform(emu, tag):
+def test_fused_rendervar_kernel_matches_reference_transform(backend, tag):
     """gs_activate_* == transform_to_frame + transformed_params2rendervar of the reference (golden), forward;
     backward == autograd of the torch mirror."""
     from activesplat_amd import mapping as M
@@ -357,9 +372,9 @@ def test_fused_rendervar_kernel_matches_reference_transform(emu, tag):
     params = {k: T(d[f"{tag}_{k}"]).clone().requires_grad_(True) for k in keys}
     rv = M.fused_rendervar(params, 3)
     for k in ("means3D", "rotations", "opacities", "scales"):
-        np.testing.assert_allclose(rv[k].detach().numpy(), d[f"{tag}_rv_{k}"], atol=3e-6, rtol=2e-6, err_msg=k)
+        np.testing.assert_allclose(rv[k].detach().cpu().numpy(), d[f"{tag}_rv_{k}"], atol=3e-6, rtol=2e-6, err_msg=k)
     g = torch.Generator().manual_seed(0)
-    w = {k: torch.randn(rv[k].shape, generator=g) for k in ("means3D", "rotations", "opacities", "scales")}
+    w = {k: torch.randn(rv[k].shape, generator=g).to(backend) for k in ("means3D", "rotations", "opacities", "scales")}
     sum((rv[k] * w[k]).sum() for k in w).backward()
     got = {k: params[k].grad.clone() for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales")}
     p2 = {k: T(d[f"{tag}_{k}"]).clone().requires_grad_(True) for k in keys}
@@ -367,4 +382,4 @@ def test_fused_rendervar_kernel_matches_reference_transform(emu, tag):
     rv2 = M.transformed_params2rendervar(p2, tg)
     sum((rv2[k] * w[k]).sum() for k in w).backward()
     for k in got:
-        np.testing.assert_allclose(got[k].numpy(), p2[k].grad.numpy(), atol=2e-6 * float(p2[k].grad.abs().max()), rtol=1e-4, err_msg=k)
+        np.testing.assert_allclose(got[k].cpu().numpy(), p2[k].grad.cpu().numpy(), atol=2e-6 * float(p2[k].grad.abs().max()), rtol=1e-4, err_msg=k)

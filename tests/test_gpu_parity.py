@@ -155,6 +155,7 @@ def test_zero_gaussians(hip):
 
 def test_optimistic_launch_hit_and_miss_equal_exact_launch(hip):
     pc.check_optimistic_launch(hip)
+    pc.check_optimistic_tile_list_growth(hip)
 
 
 def test_full_size_config2_sh3_against_oracle_and_properties(hip, oracle32):
