@@ -252,7 +252,7 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, 
 
 int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_tile_instances, void* geom_state,
                       void* bin_state, uint32_t* point_list, void* image_state, float* out_color, float* out_depth,
-                      float* out_opacity, float* out_depth_sq, gs_stream_t stream)
+                      float* out_opacity, float* out_depth_sq, void* backward_scratch, gs_stream_t stream)
 {
     gs::Cam k;
     if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_render_forward: invalid camera settings");
@@ -305,7 +305,7 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_ti
         e = gs::launch_blend_forward(k, ranges, point_list, gp.geom, out_color, out_depth, out_opacity,
                                      (float*)(ib + IL.final_T), (uint32_t*)(ib + IL.n_contrib), out_depth_sq,
                                      BL.path == GS_SORT_TILE_LDS ? (uint32_t)D : 0xffffffffu, (int)BL.segments,
-                                     BL.segments > 1 ? (float*)(bb + BL.seg_T) : nullptr, (uint32_t)P, st);
+                                     BL.segments > 1 ? (float*)(bb + BL.seg_T) : nullptr, (uint32_t)P, (float*)backward_scratch, st);
     }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: blend %s", hipGetErrorString(e));
     return GS_OK;
@@ -317,7 +317,7 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* m
                        const uint32_t* point_list, const void* image_state, const float* dL_dcolor,
                        const float* dL_ddepth, float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities, float* dL_dcolors_precomp,
                        float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* scratch,
-                       gs_stream_t stream)
+                       int32_t scratch_zeroed, gs_stream_t stream)
 {
     gs::Cam k;
     if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_render_backward: invalid camera settings");
@@ -334,7 +334,7 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* m
     GsImageLayout IL; gs_image_layout(k.W, k.H, &IL);
     const char* ib = (const char*)image_state;
     float* grad2d = (float*)scratch;
-    hipError_t e = hipMemsetAsync(grad2d, 0, (size_t)P * gs::kGradStride * 4, st);
+    hipError_t e = scratch_zeroed ? hipSuccess : hipMemsetAsync(grad2d, 0, (size_t)P * gs::kGradStride * 4, st);
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_backward: memset %s", hipGetErrorString(e));
     if (D > 0) {
         ScopedStage ps(ST_BLEND_BWD, st);

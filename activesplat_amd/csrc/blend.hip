@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ out_depth_sq, uint32_t cap, float* __restrict__ seg_T, uint32_t P)
+    float* __restrict__ out_depth_sq, uint32_t cap, float* __restrict__ seg_T, uint32_t P, float4* __restrict__ zero_fill)
 {
     constexpr int LS = kWave / NS;          // lanes per stream
     constexpr int BH = LS / 4;              // block = 4 x BH pixels
@@ -129,6 +129,13 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
     // NS rows of 64 entries per wave (+16 bytes so that the look-ahead read behind the last row stays inside the wave's slab)
     __shared__ __attribute__((aligned(16))) uint8_t s_list[kBlock / kWave][NS * kWave + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // side job (SEG = 0 only): this workgroup's slice of the backward's gradient records is zero-filled here -- plain
+    // fire-and-forget 16-byte stores next to an arithmetic-bound loop instead of a separate fill launch before the backward
+    if (SEG == 0 && zero_fill) {
+        const size_t total = (size_t)P * (kGradStride / 4), per = (total + gridDim.x - 1) / gridDim.x;
+        const size_t z0 = (size_t)blockIdx.x * per, z1 = min(total, z0 + per);
+        for (size_t z = z0 + tid; z < z1; z += kBlock) zero_fill[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     TileCtx c;
     if (!tile_ctx(cam, wave, lane, c)) return;
     // lane -> pixel: stream sid owns block (sid & 1, sid >> 1) of the quadrant
@@ -529,16 +536,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
 
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
-                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, uint32_t P, hipStream_t st)
+                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, uint32_t P, float* zero_fill, hipStream_t st)
 {
     const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
 #define GS_FWD(DSQ, SEG, GRID)                                                                                                     \
     hipLaunchKernelGGL((blend_forward_streams_kernel<DSQ, kFwdStreams, SEG>), GRID, dim3(kBlock), 0, st, cam, ranges, point_list, geom, \
-                       out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap, seg_T, P)
+                       out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap, seg_T, P, (float4*)zero_fill)
     if (segments > 1 && seg_T) {
         // segmented compositing: the sums are added with atomics, so the images start from zero
         const size_t HW = (size_t)cam.W * cam.H;
-        hipError_t e = hipMemsetAsync(out_color, 0, 3 * HW * sizeof(float), st);
+        hipError_t e = zero_fill ? hipMemsetAsync(zero_fill, 0, (size_t)P * kGradStride * sizeof(float), st) : hipSuccess;
+        if (e == hipSuccess) e = hipMemsetAsync(out_color, 0, 3 * HW * sizeof(float), st);
         if (e == hipSuccess) e = hipMemsetAsync(out_depth, 0, HW * sizeof(float), st);
         if (e == hipSuccess && out_depth_sq) e = hipMemsetAsync(out_depth_sq, 0, HW * sizeof(float), st);
         if (e == hipSuccess) e = hipMemsetAsync(n_contrib, 0, HW * sizeof(uint32_t), st);

@@ -129,9 +129,13 @@ __device__ __forceinline__ void sh_rows_from_lds(const float* lds, float* __rest
 // phases instead of taking turns.  row0 * K * 4 bytes is 16-byte aligned because row0 is a multiple of 32.
 constexpr int kShHalf = 32;
 // row_mask: bit r set = row r is needed (rows of culled Gaussians are not fetched; their slab contents stay undefined)
-__device__ __forceinline__ void sh_wave_rows_to_lds(float* slab, const float* __restrict__ src, int row0, int nrows, int K, int lane,
+// KC > 0: the row width is a compile-time constant (16 coefficients: KC = 48) -- the element -> (row, column) divisions of the
+// copy loops fold into multiplies; KC = 0: runtime K
+template <int KC = 0>
+__device__ __forceinline__ void sh_wave_rows_to_lds(float* slab, const float* __restrict__ src, int row0, int nrows, int Krt, int lane,
                                                     uint32_t row_mask = 0xffffffffu)
 {
+    const int K = KC > 0 ? KC : Krt;
     const int stride = sh_row_stride(K), total = nrows * K, total4 = total >> 2;
     const float* s = src + (size_t)row0 * K;
     const float4* s4 = reinterpret_cast<const float4*>(s);
@@ -152,8 +156,10 @@ __device__ __forceinline__ void sh_wave_rows_to_lds(float* slab, const float* __
         if ((row_mask >> r) & 1u) slab[r * stride + (e - r * K)] = s[e];
     }
 }
-__device__ __forceinline__ void sh_wave_rows_from_lds(const float* slab, float* __restrict__ dst, int row0, int nrows, int K, int lane)
+template <int KC = 0>
+__device__ __forceinline__ void sh_wave_rows_from_lds(const float* slab, float* __restrict__ dst, int row0, int nrows, int Krt, int lane)
 {
+    const int K = KC > 0 ? KC : Krt;
     const int stride = sh_row_stride(K), total = nrows * K, total4 = total >> 2;
     float* d = dst + (size_t)row0 * K;
     float4* d4 = reinterpret_cast<float4*>(d);
@@ -193,7 +199,7 @@ hipError_t launch_emit(const Cam& cam, int P, GeomPtrs gp, uint64_t* keys, uint3
 hipError_t launch_ranges(int64_t D, const uint64_t* keys_sorted, uint2* ranges, hipStream_t st);
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
-                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, uint32_t P, hipStream_t st);
+                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, uint32_t P, float* zero_fill, hipStream_t st);
 hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  const float* dL_ddepth, float* grad2d, hipStream_t st);

@@ -47,7 +47,9 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
-template <bool HAS_SH>
+// SH: 0 = colours given, 1 = coefficient rows of any width through per-wave LDS slabs, 3 = the same for 16-coefficient rows
+// (row width 48 known at compile time: the copy loops' element -> (row, column) divisions fold away)
+template <int SH>
 __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales,
@@ -55,8 +57,10 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
 {
     // LDS: means | one pool that holds, in turn, the per-wave SH slabs (HAS_SH, first phase) and the staged
     // scale+rotation (or covariance) rows and colours (second phase)
-    constexpr int kGeoFloats = kBlock * 7, kColFloats = HAS_SH ? 0 : kBlock * 3;
-    constexpr int kSlabFloats = HAS_SH ? (kBlock / kWave) * kShHalf * kShPad : 0;
+    constexpr bool HAS_SH = SH != 0;
+    constexpr bool SLAB = SH == 1 || SH == 3;
+    constexpr int kGeoFloats = kBlock * 7, kColFloats = SLAB ? 0 : kBlock * 3;
+    constexpr int kSlabFloats = SLAB ? (kBlock / kWave) * kShHalf * kShPad : 0;
     constexpr int kPoolFloats = (kGeoFloats + kColFloats) > kSlabFloats ? (kGeoFloats + kColFloats) : kSlabFloats;
     __shared__ __attribute__((aligned(16))) float s_mean[kBlock * 3];
     __shared__ __attribute__((aligned(16))) float s_pool[kPoolFloats];
@@ -74,10 +78,10 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     if (base + tid < cam.gx * cam.gy) gp.tile_total[base + tid] = 0u;
     const int i = base + tid;
     stage_rows<3>(s_mean, means3D, base, nrows, tid);
-    if (!HAS_SH) {
+    if (!SLAB) {
         if (cov3Dp) stage_rows<6>(s_cov, cov3Dp, base, nrows, tid);
         else { stage_rows<3>(s_scale, scales, base, nrows, tid); stage_rows<4>(s_rot, rots, base, nrows, tid); }
-        stage_rows<3>(s_col, colors, base, nrows, tid);
+        if (SH == 0) stage_rows<3>(s_col, colors, base, nrows, tid);
     }
     __syncthreads();
 
@@ -85,8 +89,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     // 32 rows at a time (coalesced 16 B/lane global reads; lane = row reads at an odd stride are conflict-free)
     float sh_rgb[3] = {0.f, 0.f, 0.f};
     uint32_t sh_clamp = 0;
-    if (HAS_SH) {
-        const int M = cam.sh_coeffs, K = M * 3, nbasis = (cam.sh_degree + 1) * (cam.sh_degree + 1);
+    if (SLAB) {
+        constexpr int KC = SH == 3 ? 48 : 0;
+        const int M = KC ? 16 : cam.sh_coeffs, K = M * 3, nbasis = (cam.sh_degree + 1) * (cam.sh_degree + 1);
         const int stride = sh_row_stride(K);
         const int lane = tid & 63, wave = tid >> 6;
         float* slab = s_sh + wave * kShHalf * kShPad;
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
             const int row0 = base + wave * kWave + h * kShHalf;
             if (row0 >= P) break;                                  // wave-uniform
             __builtin_amdgcn_wave_barrier();
-            sh_wave_rows_to_lds(slab, shs, row0, min(kShHalf, P - row0), K, lane);
+            sh_wave_rows_to_lds<KC>(slab, shs, row0, min(kShHalf, P - row0), K, lane);
             __builtin_amdgcn_wave_barrier();
             if ((lane >> 5) == h && base + tid < P) {
                 const float dx = s_mean[tid * 3] - cam.campos[0], dy = s_mean[tid * 3 + 1] - cam.campos[1], dz = s_mean[tid * 3 + 2] - cam.campos[2];
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
         }
     }
 
-    if (HAS_SH) {                                        // the slabs are done: reuse the pool for the geometry rows
+    if (SLAB) {                                          // the slabs are done: reuse the pool for the geometry rows
         __syncthreads();
         if (cov3Dp) stage_rows<6>(s_cov, cov3Dp, base, nrows, tid);
         else { stage_rows<3>(s_scale, scales, base, nrows, tid); stage_rows<4>(s_rot, rots, base, nrows, tid); }
@@ -261,11 +266,14 @@ hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D
                                      uint32_t* d_num_rendered, hipStream_t st)
 {
     const int nb = (P + kBlock - 1) / kBlock;
-    if (nb > 0 && shs)
-        hipLaunchKernelGGL(preprocess_forward_kernel<true>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
+    if (nb > 0 && shs && cam.sh_coeffs == 16)
+        hipLaunchKernelGGL(preprocess_forward_kernel<3>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
+                           scales, rots, cov3Dp, radii, gp);
+    else if (nb > 0 && shs)
+        hipLaunchKernelGGL(preprocess_forward_kernel<1>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
                            scales, rots, cov3Dp, radii, gp);
     else if (nb > 0)
-        hipLaunchKernelGGL(preprocess_forward_kernel<false>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
+        hipLaunchKernelGGL(preprocess_forward_kernel<0>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
                            scales, rots, cov3Dp, radii, gp);
     // tile_total must be zero even when the grid above does not cover every tile (tiny P, many tiles)
     if ((size_t)nb * kBlock < (size_t)cam.gx * cam.gy) {

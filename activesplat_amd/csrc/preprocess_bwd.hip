@@ -47,8 +47,10 @@ __device__ __forceinline__ void sh_basis_and_grad(int deg, float x, float y, flo
     }
 }
 
-template <bool HAS_SH>
-__global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
+// SH: 0 = colours given, 1 = coefficient rows of any width through per-wave LDS slabs, 3 = the same for 16-coefficient rows
+// (row width 48 known at compile time)
+template <int SH>
+__global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov3Dp,
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const float* __restrict__ grad2d,
@@ -57,7 +59,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     float* __restrict__ drots, float* __restrict__ dcov3D)
 {
     // per-wave slabs: 32 coefficient rows in, their gradients written back IN PLACE (each element is read before it is overwritten)
-    __shared__ __attribute__((aligned(16))) float s_sh[HAS_SH ? (kBlock / kWave) * kShHalf * kShPad : 1];
+    constexpr bool HAS_SH = SH != 0;
+    constexpr bool SLAB = SH == 1 || SH == 3;
+    __shared__ __attribute__((aligned(16))) float s_sh[SLAB ? (kBlock / kWave) * kShHalf * kShPad : 1];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kBlock + tid;
     const bool in_range = i < P;
@@ -74,8 +78,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     const float px = means3D[3 * ic], py = means3D[3 * ic + 1], pz = means3D[3 * ic + 2];
     const float drgb[3] = {gb.z, gb.w, gc.x};
     // ---- colour / SH: one wavefront's 64 coefficient rows per LDS pass, coalesced global traffic by all threads ----
-    if (HAS_SH) {
-        const int deg = cam.sh_degree, nb = (deg + 1) * (deg + 1), M = cam.sh_coeffs, K = M * 3;
+    if (SLAB) {
+        constexpr int KC = SH == 3 ? 48 : 0;
+        const int deg = cam.sh_degree, nb = (deg + 1) * (deg + 1), M = KC ? 16 : cam.sh_coeffs, K = M * 3;
         const int stride = sh_row_stride(K);
         const int lane = tid & 63, wave = tid >> 6;
         float* slab = s_sh + wave * kShHalf * kShPad;
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
             __builtin_amdgcn_wave_barrier();
             // only live Gaussians read their coefficients (a culled one's gradient row is all zeros)
             const uint32_t live_rows = (uint32_t)(__ballot(live) >> (h * kShHalf));
-            sh_wave_rows_to_lds(slab, shs, row0, nrows, K, lane, live_rows);
+            sh_wave_rows_to_lds<KC>(slab, shs, row0, nrows, K, lane, live_rows);
             __builtin_amdgcn_wave_barrier();
             if ((lane >> 5) == h && in_range) {
                 float* dsh = slab + (lane & 31) * stride;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            sh_wave_rows_from_lds(slab, dshs, row0, nrows, K, lane);
+            sh_wave_rows_from_lds<KC>(slab, dshs, row0, nrows, K, lane);
         }
         if (!in_range) return;
     }
@@ -242,11 +247,14 @@ hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3
                                       float* dscales, float* drots, float* dcov3D, hipStream_t st)
 {
     const int nb = (P + kBlock - 1) / kBlock;
-    if (nb > 0 && shs)
-        hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
+    if (nb > 0 && shs && cam.sh_coeffs == 16)
+        hipLaunchKernelGGL(preprocess_backward_kernel<3>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
+                           cov3Dp, radii, clamped, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
+    else if (nb > 0 && shs)
+        hipLaunchKernelGGL(preprocess_backward_kernel<1>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
                            cov3Dp, radii, clamped, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
     else if (nb > 0)
-        hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
+        hipLaunchKernelGGL(preprocess_backward_kernel<0>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
                            cov3Dp, radii, clamped, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
     return hipGetLastError();
 }

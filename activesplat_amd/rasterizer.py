@@ -128,13 +128,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         depth = torch.empty(1, H, W, dtype=torch.float32, device=device)
         opacity = torch.empty(1, H, W, dtype=torch.float32, device=device)
         depth_sq = torch.empty(1, H, W, dtype=torch.float32, device=device) if fused else None
+        # the backward's gradient records: allocated now (when a backward can follow) so that the blend kernel of this
+        # forward zero-fills them as a side job instead of a fill launch in front of the backward
+        scratch = None
+        if any(ctx.needs_input_grad[:8]) and P > 0:
+            scratch = torch.empty(int(lib.gs_backward_scratch_bytes(P)), dtype=torch.uint8, device=device)
 
         def render(cap_d, cap_tile):
             bl_ = _lib.GsBinLayout(); _lib.check(lib.gs_bin_layout(cap_d, cap_tile, W, H, C.byref(bl_)))
             binning_ = torch.empty(bl_.total_bytes, dtype=torch.uint8, device=device)
             plist_ = torch.empty(max(cap_d, 1), dtype=torch.int32, device=device)
             _lib.check(lib.gs_render_forward(C.byref(cam), P, cap_d, cap_tile, _ptr(geom), _ptr(binning_), _ptr(plist_), _ptr(image),
-                                             _ptr(color), _ptr(depth), _ptr(opacity), _ptr(depth_sq), st))
+                                             _ptr(color), _ptr(depth), _ptr(opacity), _ptr(depth_sq), _ptr(scratch), st))
             return bl_, binning_, plist_
 
         # Optimistic launch: the binning workspace is sized from the previous frame of this (P, W, H) stream (+25 %), the
@@ -169,6 +174,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         _capacity[key] = (max(old[0], int(D * 1.25) + 4096), max(old[1], int(max_tile * 1.25) + 64))
         last_stats["num_rendered"], last_stats["P"], last_stats["max_tile_instances"] = D, P, max_tile
         ctx.rs, ctx.D, ctx.keep, ctx.fused, ctx.cam = rs, D, keep, fused, cam      # the backward reuses the camera block
+        ctx.scratch, ctx.scratch_clean = scratch, scratch is not None
         ctx.has = (shs is not None, colors_precomp is not None, scales is not None, rotations is not None,
                    cov3D_precomp is not None)
         if rs.debug:
@@ -205,13 +211,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         d_sc = z(P, 3) if has_sc else None
         d_rot = z(P, 4) if has_rot else None
         d_cov = z(P, 6) if has_cov else None
-        scratch = torch.empty(int(lib.gs_backward_scratch_bytes(P)), dtype=torch.uint8, device=device)
+        scratch, clean = ctx.scratch, ctx.scratch_clean
+        if scratch is None:
+            scratch, clean = torch.empty(int(lib.gs_backward_scratch_bytes(P)), dtype=torch.uint8, device=device), False
+        ctx.scratch_clean = False                        # a second backward through the same graph finds it dirty
         _lib.check(lib.gs_render_backward(
             C.byref(cam), P, ctx.D, _ptr(means3D), _ptr(shs if has_sh else None), _ptr(colors if has_col else None),
             _ptr(scales if has_sc else None), _ptr(rots if has_rot else None), _ptr(cov3Dp if has_cov else None),
             _ptr(radii), _ptr(geom), _ptr(point_list), _ptr(image), _ptr(grad_color), _ptr(grad_depth),
             _ptr(d_m2d), _ptr(d_m3d), _ptr(d_op), _ptr(d_col), _ptr(d_shs), _ptr(d_sc), _ptr(d_rot), _ptr(d_cov),
-            _ptr(scratch), _stream(device)))
+            _ptr(scratch), 1 if clean else 0, _stream(device)))
         return d_m3d, d_m2d, d_shs, d_col, d_op, d_sc, d_rot, d_cov, None, None
 
 

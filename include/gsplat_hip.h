@@ -150,15 +150,20 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P,
  * gs_bin_layout reports GS_SORT_TILE_LDS for them: no kernel reads or writes past D, so a host may enqueue this call
  * right behind gs_preprocess_forward with bounds from the previous frame, read h_counts afterwards, and simply call it
  * again with the exact counts in the rare frame where they exceed the bounds (the call is idempotent; a frame whose
- * true counts exceed the bounds it was launched with has unspecified outputs). */
+ * true counts exceed the bounds it was launched with has unspecified outputs).
+ * backward_scratch (nullable, gs_backward_scratch_bytes(P) bytes): the gradient records gs_render_backward accumulates into
+ * are zero-filled by the blend workgroups of THIS call (stores riding along an arithmetic-bound kernel) instead of by a
+ * separate fill in front of the backward; pass the same buffer to gs_render_backward with scratch_zeroed = 1. */
 int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_tile_instances,
                       void* geom_state, void* bin_state, uint32_t* point_list, void* image_state,
                       float* out_color, float* out_depth, float* out_opacity, float* out_depth_sq,
-                      gs_stream_t stream);
+                      void* backward_scratch, gs_stream_t stream);
 
 /* Backward of `out_color` (and, when dL_ddepth [1,H,W] is non-NULL, of `out_depth`) w.r.t. every input.  Any dL_d* output pointer may be NULL if that input
  * was not given (shs vs colors_precomp, scales/rotations vs cov3D_precomp).
- * dL_dmeans2D [P,3] receives the NDC-scaled screen-space gradient (x*0.5W, y*0.5H, 0). */
+ * dL_dmeans2D [P,3] receives the NDC-scaled screen-space gradient (x*0.5W, y*0.5H, 0).
+ * scratch: gs_backward_scratch_bytes(P) bytes; scratch_zeroed != 0 promises that it is all zero (see gs_render_forward's
+ * backward_scratch) -- the call leaves it dirty either way. */
 int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D,
                        const float* means3D, const float* shs, const float* colors_precomp,
                        const float* scales, const float* rotations, const float* cov3D_precomp,
@@ -166,7 +171,8 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D,
                        const void* image_state, const float* dL_dcolor, const float* dL_ddepth,
                        float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities,
                        float* dL_dcolors_precomp, float* dL_dshs, float* dL_dscales,
-                       float* dL_drotations, float* dL_dcov3D, void* scratch, gs_stream_t stream);
+                       float* dL_drotations, float* dL_dcov3D, void* scratch, int32_t scratch_zeroed,
+                       gs_stream_t stream);
 
 /* Fused dense Adam step over one flat parameter tensor with torch.optim.Adam semantics
  * (non-amsgrad, no weight decay): splatam.py:118-124 uses betas (0.9,0.999), eps 1e-15.

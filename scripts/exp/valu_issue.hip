@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void k_issue(float* out, float seed)
     const v2f pc1 = {c1, c1}, pc2 = {c2, c2};
     float* my = lds + tid * 20;
     float* mine17 = lds + (tid & 63) * 17 + (tid >> 6) * 1100;
+    unsigned long long acc_mask = 0; const unsigned long long smask = __ballot((tid & 1) != 0 && seed > 0.f);
     for (int it = 0; it < ITER; it++) {
         if (KIND == 0) {            // v_fma_f32
 #define S(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c1), "v"(c2));
@@ -114,8 +115,58 @@ __global__ __launch_bounds__(256) void k_issue(float* out, float seed)
             BODY8(S)
 #undef S
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (KIND == 18) {    // v_cndmask_b32_e64 with an SGPR-pair mask that no VALU wrote
+#define S(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c1), "s"(smask));
+            BODY8(S)
+#undef S
+        } else if (KIND == 19) {    // v_cmp (-> vcc) + v_cndmask (vcc) pairs: 32 + 32 instructions
+#define S(i) asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c1) : "vcc");
+            REP8(S) REP8(S) REP8(S) REP8(S)
+#undef S
+        } else if (KIND == 20) {    // v_cmp_gt_f32_e64 -> SGPR pair only
+#define S(i) { unsigned long long m_; asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m_) : "v"(a[i]), "v"(c1)); acc_mask ^= m_; }
+            BODY8(S)
+#undef S
+        } else if (KIND == 21) {    // v_max_f32
+#define S(i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            BODY8(S)
+#undef S
+        } else if (KIND == 22) {    // v_fmac_f32 (VOP2)
+#define S(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(c1), "v"(c2));
+            BODY8(S)
+#undef S
+        } else if (KIND == 23) {    // v_mov_b32
+#define S(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(c1));
+            BODY8(S)
+#undef S
+        } else if (KIND == 24) {    // v_add_f32
+#define S(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c2));
+            BODY8(S)
+#undef S
+        } else if (KIND == 25) {    // s_nop 1 between v_mul (DPP hazard idiom): 32 + 32
+#define S(i) asm volatile("s_nop 1\n\tv_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            REP8(S) REP8(S) REP8(S) REP8(S)
+#undef S
+        } else if (KIND == 26) {    // v_cndmask_b32 vop2 with vcc written once per iteration by a v_cmp
+            asm volatile("v_cmp_gt_f32 vcc, %0, %1" :: "v"(a[0]), "v"(c1) : "vcc");
+#define S(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c1) : );
+            BODY8(S)
+#undef S
+        } else if (KIND == 27) {    // v_mul_f32 by an SGPR operand
+#define S(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "s"(seed));
+            BODY8(S)
+#undef S
+        } else if (KIND == 28) {    // v_readlane_b32 + s use
+#define S(i) { unsigned r_; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(r_) : "v"(a[i])); acc_mask += r_; }
+            BODY8(S)
+#undef S
+        } else if (KIND == 29) {    // v_fma_f32 with operands spread over register banks: a[i] = a[i] * a[(i+1)&7] + a[(i+2)&7]
+#define S(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+            BODY8(S)
+#undef S
         }
     }
+    if (acc_mask == 0x123456789ull) out[1] = 1.f;
     float s = 0.f;
     for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y;
     if (s == 12345.678f) out[0] = s + lds[tid];
@@ -123,7 +174,9 @@ __global__ __launch_bounds__(256) void k_issue(float* out, float seed)
 
 const char* kNames[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_add_f32_dpp(row_ror)", "v_exp_f32", "v_rcp_f32",
                         "v_cndmask_b32", "v_mul_f32", "v_mov_b32_dpp(quad)", "mix 3fma:1exp", "ds_read_b128", "ds_write_b32", "ds_add_f32",
-                        "ds_read_b32 s17", "v_fma_f32 2 chains", "ds_write_b128", "ds_bpermute_b32"};
+                        "ds_read_b32 s17", "v_fma_f32 2 chains", "ds_write_b128", "ds_bpermute_b32",
+                        "v_cndmask_e64 sgpr mask", "v_cmp+v_cndmask vcc (pairs)", "v_cmp_e64 -> sgpr", "v_max_f32", "v_fmac_f32", "v_mov_b32", "v_add_f32",
+                        "s_nop1+v_mul (pairs)", "v_cndmask vcc (cmp hoisted)", "v_mul_f32 sgpr src", "v_readlane_b32", "v_fma_f32 mixed banks"};
 
 template <int KIND>
 void run(float* d_out, int waves_per_simd)
@@ -151,14 +204,21 @@ void run(float* d_out, int waves_per_simd)
 }
 
 template <int KIND>
-void sweep(float* d_out) { run<KIND>(d_out, 1); run<KIND>(d_out, 2); run<KIND>(d_out, 5); run<KIND>(d_out, 8); }
+void sweep(float* d_out) { run<KIND>(d_out, 1); run<KIND>(d_out, 5); run<KIND>(d_out, 8); }
 
-int main()
+int main(int argc, char** argv)
 {
     float* d_out;
     CHECK(hipMalloc(&d_out, 1024));
+    const bool all = argc < 2;
+    if (all) {
     sweep<0>(d_out); sweep<1>(d_out); sweep<2>(d_out); sweep<3>(d_out); sweep<4>(d_out); sweep<5>(d_out); sweep<6>(d_out); sweep<7>(d_out);
     sweep<8>(d_out); sweep<9>(d_out); sweep<10>(d_out); sweep<11>(d_out); sweep<12>(d_out); sweep<13>(d_out); sweep<14>(d_out);
     sweep<15>(d_out); sweep<16>(d_out); sweep<17>(d_out);
+    }
+    {
+    sweep<18>(d_out); sweep<19>(d_out); sweep<20>(d_out); sweep<21>(d_out); sweep<22>(d_out); sweep<23>(d_out); sweep<24>(d_out);
+    sweep<25>(d_out); sweep<26>(d_out); sweep<27>(d_out); sweep<28>(d_out); sweep<29>(d_out);
+    }
     return 0;
 }

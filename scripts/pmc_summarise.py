@@ -32,7 +32,7 @@ for k, v in out.items():
         v["traffic_bytes"] = v["hbm_read_bytes_x2_gfx950"] + v["hbm_write_bytes"]
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_pmc_summary.json")
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
-for k in ("blend_backward_kernel", "blend_forward_kernel"):
-    if k in out:
-        print(k, {c: round(x) for c, x in out[k].items() if c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "traffic_bytes", "hbm_write_bytes", "hbm_read_bytes_x2_gfx950")})
+for k in sorted(out):
+    print(k, {c: round(x) for c, x in out[k].items() if c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES",
+                                                             "GRBM_GUI_ACTIVE", "traffic_bytes", "hbm_write_bytes", "hbm_read_bytes_x2_gfx950")})
 print("wrote", dst)

@@ -12,7 +12,7 @@ from activesplat_amd import GaussianRasterizer, _lib, setup_camera  # noqa: E402
 from activesplat_amd import synthetic as syn  # noqa: E402
 
 
-def run(N=500_000, W=640, H=480, steps=30, warmup=5, backward=True):
+def run(N=500_000, W=640, H=480, steps=int(os.environ.get("STEPS", 30)), warmup=int(os.environ.get("WARMUP", 5)), backward=True):
     dev = torch.device("cuda")
     sh = os.environ.get("SH")
     cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=dev, sh_degree=int(sh) if sh else 0)
