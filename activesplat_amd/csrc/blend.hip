@@ -49,6 +49,26 @@ __device__ __forceinline__ bool tile_ctx(const Cam& cam, int wave, int lane, Til
     return true;
 }
 
+// The same for workgroups of NW < 4 wavefronts (the quadrants of a tile are independent): workgroup b of XCD b & 7 takes
+// quadrant-group (b >> 3) of that XCD's tile band, so a tile's quadrants run on one XCD and its records stay in one L2.
+template <int NW>
+__device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, TileCtx& c)
+{
+    if (NW == 4) return tile_ctx(cam, wave, lane, c);
+    constexpr int G = 4 / NW;                               // workgroups per tile
+    const int ntiles = cam.gx * cam.gy, per = (ntiles + 7) >> 3;
+    const int idx = (int)(blockIdx.x >> 3);
+    c.tile = (int)(blockIdx.x & 7) * per + idx / G;
+    if (idx / G >= per || c.tile >= ntiles) return false;
+    const int quad = (idx % G) * NW + wave;
+    c.tx = c.tile % cam.gx; c.ty = c.tile / cam.gx;
+    const int qx = c.tx * kTile + (quad & 1) * kQuad, qy = c.ty * kTile + (quad >> 1) * kQuad;
+    c.px = qx + (lane & 7); c.py = qy + (lane >> 3);
+    c.qx0 = (float)qx; c.qy0 = (float)qy; c.pxf = (float)c.px; c.pyf = (float)c.py;
+    c.inside = c.px < cam.W && c.py < cam.H;
+    return true;
+}
+
 // does the record's alpha-visible box overlap the 8x8 quadrant at pixel origin (qx0,qy0)?
 __device__ __forceinline__ bool quadrant_hit(const float4& q0, const float4& q2, float qx0, float qy0)
 {
@@ -275,90 +295,53 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Backward: back-to-front replay.  Same independent-quadrant walk and the same four record streams as the forward (one
-// per 16-lane DPP row = 4x4 pixel block of the quadrant), lists built deepest-first, two list entries per iteration:
-//   * branch-free replay step per record (T divided back, behind-colour accumulator, dL/dalpha);
-//   * the ten per-pixel partials are reduced WITHIN each row by a transposed DPP butterfly (row_reduce10: 22-29 VALU, no
-//     cross-row traffic, the totals land one component per lane);
-//   * the row totals go to per-wave LDS accumulators (one 16-float slot per staged record): plain read-add-write when the
-//     four rows hold distinct records in that step, ds_add_f32 at the list positions where two rows hold the same record
-//     (found once per chunk: lane t compares position t of the four lists); after the chunk every record that received
-//     something is flushed with ONE global fp32 atomic request (6 records x 10 components per instruction).
-//   Why: adding every (row, record) total straight to HBM made the kernel atomic-bound -- the memory-side atomic units
-//   saturate near 140 G dword atomics/s (38.5 M per frame = 272 us against 186 us with the atomics removed); LDS float
-//   atomics retire ~1 lane per clock per CU, hence the plain path.  The global records are 64-byte aligned
-//   (kGradStride = 16 floats): device-scope atomics are read-modify-writes of whole lines at the memory side on this
-//   multi-XCD part, and a 48-byte stride that lets half the records straddle two lines cost +100 us per launch.
-//   Resources: 30 KB of LDS and <= 96 VGPRs per workgroup/wave -- FIVE workgroups per CU must stay resident (1200 tile
-//   workgroups / 256 CUs = 4.7); four cost 25 % (see amdgpu_waves_per_eu below).
-// ---------------------------------------------------------------------------------------------------
-// Transposed in-row butterfly: the 16-lane row sums of up to TEN values in 29 VALU (instead of 9 x 4 DPP adds
-// plus an 8-deep select chain).  At every level two registers are merged into one: each lane keeps the
-// register its half is responsible for and receives, through one DPP add, the partner lane's copy of
-// the same register.  Partner maps: lane^8 (row_ror:8), mirror within 8 (row_half_mirror), lane^2 and
-// lane^1 (quad_perm).  Afterwards lane l of the row holds the row total of component row_comp(l).
-#define GS_DPP_ADD(keep, send, ctrl) ((keep) + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), ctrl, 0xf, 0xf, true)))
-// Merge of two registers at a level whose lane split coincides with DPP banks (4 consecutive lanes): the lanes of the banks in
-// mask M0 end with x0 + x0[partner], the others with x1 + x1[partner] -- two bank-masked v_add_f32_dpp, no select.  (The
-// generic form needs two v_cndmask and one DPP add.)  s_nop 1: the two wait states a DPP read needs after a VALU write.
-#ifndef GS_ROW_MERGE
-#define GS_ROW_MERGE(dst, x0, x1, CTRL_STR, CTRL, M0_STR, M1_STR, M0)                                                         \
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 " CTRL_STR " row_mask:0xf bank_mask:" M0_STR "\n\t"                              \
-        "v_add_f32_dpp %0, %2, %2 " CTRL_STR " row_mask:0xf bank_mask:" M1_STR                                                \
-        : "=&v"(dst) : "v"(x0), "v"(x1))
-#endif
-__device__ __forceinline__ float row_reduce10(const float (&v)[10], bool b8, bool b4, bool b2, bool b1)
-{
-    // level A: partner lane^8 (row_ror:8); lanes 0-7 = banks 0,1 keep the even register, lanes 8-15 the odd one
-    float a0, a1, a2, a3, a4;
-    GS_ROW_MERGE(a0, v[0], v[1], "row_ror:8", 0x128, "0x3", "0xc", 0x3);
-    GS_ROW_MERGE(a1, v[2], v[3], "row_ror:8", 0x128, "0x3", "0xc", 0x3);
-    GS_ROW_MERGE(a2, v[4], v[5], "row_ror:8", 0x128, "0x3", "0xc", 0x3);
-    GS_ROW_MERGE(a3, v[6], v[7], "row_ror:8", 0x128, "0x3", "0xc", 0x3);
-    GS_ROW_MERGE(a4, v[8], v[9], "row_ror:8", 0x128, "0x3", "0xc", 0x3);
-    // level B: partner = mirror within the 8-lane half (row_half_mirror); lanes with bit 2 clear = banks 0,2
-    float c0, c1;
-    GS_ROW_MERGE(c0, a0, a1, "row_half_mirror", 0x141, "0x5", "0xa", 0x5);
-    GS_ROW_MERGE(c1, a2, a3, "row_half_mirror", 0x141, "0x5", "0xa", 0x5);
-    const float c2 = GS_DPP_ADD(a4, a4, 0x141);
-    // level C: partner lane^2
-    const float e0 = GS_DPP_ADD(b2 ? c1 : c0, b2 ? c0 : c1, 0x4E);              // quad_perm:[2,3,0,1]
-    const float e1 = GS_DPP_ADD(c2, c2, 0x4E);
-    // level D: partner lane^1
-    return GS_DPP_ADD(b1 ? e1 : e0, b1 ? e0 : e1, 0xB1);                         // quad_perm:[1,0,3,2]
-}
-// component carried by lane l16 of a row after row_reduce10 (odd lanes hold component 8 (lanes 1..7) or
-// 9 (lanes 9..15): lanes 1 and 9 are used)
-__device__ __forceinline__ int row_comp(int l16, bool with9)
-{
-    if (l16 & 1) return l16 == 1 ? 8 : ((l16 == 9 && with9) ? 9 : -1);
-    return ((l16 & 2) ? 4 : 0) + ((l16 & 4) ? 2 : 0) + ((l16 & 8) ? 1 : 0);
-}
-
-// Per-Gaussian 2-D gradient record accumulated here (raw moments; the conic algebra is finished per
-// Gaussian in preprocess_bwd.hip):  with Z = G dL/dG, d = mean - pixel
+// Backward: back-to-front replay in two phases per batch of list positions.  Same independent-quadrant walk and the same four
+// record streams as the forward (one per 16-lane row = 4x4 pixel block of the quadrant), lists built deepest-first.
+//
+// Per-Gaussian 2-D gradient record accumulated here (raw moments; the conic algebra is finished per Gaussian in
+// preprocess_bwd.hip):  with Z = G dL/dG, d = mean - pixel
 //   0: sum Z dx   1: sum Z dy   2: sum Z dx dx   3: sum Z dx dy   4: sum Z dy dy   5: sum G dL/dalpha   6..8: sum w dL/dC
-//   9: sum w dL/d(depth)   (DEPTH_GRAD: the depth output is one more blended channel whose per-Gaussian value
-//      is the view-space z; this is the fused replacement of the reference's second, [z,1,z^2] raster pass)
-// 1200 tile workgroups on 256 CUs = 4.7 resident waves per SIMD: the kernel must fit FIVE waves per SIMD (<= 96 VGPRs after the
-// allocation granularity); at 97 VGPRs the depth-gradient instantiation dropped to four and ran 277 us instead of ~215
-template <bool DEPTH_GRAD>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void blend_backward_kernel(
+//   9: sum w dL/d(depth)   (DEPTH_GRAD: the depth output is one more blended channel whose per-Gaussian value is the
+//      view-space z; this is the fused replacement of the reference's second, [z,1,z^2] raster pass)
+//
+// The expensive part of a one-phase walk (round 1: 213 us on BASELINE configs[1]) was summing those ten moments over the 16 pixels
+// of a row for every (row, record) pair: a transposed DPP butterfly (35 DPP adds + selects per two-record iteration, each a 4.2-cycle
+// issue slot against 2.7 for a plain add -- scripts/exp/valu_issue.hip) plus LDS float atomics (3 clk per lane) wherever two rows
+// held the same record.  Here the replay (lane = pixel) only produces the two per-pixel SCALARS every moment is built from --
+// GdA = G dL/dalpha (Z = opacity x GdA) and w = alpha T -- and hands them through a per-wave LDS exchange to a second phase in
+// which a lane is a (row, list position) PAIR that owns all 16 pixels of its block:
+//   phase A (up to 16 list positions per batch, two per iteration): alpha, branch-free replay step (T divided back, one
+//           behind-colour accumulator, dL/dalpha), 2 x ds_write_b32 per record, lane-contiguous;
+//   phase B (once per batch): lane (position t, row r) reads its block's 2 x 16 scalars with eight conflict-free ds_read_b128
+//           (plane rows are 68 floats apart), forms the ten moments with plain FMAs against ITS pixels' coordinates and dL/dcolour
+//           (48 registers, loaded once per kernel), factored into column / row sums; writes them as the pair's 12-float slot;
+//   gather : lane = staged record j knows its position in each row's list (its own mbcnt rank from the list build), so it reads the
+//           slots of its <= 4 pairs of this batch and adds them to ten REGISTER accumulators -- no LDS read-modify-write, no atomics;
+//   flush  : once per 64-record chunk the records some row hit put their sums into the idle exchange planes and leave with one
+//           global fp32 atomic request per (quadrant, record), 6 records x 10 components per instruction, into 64-byte-aligned
+//           gradient records (a device-scope atomic is a read-modify-write of a whole line at the memory side on this multi-XCD part).
+// Measured (profiles/README.md, round 2): 184 us on configs[1], 262 us at 2 M Gaussians; VALU wave-instructions per launch 99 M -> 70 M.
+// LDS 11.8 KB per wave; the wavefronts share nothing, so a workgroup is ONE wavefront (NW = 1): LDS and CU slots are handed out at
+// that granularity and 4800 small workgroups drain more evenly than 1200 whole-tile ones.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kBT = 16;                // list positions per batch: 16 x 4 rows = one (row, position) pair per lane in phase B
+constexpr int kMT = kWave + 4;         // floats per position in an exchange plane: +4 makes phase B's b128 reads conflict-free
+constexpr int kPairStride = 12;        // floats per pair / record slot in the sum exchanges: components 0-4 at [0,5), 5-9 at [6,11)
+constexpr int kMPlane = (kBT - 1) * kMT + kWave;   // floats of one exchange plane
+
+template <bool DEPTH_GRAD, int NW>
+__global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, float* __restrict__ grad2d)
 {
-    __shared__ float4 s_rec[kBlock / kWave][3][kWave + 1];           // + the sentinel slot
-    __shared__ __attribute__((aligned(16))) uint8_t s_list[kBlock / kWave][4 * kWave + 16];  // per-row record lists of the staged chunk (+ look-ahead pad)
-    // per-wave gradient accumulators of the staged chunk: slot j = record j, 16 floats like the global record.  The rows add
-    // their reduced moments here (LDS atomics) and the chunk is flushed ONCE per record with global atomics: the kernel is
-    // bound by the memory-side atomic units (38.5 M dword atomics per frame when every (row, record) pair went to HBM
-    // directly: 272 us, against 186 us with the atomics removed), and a record is seen by 2.2 of the 4 rows on average.
-    __shared__ __attribute__((aligned(16))) float s_acc[kBlock / kWave][kWave * kGradStride];
+    __shared__ float4 s_rec[NW][3][kWave + 1];           // + the sentinel slot
+    __shared__ __attribute__((aligned(16))) uint8_t s_list[NW][4 * kWave + 16];
+    __shared__ __attribute__((aligned(16))) float s_m[NW][2][kMPlane];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
-    if (!tile_ctx(cam, wave, lane, c)) return;
-    // lane -> pixel: row (lane>>4) = 4x4 sub-block, (lane&15) = pixel inside it
+    if (!tile_ctx_nw<NW>(cam, wave, lane, c)) return;
+    // phase A role: row (lane>>4) = 4x4 sub-block, (lane&15) = pixel inside it
     const int row = lane >> 4, l16 = lane & 15;
     const int px = (int)c.qx0 + (row & 1) * 4 + (l16 & 3), py = (int)c.qy0 + (row >> 1) * 4 + (l16 >> 2);
     const bool inside = px < cam.W && py < cam.H;
@@ -366,10 +349,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
     write_sentinel(s0, s1, s2, lane);
     const uint8_t* my_list = s_list[wave] + row * kWave;
-    float* acc_lds = s_acc[wave];
-#pragma unroll
-    for (int k = 0; k < kGradStride; k++) acc_lds[k * kWave + lane] = 0.0f;          // zeroed once; the flush re-zeroes what it drains
+    float* pair_lds = s_m[wave][0];                          // the pair sums overwrite the scalars phase B has consumed
+    float* m1p = s_m[wave][0]; float* m2p = s_m[wave][1];
     const int fl_rec = lane / 10, fl_comp = lane - fl_rec * 10;                  // flush mapping: 6 records x 10 components per instruction
+    const int fl_off = fl_comp < 5 ? fl_comp : fl_comp + 1;
     const uint2 range = ranges[c.tile];
     const uint32_t* list = point_list + range.x;
     const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
@@ -382,16 +365,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
     const float tfbg = Tf * (cam.bg[0] * d0 + cam.bg[1] * d1 + cam.bg[2] * d2);    // background term of dL/dalpha
     float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accz = 0.f;
 
-    // the deepest contributor of any pixel of this quadrant bounds the replay
     uint32_t wmax = last;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor(wmax, m));
     if (wmax == 0) return;
 
-    const bool b8 = (l16 & 8) != 0, b4 = (l16 & 4) != 0, b2 = (l16 & 2) != 0, b1 = (l16 & 1) != 0;
-    const int my_comp = row_comp(l16, DEPTH_GRAD);
+    // phase B role: the block of row rb at list position tb of the batch; its 16 pixels' dL/dcolour stay in registers
+    const int tb = lane >> 2, rb = lane & 3;
+    const int bxb = (int)c.qx0 + (rb & 1) * 4, byb = (int)c.qy0 + (rb >> 1) * 4;
+    float e0[16], e1[16], e2[16], ez[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int x = bxb + (i & 3), y = byb + (i >> 2);
+        const bool in = x < cam.W && y < cam.H;
+        const size_t p = (size_t)y * cam.W + x;
+        e0[i] = in ? dL_dcolor[p] : 0.f; e1[i] = in ? dL_dcolor[HW + p] : 0.f; e2[i] = in ? dL_dcolor[2 * HW + p] : 0.f;
+        ez[i] = (DEPTH_GRAD && in) ? dL_ddepth[p] : 0.f;
+    }
+    const float bxf = (float)bxb, byf = (float)byb;
+    const int m_rd = tb * kMT + rb * 16;                         // phase B read offset inside a plane
+    const uint8_t* list_b = s_list[wave] + rb * kWave + tb;
+
     const int cmax = (int)((wmax - 1) / kWave);
-    // pipeline prologue (walking chunks downwards): ids of chunks cmax and cmax-1, records of chunk cmax
     uint32_t id_next = (uint32_t)cmax * kWave + lane < wmax ? list[cmax * kWave + lane] : kNoId;
     uint32_t id_next2 = cmax >= 1 ? list[(cmax - 1) * kWave + lane] : kNoId;
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
@@ -410,123 +405,154 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
         const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
         if ((m0 | m1 | m2 | m3) == 0ull) continue;
         stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
-        // per-row lists in LDS, DEEPEST record first: sentinel fill (one store per lane = 4 x 64 bytes), then every lane
-        // whose record hits row r drops its index at position (#hits of row r above this lane)
-        reinterpret_cast<uint32_t*>(s_list[wave])[lane] = 0x40404040u;
+        reinterpret_cast<uint32_t*>(s_list[wave])[lane] = 0x40404040u;          // sentinel fill: one store per lane = 4 x 64 bytes
         __builtin_amdgcn_wave_barrier();
         const int n0 = (int)__popcll(m0), n1 = (int)__popcll(m1), n2 = (int)__popcll(m2), n3 = (int)__popcll(m3);
 #define GS_RANK(m) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u)))
-        if (h0) s_list[wave][0 * kWave + n0 - 1 - GS_RANK(m0)] = (uint8_t)lane;
-        if (h1) s_list[wave][1 * kWave + n1 - 1 - GS_RANK(m1)] = (uint8_t)lane;
-        if (h2) s_list[wave][2 * kWave + n2 - 1 - GS_RANK(m2)] = (uint8_t)lane;
-        if (h3) s_list[wave][3 * kWave + n3 - 1 - GS_RANK(m3)] = (uint8_t)lane;
+        // deepest record first; the lane (= record) remembers where it sits in every row's list (0xff: not in that row's list)
+        const int p0 = h0 ? n0 - 1 - GS_RANK(m0) : 0xff, p1 = h1 ? n1 - 1 - GS_RANK(m1) : 0xff;
+        const int p2 = h2 ? n2 - 1 - GS_RANK(m2) : 0xff, p3 = h3 ? n3 - 1 - GS_RANK(m3) : 0xff;
+        if (h0) s_list[wave][0 * kWave + p0] = (uint8_t)lane;
+        if (h1) s_list[wave][1 * kWave + p1] = (uint8_t)lane;
+        if (h2) s_list[wave][2 * kWave + p2] = (uint8_t)lane;
+        if (h3) s_list[wave][3 * kWave + p3] = (uint8_t)lane;
 #undef GS_RANK
+        float racc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    // this record's moments, summed over rows and batches
         const int ntrips = max(max(n0, n1), max(n2, n3));
         __builtin_amdgcn_wave_barrier();
-        // list positions at which two rows hold the SAME record (lane t looks at position t of the four lists)
-        unsigned long long clash_mask;
-        {
-            const uint8_t* L = s_list[wave];
-            const int e0 = L[lane], e1 = L[kWave + lane], e2 = L[2 * kWave + lane], e3 = L[3 * kWave + lane];
-            clash_mask = __ballot((e0 != kWave && (e0 == e1 || e0 == e2 || e0 == e3)) || (e1 != kWave && (e1 == e2 || e1 == e3)) ||
-                                  (e2 != kWave && e2 == e3));
-        }
-        // TWO list entries per iteration (one 16-bit LDS read, fetched one iteration ahead): the alpha evaluations and the two
-        // in-row reductions of a pair are independent instruction chains that the scheduler interleaves; only the short
-        // T / behind-colour update is serial.  An odd tail pairs the last record with the sentinel.
-        uint32_t jj2_next = *reinterpret_cast<const uint16_t*>(my_list);
-        for (int t = 0; t < ntrips; t += 2) {
-            const uint32_t jj2 = jj2_next;
-            jj2_next = *reinterpret_cast<const uint16_t*>(my_list + t + 2);
-            const int jj[2] = {(int)(jj2 & 0xffu), (int)(jj2 >> 8)};
-            float4 a0[2], a1[2], a2[2];
-            float dx[2], dy[2], G[2], alpha[2];
-            bool ok[2];
+        for (int t0 = 0; t0 < ntrips; t0 += kBT) {
+            // ---- phase A: up to kBT list positions, two per iteration ----
+            const int tend = min(kBT, ntrips - t0);
+            uint32_t jj2_next = *reinterpret_cast<const uint16_t*>(my_list + t0);
+            for (int t = 0; t < tend; t += 2) {
+                const uint32_t jj2 = jj2_next;
+                jj2_next = *reinterpret_cast<const uint16_t*>(my_list + t0 + t + 2);
+                const int jj[2] = {(int)(jj2 & 0xffu), (int)(jj2 >> 8)};
+                float4 a0[2], a1[2], a2[2];
+                float dx[2], dy[2], G[2], alpha[2];
+                bool ok[2];
 #pragma unroll
-            for (int u = 0; u < 2; u++) { a0[u] = s0[jj[u]]; a1[u] = s1[jj[u]]; a2[u] = s2[jj[u]]; }
+                for (int u = 0; u < 2; u++) { a0[u] = s0[jj[u]]; a1[u] = s1[jj[u]]; a2[u] = s2[jj[u]]; }
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t pos = (uint32_t)ch * kWave + (uint32_t)jj[u];       // 0-based position in the tile list
-                dx[u] = a0[u].x - pxf; dy[u] = a0[u].y - pyf;
-                const float p = (a0[u].z * dx[u] + a0[u].w * dy[u]) * dx[u] + (a1[u].x * dy[u]) * dy[u];
-                G[u] = __builtin_amdgcn_exp2f(p);
-                alpha[u] = fminf(0.99f, a1[u].y * G[u]);
-                ok[u] = pos < last && p <= 0.0f && alpha[u] >= kAlphaMin;
-            }
-            const unsigned long long okm0 = __ballot(ok[0]), okm1 = __ballot(ok[1]);
-            if ((okm0 | okm1) == 0ull) continue;
-            // branch-free replay steps, deeper record first.  `acc` is the colour composited BEHIND the current record; after
-            // the record's gradient is taken it absorbs the record: acc += alpha (c - acc).  Lanes that do not contribute run
-            // with alpha = 0, G = 0 (T, acc unchanged, all partials zero).
-            float v[2][10];
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const float a_eff = ok[u] ? alpha[u] : 0.0f;
-                const float G_eff = ok[u] ? G[u] : 0.0f;
-                const float rcp = __builtin_amdgcn_rcpf(1.0f - a_eff);
-                T = T * rcp;                                      // transmittance in front of this record
-                const float df0 = a1[u].z - acc0, df1 = a1[u].w - acc1, df2 = a2[u].x - acc2;
-                float dot = df0 * d0 + df1 * d1 + df2 * d2;
-                if (DEPTH_GRAD) {
-                    const float dfz = a2[u].y - accz;
-                    dot += dfz * dz_;
-                    accz += a_eff * dfz;
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t pos = (uint32_t)ch * kWave + (uint32_t)jj[u];       // 0-based position in the tile list
+                    dx[u] = a0[u].x - pxf; dy[u] = a0[u].y - pyf;
+                    const float p = (a0[u].z * dx[u] + a0[u].w * dy[u]) * dx[u] + (a1[u].x * dy[u]) * dy[u];
+                    G[u] = __builtin_amdgcn_exp2f(p);
+                    alpha[u] = fminf(0.99f, a1[u].y * G[u]);
+                    ok[u] = pos < last && p <= 0.0f && alpha[u] >= kAlphaMin;
                 }
-                const float dL_dalpha = dot * T - tfbg * rcp;
-                const float w = a_eff * T;
-                acc0 += a_eff * df0; acc1 += a_eff * df1; acc2 += a_eff * df2;
-                const float GdA = G_eff * dL_dalpha;
-                const float Z = a1[u].y * GdA;                    // G dL/dG
-                const float zx = Z * dx[u], zy = Z * dy[u];
-                v[u][0] = zx; v[u][1] = zy; v[u][2] = zx * dx[u]; v[u][3] = zx * dy[u]; v[u][4] = zy * dy[u]; v[u][5] = GdA;
-                v[u][6] = w * d0; v[u][7] = w * d1; v[u][8] = w * d2; v[u][9] = DEPTH_GRAD ? w * dz_ : 0.0f;
-            }
-            const float x0 = row_reduce10(v[0], b8, b4, b2, b1);
-            const float x1 = row_reduce10(v[1], b8, b4, b2, b1);
-            // every row that had a contributing pixel adds its 9 (10) components to ITS record: one hardware fp32 atomic
-            // instruction, 9-10 lanes per row, each record's components inside one 64-byte line (kGradStride = 16)
-            const bool any0 = ((okm0 >> (row * 16)) & 0xffffull) != 0ull, any1 = ((okm1 >> (row * 16)) & 0xffffull) != 0ull;
-            // LDS float atomics retire ~1 lane per clock: use them only when two rows hold the SAME record in this step (44 % of
-            // the steps); otherwise every row owns its slot and a plain read-add-write is enough (LDS ops of a wave stay in order)
-            const float xs[2] = {x0, x1};
-            const bool anys[2] = {any0, any1};
+                float* w1 = m1p + (t * kMT + lane); float* w2 = m2p + (t * kMT + lane);
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const bool clash = ((clash_mask >> (t + u)) & 1ull) != 0ull;
-                float* a = acc_lds + jj[u] * kGradStride + my_comp;
-                if (clash) { if (anys[u] && my_comp >= 0) atomicAdd(a, xs[u]); }
-                else if (anys[u] && my_comp >= 0) *a = *a + xs[u];
-                // the next step's slot of another row may be THIS step's slot of this row: keep the LDS accesses of the two
-                // steps in program order (LDS executes a wave's operations in order)
-                __builtin_amdgcn_wave_barrier();
+                for (int u = 0; u < 2; u++) {
+                    // branch-free replay step (deeper record first); lanes that do not contribute run with alpha = 0, G = 0
+                    const float a_eff = ok[u] ? alpha[u] : 0.0f;
+                    const float G_eff = ok[u] ? G[u] : 0.0f;
+                    const float rcp = __builtin_amdgcn_rcpf(1.0f - a_eff);
+                    T = T * rcp;                                      // transmittance in front of this record
+                    const float df0 = a1[u].z - acc0, df1 = a1[u].w - acc1, df2 = a2[u].x - acc2;
+                    float dot = df0 * d0 + df1 * d1 + df2 * d2;
+                    if (DEPTH_GRAD) {
+                        const float dfz = a2[u].y - accz;
+                        dot += dfz * dz_;
+                        accz += a_eff * dfz;
+                    }
+                    const float dL_dalpha = dot * T - tfbg * rcp;
+                    acc0 += a_eff * df0; acc1 += a_eff * df1; acc2 += a_eff * df2;
+                    const float GdA = G_eff * dL_dalpha;
+                    w1[u * kMT] = GdA;                                // (Z = G dL/dG = opacity x GdA is formed in phase B)
+                    w2[u * kMT] = a_eff * T;                          // blend weight
+                }
             }
+            __builtin_amdgcn_wave_barrier();
+            // ---- phase B: lane = (half hb, position tb, row rb) ----
+            {
+                const int jjb = (int)list_b[t0];
+                const float4 rc = s0[jjb];
+                const float opb = s1[jjb].y;
+                const float4* gp4 = reinterpret_cast<const float4*>(m1p + m_rd);
+                const float4* wp4 = reinterpret_cast<const float4*>(m2p + m_rd);
+                const float4 g0 = gp4[0], g1 = gp4[1], g2 = gp4[2], g3 = gp4[3];
+                const float4 v0 = wp4[0], v1 = wp4[1], v2 = wp4[2], v3 = wp4[3];
+                const float gg[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
+                const float ww[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+                const float ddx[4] = {rc.x - bxf, rc.x - (bxf + 1.0f), rc.x - (bxf + 2.0f), rc.x - (bxf + 3.0f)};
+                const float ddy[4] = {rc.y - byf, rc.y - (byf + 1.0f), rc.y - (byf + 2.0f), rc.y - (byf + 3.0f)};
+                // moments of the 4x4 block, factored: column sums for the x moments, row sums for the y moments, row-wise x-weighted
+                // sums for the cross moment; Z = G dL/dG = opacity x GdA is applied once per sum
+                float gc[4], gr[4], rx[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    gc[q] = (gg[q] + gg[4 + q]) + (gg[8 + q] + gg[12 + q]);
+                    gr[q] = (gg[4 * q] + gg[4 * q + 1]) + (gg[4 * q + 2] + gg[4 * q + 3]);
+                    rx[q] = fmaf(gg[4 * q + 3], ddx[3], fmaf(gg[4 * q + 2], ddx[2], fmaf(gg[4 * q + 1], ddx[1], gg[4 * q] * ddx[0])));
+                }
+                const float t0x = gc[0] * ddx[0], t1x = gc[1] * ddx[1], t2x = gc[2] * ddx[2], t3x = gc[3] * ddx[3];
+                const float u0 = gr[0] * ddy[0], u1 = gr[1] * ddy[1], u2 = gr[2] * ddy[2], u3 = gr[3] * ddy[3];
+                float sm[10];
+                sm[0] = opb * ((rx[0] + rx[1]) + (rx[2] + rx[3]));
+                sm[1] = opb * ((u0 + u1) + (u2 + u3));
+                sm[2] = opb * fmaf(t3x, ddx[3], fmaf(t2x, ddx[2], fmaf(t1x, ddx[1], t0x * ddx[0])));
+                sm[3] = opb * fmaf(rx[3], ddy[3], fmaf(rx[2], ddy[2], fmaf(rx[1], ddy[1], rx[0] * ddy[0])));
+                sm[4] = opb * fmaf(u3, ddy[3], fmaf(u2, ddy[2], fmaf(u1, ddy[1], u0 * ddy[0])));
+                sm[5] = (gr[0] + gr[1]) + (gr[2] + gr[3]);
+                sm[6] = ww[0] * e0[0]; sm[7] = ww[0] * e1[0]; sm[8] = ww[0] * e2[0]; sm[9] = DEPTH_GRAD ? ww[0] * ez[0] : 0.0f;
+#pragma unroll
+                for (int i = 1; i < 16; i++) {
+                    sm[6] = fmaf(ww[i], e0[i], sm[6]); sm[7] = fmaf(ww[i], e1[i], sm[7]); sm[8] = fmaf(ww[i], e2[i], sm[8]);
+                    if (DEPTH_GRAD) sm[9] = fmaf(ww[i], ez[i], sm[9]);
+                }
+                // pair sums -> LDS (over the scalars just consumed: every lane has issued its reads; LDS serves a wave in order),
+                // then every RECORD lane picks up the pairs of its record
+                __builtin_amdgcn_wave_barrier();
+                float4* ps = reinterpret_cast<float4*>(pair_lds + lane * kPairStride);
+                ps[0] = make_float4(sm[0], sm[1], sm[2], sm[3]);
+                ps[1] = make_float4(sm[4], 0.f, sm[5], sm[6]);
+                ps[2] = make_float4(sm[7], sm[8], sm[9], 0.f);
+            }
+            __builtin_amdgcn_wave_barrier();
+            {
+                const int pr[4] = {p0 - t0, p1 - t0, p2 - t0, p3 - t0};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if ((unsigned)pr[r] < (unsigned)kBT) {
+                        const float4* q = reinterpret_cast<const float4*>(pair_lds + (pr[r] * 4 + r) * kPairStride);
+                        const float4 qa = q[0], qb = q[1], qc = q[2];
+                        racc[0] += qa.x; racc[1] += qa.y; racc[2] += qa.z; racc[3] += qa.w; racc[4] += qb.x;
+                        racc[5] += qb.z; racc[6] += qb.w; racc[7] += qc.x; racc[8] += qc.y; racc[9] += qc.z;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        // flush: the records some row hit (union of the four ballots), 6 records x 10 components per global atomic instruction,
-        // software-pipelined (slot index two groups ahead, value and Gaussian id one group ahead).  Components that received
-        // nothing stay out, so a record none of whose pixels passed alpha >= 1/255 costs no request.
+        // flush: the records some row hit (union of the four ballots) put their ten sums into the (now idle) exchange planes; then
+        // 6 records x 10 components per global atomic instruction, software-pipelined
         __builtin_amdgcn_wave_barrier();
         {
             const unsigned long long many = m0 | m1 | m2 | m3;
             const int n_any = (int)__popcll(many);
+            float* fls = s_m[wave][0];                          // 64 x 12 floats <= 2 planes
             uint8_t* ulist = s_list[wave];                     // the row lists are spent: reuse their space for the union list
-            if ((many >> lane) & 1ull)
+            if ((many >> lane) & 1ull) {
                 ulist[(int)__builtin_amdgcn_mbcnt_hi((uint32_t)(many >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)many, 0u))] = (uint8_t)lane;
+                float4* f4 = reinterpret_cast<float4*>(fls + lane * kPairStride);
+                f4[0] = make_float4(racc[0], racc[1], racc[2], racc[3]);
+                f4[1] = make_float4(racc[4], 0.f, racc[5], racc[6]);
+                f4[2] = make_float4(racc[7], racc[8], racc[9], 0.f);
+            }
             __builtin_amdgcn_wave_barrier();
             const int krec = min(fl_rec, 5);                   // lanes 60..63 idle along with record 5's mapping (never valid)
-            int slot_c = (int)ulist[krec];                                          // group 0
-            int slot_n = (int)ulist[6 + krec];                                      // group 1 (entries beyond n_any are stale: masked below)
+            int slot_c = (int)ulist[krec];
+            int slot_n = (int)ulist[6 + krec];
             bool valid_c = lane < 60 && krec < n_any;
-            float val_c = valid_c ? acc_lds[slot_c * kGradStride + fl_comp] : 0.0f;
+            float val_c = valid_c ? fls[slot_c * kPairStride + fl_off] : 0.0f;
             uint32_t id_c = valid_c ? __float_as_uint(s2[slot_c].z) : 0u;
             for (int g = 0; g < n_any; g += 6) {
                 const bool valid_n = lane < 60 && g + 6 + krec < n_any;
-                const float val_n = valid_n ? acc_lds[slot_n * kGradStride + fl_comp] : 0.0f;
+                const float val_n = valid_n ? fls[slot_n * kPairStride + fl_off] : 0.0f;
                 const uint32_t id_n = valid_n ? __float_as_uint(s2[slot_n].z) : 0u;
                 const int slot_nn = (int)ulist[min(g + 12 + krec, 4 * kWave + 15)];
-                if (val_c != 0.0f) {
-                    acc_lds[slot_c * kGradStride + fl_comp] = 0.0f;
-                    atomicAdd(grad2d + (size_t)id_c * kGradStride + fl_comp, val_c);
-                }
+                if (val_c != 0.0f) atomicAdd(grad2d + (size_t)id_c * kGradStride + fl_comp, val_c);
                 slot_c = slot_n; slot_n = slot_nn; val_c = val_n; id_c = id_n;
             }
         }
@@ -564,12 +590,13 @@ hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  const float* dL_ddepth, float* grad2d, hipStream_t st)
 {
-    const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
+    // one-wavefront workgroups (see blend_backward_kernel): per XCD band ceil(tiles/8) tiles x 4 quadrants
+    const int per = (cam.gx * cam.gy + 7) >> 3;
     if (dL_ddepth)
-        hipLaunchKernelGGL(blend_backward_kernel<true>, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
+        hipLaunchKernelGGL((blend_backward_kernel<true, 1>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom,
                            final_T, n_contrib, dL_dcolor, dL_ddepth, grad2d);
     else
-        hipLaunchKernelGGL(blend_backward_kernel<false>, dim3(nb), dim3(kBlock), 0, st, cam, ranges, point_list, geom,
+        hipLaunchKernelGGL((blend_backward_kernel<false, 1>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom,
                            final_T, n_contrib, dL_dcolor, dL_ddepth, grad2d);
     return hipGetLastError();
 }
