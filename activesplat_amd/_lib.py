@@ -51,7 +51,8 @@ SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_sc
            "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_preprocess_forward", "gs_render_forward", "gs_render_backward", "gs_adam_step", "gs_adam_step_multi",
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
            "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward",
-           "gs_grow_scratch_bytes", "gs_grow_gaussians", "gs_keyframe_overlap", "gs_visibility_stats", "gs_accumulate_grad2d")
+           "gs_grow_scratch_bytes", "gs_grow_gaussians", "gs_keyframe_overlap", "gs_visibility_stats", "gs_accumulate_grad2d",
+           "gs_gather_rows_zero_tail", "gs_densify_classify", "gs_densify_children")
 
 
 def _bind(lib):
@@ -92,6 +93,12 @@ def _bind(lib):
     lib.gs_compact_index.restype = C.c_int
     lib.gs_gather_rows.argtypes = [i64, i32, vp, vp, vp, vp]
     lib.gs_gather_rows.restype = C.c_int
+    lib.gs_gather_rows_zero_tail.argtypes = [i64, i64, i32, vp, vp, vp, vp]
+    lib.gs_gather_rows_zero_tail.restype = C.c_int
+    lib.gs_densify_classify.argtypes = [i32, i32, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp, vp, vp, vp]
+    lib.gs_densify_classify.restype = C.c_int
+    lib.gs_densify_children.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.gs_densify_children.restype = C.c_int
     lib.gs_grow_scratch_bytes.argtypes = [i32, i32]
     lib.gs_grow_scratch_bytes.restype = C.c_uint64
     lib.gs_grow_gaussians.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp]

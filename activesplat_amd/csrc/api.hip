@@ -442,8 +442,45 @@ int gs_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32
 int gs_gather_rows(int64_t n_out, int32_t row_floats, const uint32_t* src_index, const float* src, float* dst, gs_stream_t stream)
 {
     if (n_out < 0 || row_floats <= 0 || (n_out > 0 && (!src_index || !src || !dst))) return fail(GS_EINVAL, "gs_gather_rows: bad argument");
-    hipError_t e = gs::launch_gather_rows(n_out, row_floats, src_index, src, dst, (hipStream_t)stream);
+    hipError_t e = gs::launch_gather_rows(n_out, row_floats, src_index, src, dst, n_out, (hipStream_t)stream);
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_gather_rows: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_gather_rows_zero_tail(int64_t n_out, int64_t n_copy, int32_t row_floats, const uint32_t* src_index, const float* src, float* dst,
+                             gs_stream_t stream)
+{
+    if (n_out < 0 || n_copy < 0 || n_copy > n_out || row_floats <= 0 || (n_out > 0 && !dst) || (n_copy > 0 && (!src_index || !src)))
+        return fail(GS_EINVAL, "gs_gather_rows_zero_tail: bad argument");
+    hipError_t e = gs::launch_gather_rows(n_out, row_floats, src_index, src, dst, n_copy, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_gather_rows_zero_tail: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_densify_classify(int32_t N, int32_t scale_dim, const float* log_scales, const float* logit_opacities, const float* grad_accum,
+                        const float* denom, const float* d_scene_radius, float grad_thresh, float opacity_thresh, int32_t remove_big,
+                        int32_t num_to_split_into, uint8_t* keep_orig, uint8_t* keep_clone, uint8_t* keep_child, uint8_t* split_mask,
+                        gs_stream_t stream)
+{
+    if (N < 0 || (scale_dim != 1 && scale_dim != 3) || num_to_split_into < 1 || !d_scene_radius ||
+        (N > 0 && (!log_scales || !logit_opacities || !keep_orig)) || ((grad_accum == nullptr) != (denom == nullptr)))
+        return fail(GS_EINVAL, "gs_densify_classify: bad argument");
+    hipError_t e = gs::launch_densify_classify(N, scale_dim, log_scales, logit_opacities, grad_accum, denom, d_scene_radius, grad_thresh,
+                                               opacity_thresh, remove_big, num_to_split_into, keep_orig, keep_clone, keep_child, split_mask,
+                                               (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_densify_classify: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_densify_children(int32_t n_child, int32_t scale_dim, int32_t num_to_split_into, const float* unnorm_rotations, const float* samples,
+                        float* means3D, float* log_scales, gs_stream_t stream)
+{
+    if (n_child < 0 || (scale_dim != 1 && scale_dim != 3) || num_to_split_into < 1 ||
+        (n_child > 0 && (!unnorm_rotations || !samples || !means3D || !log_scales)))
+        return fail(GS_EINVAL, "gs_densify_children: bad argument");
+    hipError_t e = gs::launch_densify_children(n_child, scale_dim, num_to_split_into, unnorm_rotations, samples, means3D, log_scales,
+                                               (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_densify_children: %s", hipGetErrorString(e));
     return GS_OK;
 }
 

@@ -68,25 +68,27 @@ __global__ __launch_bounds__(kCompactBlock) void compact_write_kernel(int64_t n,
     if (k) src_index[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
 }
 
+// rows [0, n_copy) are gathered, rows [n_copy, n_out) zero-filled (the Adam moments of appended Gaussians start from zero:
+// slam_external.py:131-134)
 __global__ __launch_bounds__(kBlock) void gather_rows_kernel(int64_t total, int row_floats, const uint32_t* __restrict__ src_index,
-                                                              const float* __restrict__ src, float* __restrict__ dst)
+                                                              const float* __restrict__ src, float* __restrict__ dst, int64_t n_copy)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
         const int64_t r = e / row_floats;
         const int c = (int)(e - r * row_floats);
-        dst[e] = src[(int64_t)src_index[r] * row_floats + c];
+        dst[e] = r < n_copy ? src[(int64_t)src_index[r] * row_floats + c] : 0.0f;
     }
 }
 
 // rows of a multiple of 4 floats (quaternions, SH coefficient rows and their Adam moments): 16 B per lane, 32-bit index math
 __global__ __launch_bounds__(kBlock) void gather_rows_vec4_kernel(uint32_t total4, uint32_t row4, const uint32_t* __restrict__ src_index,
-                                                                   const float4* __restrict__ src, float4* __restrict__ dst)
+                                                                   const float4* __restrict__ src, float4* __restrict__ dst, uint32_t n_copy)
 {
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < total4; e += stride) {
         const uint32_t r = e / row4, c = e - r * row4;
-        dst[e] = src[(size_t)src_index[r] * row4 + c];
+        dst[e] = r < n_copy ? src[(size_t)src_index[r] * row4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -102,7 +104,7 @@ hipError_t launch_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_in
     return hipGetLastError();
 }
 
-hipError_t launch_gather_rows(int64_t n_out, int row_floats, const uint32_t* src_index, const float* src, float* dst, hipStream_t st)
+hipError_t launch_gather_rows(int64_t n_out, int row_floats, const uint32_t* src_index, const float* src, float* dst, int64_t n_copy, hipStream_t st)
 {
     const int64_t total = n_out * row_floats;
     if (total <= 0) return hipSuccess;
@@ -111,12 +113,12 @@ hipError_t launch_gather_rows(int64_t n_out, int row_floats, const uint32_t* src
         uint32_t nb4 = (total4 + kBlock - 1) / kBlock;
         if (nb4 > 256 * 16) nb4 = 256 * 16;
         hipLaunchKernelGGL(gather_rows_vec4_kernel, dim3(nb4), dim3(kBlock), 0, st, total4, (uint32_t)(row_floats >> 2), src_index,
-                           reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst));
+                           reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), (uint32_t)n_copy);
         return hipGetLastError();
     }
     int64_t nb = (total + kBlock - 1) / kBlock;
     if (nb > 256 * 16) nb = 256 * 16;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, total, row_floats, src_index, src, dst);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, total, row_floats, src_index, src, dst, n_copy);
     return hipGetLastError();
 }
 

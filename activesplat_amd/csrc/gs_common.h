@@ -225,7 +225,13 @@ hipError_t launch_keyframe_overlap(int n_pts, const float* pts, int n_kf, const 
                                    uint32_t* counts, hipStream_t st);
 uint64_t compact_scratch_bytes(int64_t n);
 hipError_t launch_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32_t* d_count, void* scratch, hipStream_t st);
-hipError_t launch_gather_rows(int64_t n_out, int row_floats, const uint32_t* src_index, const float* src, float* dst, hipStream_t st);
+hipError_t launch_gather_rows(int64_t n_out, int row_floats, const uint32_t* src_index, const float* src, float* dst, int64_t n_copy, hipStream_t st);
+hipError_t launch_densify_classify(int N, int scale_dim, const float* log_scales, const float* logit_op, const float* accum,
+                                   const float* denom, const float* scene_radius, float grad_thresh, float opacity_thresh,
+                                   int remove_big, int n_split, uint8_t* keep_orig, uint8_t* keep_clone, uint8_t* keep_child,
+                                   uint8_t* split_mask, hipStream_t st);
+hipError_t launch_densify_children(int n_child, int scale_dim, int n_split, const float* rots, const float* samples, float* means3D,
+                                   float* log_scales, hipStream_t st);
 
 // sort backend (sort_rocprim.hip): stable ascending radix sort of (key64, val32) pairs on bits [0,end_bit)
 size_t sort_temp_bytes(int64_t D, int end_bit);

@@ -17,6 +17,13 @@ gs_compact_index + gs_gather_rows pair shared by the parameter, both Adam moment
 statistics.  The optimiser keeps torch.optim's `param_groups` / `state[param]` layout so that code written
 against the reference's surgery functions keeps working.
 
+Fused surgery (default, `fused=True`): the clone / split / cull decisions of one densify or prune event are taken by ONE kernel
+(gs_densify_classify), their three masks become index lists through the ballot/popcount compaction, and every tensor --
+parameter, both Adam moments, statistics -- is produced by ONE row gather (gs_gather_rows_zero_tail: rows of new Gaussians
+zero-filled in the moments); the split children's offset and scale are applied in place by gs_densify_children.  Same rows in
+the same order as the step-by-step formulation (`fused=False`: clone -> cat -> split -> cat -> remove -> cull -> remove, the
+reference's call pattern, four index builds and ~40 torch launches per event).
+
 densify: the reference's slam_external.densify only executes for isotropic scales without a 'timestep'
 variable.  This mirror reproduces that case exactly and defines the missing ones the way
 the reference's own dead copy (utils/gs_external.py:191-253) and the original 3DGS do: anisotropic split
@@ -153,6 +160,71 @@ def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+def gather_rows_zero_tail(src: torch.Tensor, index: torch.Tensor, n_copy: int) -> torch.Tensor:
+    """dst[r] = src[index[r]] for r < n_copy, zeros for n_copy <= r < len(index) -- one launch."""
+    lib = _lib.get()
+    src = src.detach().contiguous().float()
+    n_out = index.numel()
+    row = src.numel() // max(src.shape[0], 1)
+    dst = torch.empty((n_out,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    if n_out:
+        _lib.check(lib.gs_gather_rows_zero_tail(n_out, n_copy, row, index.data_ptr(), src.data_ptr(), dst.data_ptr(), _stream(src)))
+    return dst
+
+
+def _index_of(mask_u8: torch.Tensor) -> torch.Tensor:
+    lib = _lib.get()
+    n = mask_u8.numel()
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=mask_u8.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=mask_u8.device)
+    scratch = torch.empty(int(lib.gs_compact_scratch_bytes(n)), dtype=torch.uint8, device=mask_u8.device)
+    _lib.check(lib.gs_compact_index(n, mask_u8.data_ptr(), idx.data_ptr(), cnt.data_ptr(), scratch.data_ptr(), _stream(mask_u8)))
+    return idx, cnt
+
+
+def _classify(params, variables, opacity_thresh, remove_big, densify_args=None):
+    """gs_densify_classify -> uint8 masks [4, N]: keep_orig, keep_clone, keep_child, split (the last three zero when pruning)."""
+    lib = _lib.get()
+    ls, lo = params["log_scales"].detach().contiguous(), params["logit_opacities"].detach().contiguous()
+    N, dev = int(ls.shape[0]), ls.device
+    masks = torch.zeros(4, max(N, 1), dtype=torch.uint8, device=dev)
+    radius = variables["scene_radius"]
+    radius = (radius if torch.is_tensor(radius) else torch.tensor(float(radius))).to(device=dev, dtype=torch.float32).reshape(1)
+    acc = den = None
+    thr, nsplit = 0.0, 1
+    if densify_args is not None:
+        acc = variables["means2D_gradient_accum"].contiguous().float()
+        den = variables["denom"].contiguous().float()
+        thr, nsplit = densify_args
+    _lib.check(lib.gs_densify_classify(N, int(ls.shape[1]), ls.data_ptr(), lo.data_ptr(), None if acc is None else acc.data_ptr(),
+                                       None if den is None else den.data_ptr(), radius.data_ptr(), float(thr), float(opacity_thresh),
+                                       1 if remove_big else 0, int(nsplit), masks[0].data_ptr(),
+                                       masks[1].data_ptr() if acc is not None else None, masks[2].data_ptr() if acc is not None else None,
+                                       masks[3].data_ptr() if acc is not None else None, _stream(ls)))
+    return masks
+
+
+def _apply_index(index, n_copy, params, variables, optimizer, zero_stats):
+    """ONE gather per tensor: parameters copy all rows of `index`; Adam moments copy the first n_copy rows (the Gaussians that were
+    there before) and start the appended ones from zero; statistics are reset (densify) or compacted (prune)."""
+    n_out, dev = int(index.numel()), index.device
+    for k in [k for k in params.keys() if k not in _SKIP]:
+        g = _group(optimizer, k)
+        old = g["params"][0]
+        st = optimizer.state.get(old, None)
+        new_st = None
+        if st is not None and len(st):
+            new_st = dict(st, exp_avg=gather_rows_zero_tail(st["exp_avg"], index, n_copy),
+                          exp_avg_sq=gather_rows_zero_tail(st["exp_avg_sq"], index, n_copy))
+        params[k] = _replace_param(optimizer, g, gather_rows(old, index), new_st)
+    for k in ("means2D_gradient_accum", "denom", "max_2D_radius"):
+        if k in variables:
+            variables[k] = torch.zeros(n_out, device=dev) if zero_stats else gather_rows(variables[k], index)
+    if "timestep" in variables:
+        variables["timestep"] = gather_rows(variables["timestep"], index)      # clones and children inherit the parent's
+    return params, variables
+
+
 def _replace_param(optimizer, group, new_tensor, new_state):
     old = group["params"][0]
     optimizer.state.pop(old, None)
@@ -212,30 +284,74 @@ def _too_big(params, variables, factor):
     return torch.exp(params["log_scales"]).max(dim=1).values > factor * variables["scene_radius"]
 
 
-def prune_gaussians(params, variables, optimizer, iter, prune_dict):
+def prune_gaussians(params, variables, optimizer, iter, prune_dict, fused=True):
     if iter <= prune_dict["stop_after"]:
         if iter >= prune_dict["start_after"] and iter % prune_dict["prune_every"] == 0:
             thr = prune_dict["final_removal_opacity_threshold"] if iter == prune_dict["stop_after"] \
                 else prune_dict["removal_opacity_threshold"]
-            to_remove = (torch.sigmoid(params["logit_opacities"]) < thr).squeeze(-1)
-            if iter >= prune_dict["remove_big_after"]:
-                to_remove = to_remove | _too_big(params, variables, 0.1)
-            params, variables = remove_points(to_remove, params, variables, optimizer)
+            remove_big = iter >= prune_dict["remove_big_after"]
+            if fused:
+                idx, cnt = _index_of(_classify(params, variables, thr, remove_big)[0])
+                n = int(cnt.item())
+                params, variables = _apply_index(idx[:n], n, params, variables, optimizer, zero_stats=False)
+            else:
+                to_remove = (torch.sigmoid(params["logit_opacities"]) < thr).squeeze(-1)
+                if remove_big:
+                    to_remove = to_remove | _too_big(params, variables, 0.1)
+                params, variables = remove_points(to_remove, params, variables, optimizer)
         if iter > 0 and iter % prune_dict["reset_opacities_every"] == 0 and prune_dict["reset_opacities"]:
             new = {"logit_opacities": inverse_sigmoid(torch.ones_like(params["logit_opacities"]) * 0.01)}
             params = update_params_and_optimizer(new, params, optimizer)
     return params, variables
 
 
-def densify(params, variables, optimizer, iter, densify_dict, samples=None):
+def _densify_fused(params, variables, optimizer, iter, densify_dict, samples):
+    """One classification, one index, one gather per tensor.  Output rows, as the reference orders them: surviving originals
+    (split parents gone), surviving clones, then num_to_split_into blocks of surviving children (parents ascending in a block)."""
+    lib = _lib.get()
+    n_split = int(densify_dict["num_to_split_into"])
+    thr = densify_dict["final_removal_opacity_threshold"] if iter == densify_dict["stop_after"] \
+        else densify_dict["removal_opacity_threshold"]
+    masks = _classify(params, variables, thr, iter >= densify_dict["remove_big_after"], (densify_dict["grad_thresh"], n_split))
+    (i_orig, c_orig), (i_clone, c_clone), (i_child, c_child) = _index_of(masks[0]), _index_of(masks[1]), _index_of(masks[2])
+    n_orig, n_clone, n_child = (int(v) for v in torch.cat((c_orig, c_clone, c_child)).tolist())     # the event's one host read
+    index = torch.cat((i_orig[:n_orig], i_clone[:n_clone], i_child[:n_child].repeat(n_split)))
+    params, variables = _apply_index(index, n_orig, params, variables, optimizer, zero_stats=True)
+    n_kids = n_child * n_split
+    if n_kids:
+        dev = index.device
+        base = n_orig + n_clone
+        ls = params["log_scales"].detach()
+        kid_ls = ls[base:]
+        if samples is None:
+            stds = torch.exp(kid_ls)
+            stds = stds.repeat(1, 3) if stds.shape[1] == 1 else stds          # anisotropic: per-axis (SURVEY App. E1)
+            kid_samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
+        else:
+            # injected offsets are indexed like the reference's un-culled split list: block c, rank of the parent among ALL split parents
+            rank = torch.cumsum(masks[3].to(torch.int64), 0) - 1
+            n_all = int(masks[3].sum().item())
+            parents = i_child[:n_child].to(torch.int64)
+            rows = torch.cat([c * n_all + rank[parents] for c in range(n_split)])
+            kid_samples = samples.to(dev).float()[rows].contiguous()
+        means, rots = params["means3D"].detach(), params["unnorm_rotations"].detach()
+        kid_rots = rots[base:].contiguous()
+        _lib.check(lib.gs_densify_children(n_kids, int(ls.shape[1]), n_split, kid_rots.data_ptr(), kid_samples.contiguous().data_ptr(),
+                                           means[base:].data_ptr(), kid_ls.data_ptr(), _stream(means)))
+    return params, variables
+
+
+def densify(params, variables, optimizer, iter, densify_dict, samples=None, fused=True):
     """Clone small / split large high-gradient Gaussians, then cull (slam_external.py:195-247).
     `samples` optionally injects the N(0, scale) split offsets ([n_split * num_to_split_into, 3]) so that a run
-    can be replayed exactly; otherwise torch.normal draws them."""
+    can be replayed exactly; otherwise torch.normal draws them.  fused=False runs the reference's step-by-step call pattern."""
     if iter > densify_dict["stop_after"]:
         return params, variables
     variables = accumulate_mean2d_gradient(variables)
     grad_thresh = densify_dict["grad_thresh"]
-    if iter >= densify_dict["start_after"] and iter % densify_dict["densify_every"] == 0:
+    if fused and iter >= densify_dict["start_after"] and iter % densify_dict["densify_every"] == 0:
+        params, variables = _densify_fused(params, variables, optimizer, iter, densify_dict, samples)
+    elif iter >= densify_dict["start_after"] and iter % densify_dict["densify_every"] == 0:
         keys = [k for k in params.keys() if k not in _SKIP]
         dev = params["means3D"].device
         grads = variables["means2D_gradient_accum"] / variables["denom"]

@@ -230,6 +230,27 @@ int gs_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32
                      gs_stream_t stream);
 int gs_gather_rows(int64_t n_out, int32_t row_floats, const uint32_t* src_index, const float* src, float* dst,
                    gs_stream_t stream);
+/* The same gather for rows [0, n_copy); rows [n_copy, n_out) of dst are zero-filled by the same launch (Adam moments of appended
+ * Gaussians, slam_external.py:131-134). */
+int gs_gather_rows_zero_tail(int64_t n_out, int64_t n_copy, int32_t row_floats, const uint32_t* src_index, const float* src,
+                             float* dst, gs_stream_t stream);
+
+/* Densify / prune decisions of slam_external.py:171-247 in ONE launch.  Per Gaussian i of the N present before the event:
+ *   keep_orig[i]  = 1 if it stays (not split, not culled)
+ *   keep_clone[i] = 1 if it is cloned AND the clone survives the cull        (nullable; densify only)
+ *   keep_child[i] = 1 if it is split AND its children survive the cull       (nullable; densify only)
+ *   split_mask[i] = 1 if it is split (before the cull; indexes injected samples)   (nullable)
+ * grad_accum/denom NULL = prune only (slam_external.py:171-192: keep_orig = not culled).  d_scene_radius: DEVICE pointer to
+ * variables['scene_radius'] (no host read-back).  scale_dim = 1 (isotropic) or 3.  remove_big: the `iter >= remove_big_after`
+ * clause (scale > 0.1 scene_radius). */
+int gs_densify_classify(int32_t N, int32_t scale_dim, const float* log_scales, const float* logit_opacities,
+                        const float* grad_accum, const float* denom, const float* d_scene_radius, float grad_thresh,
+                        float opacity_thresh, int32_t remove_big, int32_t num_to_split_into, uint8_t* keep_orig,
+                        uint8_t* keep_clone, uint8_t* keep_child, uint8_t* split_mask, gs_stream_t stream);
+/* Split children (a contiguous block of rows): means3D += R(normalised unnorm_rotation) * sample, log_scale = log(exp(log_scale) /
+ * (0.8 n)) in place (slam_external.py:224-230).  samples [n_child,3] are the N(0, scale) offsets. */
+int gs_densify_children(int32_t n_child, int32_t scale_dim, int32_t num_to_split_into, const float* unnorm_rotations,
+                        const float* samples, float* means3D, float* log_scales, gs_stream_t stream);
 
 /* Densification statistics, one launch each.
  * gs_visibility_stats : seen[i] = radii[i] > 0 (uint8, nullable); max_2D_radius[i] = max(max_2D_radius[i], radii[i]) (nullable)

@@ -242,6 +242,75 @@ def test_densify_anisotropic_with_timestep_runs(backend):
     assert variables["timestep"].max() <= N - 1 and torch.isfinite(params["means3D"]).all()
 
 
+def _random_map(backend, N, iso, seed):
+    from activesplat_amd import optim as O
+    g = torch.Generator().manual_seed(seed)
+    ls = torch.randn(N, 1 if iso else 3, generator=g) * 0.9 - 4.0
+    raw = dict(means3D=torch.randn(N, 3, generator=g), rgb_colors=torch.rand(N, 3, generator=g), unnorm_rotations=torch.randn(N, 4, generator=g),
+               logit_opacities=torch.randn(N, 1, generator=g) * 3, log_scales=ls,
+               cam_unnorm_rots=torch.randn(1, 4, 2, generator=g), cam_trans=torch.randn(1, 3, 2, generator=g))
+    params = {k: torch.nn.Parameter(v.to(backend)) for k, v in raw.items()}
+    lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
+    opt = O.initialize_optimizer(params, lrs)
+    for k, p in params.items():
+        p.grad = None if k.startswith("cam_") else torch.randn(p.shape, generator=g).to(backend)
+    opt.step(); opt.zero_grad(set_to_none=True)
+    m2d = torch.zeros(N, 3, requires_grad=True, device=backend); m2d.grad = (torch.randn(N, 3, generator=g) * 3e-4).to(backend)
+    var = dict(means2D=m2d, seen=(torch.rand(N, generator=g) > 0.3).to(backend), means2D_gradient_accum=(torch.rand(N, generator=g) * 4e-4).to(backend),
+               denom=(torch.rand(N, generator=g) * 3).floor().to(backend), max_2D_radius=torch.rand(N, generator=g).to(backend),
+               timestep=torch.arange(N).float().to(backend), scene_radius=torch.tensor(1.7).to(backend))
+    return params, var, opt, g
+
+
+@pytest.mark.parametrize("iso", [True, False])
+def test_fused_densify_and_prune_equal_the_stepwise_call_pattern(backend, iso):
+    """One classification + one gather per tensor (optim.densify / prune_gaussians, fused=True) against the reference's
+    clone -> cat -> split -> cat -> remove -> cull -> remove sequence (fused=False) on a map where every branch fires:
+    clones, splits, opacity culls, too-big culls (of originals AND of freshly split children), 0/0 gradients."""
+    from activesplat_amd import optim as O
+    N = 3000
+    ddict = dict(start_after=0, remove_big_after=0, stop_after=100, densify_every=10, grad_thresh=0.0002, num_to_split_into=2,
+                 removal_opacity_threshold=0.05, final_removal_opacity_threshold=0.05, reset_opacities=False, reset_opacities_every=3000)
+    out = []
+    for fused in (True, False):
+        params, var, opt, g = _random_map(backend, N, iso, 11)
+        samples = (torch.randn(2 * N, 3, generator=g) * 0.02).to(backend)      # more rows than any split list: indexed like the reference's
+        # how many rows the reference would draw: 2 x number of split parents
+        grads = var["means2D_gradient_accum"] + 0.0
+        with torch.no_grad():
+            acc = grads + torch.where(var["seen"], torch.norm(var["means2D"].grad[:, :2], dim=-1), torch.zeros_like(grads))
+            den = var["denom"] + var["seen"].float()
+            gr = acc / den; gr[gr.isnan()] = 0.0
+            n_all = int(((gr >= 0.0002) & (torch.exp(params["log_scales"]).max(dim=1).values > 0.01 * 1.7)).sum())
+        p2, v2 = O.densify(params, var, opt, 10, ddict, samples=samples[: 2 * n_all], fused=fused)
+        out.append((p2, v2, opt))
+    (pa, va, oa), (pb, vb, ob) = out
+    n = pa["means3D"].shape[0]
+    assert n == pb["means3D"].shape[0] and n != N
+    for k in KEYS[:5]:
+        tol = dict(rtol=2e-6, atol=1e-7) if k in ("means3D", "log_scales") else dict(rtol=0, atol=0)
+        np.testing.assert_allclose(pa[k].detach().cpu().numpy(), pb[k].detach().cpu().numpy(), err_msg=k, **tol)
+        for m in ("exp_avg", "exp_avg_sq"):
+            np.testing.assert_array_equal(oa.state[pa[k]][m].cpu().numpy(), ob.state[pb[k]][m].cpu().numpy(), err_msg=k + m)
+        assert float(oa.state[pa[k]]["step"]) == float(ob.state[pb[k]]["step"]) == 1
+    for k in ("means2D_gradient_accum", "denom", "max_2D_radius", "timestep"):
+        np.testing.assert_array_equal(va[k].cpu().numpy(), vb[k].cpu().numpy(), err_msg=k)
+    # prune (opacity + too big)
+    pdict = dict(start_after=0, remove_big_after=0, stop_after=100, prune_every=5, removal_opacity_threshold=0.05,
+                 final_removal_opacity_threshold=0.05, reset_opacities=False, reset_opacities_every=500)
+    res = []
+    for fused in (True, False):
+        params, var, opt, _ = _random_map(backend, N, iso, 12)
+        res.append(O.prune_gaussians(params, var, opt, 5, pdict, fused=fused) + (opt,))
+    (pa, va, oa), (pb, vb, ob) = res
+    assert 0 < pa["means3D"].shape[0] == pb["means3D"].shape[0] < N
+    for k in KEYS[:5]:
+        np.testing.assert_array_equal(pa[k].detach().cpu().numpy(), pb[k].detach().cpu().numpy(), err_msg=k)
+        np.testing.assert_array_equal(oa.state[pa[k]]["exp_avg"].cpu().numpy(), ob.state[pb[k]]["exp_avg"].cpu().numpy())
+    for k in ("means2D_gradient_accum", "denom", "max_2D_radius", "timestep"):
+        np.testing.assert_array_equal(va[k].cpu().numpy(), vb[k].cpu().numpy(), err_msg=k)
+
+
 def test_pointcloud_and_growth_match_reference(monkeypatch):
     from activesplat_amd import mapping as M
     d = load("pointcloud.npz")

@@ -240,3 +240,20 @@ def test_adam_streaming_path_for_tensors_beyond_the_last_level_cache(hip):
         oa.step(); ob.step()
     assert torch.allclose(a, b, rtol=3e-6, atol=1e-7)
     assert torch.allclose(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=3e-6, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_configs2_optimise_loop_2m_sh3(hip):
+    """BASELINE configs[2] at full size: 2 M Gaussians, SH degree 3, 640x480, 100 iterations with fused Adam and a densify event at
+    iteration 50 -- with the fused densify (one classification, one gather per tensor) and with the reference's step-by-step call
+    pattern.  Both must end with the same number of Gaussians after the event and a lower loss than they started with."""
+    from tests import util
+    torch.manual_seed(0)
+    a = util.configs2_optimise_loop(2_000_000, 100, "cuda", fused_densify=True)
+    torch.manual_seed(0)
+    b = util.configs2_optimise_loop(2_000_000, 100, "cuda", fused_densify=False)
+    assert a["counts"] and a["counts"] == b["counts"], (a["counts"], b["counts"])
+    assert a["counts"][0] != 2_000_000
+    for r in (a, b):
+        assert np.isfinite(r["losses"]).all() and r["losses"][1] < r["losses"][0], r["losses"]
+    assert abs(a["losses"][1] - b["losses"][1]) < 2e-2 * abs(b["losses"][1])      # the split offsets are drawn from different streams
