@@ -69,21 +69,23 @@ def all_reduce_statistics(variables, group=None):
 
 
 def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank=None, world=None, buf=None,
-                          sharded_adam=False, streams=1):
+                          sharded_adam=False, streams=1, densify_statistics=False):
     """One optimiser step over a batch of keyframes sharded across ranks.
     loss_fn(params, keyframe, variables) -> (loss, variables).  Returns the local loss sum.
 
     streams > 1 (GPU only): this rank's keyframes are independent until the optimiser step, so they are rendered on
     `streams` HIP streams in turn -- one frame's kernels fill the tails and the placement imbalance of the other's
     (two streams: 2404 -> 3062 frames/s on BASELINE configs[1], `two_stream_fps` in the bench line).  Each keyframe's
-    gradients are taken with autograd.grad on its own stream and summed after the streams have joined."""
+    gradients are taken with autograd.grad on its own stream and summed after the streams have joined.
+    autograd.grad does not populate `means2D.grad`, which the densifier's statistics read (optim.accumulate_mean2d_gradient):
+    a caller that densifies from this step's statistics passes densify_statistics=True and gets the serial walk."""
     on = dist.is_available() and dist.is_initialized()
     rank = (dist.get_rank() if on else 0) if rank is None else rank
     world = (dist.get_world_size() if on else 1) if world is None else world
     optimizer.zero_grad(set_to_none=True)
     mine = list(shard_keyframes(len(keyframes), rank, world))
     dev = params[GRAD_KEYS[0]].device
-    if streams > 1 and dev.type == "cuda" and len(mine) > 1:
+    if streams > 1 and dev.type == "cuda" and len(mine) > 1 and not densify_statistics:
         keys = [k for k in GRAD_KEYS if k in params]
         main = torch.cuda.current_stream(dev)
         pool = [torch.cuda.Stream(device=dev) for _ in range(streams)]
@@ -106,6 +108,10 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
                 losses.append(loss.detach())
         for s in pool:
             main.wait_stream(s)
+        # the partial sums and losses were allocated on the side streams and are consumed (and later freed) on `main`:
+        # tell the caching allocator, or a block could be handed out again while `main` still reads it
+        for t in [x for p_ in partial if p_ is not None for x in p_] + losses:
+            t.record_stream(main)
         variables = vs[(len(mine) - 1) % streams]                  # `means2D` / `seen` of the last keyframe, as in the serial loop
         if "max_2D_radius" in variables:
             for v in vs:
@@ -122,7 +128,9 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
             loss, variables = loss_fn(params, keyframes[i], variables)
             loss.backward()                       # autograd accumulates into .grad across this rank's keyframes
             total += float(loss.detach())
-    if sharded_adam and on and world > 1:
+    if world <= 1 or not on:
+        optimizer.step()                         # one rank (or a caller that overrides rank/world to run the batch alone): no collective
+    elif sharded_adam:
         reduce_scatter_adam_step(params, optimizer)
     else:
         buf = all_reduce_gradients(params, buf)

@@ -22,6 +22,7 @@ All compute is in libgsplat_hip.so through the C ABI of include/gsplat_hip.h; th
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import NamedTuple
 
 import torch
@@ -55,7 +56,24 @@ _capacity = {}
 #: set False to always size the binning workspace from the exact counts (one mid-pipeline host sync per forward)
 optimistic = True
 
-_pinned = {}
+#: pinned host counter pairs (D, largest tile list), one per (thread, device, stream): the scan kernel stores straight into
+#: them, so two forwards in flight -- another stream of a keyframe batch, the planner / visualiser thread of the reference's
+#: threaded layout (SURVEY section 8b "Threading") -- must never share one
+_tls = threading.local()
+_capacity_lock = threading.Lock()
+
+
+def _host_counters(device):
+    pool = getattr(_tls, "pinned", None)
+    if pool is None:
+        pool = _tls.pinned = {}
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = pool.get(key)
+    if buf is None:
+        if len(pool) >= 64:                              # short-lived streams: do not grow without bound
+            pool.pop(next(iter(pool)))
+        buf = pool[key] = torch.zeros(2, dtype=torch.int32).pin_memory()
+    return buf
 
 
 def _ptr(t):
@@ -115,12 +133,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         image = torch.empty(il.total_bytes, dtype=torch.uint8, device=device)
         radii = torch.empty(P, dtype=torch.int32, device=device)
         d_num = torch.empty(2, dtype=torch.int32, device=device)
-        if device.type == "cuda":
-            h_num = _pinned.get("h_num")
-            if h_num is None:
-                h_num = _pinned["h_num"] = torch.zeros(2, dtype=torch.int32).pin_memory()
-        else:
-            h_num = torch.zeros(2, dtype=torch.int32)
+        h_num = _host_counters(device) if device.type == "cuda" else torch.zeros(2, dtype=torch.int32)
         _lib.check(lib.gs_preprocess_forward(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
                                              _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
                                              _ptr(radii), _ptr(geom), _ptr(image), _ptr(d_num), _ptr(h_num), st))
@@ -148,7 +161,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         # true counts exceed the guess is re-launched with exact sizes (gs_render_forward is capacity-safe and idempotent).
         done = None
         key = (P, W, H, device.index)
-        guess = _capacity.get(key) if optimistic else None
+        with _capacity_lock:
+            guess = _capacity.get(key) if optimistic else None
         if guess is not None:
             if device.type == "cuda":
                 ev = torch.cuda.Event()
@@ -168,10 +182,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         else:
             bl, binning, point_list = render(D, max_tile)
             last_stats["optimistic_misses"] = last_stats.get("optimistic_misses", 0) + (1 if guess is not None else 0)
-        old = _capacity.get(key, (0, 0))                        # monotone: views that alternate settle on the largest
-        if len(_capacity) >= 64 and key not in _capacity:       # P changes with every densify / growth step: keep the table small
-            _capacity.pop(next(iter(_capacity)))
-        _capacity[key] = (max(old[0], int(D * 1.25) + 4096), max(old[1], int(max_tile * 1.25) + 64))
+        with _capacity_lock:
+            old = _capacity.get(key, (0, 0))                    # monotone: views that alternate settle on the largest
+            if len(_capacity) >= 64 and key not in _capacity:   # P changes with every densify / growth step: keep the table small
+                _capacity.pop(next(iter(_capacity)))
+            _capacity[key] = (max(old[0], int(D * 1.25) + 4096), max(old[1], int(max_tile * 1.25) + 64))
         last_stats["num_rendered"], last_stats["P"], last_stats["max_tile_instances"] = D, P, max_tile
         ctx.rs, ctx.D, ctx.keep, ctx.fused, ctx.cam = rs, D, keep, fused, cam      # the backward reuses the camera block
         ctx.scratch, ctx.scratch_clean = scratch, scratch is not None

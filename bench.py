@@ -4,12 +4,16 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one forward (colour + radii + depth + opacity) + one backward (all input gradients incl.
+N = 1: one "step" = one forward (colour + radii + depth + opacity) + one backward (all input gradients incl.
 means2D) of BASELINE.json configs[1]: 500k synthetic Gaussians, one 640x480 view, SH degree 0
-(colors_precomp), inputs and dL/dcolor already resident in HBM.  With N > 1 every
-rank renders its own keyframe of the same replicated scene (weak scaling: one keyframe per rank per
-step), accumulates the 14-float/Gaussian gradient locally and all-reduces it over RCCL every
-`--accum` steps (8 = the 8 keyframes per GPU of configs[3]).  Rank 0 prints ONE JSON line.
+(colors_precomp), inputs and dL/dcolor already resident in HBM.
+N > 1: BASELINE.json configs[3] -- 2 M Gaussians replicated on every rank, a batch of 64 keyframes at 640x480
+block-partitioned over the ranks (64/N each); one "step" = one optimiser step over the batch: every rank renders its
+keyframes (fused activations -> single-pass RGB-D render -> fused loss -> backward), the flat [N,14] fp32 gradient is
+reduce-scattered over RCCL, each rank runs the fused Adam on its 1/N row block and the updated rows are all-gathered
+(activesplat_amd/parallel.py).  `value` = keyframes rendered+back-propagated per second by the whole job (strong scaling:
+the batch is fixed); rank 0 also times the same 64-keyframe step alone (`single_gpu_same_workload_fps`).
+Rank 0 prints ONE JSON line.
 
 Extra legs (rank 0, N = 1 only, after the timed region):
   roofline     : per-stage hipEvent timing through the C ABI's gs_profile_* hooks over a second pass of
@@ -51,6 +55,92 @@ def stage_bytes(P, D, npix):
     }
 
 
+def run_c4(args, dev, rank, world):
+    """BASELINE configs[3]: 64 keyframes sharded over the ranks, RCCL gradient exchange, sharded fused Adam."""
+    import torch.distributed as dist
+    from activesplat_amd import mapping as M, optim as O, parallel as PL, setup_camera
+    from activesplat_amd import rasterizer as R
+    from activesplat_amd import synthetic as syn
+    W, H, N, KF = args.width, args.height, args.c4_gaussians, args.keyframes
+    K = syn.intrinsics(W, H)
+    raw = syn.shell_scene(N, seed=0, W=W, H=H)
+    params = {k: torch.nn.Parameter(v.to(dev)) for k, v in raw.items()}
+    params["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([1.0, 0, 0, 0], device=dev).reshape(1, 4, 1))
+    params["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 1, device=dev))
+    lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
+    opt = O.initialize_optimizer(params, lrs)
+    variables = {k: torch.zeros(N, device=dev) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+    cam = setup_camera(W, H, K, np.eye(4), device=dev)
+    mine = set(PL.shard_keyframes(KF, rank, world)) if world > 1 else set(range(KF))
+    keyframes = []
+    for i in range(KF):
+        a = 2 * np.pi * i / KF
+        kf = dict(id=i, cam=cam, w2c=torch.eye(4, device=dev), pose7=[float(v) for v in syn.quat_from_yaw(a)] + [0.0, 0.0, 0.0])
+        if i in mine or rank == 0:                             # rank 0 also runs the whole batch alone afterwards
+            im, depth = syn.make_targets(W, H, seed=100 + i)
+            kf.update(im=im.to(dev), depth=depth.to(dev))
+        keyframes.append(kf)
+    weights = dict(im=0.5, depth=1.0)
+
+    def loss_fn(p, kf, v):
+        loss, v, _ = M.get_loss(p, kf, v, 0, weights, fused=True, fused_loss=True, fused_inputs=True, pose7=kf["pose7"])
+        return loss, v
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    state = dict(v=variables)
+
+    def step(r=None, w=None):
+        _, state["v"], _ = PL.sharded_keyframe_step(params, state["v"], keyframes, opt, loss_fn, rank=r, world=w,
+                                                    sharded_adam=True, streams=args.streams)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    D = int(R.last_stats["num_rendered"])
+    out = {
+        "metric": "render+backward frames/sec at 640x480, N Gaussians", "value": round(KF * args.steps / dt, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[3]: {N} Gaussians, {KF} keyframes at {W}x{H} block-partitioned over {world} ranks "
+                               f"({KF // max(world, 1)} per rank), one optimiser step per batch, RCCL reduce-scatter of the [N,14] fp32 gradient "
+                               "-> sharded fused Adam -> all-gather of the updated rows",
+                   "gaussians": N, "width": W, "height": H, "keyframes_per_step": KF, "keyframes_per_rank_per_step": KF // max(world, 1),
+                   "tile_instances_D_last_keyframe": D, "streams": args.streams, "grad_exchange": "reduce_scatter+all_gather, 112 MB at 2M",
+                   "loss": "fused mapping loss (L1 + SSIM + masked depth) through the single-pass RGB-D render",
+                   "parallelism": f"keyframe-sharded x{world}"},
+    }
+    # the same batch on ONE GPU (rank 0 alone, no collectives): the reference point of the strong-scaling curve
+    ref = None
+    if rank == 0 and not args.no_extras:
+        n_ref = max(1, min(3, args.steps))
+        step(0, 1)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(n_ref):
+            step(0, 1)
+        torch.cuda.synchronize()
+        ref = KF * n_ref / (time.perf_counter() - t1)
+        out["single_gpu_same_workload_fps"] = round(ref, 2)
+        out["speedup_vs_single_gpu_same_workload"] = round(out["value"] / ref, 3)
+    barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +153,9 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent steps are issued on in turn (1 = strictly "
                     "one frame after the other)")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline and cpu_baseline legs")
+    ap.add_argument("--c4-gaussians", type=int, default=2_000_000, help="N > 1 (configs[3]): Gaussians of the replicated map")
+    ap.add_argument("--keyframes", type=int, default=64, help="N > 1 (configs[3]): keyframes per optimiser step, sharded over the ranks")
+    ap.add_argument("--workload", choices=("auto", "c2", "c4"), default="auto", help="auto: configs[1] on one GPU, configs[3] on several")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,6 +179,8 @@ def main():
     from activesplat_amd import rasterizer as R
     from activesplat_amd import synthetic as syn
     _lib.get()                                              # fail loudly if the HIP library is missing
+    if args.workload == "c4" or (args.workload == "auto" and dist_on):
+        return run_c4(args, dev, rank, world)
 
     W, H, N = args.width, args.height, args.gaussians
     K = syn.intrinsics(W, H)

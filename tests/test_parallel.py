@@ -193,3 +193,29 @@ def test_two_stream_keyframe_batch_equals_serial_batch(hip):
     assert torch.equal(m1, m2)
     for k in g1:
         assert float((g1[k] - g2[k]).norm() / g1[k].norm()) < 1e-4, k
+
+
+@pytest.mark.gpu
+def test_bench_configs3_workload_two_ranks_on_one_device(hip):
+    """`bench.py --gpus 2` = BASELINE configs[3] (keyframe batch sharded over the ranks, reduce-scatter -> sharded Adam -> all-gather),
+    launched the way the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment) -- with the
+    development knobs that put both ranks on the one GPU of the test box and exchange through gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   BENCH_SAME_DEVICE="1", BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                       "--c4-gaussians", "200000", "--keyframes", "8"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "configs[3]" in d["config"]["workload"]
+    assert d["config"]["keyframes_per_rank_per_step"] == 4 and d["value"] > 0 and d["single_gpu_same_workload_fps"] > 0
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]          # only rank 0 prints
