@@ -19,7 +19,7 @@ _emulated = False
 class GsCamera(C.Structure):
     _fields_ = [("image_width", C.c_int32), ("image_height", C.c_int32), ("sh_degree", C.c_int32),
                 ("sh_coeffs", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
-                ("scale_modifier", C.c_float), ("reserved", C.c_int32), ("bg", C.c_void_p),
+                ("scale_modifier", C.c_float), ("num_views", C.c_int32), ("bg", C.c_void_p),
                 ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
 
 
@@ -52,12 +52,14 @@ SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_sc
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
            "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward",
            "gs_grow_scratch_bytes", "gs_grow_gaussians", "gs_keyframe_overlap", "gs_visibility_stats", "gs_accumulate_grad2d",
-           "gs_gather_rows_zero_tail", "gs_densify_classify", "gs_densify_children")
+           "gs_gather_rows_zero_tail", "gs_densify_classify", "gs_densify_children", "gs_atlas_layout")
 
 
 def _bind(lib):
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     lib.gs_geom_layout.argtypes = [i32, i32, i32, C.POINTER(GsGeomLayout)]
+    lib.gs_atlas_layout.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.gs_atlas_layout.restype = C.c_int
     lib.gs_set_sort_path.argtypes = [i32]
     lib.gs_set_sort_path.restype = C.c_int
     lib.gs_set_forward_segments.argtypes = [i32]

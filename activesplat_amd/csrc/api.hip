@@ -64,15 +64,27 @@ bool make_cam(const GsCamera* c, gs::Cam& k)
 {
     if (!c || c->image_width <= 0 || c->image_height <= 0 || !c->bg || !c->viewmatrix || !c->projmatrix) return false;
     if (!(c->tanfovx > 0.f) || !(c->tanfovy > 0.f)) return false;
-    k.W = c->image_width; k.H = c->image_height;
-    k.gx = (k.W + gs::kTile - 1) / gs::kTile; k.gy = (k.H + gs::kTile - 1) / gs::kTile;
+    if (c->num_views < 0 || c->num_views > 64) return false;
+    k.V = c->num_views > 1 ? c->num_views : 1;
+    k.Wv = c->image_width; k.H = c->image_height;
+    k.gxv = (k.Wv + gs::kTile - 1) / gs::kTile;
+    k.gx = k.V * k.gxv; k.gy = (k.H + gs::kTile - 1) / gs::kTile;
+    k.W = k.V > 1 ? k.gx * gs::kTile : k.Wv;               // atlas: every view padded to whole tiles
+    k.nbv = 0;                                             // set by virtual_count()
     if (k.gx >= 65536 || k.gy >= 65536) return false;
     k.tanfovx = c->tanfovx; k.tanfovy = c->tanfovy;
-    k.fx = (float)k.W / (2.0f * c->tanfovx); k.fy = (float)k.H / (2.0f * c->tanfovy);
+    k.fx = (float)k.Wv / (2.0f * c->tanfovx); k.fy = (float)k.H / (2.0f * c->tanfovy);
     k.mod = c->scale_modifier;
     k.sh_degree = c->sh_degree; k.sh_coeffs = c->sh_coeffs;
     k.bg = c->bg; k.view = c->viewmatrix; k.proj = c->projmatrix; k.campos = c->campos;
     return true;
+}
+
+// rows of the per-Gaussian state: P for one view; V x (P rounded up to whole 256-row blocks) virtual Gaussians for an atlas
+int32_t virtual_count(gs::Cam& k, int32_t P)
+{
+    k.nbv = (P + gs::kBlock - 1) / gs::kBlock;
+    return k.V > 1 ? k.V * k.nbv * gs::kBlock : P;
 }
 
 gs::GeomPtrs carve_geom(void* base, int32_t P, const gs::Cam& k)
@@ -133,6 +145,17 @@ int gs_set_forward_segments(int32_t on)
     return GS_OK;
 }
 
+int gs_atlas_layout(int32_t P, int32_t view_width, int32_t num_views, int32_t* virtual_P, int32_t* atlas_width, int32_t* view_stride)
+{
+    if (P < 0 || view_width <= 0 || num_views < 1 || num_views > 64) return fail(GS_EINVAL, "gs_atlas_layout: bad argument");
+    const int32_t gxv = (view_width + gs::kTile - 1) / gs::kTile;
+    const int32_t stride = num_views > 1 ? gxv * gs::kTile : view_width;
+    if (virtual_P) *virtual_P = num_views > 1 ? num_views * ((P + gs::kBlock - 1) / gs::kBlock) * gs::kBlock : P;
+    if (atlas_width) *atlas_width = num_views > 1 ? num_views * stride : view_width;
+    if (view_stride) *view_stride = stride;
+    return GS_OK;
+}
+
 int gs_geom_layout(int32_t P, int32_t width, int32_t height, GsGeomLayout* out)
 {
     if (!out || P < 0 || width <= 0 || height <= 0) return fail(GS_EINVAL, "gs_geom_layout: bad argument");
@@ -186,8 +209,11 @@ int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t
     // composited in parallel -- enough of them to fill the 5120 wavefront slots, each at least 1024 records long
     out->segments = 1;
     // (pass 1 walks the WHOLE list, the normal walk stops where T saturates: at 256 tiles x 11 k records the normal path is 1.8x
-    // faster, at 80 tiles x 78 k the segmented one 4.7x -- so: at most 160 tiles and lists of at least 8192)
-    if (g_segments_enabled && tiles * 4 * 8 <= gs::kWaveSlots && max_tile_instances != 0xffffffffu && max_tile_instances >= 8192) {
+    // faster, at 80 tiles x 78 k the segmented one 4.7x, at the 240 tiles x 78 k of a three-view atlas 2.5x -- so: lists of at least
+    // 8192 in at most 160 tiles, or of at least 32768 as long as the tiles alone cannot fill the wavefront slots)
+    const bool few_tiles = tiles * 4 * 8 <= gs::kWaveSlots && max_tile_instances >= 8192;
+    const bool long_lists = tiles * 4 * 2 <= gs::kWaveSlots && max_tile_instances >= 32768;
+    if (g_segments_enabled && max_tile_instances != 0xffffffffu && (few_tiles || long_lists)) {
         uint64_t S = 2 * (uint64_t)gs::kWaveSlots / ((uint64_t)tiles * 4);      // 2x oversubscribed: segments differ in work (early stop)
         const uint64_t by_len = max_tile_instances / 1024;
         if (S > by_len) S = by_len;
@@ -217,7 +243,8 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, 
     if (shs && (k.sh_degree < 0 || k.sh_degree > 3 || k.sh_coeffs < (k.sh_degree + 1) * (k.sh_degree + 1) || k.sh_coeffs > 16 || !k.campos))
         return fail(GS_EINVAL, "gs_preprocess_forward: sh_degree / sh_coeffs / campos inconsistent");
     hipStream_t st = (hipStream_t)stream;
-    gs::GeomPtrs gp = carve_geom(geom_state, P, k);
+    const int32_t Pv = virtual_count(k, P);
+    gs::GeomPtrs gp = carve_geom(geom_state, Pv, k);
     GsImageLayout IL; gs_image_layout(k.W, k.H, &IL);
     uint2* ranges = (uint2*)((char*)image_state + IL.ranges);
     const int tiles = k.gx * k.gy;
@@ -235,10 +262,10 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, 
         if (h_counts && hipHostGetDevicePointer((void**)&host_dev, h_counts, 0) != hipSuccess) { host_dev = nullptr; (void)hipGetLastError(); }
         mirrored = host_dev != nullptr;
         ScopedStage ps(ST_TILE_COUNT, st);
-        e = gs::launch_tile_count(k, P, gp, gp.tile_total, gp.tile_base, ranges, d_counts, host_dev, st);
+        e = gs::launch_tile_count(k, Pv, gp, gp.tile_total, gp.tile_base, ranges, d_counts, host_dev, st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: tile count %s", hipGetErrorString(e));
     } else {                                   // too many tiles for the LDS histogram: radix path, counts = {D, 2^32-1}
-        e = gs::launch_scan_block_sums(P, gp, d_counts, st);
+        e = gs::launch_scan_block_sums(Pv, gp, d_counts, st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: scan %s", hipGetErrorString(e));
         e = hipMemsetAsync(d_counts + 1, 0xff, sizeof(uint32_t), st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_preprocess_forward: memset %s", hipGetErrorString(e));
@@ -261,6 +288,8 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_ti
     if (D > 0 && (!bin_state || !point_list)) return fail(GS_EINVAL, "gs_render_forward: null binning workspace");
     if (D >= (int64_t)1 << 32) return fail(GS_ECAPACITY, "gs_render_forward: more than 2^32 tile instances");
     hipStream_t st = (hipStream_t)stream;
+    const int32_t Pin = P;
+    P = virtual_count(k, Pin);                             // every stage below works on the virtual Gaussians of the atlas
     gs::GeomPtrs gp = carve_geom(geom_state, P, k);
     GsImageLayout IL; gs_image_layout(k.W, k.H, &IL);
     char* ib = (char*)image_state;
@@ -321,6 +350,7 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* m
 {
     gs::Cam k;
     if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_render_backward: invalid camera settings");
+    if (k.V > 1) return fail(GS_EINVAL, "gs_render_backward: multi-view atlas renders are forward-only");
     if (P < 0 || D < 0 || !geom_state || !image_state || !dL_dcolor || !scratch)
         return fail(GS_EINVAL, "gs_render_backward: null pointer");
     if (P == 0) return GS_OK;

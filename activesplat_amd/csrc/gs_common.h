@@ -21,6 +21,10 @@ constexpr int kSortCapMax = 16384;  // largest per-tile list whose sorted chunks
 // tensors put them (uniform loads -> scalar cache).
 struct Cam {
     int W, H, gx, gy;
+    // multi-view atlas (planner panoramas): V views of Wv x H pixels side by side, view v in tile columns [v gxv, (v+1) gxv);
+    // the per-Gaussian stage runs over V x Ppad VIRTUAL Gaussians (view-major, nbv 256-row blocks per view), every later stage
+    // sees one image of W = V gxv 16 pixels.  V = 1: Wv = W, gxv = gx.
+    int V, Wv, gxv, nbv;
     float tanfovx, tanfovy, fx, fy, mod;
     int sh_degree, sh_coeffs;
     const float* bg;

@@ -72,11 +72,13 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     float* const s_sh = s_pool;
 
     const int tid = threadIdx.x;
-    const int base = blockIdx.x * kBlock;
-    const int nrows = min(kBlock, P - base);
+    const int vbase = blockIdx.x * kBlock;                     // first VIRTUAL Gaussian of this block (= output row)
+    const int view = cam.V > 1 ? (int)blockIdx.x / cam.nbv : 0;
+    const int base = (cam.V > 1 ? (int)blockIdx.x - view * cam.nbv : (int)blockIdx.x) * kBlock;   // first INPUT row
+    const int nrows = max(0, min(kBlock, P - base));
     // the per-tile instance counters of the binning stage are zeroed here (saves a memset launch)
-    if (base + tid < cam.gx * cam.gy) gp.tile_total[base + tid] = 0u;
-    const int i = base + tid;
+    if (vbase + tid < cam.gx * cam.gy) gp.tile_total[vbase + tid] = 0u;
+    const int i = base + tid, io = vbase + tid;
     stage_rows<3>(s_mean, means3D, base, nrows, tid);
     if (!SLAB) {
         if (cov3Dp) stage_rows<6>(s_cov, cov3Dp, base, nrows, tid);
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
             sh_wave_rows_to_lds<KC>(slab, shs, row0, min(kShHalf, P - row0), K, lane);
             __builtin_amdgcn_wave_barrier();
             if ((lane >> 5) == h && base + tid < P) {
-                const float dx = s_mean[tid * 3] - cam.campos[0], dy = s_mean[tid * 3 + 1] - cam.campos[1], dz = s_mean[tid * 3 + 2] - cam.campos[2];
+                const float* cp = cam.campos + 3 * view;
+                const float dx = s_mean[tid * 3] - cp[0], dy = s_mean[tid * 3 + 1] - cp[1], dz = s_mean[tid * 3 + 2] - cp[2];
                 const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
                 float b[16];
                 sh_basis(cam.sh_degree, dx * inv, dy * inv, dz * inv, b);
@@ -126,8 +129,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     }
     uint32_t ntiles = 0;
     if (i < P) {
-        const float* m = cam.view;
-        const float* q = cam.proj;
+        const float* m = cam.view + 16 * view;
+        const float* q = cam.proj + 16 * view;
         const float px = s_mean[tid * 3], py = s_mean[tid * 3 + 1], pz = s_mean[tid * 3 + 2];
         const float tx = ((m[0] * px + m[4] * py) + m[8] * pz) + m[12];
         const float ty = ((m[1] * px + m[5] * py) + m[9] * pz) + m[13];
@@ -189,9 +192,12 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
                 const float lam = fmaxf(mid + sq, mid - sq);
                 float rf = ceilf(3.0f * sqrtf(lam));
                 rf = fminf(rf, 16777216.0f);
-                const float pxx = ((ndcx + 1.0f) * (float)cam.W - 1.0f) * 0.5f;
+                const float pxv = ((ndcx + 1.0f) * (float)cam.Wv - 1.0f) * 0.5f;     // pixel x inside this view
                 const float pyy = ((ndcy + 1.0f) * (float)cam.H - 1.0f) * 0.5f;
-                const int x0 = clamp_tile((pxx - rf) / 16.0f, cam.gx), x1 = clamp_tile(((pxx + rf) + 15.0f) / 16.0f, cam.gx);
+                // the tile rect is clamped to the view's own columns, then moved to the view's slot of the atlas
+                const int xs = view * cam.gxv;
+                const int x0 = clamp_tile((pxv - rf) / 16.0f, cam.gxv) + xs, x1 = clamp_tile(((pxv + rf) + 15.0f) / 16.0f, cam.gxv) + xs;
+                const float pxx = cam.V > 1 ? pxv + (float)(xs * kTile) : pxv;
                 const int y0 = clamp_tile((pyy - rf) / 16.0f, cam.gy), y1 = clamp_tile(((pyy + rf) + 15.0f) / 16.0f, cam.gy);
                 const int area = (x1 - x0) * (y1 - y0);
                 if (area > 0) {
@@ -222,11 +228,17 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
                 }
             }
         }
-        radii[i] = radius;
-        gp.geom[(size_t)i * 3] = g0; gp.geom[(size_t)i * 3 + 1] = g1; gp.geom[(size_t)i * 3 + 2] = g2;
-        gp.rect[i] = rc;
-        gp.tiles[i] = ntiles;
-        if (HAS_SH) gp.clamped[i] = clampbits;
+        radii[io] = radius;
+        gp.geom[(size_t)io * 3] = g0; gp.geom[(size_t)io * 3 + 1] = g1; gp.geom[(size_t)io * 3 + 2] = g2;
+        gp.rect[io] = rc;
+        gp.tiles[io] = ntiles;
+        if (HAS_SH) gp.clamped[io] = clampbits;
+    } else if (cam.V > 1) {                            // padding rows of a view's last block: never visible
+        radii[io] = 0;
+        gp.geom[(size_t)io * 3] = gp.geom[(size_t)io * 3 + 1] = gp.geom[(size_t)io * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gp.rect[io] = make_uint2(0u, 0u);
+        gp.tiles[io] = 0u;
+        if (HAS_SH) gp.clamped[io] = 0u;
     }
     // per-block tile count -> block_sums (scanned by scan_block_sums_kernel)
     const uint32_t ws = wave_sum_u32(ntiles);
@@ -265,7 +277,7 @@ hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D
                                      const float* rots, const float* cov3Dp, int32_t* radii, GeomPtrs gp,
                                      uint32_t* d_num_rendered, hipStream_t st)
 {
-    const int nb = (P + kBlock - 1) / kBlock;
+    const int nb = cam.V > 1 ? cam.V * cam.nbv : (P + kBlock - 1) / kBlock;
     if (nb > 0 && shs && cam.sh_coeffs == 16)
         hipLaunchKernelGGL(preprocess_forward_kernel<3>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
                            scales, rots, cov3Dp, radii, gp);

@@ -5,8 +5,8 @@ Reference: src/mapper/splatam/__init__.py:698-741 (get_global_invisibility) and 
 (get_local_invisibility); intrinsics src/dataloader/__init__.py:275-284; camera yaw src/utils/pose_utils.py:13-43.
 The reference spends, per node, 3 x (get_rendervars [8 elementwise torch kernels, twice] + two raster passes
 [the second one's only product, the silhouette, is discarded] + 3 blocking D2H copies).  `look_around(fused=True)`
-activates the Gaussians once (gs_activate_forward with the identity pose), runs ONE raster pass per view and
-leaves the panorama on the device; `fused=False` reproduces the reference op for op (parity tests compare them).
+activates the Gaussians once (gs_activate_forward with the identity pose), renders ALL views in one raster pass over a
+multi-view atlas (rasterizer.render_views) and leaves the panorama on the device; `fused=False` reproduces the reference op for op (parity tests compare them).
 Everything downstream of the arrays (DBSCAN clustering, convex hulls: src/mapper/__init__.py:8-80) is planner
 code and out of scope.
 """
@@ -17,7 +17,7 @@ import torch
 
 from . import mapping as M
 from .camera import setup_camera
-from .rasterizer import GaussianRasterizer
+from .rasterizer import GaussianRasterizer, render_views
 
 LOOK_HFOV_DEG, LOOK_VFOV_DEG, LOOK_W, LOOK_H = 120, 150, 120, 150        # 1 pixel = 1 degree of rotation
 VIZ_NEAR, VIZ_FAR = 0.01, 100.0                                          # config/splatam/online_habitat_sim.py:99
@@ -56,37 +56,36 @@ def _world_rendervar(params):
 
 
 @torch.no_grad()
-def look_around(params, view_c2w, scale_modifier=1.0, fused=True, views=None):
-    """-> dict(opacity [150, 120 V], rgb uint8 [150, 120 V, 3], depth [150, 120 V, 1]) device tensors, V = 360/120 = 3."""
+def look_around(params, view_c2w, scale_modifier=1.0, fused=True, views=None, batched=True):
+    """-> dict(opacity [150, 120 V], rgb uint8 [150, 120 V, 3], depth [150, 120 V, 1]) device tensors, V = 360/120 = 3.
+    fused=True, batched=True : one activation, ONE raster pass for all V views (rasterizer.render_views: multi-view atlas);
+    fused=True, batched=False: one activation, one raster pass per view;
+    fused=False              : the reference op for op (two activations + two raster passes per view)."""
     views = int(360 / LOOK_HFOV_DEG) if views is None else views
     k = look_around_k()
     cfg = dict(viz_w=LOOK_W, viz_h=LOOK_H, viz_near=VIZ_NEAR, viz_far=VIZ_FAR)
     device = params["means3D"].device
-    rv = _world_rendervar(params) if fused else None
-    ops, rgbs, deps = [], [], []
-    pool = None        # (views on separate HIP streams were tried: with segmented compositing every view fills the chip on its own)
-    for i in range(views):
-        w2c = np.linalg.inv(rot_axis(np.asarray(view_c2w, dtype=np.float64), "y", np.deg2rad(LOOK_HFOV_DEG * i)))
-        if fused:
-            cam = setup_camera(LOOK_W, LOOK_H, k, w2c, VIZ_NEAR, VIZ_FAR, scale_modifier=scale_modifier, device=device, bg=(1.0, 1.0, 1.0))
-            if pool is not None:
-                with torch.cuda.stream(pool[i]):
-                    im, _, depth, opacity = GaussianRasterizer(raster_settings=cam)(**rv)
-                    rgb = (torch.clamp(im, min=0, max=1.0) * 255).byte().permute(1, 2, 0)
-                    op, dep = opacity[0], depth.float().permute(1, 2, 0)
-                rgbs.append(rgb); ops.append(op); deps.append(dep)
-                continue
-            im, _, depth, opacity = GaussianRasterizer(raster_settings=cam)(**rv)
+    w2cs = [np.linalg.inv(rot_axis(np.asarray(view_c2w, dtype=np.float64), "y", np.deg2rad(LOOK_HFOV_DEG * i))) for i in range(views)]
+    outs = []
+    if fused:
+        rv = _world_rendervar(params)
+        cams = [setup_camera(LOOK_W, LOOK_H, k, w2c, VIZ_NEAR, VIZ_FAR, scale_modifier=scale_modifier, device=device, bg=(1.0, 1.0, 1.0))
+                for w2c in w2cs]
+        if batched and views > 1:
+            rv.pop("means2D")
+            outs = [(im, depth, opacity) for im, _, depth, opacity in render_views(cams, **rv)]
         else:
+            for cam in cams:
+                im, _, depth, opacity = GaussianRasterizer(raster_settings=cam)(**rv)
+                outs.append((im, depth, opacity))
+    else:
+        for w2c in w2cs:
             scene, scene_depth = M.get_rendervars(params, torch.tensor(w2c, dtype=torch.float32, device=device))
             im, depth, opacity, _ = M.render(w2c, k, scene, scene_depth, cfg, scale_modifier)
-        rgbs.append((torch.clamp(im, min=0, max=1.0) * 255).byte().permute(1, 2, 0))
-        ops.append(opacity[0]); deps.append(depth.float().permute(1, 2, 0))
-    if pool is not None:
-        for s in pool:
-            main.wait_stream(s)
-        for t in ops + rgbs + deps:
-            t.record_stream(main)
+            outs.append((im, depth, opacity))
+    rgbs = [(torch.clamp(im, min=0, max=1.0) * 255).byte().permute(1, 2, 0) for im, _, _ in outs]
+    ops = [opacity[0] for _, _, opacity in outs]
+    deps = [depth.float().permute(1, 2, 0) for _, depth, _ in outs]
     return {"opacity": torch.cat(ops, dim=1), "rgb": torch.cat(rgbs, dim=1).contiguous(), "depth": torch.cat(deps, dim=1)}
 
 

@@ -282,3 +282,66 @@ class GaussianRasterizer(nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
+
+
+@torch.no_grad()
+def render_views(settings_list, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+    """Forward-only render of V views of ONE set of Gaussians in a single pass (the planner's look-around panoramas,
+    src/mapper/splatam/__init__.py:707-736, 765-778: three 120 x 150 views per node).  The views share size, fov, background,
+    scale modifier and SH degree and differ in their view / projection matrices and camera centre.  The per-Gaussian stage runs
+    once over V x P virtual Gaussians; binning, sorting and blending see ONE atlas image (GsCamera.num_views, gs_atlas_layout) --
+    one set of launches and one host read of the counters instead of V.
+    -> list of (color [3,H,W], radii [P] int32, depth [1,H,W], opacity [1,H,W]) per view (views of the atlas tensors)."""
+    lib = _lib.get()
+    V = len(settings_list)
+    rs0 = settings_list[0]
+    if V == 1:
+        return [GaussianRasterizer(rs0)(means3D=means3D, means2D=None, opacities=opacities, shs=shs, colors_precomp=colors_precomp,
+                                        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)]
+    for rs in settings_list[1:]:
+        if (rs.image_width, rs.image_height, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.sh_degree) != \
+                (rs0.image_width, rs0.image_height, rs0.tanfovx, rs0.tanfovy, rs0.scale_modifier, rs0.sh_degree):
+            raise Exception("render_views: the views must share size, field of view, scale modifier and SH degree")
+    if (shs is None) == (colors_precomp is None):
+        raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+    device = means3D.device
+    if device.type != "cuda" and not _lib.emulated():
+        raise RuntimeError("activesplat_amd rasteriser needs ROCm device tensors (no CPU fallback)")
+    P, W, H = int(means3D.shape[0]), int(rs0.image_width), int(rs0.image_height)
+    means3D, shs, colors_precomp = _f32(means3D, device), _f32(shs, device), _f32(colors_precomp, device)
+    opacities, scales, rotations, cov3D_precomp = _f32(opacities, device), _f32(scales, device), _f32(rotations, device), _f32(cov3D_precomp, device)
+    M = 0 if shs is None else int(shs.shape[1])
+    keep = dict(bg=_f32(rs0.bg, device).reshape(-1),
+                view=torch.stack([_f32(rs.viewmatrix, device).reshape(16) for rs in settings_list]).contiguous(),
+                proj=torch.stack([_f32(rs.projmatrix, device).reshape(16) for rs in settings_list]).contiguous(),
+                campos=torch.stack([_f32(rs.campos, device).reshape(3) for rs in settings_list]).contiguous())
+    cam = _lib.GsCamera(W, H, int(rs0.sh_degree), M, float(rs0.tanfovx), float(rs0.tanfovy), float(rs0.scale_modifier), V,
+                        keep["bg"].data_ptr(), keep["view"].data_ptr(), keep["proj"].data_ptr(), keep["campos"].data_ptr())
+    pv, aw, stride = C.c_int32(), C.c_int32(), C.c_int32()
+    _lib.check(lib.gs_atlas_layout(P, W, V, C.byref(pv), C.byref(aw), C.byref(stride)))
+    Pv, AW, S = pv.value, aw.value, stride.value
+    st = _stream(device)
+    gl = _lib.GsGeomLayout(); _lib.check(lib.gs_geom_layout(Pv, AW, H, C.byref(gl)))
+    il = _lib.GsImageLayout(); _lib.check(lib.gs_image_layout(AW, H, C.byref(il)))
+    geom = torch.empty(gl.total_bytes, dtype=torch.uint8, device=device)
+    image = torch.empty(il.total_bytes, dtype=torch.uint8, device=device)
+    radii = torch.empty(max(Pv, 1), dtype=torch.int32, device=device)
+    d_num = torch.empty(2, dtype=torch.int32, device=device)
+    h_num = _host_counters(device) if device.type == "cuda" else torch.zeros(2, dtype=torch.int32)
+    _lib.check(lib.gs_preprocess_forward(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
+                                         _ptr(rotations), _ptr(cov3D_precomp), _ptr(radii), _ptr(geom), _ptr(image), _ptr(d_num), _ptr(h_num), st))
+    if device.type == "cuda":
+        torch.cuda.current_stream(device).synchronize()      # D and the longest tile list size the binning workspace
+    D, max_tile = int(h_num[0].item()) & 0xFFFFFFFF, int(h_num[1].item()) & 0xFFFFFFFF
+    bl = _lib.GsBinLayout(); _lib.check(lib.gs_bin_layout(D, max_tile, AW, H, C.byref(bl)))
+    binning = torch.empty(bl.total_bytes, dtype=torch.uint8, device=device)
+    plist = torch.empty(max(D, 1), dtype=torch.int32, device=device)
+    color = torch.empty(3, H, AW, dtype=torch.float32, device=device)
+    depth = torch.empty(1, H, AW, dtype=torch.float32, device=device)
+    opacity = torch.empty(1, H, AW, dtype=torch.float32, device=device)
+    _lib.check(lib.gs_render_forward(C.byref(cam), P, D, max_tile, _ptr(geom), _ptr(binning), _ptr(plist), _ptr(image),
+                                     _ptr(color), _ptr(depth), _ptr(opacity), None, None, st))
+    last_stats["num_rendered"], last_stats["P"], last_stats["max_tile_instances"] = D, P, max_tile
+    rows = Pv // V
+    return [(color[:, :, v * S:v * S + W], radii[v * rows:v * rows + P], depth[:, :, v * S:v * S + W], opacity[:, :, v * S:v * S + W])
+            for v in range(V)]

@@ -59,7 +59,8 @@ typedef struct GsCamera {
     float tanfovx;
     float tanfovy;
     float scale_modifier;
-    int32_t reserved;
+    int32_t num_views;      /* 0/1: one view.  V > 1: multi-view ATLAS (forward only, see gs_atlas_layout): viewmatrix / projmatrix /
+                             * campos hold V consecutive blocks; image_width is the width of ONE view */
     const float* bg;          /* [3] */
     const float* viewmatrix;  /* [16] = w2c^T row-major */
     const float* projmatrix;  /* [16] = (P w2c)^T row-major */
@@ -103,6 +104,13 @@ typedef struct GsBinLayout {
     uint64_t seg_T;         /* float [tiles][segments][256]: per-segment transmittance of the segmented forward */
 } GsBinLayout;
 
+/* Multi-view atlas (the planner's look-around: V small views of one map, src/mapper/splatam/__init__.py:707-736): with
+ * GsCamera.num_views = V > 1 the per-Gaussian stage runs once over V x P virtual Gaussians (view-major, each view's rows
+ * padded to whole 256-row blocks) and binning, sorting and blending see ONE image of V view slots side by side, every slot
+ * padded to whole tiles.  Sizes for the caller: virtual_P = rows of radii[] and the P to pass to gs_geom_layout; atlas_width =
+ * the width to pass to the layout functions and the row length of the output images; view v occupies columns
+ * [v * view_stride, v * view_stride + view_width).  gs_preprocess_forward / gs_render_forward still take the INPUT count P. */
+int gs_atlas_layout(int32_t P, int32_t view_width, int32_t num_views, int32_t* virtual_P, int32_t* atlas_width, int32_t* view_stride);
 int gs_geom_layout(int32_t P, int32_t width, int32_t height, GsGeomLayout* out);
 int gs_image_layout(int32_t width, int32_t height, GsImageLayout* out);
 int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t height, GsBinLayout* out);
@@ -192,7 +200,8 @@ typedef struct GsAdamTensor {
     float* exp_avg_sq;
     double lr, beta1, beta2, eps;
     int32_t step;
-    int32_t reserved;
+    int32_t num_views;      /* 0/1: one view.  V > 1: multi-view ATLAS (forward only, see gs_atlas_layout): viewmatrix / projmatrix /
+                             * campos hold V consecutive blocks; image_width is the width of ONE view */
 } GsAdamTensor;
 int gs_adam_step_multi(int32_t count, const GsAdamTensor* tensors, gs_stream_t stream);
 

@@ -13,7 +13,8 @@ def bench(fn, n=20):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
 print(f"N={N}: reference call pattern {bench(lambda: LA.look_around(params, c2w, fused=False)):.3f} ms / panorama")
-print(f"N={N}: fused                   {bench(lambda: LA.look_around(params, c2w, fused=True)):.3f} ms / panorama")
+print(f"N={N}: fused, one pass per view {bench(lambda: LA.look_around(params, c2w, fused=True, batched=False)):.3f} ms / panorama")
+print(f"N={N}: fused, multi-view atlas {bench(lambda: LA.look_around(params, c2w, fused=True, batched=True)):.3f} ms / panorama")
 _cuda = torch.device("cuda").type
 class _One:  # single-stream variant: pretend there is one view per call
     pass
@@ -22,6 +23,6 @@ print(f"N={N}: fused, three single-view calls {t1:.3f} ms / panorama")
 from activesplat_amd import _lib, rasterizer as R
 lib = _lib.get(); lib.gs_profile_enable(1)
 for _ in range(10):
-    LA.look_around(params, c2w, fused=True, views=1)
+    LA.look_around(params, c2w, fused=True)
 torch.cuda.synchronize()
 print({k: round(ms / c * 1e3, 1) for k, (ms, c) in _lib.profile_collect().items() if c}, R.last_stats)
