@@ -218,7 +218,7 @@ int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t
         const uint64_t by_len = max_tile_instances / 1024;
         if (S > by_len) S = by_len;
         if (S > 32) S = 32;
-        if (S >= 2) { out->segments = S; out->seg_T = o; o = align_up(o + (uint64_t)tiles * S * gs::kBlock * 4); }
+        if (S >= 2) { out->segments = S; out->seg_T = o; o = align_up(o + (uint64_t)tiles * S * gs::kBlock * 4 + (uint64_t)tiles * 16); }
     }
     out->total_bytes = o;
     return GS_OK;

@@ -175,6 +175,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
     float T = 1.0f;
     bool next_stopped = true;                   // SEG = 2: the following segment finds this pixel stopped at its entry
     float* my_seg_T = nullptr;
+    uint32_t* seg_flag = nullptr;
     if (SEG != 0) {
         const uint32_t S = gridDim.y, seg = blockIdx.y;
         const uint32_t L = (((n_all + S - 1) / S + kWave - 1) / kWave) * kWave;       // chunk-aligned segment length
@@ -182,6 +183,15 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
         n = min(n_all, first + L);
         float* tile_T = seg_T + ((size_t)c.tile * S) * kBlock + wave * kWave + lane;   // [tile][segment][quadrant][lane]
         my_seg_T = tile_T + (size_t)seg * kBlock;
+        if (SEG == 1) {
+            // an EARLIER segment that takes every pixel of this quadrant below the stop threshold on its own makes this one
+            // irrelevant (all its pixels are stopped at entry whatever it holds): such segments leave a bit in the quadrant's
+            // flag word (behind the transmittances).  Segments are dispatched in order, so the bit is usually there in time; if
+            // it is not, the segment simply does its work -- the result does not depend on the timing.
+            seg_flag = reinterpret_cast<uint32_t*>(seg_T + (size_t)cam.gx * cam.gy * S * kBlock) + c.tile * 4 + wave;
+            const uint32_t f = __hip_atomic_load(seg_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (f & ((1u << seg) - 1u)) { my_seg_T[0] = 1.0f; return; }
+        }
         if (SEG == 2) {
             for (uint32_t q = 0; q < seg; q++) T *= tile_T[(size_t)q * kBlock];
             next_stopped = seg + 1 == S ? true : (T * my_seg_T[0] < kTmin);
@@ -264,9 +274,14 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
             }
             __builtin_amdgcn_wave_barrier();
             if (SEG != 1 && __all(done)) break;
+            if (SEG == 1 && __all(!inside || T < kTmin)) break;      // every pixel is below the stop threshold: the rest cannot matter
         }
     }
-    if (SEG == 1) { my_seg_T[0] = T; return; }
+    if (SEG == 1) {
+        my_seg_T[0] = T;
+        if (__all(!inside || T < kTmin) && lane == 0) atomicOr(seg_flag, 1u << blockIdx.y);
+        return;
+    }
     if (SEG == 2) {
         if (inside && !stopped_at_entry) {
             const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
@@ -572,6 +587,8 @@ hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint3
         // segmented compositing: the sums are added with atomics, so the images start from zero
         const size_t HW = (size_t)cam.W * cam.H;
         hipError_t e = zero_fill ? hipMemsetAsync(zero_fill, 0, (size_t)P * kGradStride * sizeof(float), st) : hipSuccess;
+        if (e == hipSuccess)       // the quadrants' "an earlier segment saturates" flag words behind the transmittances
+            e = hipMemsetAsync(seg_T + (size_t)cam.gx * cam.gy * segments * kBlock, 0, (size_t)cam.gx * cam.gy * 4 * sizeof(uint32_t), st);
         if (e == hipSuccess) e = hipMemsetAsync(out_color, 0, 3 * HW * sizeof(float), st);
         if (e == hipSuccess) e = hipMemsetAsync(out_depth, 0, HW * sizeof(float), st);
         if (e == hipSuccess && out_depth_sq) e = hipMemsetAsync(out_depth_sq, 0, HW * sizeof(float), st);

@@ -14,8 +14,11 @@ habitat).  It reproduces the CALL PATTERN and SCHEDULE of the hot loop, nothing 
                                   id % map_every == 0 (__init__.py:395-397); each: np.random.randint keyframe pick,
                                   get_loss (two raster passes), backward, optional prune / densify, Adam step,
                                   zero_grad(set_to_none) (__init__.py:447-480)
-  keyframes                     : appended when id == 0, (id+1) % keyframe_every == 0 or id == step_num - 2
-                                  (__init__.py:514-524)
+  keyframes                     : appended when id == 0, (id+1) % keyframe_every == 0 or id == step_num - 2, unless the
+                                  frame's ground-truth pose holds inf / nan (__init__.py:514-524)
+  every frame once a map exists : get_high_loss_samples' render of the map at the frame's pose (two raster passes in the
+                                  reference, one with fused_render) and its "rendered surface in front of a measured one" mask
+                                  (__init__.py:184-214, 256-258); the mask's clustering (cv2 resize, DBSCAN) is planner code
 
 Inputs are already-resized frames (`color [3,H,W]` in 0..1, `depth [1,H,W]` metres, pose relative to frame 0 as
 quaternion (w,x,y,z) + translation of the w2c) -- the cv2 resize / PNG / manifest work of the reference is I/O
@@ -46,6 +49,7 @@ DEFAULT_CONFIG = dict(
     fused_inputs=False,      # transform_to_frame + activations by gs_activate_*
     fused_growth=False,      # add_new_gaussians: one forward + gs_grow_gaussians
     fused_keyframes=False,   # keyframe overlap scores by gs_keyframe_overlap (one launch for all keyframes)
+    high_loss_samples=True,  # the per-frame no-grad render of get_high_loss_samples (__init__.py:184-258) before mapping a frame
     mapping=dict(
         loss_weights=dict(im=0.5, depth=1.0), sil_thres=0.98, use_sil_for_loss=False, use_l1=True,
         ignore_outlier_depth_loss=False, add_new_gaussians=True, prune_gaussians=False,
@@ -83,6 +87,7 @@ class SplatMapper:
         self.rng = np.random.RandomState(self.cfg["seed"])
         self.stats = dict(iters=0, iter_time=0.0, frames=0, frame_time=0.0)
         self.last_losses = None
+        self.high_loss_mask = None          # bool [H,W] of the most recent frame (None before the first map exists)
 
     # -- helpers ---------------------------------------------------------------------------------
     def _w2c(self, frame_id):
@@ -104,6 +109,11 @@ class SplatMapper:
         depth = frame["depth"].to(self.device).float()
         quat = torch.as_tensor(frame["quat"], dtype=torch.float32, device=self.device)
         pos = torch.as_tensor(frame["position"], dtype=torch.float32, device=self.device)
+        if self.params is not None and cfg.get("high_loss_samples", True):
+            init = torch.eye(4, device=self.device)
+            init[:3, :3] = M.build_rotation(F.normalize(quat.view(1, 4)))
+            init[:3, 3] = pos
+            self.high_loss_mask = self.high_loss_samples_mask(init, depth)
         # densification-resolution copy of the frame (reference :362-376); defaults to the mapping resolution
         d_color = frame["densify_color"].to(self.device).float() if "densify_color" in frame else color
         d_depth = frame["densify_depth"].to(self.device).float() if "densify_depth" in frame else depth
@@ -171,12 +181,25 @@ class SplatMapper:
         if iter_per_frame > 0:
             self.stats["frames"] += 1
             self.stats["frame_time"] += time.perf_counter() - t_frame
-        if fid == 0 or (fid + 1) % cfg["keyframe_every"] == 0 or fid == cfg["step_num"] - 2:
-            with torch.no_grad():
-                self.keyframe_list.append({"id": fid, "est_w2c": self._w2c(fid), "color": color, "depth": depth})
         with torch.no_grad():
-            self.gt_w2c_all_frames.append(self._w2c(fid))
+            # the simulator's pose when the caller hands one over (run_raw), the pose written into the camera parameters otherwise
+            gt_w2c = torch.as_tensor(np.asarray(frame["gt_w2c"]), dtype=torch.float32, device=self.device) if "gt_w2c" in frame \
+                else self._w2c(fid)
+            pose_ok = bool(torch.isfinite(gt_w2c).all())
+            if (fid == 0 or (fid + 1) % cfg["keyframe_every"] == 0 or fid == cfg["step_num"] - 2) and pose_ok:
+                self.keyframe_list.append({"id": fid, "est_w2c": self._w2c(fid), "color": color, "depth": depth})
+            self.gt_w2c_all_frames.append(gt_w2c)
         return self.params
+
+    @torch.no_grad()
+    def high_loss_samples_mask(self, view_w2c, gt_depth):
+        """The render + mask half of get_high_loss_samples (__init__.py:184-214): the map rendered at the frame's pose, and
+        `rendered depth > measured depth  and  |error| > 0.3 m (measured pixels only)  and  opacity > 0.8` -- regions where the map
+        shows a surface in front of free space the sensor saw through.  Stays on the device; the caller's clustering is not ours."""
+        im, depth, opacity = self.render_rgbd(view_w2c)
+        gt = gt_depth if gt_depth.dim() == 3 else gt_depth.unsqueeze(0)
+        err = (depth - gt).abs() * (gt > 0)
+        return ((depth > gt) & (err > 0.3) & (opacity > 0.8))[0]
 
     def run_raw(self, image, depth, X_WV, frame_id, quat, position):
         """Sensor frame in (uint8 [h,w,3] image, [h,w] metric depth, 4x4 pose X_WV): pre-processing of :332-378 (pose to the

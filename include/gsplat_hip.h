@@ -101,7 +101,7 @@ typedef struct GsBinLayout {
     uint64_t keys_sorted;   /* RADIX: uint64 [D] */
     uint64_t sort_temp;     /* RADIX: scratch of the sort */
     uint64_t segments;      /* > 1: gs_render_forward composites every tile list in this many parallel segments (few tiles, long lists) */
-    uint64_t seg_T;         /* float [tiles][segments][256]: per-segment transmittance of the segmented forward */
+    uint64_t seg_T;         /* float [tiles][segments][256]: per-segment transmittance of the segmented forward, then uint32 [tiles][4] flag words */
 } GsBinLayout;
 
 /* Multi-view atlas (the planner's look-around: V small views of one map, src/mapper/splatam/__init__.py:707-736): with

@@ -108,3 +108,39 @@ def test_raw_frames_with_densification_resolution(emu):
     im, depth, opacity = mp.render_rgbd(seq[0]["w2c"])
     assert im.shape == (3, H, W) and float(opacity.mean()) > 0.3
     assert len(mp.gt_w2c_all_frames) == frames
+
+
+def test_mapper_on_emulated_kernels_equals_mapper_on_the_oracle(emu, oracle32, monkeypatch):
+    """configs[4] substitute, second half: the SAME mapping loop driven twice over the SAME synthetic RGB-D spin --
+    once on this build's kernels (host-emulated here; the GPU twin is in tests/test_gpu_parity.py), once with a rasteriser whose
+    forward and backward are the C oracle (test-only shim).  The loops must build the same map: identical schedule, the same
+    number of Gaussians up to single-pixel threshold flips, and re-renders of the sequence within 0.1 dB of each other."""
+    from activesplat_amd import mapping as M
+    a, seq, log_a = run_harness(emu, n_gt=2500, W=48, H=40, frames=6)
+    monkeypatch.setattr(M, "Renderer", util.oracle_rasterizer_class(oracle32))
+    b, _, log_b = run_harness_on(seq, 48, 40, emu)
+    monkeypatch.undo()
+    assert [(e["iters"], e["new_opt"], e["keyframes"]) for e in log_a] == [(e["iters"], e["new_opt"], e["keyframes"]) for e in log_b]
+    na, nb = a.params["means3D"].shape[0], b.params["means3D"].shape[0]
+    assert abs(na - nb) <= max(2, 0.003 * nb), (na, nb)
+    for fr in (seq[0], seq[4]):
+        seen = (fr["depth"] > 0)[0].cpu().numpy()
+        gt = fr["color"].cpu().numpy()[:, seen]
+        pa = util.psnr(a.render_rgbd(fr["w2c"])[0].cpu().numpy()[:, seen], gt)
+        pb = util.psnr(b.render_rgbd(fr["w2c"])[0].cpu().numpy()[:, seen], gt)          # b's map rendered by the product rasteriser
+        assert abs(pa - pb) < 0.1 and pa > 18.0, (pa, pb)
+    # the per-frame high-loss consumer ran on both
+    assert a.high_loss_mask is not None and a.high_loss_mask.shape == (40, 48) and a.high_loss_mask.dtype == torch.bool
+    assert int((a.high_loss_mask != b.high_loss_mask).sum()) <= 2
+
+
+def run_harness_on(seq, W, H, device, cfg=None):
+    from activesplat_amd import synthetic as syn
+    from activesplat_amd.mapper import SplatMapper
+    mp = SplatMapper(syn.intrinsics(W, H), W, H, config=dict(step_num=len(seq), **(cfg or {})), device=device)
+    log = []
+    for fr in seq:
+        opt_before, it_before = mp.optimizer, mp.stats["iters"]
+        mp.run(fr)
+        log.append(dict(id=fr["id"], new_opt=mp.optimizer is not opt_before, iters=mp.stats["iters"] - it_before, keyframes=len(mp.keyframe_list)))
+    return mp, seq, log

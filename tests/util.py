@@ -163,3 +163,39 @@ def configs2_optimise_loop(N, iters, device, fused_densify=True, densify_every=5
     if dev.type == "cuda":
         torch.cuda.synchronize()
     return dict(losses=losses, counts=counts, seconds=time.perf_counter() - t0, densify_seconds=densify_s, final_N=int(state["params"]["means3D"].shape[0]))
+
+
+# ---- TEST-ONLY: a GaussianRasterizer whose forward and backward are the C oracle (oracle/gs_oracle.c) -----------------------
+class _OracleRasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, oracle, rs, means3D, means2D, opacities, colors, scales, rotations):
+        n = lambda t: t.detach().cpu().numpy()  # noqa: E731
+        f = oracle.forward(cam_dict(rs), n(means3D), n(opacities), colors=n(colors), scales=n(scales), rotations=n(rotations))
+        ctx.oracle, ctx.f = oracle, f
+        H, W = int(rs.image_height), int(rs.image_width)
+        dev = means3D.device
+        t = lambda a, *s: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).reshape(*s).to(dev)  # noqa: E731
+        color, depth, opacity = t(f["color"], 3, H, W), t(f["out_depth"], 1, H, W), t(f["opacity"], 1, H, W)
+        radii = torch.from_numpy(np.asarray(f["radii"], dtype=np.int32).copy()).to(dev)
+        ctx.mark_non_differentiable(radii, depth, opacity)
+        return color, radii, depth, opacity
+
+    @staticmethod
+    def backward(ctx, g_color, _gr, _gd, _go):
+        g = ctx.oracle.backward(ctx.f, g_color.detach().cpu().numpy())
+        t = lambda k: torch.from_numpy(np.ascontiguousarray(np.asarray(g[k], dtype=np.float32))).to(g_color.device)  # noqa: E731
+        return (None, None, t("means3D").reshape(-1, 3), t("means2D").reshape(-1, 3), t("opacities").reshape(-1, 1),
+                t("colors_precomp").reshape(-1, 3), t("scales").reshape(-1, 3), t("rotations").reshape(-1, 4))
+
+
+def oracle_rasterizer_class(oracle):
+    """-> a drop-in for activesplat_amd.GaussianRasterizer (colors_precomp + scales/rotations call sites) backed by `oracle`."""
+    class OracleRasterizer(torch.nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def forward(self, means3D, means2D, opacities, colors_precomp=None, scales=None, rotations=None, shs=None, cov3D_precomp=None):
+            assert shs is None and cov3D_precomp is None
+            return _OracleRasterize.apply(oracle, self.raster_settings, means3D, means2D, opacities, colors_precomp, scales, rotations)
+    return OracleRasterizer
