@@ -19,7 +19,9 @@
  *      rotations [P,4] (w,x,y,z), cov3D_precomp [P,6]); base pointers 16-byte aligned;
  *   - `stream` is a hipStream_t; every entry point only enqueues work on it (no implicit sync);
  *   - return value 0 = success, otherwise a GS_E* code; gs_last_error() gives the message;
- *   - no torch types, no global mutable state except the last-error string (thread-local).
+ *   - no torch types.  Process-wide state: the last-error string (thread-local), and three development knobs that are NOT
+ *     synchronised with rendering calls on other threads -- set them while nothing is in flight: gs_set_sort_path,
+ *     gs_set_forward_segments (defaults: automatic path choice, segments on) and the gs_profile_* event log (off).
  *
  * Call sequence for one forward:
  *     gs_preprocess_forward(...)            // per-Gaussian stage + tile counting; writes the counts
@@ -28,6 +30,8 @@
  *     gs_render_forward(...)                // scatter into tile segments, per-tile depth sort, alpha-blend
  * and for the backward:
  *     gs_render_backward(...)               // per-pixel replay -> per-Gaussian grads -> input grads
+ * Optional: gs_render_forward may run optimistically right behind gs_preprocess_forward with capacities from the previous
+ * frame (see its comment), and may zero-fill the backward's scratch as a side job (backward_scratch).
  */
 #ifndef GSPLAT_HIP_H
 #define GSPLAT_HIP_H

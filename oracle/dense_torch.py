@@ -54,9 +54,11 @@ def build_cov3d(scales, rots, mod):
 
 
 def render_dense(cam: dict, means3D, opacities, colors=None, shs=None, scales=None, rotations=None,
-                 cov3D_precomp=None, means2D=None, pixel_chunk: int = 4096):
+                 cov3D_precomp=None, means2D=None, pixel_chunk: int = 4096, tiled: bool = False):
     """cam: dict(W,H,tanfovx,tanfovy,bg[3],scale_modifier,viewmatrix[4,4],projmatrix[4,4],campos[3],sh_degree).
     Matrices exactly as stored in the settings tensors (transposed, row-vector convention).
+    tiled=True walks the image tile by tile and evaluates only the Gaussians whose rect covers the tile -- the same arithmetic
+    on the same ordered lists (it IS the "CPU PyTorch forward render" of BASELINE configs[0]); tiled=False is the literal dense form.
     Returns dict(color[3,H,W], depth[1,H,W], opacity[1,H,W], radii[P], final_T[H,W], n_contrib[H,W])."""
     dt = means3D.dtype
     W, H = int(cam["W"]), int(cam["H"])
@@ -134,11 +136,27 @@ def render_dense(cam: dict, means3D, opacities, colors=None, shs=None, scales=No
     o_pix, o_a, o_b, o_c, o_op, o_rgb, o_z = pix[order], ca[order], cb[order], cc[order], op[order], rgb[order], tz[order]
     ox0, ox1, oy0, oy1 = x0[order], x1[order], y0[order], y1[order]
     cols, deps, fTs, ncs = [], [], [], []
-    for s in range(0, H * W, pixel_chunk):
-        e = min(s + pixel_chunk, H * W)
-        px, py = PX[s:e, None], PY[s:e, None]
+    if tiled:
+        chunks = []
+        for ty_ in range(gy):
+            for tx_ in range(gx):
+                yy, xx = torch.meshgrid(torch.arange(ty_ * 16, min(H, ty_ * 16 + 16)), torch.arange(tx_ * 16, min(W, tx_ * 16 + 16)), indexing="ij")
+                sel = torch.nonzero((ox0 <= tx_) & (tx_ < ox1) & (oy0 <= ty_) & (ty_ < oy1)).reshape(-1)
+                chunks.append(((yy * W + xx).reshape(-1), sel))
+    else:
+        chunks = [(torch.arange(s, min(s + pixel_chunk, H * W)), None) for s in range(0, H * W, pixel_chunk)]
+    pix_index = []
+    for pidx, sel in chunks:
+        s, e = 0, int(pidx.numel())
+        pix_index.append(pidx)
+        px, py = PX[pidx, None], PY[pidx, None]
         tix, tiy = (px / 16).floor().to(torch.int64), (py / 16).floor().to(torch.int64)
-        member = (tix >= ox0[None]) & (tix < ox1[None]) & (tiy >= oy0[None]) & (tiy < oy1[None])
+        if sel is not None:            # the tile's ordered list
+            o_pix, o_a, o_b, o_c, o_op, o_rgb, o_z = (v[order][sel] for v in (pix, ca, cb, cc, op, rgb, tz))
+            ox0_, ox1_, oy0_, oy1_ = ox0[sel], ox1[sel], oy0[sel], oy1[sel]
+        else:
+            ox0_, ox1_, oy0_, oy1_ = ox0, ox1, oy0, oy1
+        member = (tix >= ox0_[None]) & (tix < ox1_[None]) & (tiy >= oy0_[None]) & (tiy < oy1_[None])
         dx, dy = o_pix[None, :, 0] - px, o_pix[None, :, 1] - py
         power = -0.5 * (o_a[None] * dx * dx + o_c[None] * dy * dy) - o_b[None] * dx * dy
         G = torch.exp(torch.clamp(power, max=0.0))
@@ -159,5 +177,10 @@ def render_dense(cam: dict, means3D, opacities, colors=None, shs=None, scales=No
         pos = torch.cumsum(member.to(torch.int64), 1)
         ncs.append((pos * keep).max(dim=1).values if keep.shape[1] > 0 else torch.zeros(e - s, dtype=torch.int64))
     col = torch.cat(cols, 1); dep = torch.cat(deps); fT = torch.cat(fTs); ncon = torch.cat(ncs)
+    if tiled:                         # back to row-major pixel order
+        inv = torch.empty(H * W, dtype=torch.int64)
+        allp = torch.cat(pix_index)
+        inv[allp] = torch.arange(H * W)
+        col, dep, fT, ncon = col[:, inv], dep[inv], fT[inv], ncon[inv]
     return dict(color=col.reshape(3, H, W), depth=dep.reshape(1, H, W), opacity=(1 - fT).reshape(1, H, W),
                 radii=radii, final_T=fT.reshape(H, W).detach(), n_contrib=ncon.reshape(H, W))

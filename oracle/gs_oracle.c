@@ -60,6 +60,13 @@ typedef struct {
 
 int gso_real_size(void) { return (int)sizeof(real); }
 
+/* Host threads of the pixel loops and of the per-Gaussian backward (OpenMP).  Default 1: the parity tests want the fixed,
+ * sequential summation order.  bench.py's cpu_baseline leg sets it to the host's core count; the backward's per-Gaussian sums are
+ * then added with atomics (any order). */
+static int g_threads = 1;
+void gso_set_threads(int n) { g_threads = n > 1 ? n : 1; }
+#define GSO_ADD(dst, val) do { if (par) { _Pragma("omp atomic") dst += (val); } else dst += (val); } while (0)
+
 /* ------------------------------------------------------------------------------------------
  * SH evaluation (SURVEY App. A.2 [UP]: the 3DGS paper's public real-SH basis, +0.5, clamp >=0)
  * ---------------------------------------------------------------------------------------- */
@@ -313,6 +320,7 @@ void gso_blend_forward(const GsoCam *cam, int NC, const real *bg, const uint32_t
                        real *out_depth_sq /* nullable: sum z^2 alpha T (the reference's third depth/silhouette channel) */)
 {
     const int W = cam->W, H = cam->H, gx = (W + TILE - 1) / TILE;
+#pragma omp parallel for schedule(dynamic, 2) num_threads(g_threads)
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             const int t = (y / TILE) * gx + (x / TILE);
@@ -362,6 +370,8 @@ void gso_blend_backward(const GsoCam *cam, int NC, const real *bg, const uint32_
     memset(dL_dxy, 0, sizeof(real) * 2 * (size_t)P); memset(dL_dconic, 0, sizeof(real) * 3 * (size_t)P);
     memset(dL_dopacity, 0, sizeof(real) * (size_t)P); memset(dL_dfeat, 0, sizeof(real) * (size_t)NC * P);
     if (dL_dz) memset(dL_dz, 0, sizeof(real) * (size_t)P);
+    const int par = g_threads > 1;
+#pragma omp parallel for schedule(dynamic, 2) num_threads(g_threads)
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             const int t = (y / TILE) * gx + (x / TILE);
@@ -392,13 +402,13 @@ void gso_blend_backward(const GsoCam *cam, int NC, const real *bg, const uint32_
                     accum[ch] = last_alpha * lastc[ch] + (R(1) - last_alpha) * accum[ch];
                     lastc[ch] = c;
                     dL_dalpha += (c - accum[ch]) * dpx[ch];
-                    dL_dfeat[(size_t)NC * g + ch] += w * dpx[ch];
+                    GSO_ADD(dL_dfeat[(size_t)NC * g + ch], w * dpx[ch]);
                 }
                 if (dL_ddepth) {          /* the depth output is one more blended channel (background 0) */
                     accumz = last_alpha * lastz + (R(1) - last_alpha) * accumz;
                     lastz = depth[g];
                     dL_dalpha += (depth[g] - accumz) * dd;
-                    dL_dz[g] += w * dd;
+                    GSO_ADD(dL_dz[g], w * dd);
                 }
                 dL_dalpha *= T;
                 last_alpha = alpha;
@@ -406,12 +416,12 @@ void gso_blend_backward(const GsoCam *cam, int NC, const real *bg, const uint32_
                 const real dL_dG = co[3] * dL_dalpha;
                 const real gdx = G * dx, gdy = G * dy;
                 /* d = mean - pixel, so dG/dmean = dG/dd */
-                dL_dxy[2 * g] += dL_dG * (-gdx * co[0] - gdy * co[1]);
-                dL_dxy[2 * g + 1] += dL_dG * (-gdy * co[2] - gdx * co[1]);
-                dL_dconic[3 * g] += R(-0.5) * gdx * dx * dL_dG;
-                dL_dconic[3 * g + 1] += -gdx * dy * dL_dG;
-                dL_dconic[3 * g + 2] += R(-0.5) * gdy * dy * dL_dG;
-                dL_dopacity[g] += G * dL_dalpha;
+                GSO_ADD(dL_dxy[2 * g], dL_dG * (-gdx * co[0] - gdy * co[1]));
+                GSO_ADD(dL_dxy[2 * g + 1], dL_dG * (-gdy * co[2] - gdx * co[1]));
+                GSO_ADD(dL_dconic[3 * g], R(-0.5) * gdx * dx * dL_dG);
+                GSO_ADD(dL_dconic[3 * g + 1], -gdx * dy * dL_dG);
+                GSO_ADD(dL_dconic[3 * g + 2], R(-0.5) * gdy * dy * dL_dG);
+                GSO_ADD(dL_dopacity[g], G * dL_dalpha);
             }
         }
 }
@@ -434,6 +444,7 @@ void gso_preprocess_backward(const GsoCam *cam, const real *means3D, const real 
     const real *m = cam->viewmatrix, *q = cam->projmatrix;
     const real fx = (real)W / (R(2) * cam->tanfovx), fy = (real)H / (R(2) * cam->tanfovy);
     const int M = cam->sh_coeffs;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int i = 0; i < P; i++) {
         for (int k = 0; k < 3; k++) { dL_dmeans2D[3 * i + k] = 0; dL_dmeans3D[3 * i + k] = 0; dL_dscales[3 * i + k] = 0; dL_dcolors[3 * i + k] = 0; }
         for (int k = 0; k < 4; k++) dL_drots[4 * i + k] = 0;

@@ -54,6 +54,10 @@ class Oracle:
         self._Cam = _Cam32 if precision == "f32" else _Cam64
 
     # -- helpers -------------------------------------------------------------------------
+    def set_threads(self, n: int) -> None:
+        """Host threads of the pixel loops (default 1 = the deterministic sequential order the parity tests use)."""
+        self.lib.gso_set_threads(int(n))
+
     def _r(self, a):
         return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=self.real))
 
