@@ -25,7 +25,7 @@ class GsCamera(C.Structure):
 
 class GsGeomLayout(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "geom", "rect", "tiles_touched", "offsets", "block_sums", "clamped",
-                                          "tile_total", "tile_base")]
+                                          "tile_total", "tile_base", "sh_jac")]
 
 
 class GsImageLayout(C.Structure):
@@ -70,9 +70,9 @@ def _bind(lib):
     lib.gs_backward_scratch_bytes.restype = C.c_uint64
     lib.gs_last_error.restype = C.c_char_p
     lib.gs_version.restype = C.c_char_p
-    lib.gs_preprocess_forward.argtypes = [C.POINTER(GsCamera), i32] + [vp] * 7 + [vp, vp, vp, vp, vp, vp]
+    lib.gs_preprocess_forward.argtypes = [C.POINTER(GsCamera), i32] + [vp] * 7 + [vp, vp, vp, vp, vp, i32, vp]
     lib.gs_render_forward.argtypes = [C.POINTER(GsCamera), i32, i64, C.c_uint32] + [vp] * 8 + [vp, vp]
-    lib.gs_render_backward.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 6 + [vp] * 6 + [vp] * 8 + [vp, i32, vp]
+    lib.gs_render_backward.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 6 + [vp] * 6 + [vp] * 8 + [vp, i32, i32, vp]
     lib.gs_adam_step.argtypes = [i64, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, i32, vp]
     lib.gs_adam_step_multi.argtypes = [i32, C.POINTER(GsAdamTensor), vp]
     lib.gs_profile_enable.argtypes = [i32]

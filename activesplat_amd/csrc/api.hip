@@ -97,6 +97,7 @@ gs::GeomPtrs carve_geom(void* base, int32_t P, const gs::Cam& k)
     g.offsets = (uint32_t*)(b + L.offsets); g.block_sums = (uint32_t*)(b + L.block_sums);
     g.clamped = (uint32_t*)(b + L.clamped);
     g.tile_total = (uint32_t*)(b + L.tile_total); g.tile_base = (uint32_t*)(b + L.tile_base);
+    g.sh_jac = (float4*)(b + L.sh_jac);
     return g;
 }
 
@@ -172,6 +173,7 @@ int gs_geom_layout(int32_t P, int32_t width, int32_t height, GsGeomLayout* out)
     out->clamped = o; o = align_up(o + n * 4);
     out->tile_total = o; o = align_up(o + tiles * 4);
     out->tile_base = o; o = align_up(o + (tiles <= (uint64_t)gs::kMaxLdsTiles ? rows * tiles * 4 : 4));
+    out->sh_jac = o; o = align_up(o + n * 48);
     out->total_bytes = o;
     return GS_OK;
 }
@@ -229,7 +231,7 @@ uint64_t gs_backward_scratch_bytes(int32_t P) { return align_up((uint64_t)(P > 0
 int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, const float* shs,
                           const float* colors_precomp, const float* opacities, const float* scales,
                           const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_state,
-                          void* image_state, uint32_t* d_counts, uint32_t* h_counts, gs_stream_t stream)
+                          void* image_state, uint32_t* d_counts, uint32_t* h_counts, int32_t want_backward, gs_stream_t stream)
 {
     gs::Cam k;
     if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_preprocess_forward: invalid camera settings");
@@ -245,6 +247,7 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, 
     hipStream_t st = (hipStream_t)stream;
     const int32_t Pv = virtual_count(k, P);
     gs::GeomPtrs gp = carve_geom(geom_state, Pv, k);
+    if (!(want_backward && shs)) gp.sh_jac = nullptr;        // written only for SH inputs whose backward will follow
     GsImageLayout IL; gs_image_layout(k.W, k.H, &IL);
     uint2* ranges = (uint2*)((char*)image_state + IL.ranges);
     const int tiles = k.gx * k.gy;
@@ -346,7 +349,7 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* m
                        const uint32_t* point_list, const void* image_state, const float* dL_dcolor,
                        const float* dL_ddepth, float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities, float* dL_dcolors_precomp,
                        float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* scratch,
-                       int32_t scratch_zeroed, gs_stream_t stream)
+                       int32_t scratch_zeroed, int32_t have_sh_jacobian, gs_stream_t stream)
 {
     gs::Cam k;
     if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_render_backward: invalid camera settings");
@@ -374,7 +377,7 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* m
     }
     {
         ScopedStage ps(ST_PREPROCESS_BWD, st);
-        e = gs::launch_preprocess_backward(k, P, means3D, shs, scales, rotations, cov3D_precomp, radii, gp.clamped, grad2d,
+        e = gs::launch_preprocess_backward(k, P, means3D, shs, scales, rotations, cov3D_precomp, radii, gp.clamped, (shs && have_sh_jacobian) ? gp.sh_jac : nullptr, grad2d,
                                            dL_dmeans2D, dL_dmeans3D, dL_dopacities, dL_dcolors_precomp, dL_dshs, dL_dscales,
                                            dL_drotations, dL_dcov3D, st);
     }

@@ -46,6 +46,7 @@ struct GeomPtrs {
     uint32_t* clamped;   // uchar4 packed
     uint32_t* tile_total;  // [tiles]
     uint32_t* tile_base;   // [ceil(P/kBinChunk)][tiles]
+    float4* sh_jac;        // [P][3]: d(rgb before the clamp)/d(unit view direction), 3x3 row-major in 9 of 12 floats (SH inputs with a backward to follow)
 };
 
 // ---- wave-64 helpers ---------------------------------------------------------------------------
@@ -183,6 +184,85 @@ __device__ __forceinline__ void sh_wave_rows_from_lds(const float* slab, float* 
     }
 }
 
+// real-SH basis of the 3DGS family and its gradient w.r.t. the unit direction
+__device__ __forceinline__ void sh_basis_and_grad(int deg, float x, float y, float z, float* b, float* bx, float* by, float* bz)
+{
+    for (int k = 0; k < 16; k++) { b[k] = 0.f; bx[k] = 0.f; by[k] = 0.f; bz[k] = 0.f; }
+    const float C1 = 0.4886025119029199f;
+    b[0] = 0.28209479177387814f;
+    if (deg > 0) {
+        b[1] = -C1 * y; b[2] = C1 * z; b[3] = -C1 * x;
+        by[1] = -C1; bz[2] = C1; bx[3] = -C1;
+        if (deg > 1) {
+            const float c20 = 1.0925484305920792f, c21 = -1.0925484305920792f, c22 = 0.31539156525252005f,
+                        c23 = -1.0925484305920792f, c24 = 0.5462742152960396f;
+            const float xx = x * x, yy = y * y, zz = z * z;
+            b[4] = c20 * x * y; b[5] = c21 * y * z; b[6] = c22 * (2.f * zz - xx - yy); b[7] = c23 * x * z; b[8] = c24 * (xx - yy);
+            bx[4] = c20 * y; by[4] = c20 * x;
+            by[5] = c21 * z; bz[5] = c21 * y;
+            bx[6] = c22 * (-2.f * x); by[6] = c22 * (-2.f * y); bz[6] = c22 * (4.f * z);
+            bx[7] = c23 * z; bz[7] = c23 * x;
+            bx[8] = c24 * (2.f * x); by[8] = c24 * (-2.f * y);
+            if (deg > 2) {
+                const float c30 = -0.5900435899266435f, c31 = 2.890611442640554f, c32 = -0.4570457994644658f,
+                            c33 = 0.3731763325901154f, c34 = -0.4570457994644658f, c35 = 1.445305721320277f,
+                            c36 = -0.5900435899266435f;
+                b[9] = c30 * y * (3.f * xx - yy); b[10] = c31 * x * y * z; b[11] = c32 * y * (4.f * zz - xx - yy);
+                b[12] = c33 * z * (2.f * zz - 3.f * xx - 3.f * yy); b[13] = c34 * x * (4.f * zz - xx - yy);
+                b[14] = c35 * z * (xx - yy); b[15] = c36 * x * (xx - 3.f * yy);
+                bx[9] = c30 * (6.f * x * y); by[9] = c30 * (3.f * xx - 3.f * yy);
+                bx[10] = c31 * y * z; by[10] = c31 * x * z; bz[10] = c31 * x * y;
+                bx[11] = c32 * (-2.f * x * y); by[11] = c32 * (4.f * zz - xx - 3.f * yy); bz[11] = c32 * (8.f * y * z);
+                bx[12] = c33 * (-6.f * x * z); by[12] = c33 * (-6.f * y * z); bz[12] = c33 * (6.f * zz - 3.f * xx - 3.f * yy);
+                bx[13] = c34 * (4.f * zz - 3.f * xx - yy); by[13] = c34 * (-2.f * x * y); bz[13] = c34 * (8.f * x * z);
+                bx[14] = c35 * (2.f * x * z); by[14] = c35 * (-2.f * y * z); bz[14] = c35 * (xx - yy);
+                bx[15] = c36 * (3.f * xx - 3.f * yy); by[15] = c36 * (-6.f * x * y);
+            }
+        }
+    }
+}
+
+
+// J[ch][xyz] = sum_k coef[k][ch] * grad b_k(x, y, z) for the active degree, WITHOUT materialising the 48 gradient values: one
+// coefficient at a time, three FMAs per channel (rows `sh` hold coef[k][ch] at 3k + ch).  Used by the forward to spare the backward a
+// second read of the coefficient rows.
+#define GS_SHJ(k, gx, gy, gz)                                                                                                  \
+    do {                                                                                                                        \
+        const float c0_ = sh[3 * (k)], c1_ = sh[3 * (k) + 1], c2_ = sh[3 * (k) + 2];                                            \
+        const float gx_ = (gx), gy_ = (gy), gz_ = (gz);                                                                         \
+        J[0] = fmaf(c0_, gx_, J[0]); J[1] = fmaf(c0_, gy_, J[1]); J[2] = fmaf(c0_, gz_, J[2]);                                  \
+        J[3] = fmaf(c1_, gx_, J[3]); J[4] = fmaf(c1_, gy_, J[4]); J[5] = fmaf(c1_, gz_, J[5]);                                  \
+        J[6] = fmaf(c2_, gx_, J[6]); J[7] = fmaf(c2_, gy_, J[7]); J[8] = fmaf(c2_, gz_, J[8]);                                  \
+    } while (0)
+__device__ __forceinline__ void sh_direction_jacobian(int deg, float x, float y, float z, const float* sh, float (&J)[9])
+{
+#pragma unroll
+    for (int q = 0; q < 9; q++) J[q] = 0.0f;
+    if (deg < 1) return;
+    const float C1 = 0.4886025119029199f;
+    GS_SHJ(1, 0.f, -C1, 0.f); GS_SHJ(2, 0.f, 0.f, C1); GS_SHJ(3, -C1, 0.f, 0.f);
+    if (deg < 2) return;
+    const float c20 = 1.0925484305920792f, c21 = -1.0925484305920792f, c22 = 0.31539156525252005f, c23 = -1.0925484305920792f,
+                c24 = 0.5462742152960396f;
+    GS_SHJ(4, c20 * y, c20 * x, 0.f);
+    GS_SHJ(5, 0.f, c21 * z, c21 * y);
+    GS_SHJ(6, c22 * (-2.f * x), c22 * (-2.f * y), c22 * (4.f * z));
+    GS_SHJ(7, c23 * z, 0.f, c23 * x);
+    GS_SHJ(8, c24 * (2.f * x), c24 * (-2.f * y), 0.f);
+    if (deg < 3) return;
+    const float c30 = -0.5900435899266435f, c31 = 2.890611442640554f, c32 = -0.4570457994644658f, c33 = 0.3731763325901154f,
+                c34 = -0.4570457994644658f, c35 = 1.445305721320277f, c36 = -0.5900435899266435f;
+    const float xx = x * x, yy = y * y, zz = z * z;
+    GS_SHJ(9, c30 * (6.f * x * y), c30 * (3.f * xx - 3.f * yy), 0.f);
+    GS_SHJ(10, c31 * y * z, c31 * x * z, c31 * x * y);
+    GS_SHJ(11, c32 * (-2.f * x * y), c32 * (4.f * zz - xx - 3.f * yy), c32 * (8.f * y * z));
+    GS_SHJ(12, c33 * (-6.f * x * z), c33 * (-6.f * y * z), c33 * (6.f * zz - 3.f * xx - 3.f * yy));
+    GS_SHJ(13, c34 * (4.f * zz - 3.f * xx - yy), c34 * (-2.f * x * y), c34 * (8.f * x * z));
+    GS_SHJ(14, c35 * (2.f * x * z), c35 * (-2.f * y * z), c35 * (xx - yy));
+    GS_SHJ(15, c36 * (3.f * xx - 3.f * yy), c36 * (-6.f * x * y), 0.f);
+}
+#undef GS_SHJ
+
 // ---- launchers implemented in the individual translation units -------------------------------------
 hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D, const float* shs,
                                      const float* colors, const float* opac, const float* scales,
@@ -191,7 +271,7 @@ hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D
 hipError_t launch_scan_block_sums(int P, GeomPtrs gp, uint32_t* d_total, hipStream_t st);
 hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3D, const float* shs,
                                       const float* scales, const float* rots, const float* cov3Dp,
-                                      const int32_t* radii, const uint32_t* clamped, const float* grad2d,
+                                      const int32_t* radii, const uint32_t* clamped, const float4* sh_jac, const float* grad2d,
                                       float* dmeans2D, float* dmeans3D, float* dopac, float* dcolors, float* dshs,
                                       float* dscales, float* drots, float* dcov3D, hipStream_t st);
 hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,

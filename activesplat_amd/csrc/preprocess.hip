@@ -111,8 +111,16 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
                 sh_basis(cam.sh_degree, dx * inv, dy * inv, dz * inv, b);
                 const float* sh = slab + (lane & 31) * stride;
                 float acc[3] = {0.f, 0.f, 0.f};
+                // (the colour is not part of the bit-level spec of this translation unit: fused multiply-adds here)
                 for (int k = 0; k < nbasis; k++) {
-                    acc[0] += b[k] * sh[3 * k]; acc[1] += b[k] * sh[3 * k + 1]; acc[2] += b[k] * sh[3 * k + 2];
+                    acc[0] = fmaf(b[k], sh[3 * k], acc[0]); acc[1] = fmaf(b[k], sh[3 * k + 1], acc[1]); acc[2] = fmaf(b[k], sh[3 * k + 2], acc[2]);
+                }
+                if (gp.sh_jac) {
+                    // for the backward: J[ch] = sum_k coef[k][ch] grad b_k (3x3), so that it need not read the coefficient rows again
+                    float J[9];
+                    sh_direction_jacobian(cam.sh_degree, dx * inv, dy * inv, dz * inv, sh, J);
+                    float4* jo = gp.sh_jac + (size_t)io * 3;
+                    jo[0] = make_float4(J[0], J[1], J[2], J[3]); jo[1] = make_float4(J[4], J[5], J[6], J[7]); jo[2] = make_float4(J[8], 0.f, 0.f, 0.f);
                 }
                 acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
                 sh_clamp = (acc[0] < 0.f ? 1u : 0u) | (acc[1] < 0.f ? 0x100u : 0u) | (acc[2] < 0.f ? 0x10000u : 0u);

@@ -10,51 +10,14 @@
 
 namespace gs {
 
-__device__ __forceinline__ void sh_basis_and_grad(int deg, float x, float y, float z, float* b, float* bx, float* by, float* bz)
-{
-    for (int k = 0; k < 16; k++) { b[k] = 0.f; bx[k] = 0.f; by[k] = 0.f; bz[k] = 0.f; }
-    const float C1 = 0.4886025119029199f;
-    b[0] = 0.28209479177387814f;
-    if (deg > 0) {
-        b[1] = -C1 * y; b[2] = C1 * z; b[3] = -C1 * x;
-        by[1] = -C1; bz[2] = C1; bx[3] = -C1;
-        if (deg > 1) {
-            const float c20 = 1.0925484305920792f, c21 = -1.0925484305920792f, c22 = 0.31539156525252005f,
-                        c23 = -1.0925484305920792f, c24 = 0.5462742152960396f;
-            const float xx = x * x, yy = y * y, zz = z * z;
-            b[4] = c20 * x * y; b[5] = c21 * y * z; b[6] = c22 * (2.f * zz - xx - yy); b[7] = c23 * x * z; b[8] = c24 * (xx - yy);
-            bx[4] = c20 * y; by[4] = c20 * x;
-            by[5] = c21 * z; bz[5] = c21 * y;
-            bx[6] = c22 * (-2.f * x); by[6] = c22 * (-2.f * y); bz[6] = c22 * (4.f * z);
-            bx[7] = c23 * z; bz[7] = c23 * x;
-            bx[8] = c24 * (2.f * x); by[8] = c24 * (-2.f * y);
-            if (deg > 2) {
-                const float c30 = -0.5900435899266435f, c31 = 2.890611442640554f, c32 = -0.4570457994644658f,
-                            c33 = 0.3731763325901154f, c34 = -0.4570457994644658f, c35 = 1.445305721320277f,
-                            c36 = -0.5900435899266435f;
-                b[9] = c30 * y * (3.f * xx - yy); b[10] = c31 * x * y * z; b[11] = c32 * y * (4.f * zz - xx - yy);
-                b[12] = c33 * z * (2.f * zz - 3.f * xx - 3.f * yy); b[13] = c34 * x * (4.f * zz - xx - yy);
-                b[14] = c35 * z * (xx - yy); b[15] = c36 * x * (xx - 3.f * yy);
-                bx[9] = c30 * (6.f * x * y); by[9] = c30 * (3.f * xx - 3.f * yy);
-                bx[10] = c31 * y * z; by[10] = c31 * x * z; bz[10] = c31 * x * y;
-                bx[11] = c32 * (-2.f * x * y); by[11] = c32 * (4.f * zz - xx - 3.f * yy); bz[11] = c32 * (8.f * y * z);
-                bx[12] = c33 * (-6.f * x * z); by[12] = c33 * (-6.f * y * z); bz[12] = c33 * (6.f * zz - 3.f * xx - 3.f * yy);
-                bx[13] = c34 * (4.f * zz - 3.f * xx - yy); by[13] = c34 * (-2.f * x * y); bz[13] = c34 * (8.f * x * z);
-                bx[14] = c35 * (2.f * x * z); by[14] = c35 * (-2.f * y * z); bz[14] = c35 * (xx - yy);
-                bx[15] = c36 * (3.f * xx - 3.f * yy); by[15] = c36 * (-6.f * x * y);
-            }
-        }
-    }
-}
-
 // SH: 0 = colours given, 1 = coefficient rows of any width through per-wave LDS slabs, 3 = the same for 16-coefficient rows
 // (row width 48 known at compile time)
 template <int SH>
 __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov3Dp,
-    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const float* __restrict__ grad2d,
-    float* __restrict__ dmeans2D, float* __restrict__ dmeans3D, float* __restrict__ dopac,
+    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const float4* __restrict__ sh_jac,
+    const float* __restrict__ grad2d, float* __restrict__ dmeans2D, float* __restrict__ dmeans3D, float* __restrict__ dopac,
     float* __restrict__ dcolors, float* __restrict__ dshs, float* __restrict__ dscales,
     float* __restrict__ drots, float* __restrict__ dcov3D)
 {
@@ -89,9 +52,11 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
             if (row0 >= P) break;                                  // wave-uniform
             const int nrows = min(kShHalf, P - row0);
             __builtin_amdgcn_wave_barrier();
-            // only live Gaussians read their coefficients (a culled one's gradient row is all zeros)
+            // the colour's dependence on the mean (through the view direction) needs sum_k coef[k][ch] grad b_k: the forward saved that
+            // 3x3 block per Gaussian (sh_jac), so the coefficient rows -- 192 B per Gaussian at 16 coefficients -- are NOT read again;
+            // without it (a forward that was not told a backward follows) only live Gaussians read their rows
             const uint32_t live_rows = (uint32_t)(__ballot(live) >> (h * kShHalf));
-            sh_wave_rows_to_lds<KC>(slab, shs, row0, nrows, K, lane, live_rows);
+            if (!sh_jac) sh_wave_rows_to_lds<KC>(slab, shs, row0, nrows, K, lane, live_rows);
             __builtin_amdgcn_wave_barrier();
             if ((lane >> 5) == h && in_range) {
                 float* dsh = slab + (lane & 31) * stride;
@@ -103,14 +68,25 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
                     sh_basis_and_grad(deg, ux, uy, uz, b, bx, by, bz);
                     const uint32_t cl = clamped[i];
                     float du[3] = {0.f, 0.f, 0.f};
-                    for (int ch = 0; ch < 3; ch++) {
-                        const float g = ((cl >> (8 * ch)) & 1u) ? 0.f : drgb[ch];
-                        for (int k = 0; k < nb; k++) {
-                            const float coef = dsh[3 * k + ch];
-                            dsh[3 * k + ch] = g * b[k];
-                            du[0] += g * coef * bx[k]; du[1] += g * coef * by[k]; du[2] += g * coef * bz[k];
+                    if (sh_jac) {
+                        const float4 j0 = sh_jac[(size_t)i * 3], j1 = sh_jac[(size_t)i * 3 + 1], j2 = sh_jac[(size_t)i * 3 + 2];
+                        const float jr[3][3] = {{j0.x, j0.y, j0.z}, {j0.w, j1.x, j1.y}, {j1.z, j1.w, j2.x}};
+                        for (int ch = 0; ch < 3; ch++) {
+                            const float g = ((cl >> (8 * ch)) & 1u) ? 0.f : drgb[ch];
+                            du[0] += g * jr[ch][0]; du[1] += g * jr[ch][1]; du[2] += g * jr[ch][2];
+                            for (int k = 0; k < nb; k++) dsh[3 * k + ch] = g * b[k];
+                            for (int k = nb; k < M; k++) dsh[3 * k + ch] = 0.f;
                         }
-                        for (int k = nb; k < M; k++) dsh[3 * k + ch] = 0.f;
+                    } else {
+                        for (int ch = 0; ch < 3; ch++) {
+                            const float g = ((cl >> (8 * ch)) & 1u) ? 0.f : drgb[ch];
+                            for (int k = 0; k < nb; k++) {
+                                const float coef = dsh[3 * k + ch];
+                                dsh[3 * k + ch] = g * b[k];
+                                du[0] += g * coef * bx[k]; du[1] += g * coef * by[k]; du[2] += g * coef * bz[k];
+                            }
+                            for (int k = nb; k < M; k++) dsh[3 * k + ch] = 0.f;
+                        }
                     }
                     const float dot = ux * du[0] + uy * du[1] + uz * du[2];
                     dmean[0] += (du[0] - ux * dot) * inv; dmean[1] += (du[1] - uy * dot) * inv; dmean[2] += (du[2] - uz * dot) * inv;
@@ -242,20 +218,20 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
 
 hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3D, const float* shs,
                                       const float* scales, const float* rots, const float* cov3Dp,
-                                      const int32_t* radii, const uint32_t* clamped, const float* grad2d,
+                                      const int32_t* radii, const uint32_t* clamped, const float4* sh_jac, const float* grad2d,
                                       float* dmeans2D, float* dmeans3D, float* dopac, float* dcolors, float* dshs,
                                       float* dscales, float* drots, float* dcov3D, hipStream_t st)
 {
     const int nb = (P + kBlock - 1) / kBlock;
     if (nb > 0 && shs && cam.sh_coeffs == 16)
         hipLaunchKernelGGL(preprocess_backward_kernel<3>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
-                           cov3Dp, radii, clamped, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
+                           cov3Dp, radii, clamped, sh_jac, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
     else if (nb > 0 && shs)
         hipLaunchKernelGGL(preprocess_backward_kernel<1>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
-                           cov3Dp, radii, clamped, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
+                           cov3Dp, radii, clamped, sh_jac, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
     else if (nb > 0)
         hipLaunchKernelGGL(preprocess_backward_kernel<0>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
-                           cov3Dp, radii, clamped, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
+                           cov3Dp, radii, clamped, sh_jac, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
     return hipGetLastError();
 }
 

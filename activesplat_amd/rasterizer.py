@@ -134,9 +134,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         radii = torch.empty(P, dtype=torch.int32, device=device)
         d_num = torch.empty(2, dtype=torch.int32, device=device)
         h_num = _host_counters(device) if device.type == "cuda" else torch.zeros(2, dtype=torch.int32)
+        want_bwd = 1 if any(ctx.needs_input_grad[:8]) else 0
         _lib.check(lib.gs_preprocess_forward(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
                                              _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
-                                             _ptr(radii), _ptr(geom), _ptr(image), _ptr(d_num), _ptr(h_num), st))
+                                             _ptr(radii), _ptr(geom), _ptr(image), _ptr(d_num), _ptr(h_num), want_bwd, st))
         color = torch.empty(3, H, W, dtype=torch.float32, device=device)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=device)
         opacity = torch.empty(1, H, W, dtype=torch.float32, device=device)
@@ -189,7 +190,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _capacity[key] = (max(old[0], int(D * 1.25) + 4096), max(old[1], int(max_tile * 1.25) + 64))
         last_stats["num_rendered"], last_stats["P"], last_stats["max_tile_instances"] = D, P, max_tile
         ctx.rs, ctx.D, ctx.keep, ctx.fused, ctx.cam = rs, D, keep, fused, cam      # the backward reuses the camera block
-        ctx.scratch, ctx.scratch_clean = scratch, scratch is not None
+        ctx.scratch, ctx.scratch_clean, ctx.sh_jac = scratch, scratch is not None, want_bwd
         ctx.has = (shs is not None, colors_precomp is not None, scales is not None, rotations is not None,
                    cov3D_precomp is not None)
         if rs.debug:
@@ -235,7 +236,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _ptr(scales if has_sc else None), _ptr(rots if has_rot else None), _ptr(cov3Dp if has_cov else None),
             _ptr(radii), _ptr(geom), _ptr(point_list), _ptr(image), _ptr(grad_color), _ptr(grad_depth),
             _ptr(d_m2d), _ptr(d_m3d), _ptr(d_op), _ptr(d_col), _ptr(d_shs), _ptr(d_sc), _ptr(d_rot), _ptr(d_cov),
-            _ptr(scratch), 1 if clean else 0, _stream(device)))
+            _ptr(scratch), 1 if clean else 0, int(ctx.sh_jac), _stream(device)))
         return d_m3d, d_m2d, d_shs, d_col, d_op, d_sc, d_rot, d_cov, None, None
 
 
@@ -329,7 +330,7 @@ def render_views(settings_list, means3D, opacities, shs=None, colors_precomp=Non
     d_num = torch.empty(2, dtype=torch.int32, device=device)
     h_num = _host_counters(device) if device.type == "cuda" else torch.zeros(2, dtype=torch.int32)
     _lib.check(lib.gs_preprocess_forward(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
-                                         _ptr(rotations), _ptr(cov3D_precomp), _ptr(radii), _ptr(geom), _ptr(image), _ptr(d_num), _ptr(h_num), st))
+                                         _ptr(rotations), _ptr(cov3D_precomp), _ptr(radii), _ptr(geom), _ptr(image), _ptr(d_num), _ptr(h_num), 0, st))
     if device.type == "cuda":
         torch.cuda.current_stream(device).synchronize()      # D and the longest tile list size the binning workspace
     D, max_tile = int(h_num[0].item()) & 0xFFFFFFFF, int(h_num[1].item()) & 0xFFFFFFFF

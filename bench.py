@@ -27,6 +27,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")     # the CPU legs' OpenMP workers must not spin next to torch's pool
+
 import numpy as np
 import torch
 
@@ -38,6 +40,14 @@ CPU_SECONDS = 12.0           # CPU work the cpu_baseline leg is bounded to (whol
 VALU_ISSUE_PEAK = 890e9      # wave64 plain-fp32 VALU instructions/s of the chip, MEASURED (scripts/exp/valu_issue.hip, profiles/r02_valu_issue.txt:
                              # v_mul/v_add_f32 at 8 waves per SIMD; DPP / v_cndmask / v_cmp / packed fp32 issue at 0.45-0.65x of this)
 FP32_PEAK = 157.3e12         # MI355X_MICROARCH.md: fp32 vector peak
+
+
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress line on stderr (the JSON line on stdout stays the only stdout output)"""
+    print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def stage_bytes(P, D, npix):
@@ -154,6 +164,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent steps are issued on in turn (1 = strictly "
                     "one frame after the other)")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline and cpu_baseline legs")
+    ap.add_argument("--cpu-threads", type=int, default=64, help="upper bound on the host threads of the cpu_baseline leg")
     ap.add_argument("--c4-gaussians", type=int, default=2_000_000, help="N > 1 (configs[3]): Gaussians of the replicated map")
     ap.add_argument("--keyframes", type=int, default=64, help="N > 1 (configs[3]): keyframes per optimiser step, sharded over the ranks")
     ap.add_argument("--workload", choices=("auto", "c2", "c4"), default="auto", help="auto: configs[1] on one GPU, configs[3] on several")
@@ -301,6 +312,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras:
         lib = _lib.get()
+        note(f"timed region done: {fps:.1f} frames/s; roofline leg")
         # ---- roofline leg: per-stage hipEvents over a second pass of the same K steps ----
         lib.gs_profile_enable(1)
         for i in range(args.steps):
@@ -386,8 +398,9 @@ def main():
             from oracle.gs_oracle import Oracle
             from tests import util
             o = Oracle("f32")
-            cores = os.cpu_count() or 1
+            cores = min(os.cpu_count() or 1, args.cpu_threads)
             o.set_threads(cores)
+            note(f"cpu_baseline: oracle on {cores} threads")
             rv_cpu = {k: v.detach().cpu() for k, v in rv.items()}
             f = util.run_oracle(o, cam, rv_cpu, dL.cpu())          # warm-up frame (page-in, thread pool)
             t1 = time.perf_counter(); n_cpu = 0
@@ -421,7 +434,9 @@ def main():
             from tests import util
             rs0, rv0 = util.scene(10_000, W, H, seed=0)
             cam0 = util.cam_dict(rs0)
-            torch.set_num_threads(os.cpu_count() or 1)
+            note("configs[0]: tiled CPU PyTorch render")
+            th0 = torch.get_num_threads()
+            torch.set_num_threads(min(os.cpu_count() or 1, 16))       # tile-sized tensors: more threads only add fork/join cost
             with torch.no_grad():
                 t1 = time.perf_counter()
                 ref0 = DT.render_dense(cam0, rv0["means3D"], rv0["opacities"], colors=rv0["colors_precomp"], scales=rv0["scales"],
@@ -439,13 +454,18 @@ def main():
                 t_gpu = (time.perf_counter() - t1) / 20
             mse0 = float(((got0[0].cpu().double() - ref0["color"].double()) ** 2).mean())
             out["configs0"] = {"workload": "BASELINE configs[0]: 10k Gaussians, one 640x480 view, forward only",
-                               "cpu_pytorch_frames_per_s": round(1.0 / t_cpu, 3), "cpu_threads": os.cpu_count(),
+                               "cpu_pytorch_frames_per_s": round(1.0 / t_cpu, 3), "cpu_threads": torch.get_num_threads(),
                                "cpu_path": "oracle/dense_torch.render_dense(tiled=True): plain PyTorch CPU ops, tile by tile",
                                "hip_forward_frames_per_s": round(1.0 / t_gpu, 1),
                                "psnr_hip_vs_cpu_pytorch_db": round(10 * np.log10(1.0 / max(mse0, 1e-30)), 1)}
         except Exception as e:
             out["configs0"] = {"error": str(e)}
+        try:
+            torch.set_num_threads(th0)
+        except Exception:
+            pass
     if rank == 0 and world == 1 and not args.no_extras:
+        note("north-star 2M legs")
         # ---- the north-star's target configuration: forward+backward render of 2 M Gaussians at 640x480 (SH degree 0 and 3),
         # as frames/s and as fraction of the HBM roofline with SURVEY 8(d)'s algorithmic bytes (b_g = 292 / 832 B)
         try:
@@ -515,6 +535,7 @@ def main():
             out["north_star_2M"] = {"error": str(e)}
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_extras:
+        note("mapping-iteration leg")
         # ---- informational leg: one full ActiveSplat mapping iteration (get_loss + backward + Adam) on the same scene,
         # with the reference's call pattern (two raster passes, torch loss, torch activations) vs this build's fused paths
         try:
@@ -546,6 +567,7 @@ def main():
                                             "bench scene; reference_call_pattern = splatam.py:172-301 op for op on this rasteriser")
         except Exception as e:
             out["mapping_iteration"] = {"error": str(e)}
+    note("done")
     if rank == 0:
         print(json.dumps(out))
     if dist_on:

@@ -83,6 +83,7 @@ typedef struct GsGeomLayout {
     uint64_t clamped;       /* uint8  [P][4]: SH colour clamp flags (r,g,b,pad) */
     uint64_t tile_total;    /* uint32 [tiles]: instances per tile */
     uint64_t tile_base;     /* uint32 [ceil(P/4096)][tiles]: slice reserved by each binning workgroup */
+    uint64_t sh_jac;        /* float [P][12]: 3x3 d(rgb)/d(view direction) of SH inputs (9 used), written when want_backward */
 } GsGeomLayout;
 
 typedef struct GsImageLayout {
@@ -144,13 +145,15 @@ int gs_profile_collect(float* ms_sum, int32_t* calls, int32_t n_stages);
  * d_counts[1] = largest per-tile instance count; if h_counts != NULL both also reach that host buffer
  * asynchronously -- stored by the scan kernel itself when h_counts is mapped pinned memory (hipHostMalloc), by an
  * async copy otherwise (read them after synchronising `stream` or an event recorded behind this call). Exactly one of shs/colors_precomp and
- * exactly one of (scales,rotations)/cov3D_precomp must be given. */
+ * exactly one of (scales,rotations)/cov3D_precomp must be given.
+ * want_backward != 0 with shs: the stage also stores, per Gaussian, the 3x3 block sum_k coef[k] (x) grad b_k(direction) in the geom
+ * state, so that gs_render_backward (have_sh_jacobian = 1) does not read the coefficient rows a second time. */
 int gs_preprocess_forward(const GsCamera* cam, int32_t P,
                           const float* means3D, const float* shs, const float* colors_precomp,
                           const float* opacities, const float* scales, const float* rotations,
                           const float* cov3D_precomp,
                           int32_t* radii, void* geom_state, void* image_state, uint32_t* d_counts,
-                          uint32_t* h_counts, gs_stream_t stream);
+                          uint32_t* h_counts, int32_t want_backward, gs_stream_t stream);
 
 /* Stage 2: bin the instances by tile and depth-sort every tile list, then front-to-back alpha blend.
  * out_color [3,H,W], out_depth [1,H,W] (sum z*alpha*T), out_opacity [1,H,W] (1 - T_final).
@@ -175,7 +178,8 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_ti
  * was not given (shs vs colors_precomp, scales/rotations vs cov3D_precomp).
  * dL_dmeans2D [P,3] receives the NDC-scaled screen-space gradient (x*0.5W, y*0.5H, 0).
  * scratch: gs_backward_scratch_bytes(P) bytes; scratch_zeroed != 0 promises that it is all zero (see gs_render_forward's
- * backward_scratch) -- the call leaves it dirty either way. */
+ * backward_scratch) -- the call leaves it dirty either way.  have_sh_jacobian != 0: geom_state comes from a
+ * gs_preprocess_forward(want_backward = 1) call. */
 int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D,
                        const float* means3D, const float* shs, const float* colors_precomp,
                        const float* scales, const float* rotations, const float* cov3D_precomp,
@@ -184,7 +188,7 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D,
                        float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities,
                        float* dL_dcolors_precomp, float* dL_dshs, float* dL_dscales,
                        float* dL_drotations, float* dL_dcov3D, void* scratch, int32_t scratch_zeroed,
-                       gs_stream_t stream);
+                       int32_t have_sh_jacobian, gs_stream_t stream);
 
 /* Fused dense Adam step over one flat parameter tensor with torch.optim.Adam semantics
  * (non-amsgrad, no weight decay): splatam.py:118-124 uses betas (0.9,0.999), eps 1e-15.
