@@ -31,7 +31,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr uint32_t kNoId = 0xffffffffu;
 
 struct TileCtx {
-    int tile, tx, ty, px, py;
+    int tile, tx, ty, px, py, quad;
     float qx0, qy0, pxf, pyf;
     bool inside;
 };
@@ -41,7 +41,7 @@ __device__ __forceinline__ bool tile_ctx(const Cam& cam, int wave, int lane, Til
     const int ntiles = cam.gx * cam.gy, per = (ntiles + 7) >> 3;
     c.tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);          // XCD-aware band mapping
     if ((int)(blockIdx.x >> 3) >= per || c.tile >= ntiles) return false;
-    c.tx = c.tile % cam.gx; c.ty = c.tile / cam.gx;
+    c.tx = c.tile % cam.gx; c.ty = c.tile / cam.gx; c.quad = wave;
     const int qx = c.tx * kTile + (wave & 1) * kQuad, qy = c.ty * kTile + (wave >> 1) * kQuad;
     c.px = qx + (lane & 7); c.py = qy + (lane >> 3);
     c.qx0 = (float)qx; c.qy0 = (float)qy; c.pxf = (float)c.px; c.pyf = (float)c.py;
@@ -61,7 +61,7 @@ __device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, 
     c.tile = (int)(blockIdx.x & 7) * per + idx / G;
     if (idx / G >= per || c.tile >= ntiles) return false;
     const int quad = (idx % G) * NW + wave;
-    c.tx = c.tile % cam.gx; c.ty = c.tile / cam.gx;
+    c.tx = c.tile % cam.gx; c.ty = c.tile / cam.gx; c.quad = quad;
     const int qx = c.tx * kTile + (quad & 1) * kQuad, qy = c.ty * kTile + (quad >> 1) * kQuad;
     c.px = qx + (lane & 7); c.py = qy + (lane >> 3);
     c.qx0 = (float)qx; c.qy0 = (float)qy; c.pxf = (float)c.px; c.pyf = (float)c.py;
@@ -136,8 +136,8 @@ __device__ __forceinline__ void write_sentinel(float4* s0, float4* s1, float4* s
 //            product) and adds its colour / depth sums to the zero-initialised images with atomics; the last segment of a
 //            pixel that is not yet stopped at entry writes final_T, opacity and T*bg; n_contrib is an atomic max.
 //   SEG = 0: the whole list in one workgroup (the normal path; its code is untouched by the other two).
-template <bool DEPTH_SQ, int NS, int SEG>     // DEPTH_SQ: also accumulate sum z^2 alpha T (third channel of the reference's depth/silhouette pass)
-__global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
+template <bool DEPTH_SQ, int NS, int SEG, int NW>     // DEPTH_SQ: also accumulate sum z^2 alpha T (third channel of the reference's depth/silhouette pass)
+__global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
@@ -145,19 +145,19 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
 {
     constexpr int LS = kWave / NS;          // lanes per stream
     constexpr int BH = LS / 4;              // block = 4 x BH pixels
-    __shared__ float4 s_rec[kBlock / kWave][3][kWave + 1];           // + the sentinel slot
+    __shared__ float4 s_rec[NW][3][kWave + 1];           // + the sentinel slot
     // NS rows of 64 entries per wave (+16 bytes so that the look-ahead read behind the last row stays inside the wave's slab)
-    __shared__ __attribute__((aligned(16))) uint8_t s_list[kBlock / kWave][NS * kWave + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_list[NW][NS * kWave + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // side job (SEG = 0 only): this workgroup's slice of the backward's gradient records is zero-filled here -- plain
     // fire-and-forget 16-byte stores next to an arithmetic-bound loop instead of a separate fill launch before the backward
     if (SEG == 0 && zero_fill) {
         const size_t total = (size_t)P * (kGradStride / 4), per = (total + gridDim.x - 1) / gridDim.x;
         const size_t z0 = (size_t)blockIdx.x * per, z1 = min(total, z0 + per);
-        for (size_t z = z0 + tid; z < z1; z += kBlock) zero_fill[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t z = z0 + tid; z < z1; z += NW * kWave) zero_fill[z] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     TileCtx c;
-    if (!tile_ctx(cam, wave, lane, c)) return;
+    if (!tile_ctx_nw<NW>(cam, wave, lane, c)) return;
     // lane -> pixel: stream sid owns block (sid & 1, sid >> 1) of the quadrant
     const int sid = lane / LS, l = lane % LS;
     const int px = (int)c.qx0 + (sid & 1) * 4 + (l & 3), py = (int)c.qy0 + (sid >> 1) * BH + (l >> 2);
@@ -181,14 +181,14 @@ __global__ __launch_bounds__(kBlock) void blend_forward_streams_kernel(
         const uint32_t L = (((n_all + S - 1) / S + kWave - 1) / kWave) * kWave;       // chunk-aligned segment length
         first = min(n_all, seg * L);
         n = min(n_all, first + L);
-        float* tile_T = seg_T + ((size_t)c.tile * S) * kBlock + wave * kWave + lane;   // [tile][segment][quadrant][lane]
+        float* tile_T = seg_T + ((size_t)c.tile * S) * kBlock + c.quad * kWave + lane;   // [tile][segment][quadrant][lane]
         my_seg_T = tile_T + (size_t)seg * kBlock;
         if (SEG == 1) {
             // an EARLIER segment that takes every pixel of this quadrant below the stop threshold on its own makes this one
             // irrelevant (all its pixels are stopped at entry whatever it holds): such segments leave a bit in the quadrant's
             // flag word (behind the transmittances).  Segments are dispatched in order, so the bit is usually there in time; if
             // it is not, the segment simply does its work -- the result does not depend on the timing.
-            seg_flag = reinterpret_cast<uint32_t*>(seg_T + (size_t)cam.gx * cam.gy * S * kBlock) + c.tile * 4 + wave;
+            seg_flag = reinterpret_cast<uint32_t*>(seg_T + (size_t)cam.gx * cam.gy * S * kBlock) + c.tile * 4 + c.quad;
             const uint32_t f = __hip_atomic_load(seg_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (f & ((1u << seg) - 1u)) { my_seg_T[0] = 1.0f; return; }
         }
@@ -579,9 +579,11 @@ hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint3
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
                                 uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, uint32_t P, float* zero_fill, hipStream_t st)
 {
+    // whole-tile workgroups (NW = 4) here: one-wavefront workgroups measured 85 vs 80 us on configs[1] and the same at 2 M -- the
+    // four walkers of a tile gather the same records, and on one CU three of them hit its L1
     const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
 #define GS_FWD(DSQ, SEG, GRID)                                                                                                     \
-    hipLaunchKernelGGL((blend_forward_streams_kernel<DSQ, kFwdStreams, SEG>), GRID, dim3(kBlock), 0, st, cam, ranges, point_list, geom, \
+    hipLaunchKernelGGL((blend_forward_streams_kernel<DSQ, kFwdStreams, SEG, 4>), GRID, dim3(kBlock), 0, st, cam, ranges, point_list, geom, \
                        out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap, seg_T, P, (float4*)zero_fill)
     if (segments > 1 && seg_T) {
         // segmented compositing: the sums are added with atomics, so the images start from zero

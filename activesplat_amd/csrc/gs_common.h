@@ -161,6 +161,29 @@ __device__ __forceinline__ void sh_wave_rows_to_lds(float* slab, const float* __
         if ((row_mask >> r) & 1u) slab[r * stride + (e - r * K)] = s[e];
     }
 }
+// The same copy split in two for full 32-row halves of 48-float rows (six 16-byte pieces per lane): the loads of BOTH halves of a
+// wavefront's 64 rows are issued before the first half is consumed (twice the bytes in flight per wave).
+__device__ __forceinline__ void sh48_half_load(float4 (&v)[6], const float* __restrict__ src, int row0, int lane)
+{
+    const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)row0 * 48);
+#pragma unroll
+    for (int j = 0; j < 6; j++) v[j] = load_stream(&s4[lane + kWave * j]);
+}
+__device__ __forceinline__ void sh48_half_to_lds(float* slab, const float4 (&v)[6], int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const int e = (lane + kWave * j) << 2;
+        int r = e / 48, c = e - r * 48;
+        const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            slab[r * kShPad + c] = vv[t];
+            if (++c == 48) { c = 0; ++r; }
+        }
+    }
+}
+
 template <int KC = 0>
 __device__ __forceinline__ void sh_wave_rows_from_lds(const float* slab, float* __restrict__ dst, int row0, int nrows, int Krt, int lane)
 {

@@ -97,11 +97,16 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
         const int stride = sh_row_stride(K);
         const int lane = tid & 63, wave = tid >> 6;
         float* slab = s_sh + wave * kShHalf * kShPad;
+        // a wavefront whose 64 rows all exist (every one but the last of the array) loads both halves up front
+        const bool pre = KC == 48 && base + wave * kWave + kWave <= P;
+        float4 va[6], vb[6];
+        if (pre) { sh48_half_load(va, shs, base + wave * kWave, lane); sh48_half_load(vb, shs, base + wave * kWave + kShHalf, lane); }
         for (int h = 0; h < kWave / kShHalf; h++) {
             const int row0 = base + wave * kWave + h * kShHalf;
             if (row0 >= P) break;                                  // wave-uniform
             __builtin_amdgcn_wave_barrier();
-            sh_wave_rows_to_lds<KC>(slab, shs, row0, min(kShHalf, P - row0), K, lane);
+            if (pre) { if (h == 0) sh48_half_to_lds(slab, va, lane); else sh48_half_to_lds(slab, vb, lane); }
+            else sh_wave_rows_to_lds<KC>(slab, shs, row0, min(kShHalf, P - row0), K, lane);
             __builtin_amdgcn_wave_barrier();
             if ((lane >> 5) == h && base + tid < P) {
                 const float* cp = cam.campos + 3 * view;
