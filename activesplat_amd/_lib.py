@@ -25,7 +25,7 @@ class GsCamera(C.Structure):
 
 class GsGeomLayout(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "geom", "rect", "tiles_touched", "offsets", "block_sums", "clamped",
-                                          "tile_total", "tile_base", "sh_jac")]
+                                          "tile_total", "tile_base", "sh_jac", "depth_bits")]
 
 
 class GsImageLayout(C.Structure):

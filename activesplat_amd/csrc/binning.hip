@@ -32,7 +32,7 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(Cam cam, int P, GeomPtrs g
         const uint32_t x0 = rc.x & 0xffffu, x1 = rc.x >> 16;
         s_x0w[tid] = x0 | ((x1 - x0) << 16);
         s_y0[tid] = rc.y & 0xffffu;
-        s_depth[tid] = __float_as_uint(gp.geom[(size_t)i * 3 + 2].y);
+        s_depth[tid] = gp.depth_bits[i];
     }
     const uint32_t incl = wave_inclusive_scan(n, lane);
     s_incl[tid] = incl;

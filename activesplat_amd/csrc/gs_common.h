@@ -46,6 +46,7 @@ struct GeomPtrs {
     uint32_t* clamped;   // uchar4 packed
     uint32_t* tile_total;  // [tiles]
     uint32_t* tile_base;   // [ceil(P/kBinChunk)][tiles]
+    uint32_t* depth_bits;  // [P]: bit pattern of the view-space depth (the binning key), compact copy of geom[.][9] for coalesced reads
     float4* sh_jac;        // [P][3]: d(rgb before the clamp)/d(unit view direction), 3x3 row-major in 9 of 12 floats (SH inputs with a backward to follow)
 };
 

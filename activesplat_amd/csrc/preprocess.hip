@@ -245,12 +245,14 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
         gp.geom[(size_t)io * 3] = g0; gp.geom[(size_t)io * 3 + 1] = g1; gp.geom[(size_t)io * 3 + 2] = g2;
         gp.rect[io] = rc;
         gp.tiles[io] = ntiles;
+        gp.depth_bits[io] = __float_as_uint(g2.y);
         if (HAS_SH) gp.clamped[io] = clampbits;
     } else if (cam.V > 1) {                            // padding rows of a view's last block: never visible
         radii[io] = 0;
         gp.geom[(size_t)io * 3] = gp.geom[(size_t)io * 3 + 1] = gp.geom[(size_t)io * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
         gp.rect[io] = make_uint2(0u, 0u);
         gp.tiles[io] = 0u;
+        gp.depth_bits[io] = 0u;
         if (HAS_SH) gp.clamped[io] = 0u;
     }
     // per-block tile count -> block_sums (scanned by scan_block_sums_kernel)

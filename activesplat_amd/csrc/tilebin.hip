@@ -7,10 +7,10 @@
 // Why not a device-wide radix sort on MI355X: for ~1M (key,value) pairs the 6-pass sort is launch/latency
 // bound (198 us measured, 1.8 % of HBM peak).  The instances only need to be GROUPED by tile and ordered
 // by depth WITHIN a tile, so:
-//   tile_count   : workgroups of 4096 Gaussians expand rect -> tile ids with the wavefront prefix-sum
-//                  emitter and count into an LDS-private histogram (LDS atomics); one global atomic per
-//                  (workgroup, tile) reserves the workgroup's slice of the tile segment.  (Direct global
-//                  atomics per instance measured 61-140 us for 1.2M instances on 1200 counters.)
+//   tile_count   : workgroups of 2048 Gaussians walk their rects and count into an LDS-private histogram (LDS integer
+//                  atomics); the histogram becomes the workgroup's row of a [chunks][tiles] matrix, whose column-wise
+//                  exclusive scan (tile_colscan) gives every (workgroup, tile) the start of its slice of the tile segment.
+//                  (Direct global atomics per instance measured 61-140 us for 1.2M instances on 1200 counters.)
 //   tile_scan    : exclusive scan of the per-tile totals -> ranges[tile], D, max instances per tile.
 //   tile_scatter : same expansion; LDS returning atomics hand out slots inside the reserved slices;
 //                  one 8-byte (depth_bits<<32 | id) store per instance.
@@ -67,40 +67,85 @@ __global__ __launch_bounds__(THREADS) void tile_bin_kernel(Cam cam, int P, GeomP
     for (int r = 0; r < chunk / THREADS; r++) {
         const int i = cbase + r * THREADS + tid;
         if (cbase + r * THREADS >= P) break;                      // uniform
-        uint32_t n = 0;
+        uint32_t n = 0, x0 = 0, w = 1, y0 = 0, dbits = 0;
         if (i < P) {
             n = gp.tiles[i];
             if (n) {
                 const uint2 rc = gp.rect[i];
-                const uint32_t x0 = rc.x & 0xffffu, x1 = rc.x >> 16;
-                s_x0w[tid] = x0 | ((x1 - x0) << 16);
-                s_y0[tid] = rc.y & 0xffffu;
-                if (SCATTER) s_depth[tid] = __float_as_uint(gp.geom[(size_t)i * 3 + 2].y);
+                x0 = rc.x & 0xffffu; w = (rc.x >> 16) - x0; y0 = rc.y & 0xffffu;
+                if (SCATTER) dbits = gp.depth_bits[i];
             }
         }
-        const uint32_t incl = wave_inclusive_scan(n, lane);
-        s_incl[tid] = incl;
-        const uint32_t total = __shfl(incl, 63);
-        __syncthreads();
         const int gbase = cbase + r * THREADS;
-        expand_wave(s_incl + wave * kWave, s_x0w, s_y0, wave, lane, total, cam.gx, [&](uint32_t tile, int j) {
+        auto place = [&](uint32_t tile, uint32_t depth_bits, uint32_t id) {
             if (SCATTER) {
                 const uint32_t slot = atomicAdd(&s_hist[tile], 1u);
                 // cap = capacity of `pairs`: an optimistic launch (workspace sized from the previous frame, true D still in
                 // flight) must never write past it -- the host discards and repeats such a frame
-                if (slot < cap) pairs[slot] = ((unsigned long long)s_depth[j] << 32) | (uint32_t)(gbase + j);
+                if (slot < cap) pairs[slot] = ((unsigned long long)depth_bits << 32) | id;
             } else {
                 atomicAdd(&s_hist[tile], 1u);
             }
+        };
+        // Small rects (every Gaussian of the wavefront covers at most 16 tiles -- the usual case: 2.4 tiles on average in the bench
+        // scenes): every lane walks its OWN rect, one LDS integer atomic (4 clk per 64-lane instruction) per step and no
+        // search.  A wavefront that holds a large rect uses the balanced emitter below, whose cost per instance does not depend on
+        // the rect (6-step LDS binary search + an integer division per instance: 23 of the count pass's 36 us at 2 M went there).
+        if (!__any(n > 16u)) {
+            uint32_t kx = 0, ky = 0;
+            for (uint32_t k = 0; __any(k < n); k++) {
+                if (k < n) {
+                    place((y0 + ky) * (uint32_t)cam.gx + x0 + kx, dbits, (uint32_t)i);
+                    if (++kx == w) { kx = 0; ++ky; }
+                }
+            }
+            continue;                                             // (uniform per wavefront; the barriers below belong to the emitter)
+        }
+        if (n) {
+            s_x0w[tid] = x0 | (w << 16);
+            s_y0[tid] = y0;
+            if (SCATTER) s_depth[tid] = dbits;
+        }
+        const uint32_t incl = wave_inclusive_scan(n, lane);
+        s_incl[tid] = incl;
+        const uint32_t total = __shfl(incl, 63);
+        __builtin_amdgcn_wave_barrier();
+        expand_wave(s_incl + wave * kWave, s_x0w, s_y0, wave, lane, total, cam.gx, [&](uint32_t tile, int j) {
+            place(tile, SCATTER ? s_depth[j] : 0u, (uint32_t)(gbase + j));
         });
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
     if (!SCATTER) {
+        // this chunk's row of the [chunks][tiles] count matrix; tile_colscan_kernel turns the columns into slice bases.  (One global
+        // returning atomic per (chunk, tile) on the tile's total -- round 1 -- chains ~1000 same-address atomics per tile at 2 M
+        // Gaussians: 13 of the count pass's 31 us.)
         __syncthreads();
-        for (int t = tid; t < tiles; t += THREADS) {
-            const uint32_t c = s_hist[t];
-            my_base[t] = c ? atomicAdd(&tile_total[t], c) : 0u;
+        for (int t = tid; t < tiles; t += THREADS) my_base[t] = s_hist[t];
+    }
+}
+
+// Column-wise exclusive scan of the [chunks][tiles] count matrix, in place: base[c][t] = instances of tile t in the chunks before c;
+// tile_total[t] = the column sum.  32 tiles x 32 row segments per workgroup: lanes read 128 contiguous bytes of a row.
+__global__ __launch_bounds__(1024) void tile_colscan_kernel(uint32_t* __restrict__ base, int chunks, int tiles, uint32_t* __restrict__ tile_total)
+{
+    __shared__ uint32_t s_sum[32][33];
+    const int l = threadIdx.x & 31, sgm = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + l;
+    const int L = (chunks + 31) / 32, r0 = min(chunks, sgm * L), r1 = min(chunks, r0 + L);
+    uint32_t sum = 0;
+    if (t < tiles) for (int r = r0; r < r1; r++) sum += base[(size_t)r * tiles + t];
+    s_sum[sgm][l] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int q = 0; q < sgm; q++) run += s_sum[q][l];
+    if (t < tiles) {
+        for (int r = r0; r < r1; r++) {
+            const size_t idx = (size_t)r * tiles + t;
+            const uint32_t v = base[idx];
+            base[idx] = run;
+            run += v;
         }
+        if (sgm == 31) tile_total[t] = run;          // the last segment ends with the column sum (empty segments pass it through)
     }
 }
 
@@ -296,8 +341,10 @@ __global__ __launch_bounds__(THREADS) void tile_merge_kernel(const uint2* __rest
 }
 
 // 1024 threads x kBinChunk Gaussians per workgroup (measured best of 256/512/1024 threads x 1024..4096 Gaussians)
-static void bin_config(int& threads, int& chunk)
+static void bin_config(int P, int& threads, int& chunk)
 {
+    // (4096 / 8192 Gaussians per workgroup: the count pass gains a third at 2 M, the scatter pass loses as much -- fewer workgroups)
+    (void)P;
     threads = 1024; chunk = kBinChunk;
 }
 
@@ -312,9 +359,10 @@ hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_
                              uint2* ranges, uint32_t* d_counts, uint32_t* host_counts, hipStream_t st)
 {
     const int tiles = cam.gx * cam.gy;       // tile_total was zeroed by the preprocess stage
-    int threads, chunk; bin_config(threads, chunk);
+    int threads, chunk; bin_config(P, threads, chunk);
     const int nb = (P + chunk - 1) / chunk;
     if (nb > 0) launch_bin<false>(threads, nb, st, cam, P, gp, tiles, chunk, tile_total, tile_base, nullptr, nullptr, 0u);
+    hipLaunchKernelGGL(tile_colscan_kernel, dim3((tiles + 31) / 32), dim3(1024), 0, st, tile_base, nb, tiles, tile_total);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_total, tiles, ranges, d_counts, host_counts);
     return hipGetLastError();
 }
@@ -324,7 +372,7 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
                                     uint32_t cap, hipStream_t st)
 {
     const int tiles = cam.gx * cam.gy;
-    int threads, chunk; bin_config(threads, chunk);
+    int threads, chunk; bin_config(P, threads, chunk);
     const int nb = (P + chunk - 1) / chunk;
     if (nb > 0) launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
     if (max_tile_instances > 8192) {

@@ -84,6 +84,7 @@ typedef struct GsGeomLayout {
     uint64_t tile_total;    /* uint32 [tiles]: instances per tile */
     uint64_t tile_base;     /* uint32 [ceil(P/4096)][tiles]: slice reserved by each binning workgroup */
     uint64_t sh_jac;        /* float [P][12]: 3x3 d(rgb)/d(view direction) of SH inputs (9 used), written when want_backward */
+    uint64_t depth_bits;    /* uint32 [P]: float bits of the view-space depth (binning key) */
 } GsGeomLayout;
 
 typedef struct GsImageLayout {

@@ -160,6 +160,21 @@ __global__ __launch_bounds__(256) void k_issue(float* out, float seed)
 #define S(i) { unsigned r_; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(r_) : "v"(a[i])); acc_mask += r_; }
             BODY8(S)
 #undef S
+        } else if (KIND == 30) {    // ds_add_u32, distinct addresses (integer LDS atomic, no return)
+#define S(i) asm volatile("ds_add_u32 %0, %1 offset:%2" :: "v"((int)(tid * 4)), "v"(1), "n"(i * 1024) : "memory");
+            BODY8(S)
+#undef S
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (KIND == 31) {    // ds_add_rtn_u32, distinct addresses
+#define S(i) { int r_; asm volatile("ds_add_rtn_u32 %0, %1, %2 offset:%3" : "=v"(r_) : "v"((int)(tid * 4)), "v"(1), "n"(i * 1024) : "memory"); acc_mask += r_; }
+            BODY8(S)
+#undef S
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (KIND == 32) {    // ds_add_u32, random-ish addresses within 1200 bins (histogram pattern)
+#define S(i) asm volatile("ds_add_u32 %0, %1" :: "v"((int)((((tid * 2654435761u) >> (7 + i)) % 1200u) * 4)), "v"(1) : "memory");
+            BODY8(S)
+#undef S
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else if (KIND == 29) {    // v_fma_f32 with operands spread over register banks: a[i] = a[i] * a[(i+1)&7] + a[(i+2)&7]
 #define S(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
             BODY8(S)
@@ -176,7 +191,8 @@ const char* kNames[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f
                         "v_cndmask_b32", "v_mul_f32", "v_mov_b32_dpp(quad)", "mix 3fma:1exp", "ds_read_b128", "ds_write_b32", "ds_add_f32",
                         "ds_read_b32 s17", "v_fma_f32 2 chains", "ds_write_b128", "ds_bpermute_b32",
                         "v_cndmask_e64 sgpr mask", "v_cmp+v_cndmask vcc (pairs)", "v_cmp_e64 -> sgpr", "v_max_f32", "v_fmac_f32", "v_mov_b32", "v_add_f32",
-                        "s_nop1+v_mul (pairs)", "v_cndmask vcc (cmp hoisted)", "v_mul_f32 sgpr src", "v_readlane_b32", "v_fma_f32 mixed banks"};
+                        "s_nop1+v_mul (pairs)", "v_cndmask vcc (cmp hoisted)", "v_mul_f32 sgpr src", "v_readlane_b32", "v_fma_f32 mixed banks",
+                        "ds_add_u32", "ds_add_rtn_u32", "ds_add_u32 histogram"};
 
 template <int KIND>
 void run(float* d_out, int waves_per_simd)
@@ -216,9 +232,10 @@ int main(int argc, char** argv)
     sweep<8>(d_out); sweep<9>(d_out); sweep<10>(d_out); sweep<11>(d_out); sweep<12>(d_out); sweep<13>(d_out); sweep<14>(d_out);
     sweep<15>(d_out); sweep<16>(d_out); sweep<17>(d_out);
     }
-    {
+    if (argc < 3) {
     sweep<18>(d_out); sweep<19>(d_out); sweep<20>(d_out); sweep<21>(d_out); sweep<22>(d_out); sweep<23>(d_out); sweep<24>(d_out);
     sweep<25>(d_out); sweep<26>(d_out); sweep<27>(d_out); sweep<28>(d_out); sweep<29>(d_out);
     }
+    sweep<30>(d_out); sweep<31>(d_out); sweep<32>(d_out);
     return 0;
 }
