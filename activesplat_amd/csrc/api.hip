@@ -218,7 +218,8 @@ int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t
     const bool few_tiles = tiles * 4 * 8 <= gs::kWaveSlots && max_tile_instances >= 8192;
     const bool long_lists = tiles * 4 * 2 <= gs::kWaveSlots && max_tile_instances >= 32768;
     if (g_segments_enabled && max_tile_instances != 0xffffffffu && (few_tiles || long_lists)) {
-        uint64_t S = 2 * (uint64_t)gs::kWaveSlots / ((uint64_t)tiles * 4);      // 2x oversubscribed: segments differ in work (early stop)
+        uint64_t S = 3 * (uint64_t)gs::kWaveSlots / ((uint64_t)tiles * 4);      // 3x oversubscribed: segments differ in work (early stop);
+                                                                                // measured on the 240-tile atlas: 1x 1.10, 2x 1.06, 3x 0.95, 4x 0.96, 6x 1.05 ms
         const uint64_t by_len = max_tile_instances / 1024;
         if (S > by_len) S = by_len;
         if (S > 32) S = 32;

@@ -46,6 +46,16 @@ def rot_axis(view_c2w, axis, angle_rad):
     return view_c2w @ np.array(R, dtype=np.float64)
 
 
+_COLS = {}
+
+
+def _panorama_columns(views, stride, device):
+    key = (views, stride, str(device))
+    if key not in _COLS:
+        _COLS[key] = torch.cat([torch.arange(v * stride, v * stride + LOOK_W) for v in range(views)]).to(device)
+    return _COLS[key]
+
+
 def _world_rendervar(params):
     """World-frame rendervar through the fused activation kernel (identity pose)."""
     with torch.no_grad():
@@ -69,15 +79,22 @@ def look_around(params, view_c2w, scale_modifier=1.0, fused=True, views=None, ba
     outs = []
     if fused:
         rv = _world_rendervar(params)
+        if batched and views > 1:
+            # cameras built on the host (one upload for all views inside render_views), panorama assembled from the atlas with one
+            # column gather per output
+            cams = [setup_camera(LOOK_W, LOOK_H, k, w2c, VIZ_NEAR, VIZ_FAR, scale_modifier=scale_modifier, device="cpu", bg=(1.0, 1.0, 1.0))
+                    for w2c in w2cs]
+            rv.pop("means2D")
+            color, depth, opacity, stride = render_views(cams, return_atlas=True, **rv)
+            cols = _panorama_columns(views, stride, device)
+            im = color[:, :, cols]
+            return {"opacity": opacity[0][:, cols], "rgb": (torch.clamp(im, min=0, max=1.0) * 255).byte().permute(1, 2, 0).contiguous(),
+                    "depth": depth[0][:, cols].unsqueeze(-1)}
         cams = [setup_camera(LOOK_W, LOOK_H, k, w2c, VIZ_NEAR, VIZ_FAR, scale_modifier=scale_modifier, device=device, bg=(1.0, 1.0, 1.0))
                 for w2c in w2cs]
-        if batched and views > 1:
-            rv.pop("means2D")
-            outs = [(im, depth, opacity) for im, _, depth, opacity in render_views(cams, **rv)]
-        else:
-            for cam in cams:
-                im, _, depth, opacity = GaussianRasterizer(raster_settings=cam)(**rv)
-                outs.append((im, depth, opacity))
+        for cam in cams:
+            im, _, depth, opacity = GaussianRasterizer(raster_settings=cam)(**rv)
+            outs.append((im, depth, opacity))
     else:
         for w2c in w2cs:
             scene, scene_depth = M.get_rendervars(params, torch.tensor(w2c, dtype=torch.float32, device=device))

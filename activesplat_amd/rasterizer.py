@@ -286,13 +286,16 @@ class GaussianRasterizer(nn.Module):
 
 
 @torch.no_grad()
-def render_views(settings_list, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+def render_views(settings_list, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+                 return_atlas=False):
     """Forward-only render of V views of ONE set of Gaussians in a single pass (the planner's look-around panoramas,
     src/mapper/splatam/__init__.py:707-736, 765-778: three 120 x 150 views per node).  The views share size, fov, background,
     scale modifier and SH degree and differ in their view / projection matrices and camera centre.  The per-Gaussian stage runs
     once over V x P virtual Gaussians; binning, sorting and blending see ONE atlas image (GsCamera.num_views, gs_atlas_layout) --
     one set of launches and one host read of the counters instead of V.
-    -> list of (color [3,H,W], radii [P] int32, depth [1,H,W], opacity [1,H,W]) per view (views of the atlas tensors)."""
+    -> list of (color [3,H,W], radii [P] int32, depth [1,H,W], opacity [1,H,W]) per view (views of the atlas tensors);
+    return_atlas=True: (color [3,H,AW], depth [1,H,AW], opacity [1,H,AW], view_stride) -- view v is columns [v stride, v stride + W).
+    Settings whose tensors live on the host (setup_camera(device="cpu")) cost ONE host-to-device copy for all views."""
     lib = _lib.get()
     V = len(settings_list)
     rs0 = settings_list[0]
@@ -312,10 +315,17 @@ def render_views(settings_list, means3D, opacities, shs=None, colors_precomp=Non
     means3D, shs, colors_precomp = _f32(means3D, device), _f32(shs, device), _f32(colors_precomp, device)
     opacities, scales, rotations, cov3D_precomp = _f32(opacities, device), _f32(scales, device), _f32(rotations, device), _f32(cov3D_precomp, device)
     M = 0 if shs is None else int(shs.shape[1])
-    keep = dict(bg=_f32(rs0.bg, device).reshape(-1),
-                view=torch.stack([_f32(rs.viewmatrix, device).reshape(16) for rs in settings_list]).contiguous(),
-                proj=torch.stack([_f32(rs.projmatrix, device).reshape(16) for rs in settings_list]).contiguous(),
-                campos=torch.stack([_f32(rs.campos, device).reshape(3) for rs in settings_list]).contiguous())
+    if all(not rs.viewmatrix.is_cuda for rs in settings_list) and device.type == "cuda":
+        host = torch.cat([torch.stack([rs.viewmatrix.reshape(16) for rs in settings_list]).reshape(-1),
+                          torch.stack([rs.projmatrix.reshape(16) for rs in settings_list]).reshape(-1),
+                          torch.stack([rs.campos.reshape(3) for rs in settings_list]).reshape(-1), rs0.bg.reshape(3).cpu()]).float()
+        pack = host.to(device, non_blocking=True)
+        keep = dict(pack=pack, view=pack[:16 * V], proj=pack[16 * V:32 * V], campos=pack[32 * V:35 * V], bg=pack[35 * V:35 * V + 3])
+    else:
+        keep = dict(bg=_f32(rs0.bg, device).reshape(-1),
+                    view=torch.stack([_f32(rs.viewmatrix, device).reshape(16) for rs in settings_list]).contiguous(),
+                    proj=torch.stack([_f32(rs.projmatrix, device).reshape(16) for rs in settings_list]).contiguous(),
+                    campos=torch.stack([_f32(rs.campos, device).reshape(3) for rs in settings_list]).contiguous())
     cam = _lib.GsCamera(W, H, int(rs0.sh_degree), M, float(rs0.tanfovx), float(rs0.tanfovy), float(rs0.scale_modifier), V,
                         keep["bg"].data_ptr(), keep["view"].data_ptr(), keep["proj"].data_ptr(), keep["campos"].data_ptr())
     pv, aw, stride = C.c_int32(), C.c_int32(), C.c_int32()
@@ -343,6 +353,8 @@ def render_views(settings_list, means3D, opacities, shs=None, colors_precomp=Non
     _lib.check(lib.gs_render_forward(C.byref(cam), P, D, max_tile, _ptr(geom), _ptr(binning), _ptr(plist), _ptr(image),
                                      _ptr(color), _ptr(depth), _ptr(opacity), None, None, st))
     last_stats["num_rendered"], last_stats["P"], last_stats["max_tile_instances"] = D, P, max_tile
+    if return_atlas:
+        return color, depth, opacity, S
     rows = Pv // V
     return [(color[:, :, v * S:v * S + W], radii[v * rows:v * rows + P], depth[:, :, v * S:v * S + W], opacity[:, :, v * S:v * S + W])
             for v in range(V)]
