@@ -280,6 +280,9 @@ def main():
         return grads
 
     acc_s = [[torch.zeros_like(rv[k]) for k in keys] for _ in range(len(pool))] if (pool is not None and dist_on) else None
+    # untimed preparation in front of the W warm-up steps: every stream has its own pool in torch's caching allocator, and a stream's
+    # first few frames still reach hipMalloc (with --warmup 5 on two streams that spilled into the timed region)
+    run(4 * max(args.streams, 1))
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
