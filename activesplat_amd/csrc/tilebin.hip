@@ -16,8 +16,6 @@
 //                  one 8-byte (depth_bits<<32 | id) store per instance.
 //   tile_sort    : one workgroup per tile, bitonic sort of the 64-bit pairs in LDS (keys are unique, so
 //                  the result does not depend on the atomics' arrival order), writes point_list.
-#include <stdlib.h>
-
 #include "gs_common.h"
 
 namespace gs {

@@ -263,19 +263,6 @@ static inline hipemu_v2u hipemu_permlane16_swap(unsigned a, unsigned b)
 #define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) hipemu_permlane16_swap(a, b)
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp(old, src, ctrl, rm, bm, bc)
 #define __builtin_amdgcn_mov_dpp(src, ctrl, rm, bm, bc) hipemu_update_dpp(0, src, ctrl, rm, bm, bc)
-// bank-masked pair of v_add_f32_dpp (see GS_ROW_MERGE in csrc/blend.hip): lanes whose bank is in m0 get x0 + x0[partner],
-// the others x1 + x1[partner]
-static inline float hipemu_row_merge(float x0, float x1, int ctrl, int m0)
-{
-    union { float f; int i; } a, b, pa, pb;
-    a.f = x0; b.f = x1;
-    pa.i = hipemu_update_dpp(0, a.i, ctrl, 0xf, 0xf, true);
-    pb.i = hipemu_update_dpp(0, b.i, ctrl, 0xf, 0xf, true);
-    const bool in0 = ((m0 >> ((hipemu::lane_id() & 15) >> 2)) & 1) != 0;
-    return in0 ? x0 + pa.f : x1 + pb.f;
-}
-#define GS_ROW_MERGE(dst, x0, x1, CTRL_STR, CTRL, M0_STR, M1_STR, M0) dst = hipemu_row_merge(x0, x1, CTRL, M0)
-
 // ---- scalar helpers ----------------------------------------------------------------------------
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
