@@ -46,6 +46,7 @@ struct GeomPtrs {
     uint32_t* clamped;   // uchar4 packed
     uint32_t* tile_total;  // [tiles]
     uint32_t* tile_base;   // [ceil(P/kBinChunk)][tiles]
+    uint32_t* chunk_flags; // [ceil(P/1024)]: 1 = this binning chunk is scattered by the direct kernel (large rects / overfull)
     uint32_t* depth_bits;  // [P]: bit pattern of the view-space depth (the binning key), compact copy of geom[.][9] for coalesced reads
     float4* sh_jac;        // [P][3]: d(rgb before the clamp)/d(unit view direction), 3x3 row-major in 9 of 12 floats (SH inputs with a backward to follow)
 };
@@ -303,6 +304,7 @@ hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_
 hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_base, const uint2* ranges,
                                     uint32_t max_tile_instances, unsigned long long* pairs, uint32_t* point_list,
                                     uint32_t cap, hipStream_t st);
+extern int g_staged_min_chunks;
 hipError_t launch_emit(const Cam& cam, int P, GeomPtrs gp, uint64_t* keys, uint32_t* vals, hipStream_t st);
 hipError_t launch_ranges(int64_t D, const uint64_t* keys_sorted, uint2* ranges, hipStream_t st);
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,

@@ -18,6 +18,10 @@
 //                  the result does not depend on the atomics' arrival order), writes point_list.
 #include "gs_common.h"
 
+#ifndef GS_DYNAMIC_LDS
+#define GS_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
 namespace gs {
 
 // one wavefront expands its 64 Gaussians' rects; f(tile, owner_slot, k) is called once per instance
@@ -49,7 +53,8 @@ __global__ __launch_bounds__(THREADS) void tile_bin_kernel(Cam cam, int P, GeomP
                                                           uint32_t* __restrict__ tile_total,
                                                           uint32_t* __restrict__ tile_base,
                                                           const uint2* __restrict__ ranges,
-                                                          unsigned long long* __restrict__ pairs, uint32_t cap)
+                                                          unsigned long long* __restrict__ pairs, uint32_t cap, const uint32_t* __restrict__ chunk_flags,
+                                                          int nchunks)
 {
     __shared__ uint32_t s_hist[kMaxLdsTiles];      // count pass: histogram; scatter pass: cursors
     __shared__ uint32_t s_incl[THREADS];
@@ -58,10 +63,15 @@ __global__ __launch_bounds__(THREADS) void tile_bin_kernel(Cam cam, int P, GeomP
     __shared__ uint32_t s_depth[THREADS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t* my_base = tile_base + (size_t)blockIdx.x * tiles;
+    // one chunk per workgroup in the count pass; the direct scatter behind the staged one is launched with a small grid that strides
+    // over the chunks and only works on the flagged ones (usually none)
+  for (int cid = blockIdx.x; cid < nchunks; cid += gridDim.x) {
+    uint32_t* my_base = tile_base + (size_t)cid * tiles;
+    if (SCATTER && chunk_flags && chunk_flags[cid] == 0u) continue;           // this chunk went through the staged scatter
+    __syncthreads();
     for (int t = tid; t < tiles; t += THREADS) s_hist[t] = SCATTER ? ranges[t].x + my_base[t] : 0u;
     __syncthreads();
-    const int cbase = blockIdx.x * chunk;
+    const int cbase = cid * chunk;
     for (int r = 0; r < chunk / THREADS; r++) {
         const int i = cbase + r * THREADS + tid;
         if (cbase + r * THREADS >= P) break;                      // uniform
@@ -120,30 +130,129 @@ __global__ __launch_bounds__(THREADS) void tile_bin_kernel(Cam cam, int P, GeomP
         __syncthreads();
         for (int t = tid; t < tiles; t += THREADS) my_base[t] = s_hist[t];
     }
+  }
+}
+
+// Scatter, staged: the 8-byte pair stores of the direct scatter above go to ~1000 different tile segments per workgroup, one lane
+// at a time -- 4.8 M separate partial-line writes at 2 M Gaussians, 45 of that kernel's 55 us (with the stores removed it takes
+// 10 us).  Here a workgroup first sorts its chunk's instances by tile INSIDE LDS (count -> exclusive scan -> place, all with LDS
+// integer atomics), then copies them out in that order: the instances of a (chunk, tile) slice are adjacent in LDS and in HBM, so
+// adjacent lanes write adjacent addresses and a slice leaves as one request.  Chunks that hold a large rect (> 16 tiles) or more
+// instances than the staging buffer takes are flagged and left to the direct kernel.
+template <int THREADS, int ROUNDS>
+__global__ __launch_bounds__(THREADS) void tile_scatter_staged_kernel(Cam cam, int P, GeomPtrs gp, int tiles, const uint32_t* __restrict__ tile_base,
+                                                                      const uint2* __restrict__ ranges, unsigned long long* __restrict__ pairs,
+                                                                      uint32_t cap, int stage_cap, uint32_t* __restrict__ chunk_flags)
+{
+    GS_DYNAMIC_LDS(s_dyn);
+    unsigned long long* s_stage = reinterpret_cast<unsigned long long*>(s_dyn);             // [stage_cap]
+    uint32_t* s_gslot = reinterpret_cast<uint32_t*>(s_stage + stage_cap);                      // [stage_cap]
+    uint32_t* s_cur = s_gslot + stage_cap;                                                      // [tiles]: counts, then cursors
+    uint32_t* s_delta = s_cur + tiles;                                                          // [tiles]: global slot - local slot
+    __shared__ uint32_t s_w[THREADS / kWave];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cbase = blockIdx.x * THREADS * ROUNDS;
+    for (int t = tid; t < tiles; t += THREADS) s_cur[t] = 0u;
+    if (tid == 0) s_carry = 0u;
+    uint32_t n[ROUNDS], x0[ROUNDS], w[ROUNDS], y0[ROUNDS], dbits[ROUNDS];
+    bool big = false;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const int i = cbase + r * THREADS + tid;
+        n[r] = 0; x0[r] = 0; w[r] = 1; y0[r] = 0; dbits[r] = 0;
+        if (i < P) {
+            n[r] = gp.tiles[i];
+            if (n[r]) {
+                const uint2 rc = gp.rect[i];
+                x0[r] = rc.x & 0xffffu; w[r] = (rc.x >> 16) - x0[r]; y0[r] = rc.y & 0xffffu;
+                dbits[r] = gp.depth_bits[i];
+            }
+        }
+        big = big || n[r] > 16u;
+    }
+    const bool any_big = __syncthreads_or(big) != 0;           // (also orders the zero fill of s_cur before the counting)
+    if (any_big) { if (tid == 0) chunk_flags[blockIdx.x] = 1u; return; }
+    // ---- count ----
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        uint32_t kx = 0, ky = 0;
+        for (uint32_t k = 0; k < n[r]; k++) {
+            atomicAdd(&s_cur[(y0[r] + ky) * (uint32_t)cam.gx + x0[r] + kx], 1u);
+            if (++kx == w[r]) { kx = 0; ++ky; }
+        }
+    }
+    __syncthreads();
+    // ---- exclusive scan over the tiles: s_cur[t] = first local slot of tile t, s_delta[t] = (its global slot) - (its local slot) ----
+    const uint32_t* my_base = tile_base + (size_t)blockIdx.x * tiles;
+    for (int b = 0; b < tiles; b += THREADS) {
+        const int t = b + tid;
+        const uint32_t v = t < tiles ? s_cur[t] : 0u;
+        const uint32_t inc = wave_inclusive_scan(v, lane);
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t wprefix = 0;
+        for (int q = 0; q < wave; q++) wprefix += s_w[q];
+        const uint32_t carry = s_carry;
+        const uint32_t start = carry + wprefix + inc - v;
+        if (t < tiles) { s_cur[t] = start; s_delta[t] = ranges[t].x + my_base[t] - start; }
+        __syncthreads();
+        if (tid == THREADS - 1) s_carry = carry + wprefix + inc;
+        __syncthreads();
+    }
+    const uint32_t total = s_carry;
+    if (total > (uint32_t)stage_cap) { if (tid == 0) chunk_flags[blockIdx.x] = 1u; return; }      // uniform
+    if (tid == 0) chunk_flags[blockIdx.x] = 0u;
+    // ---- place into LDS, sorted by tile ----
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const uint32_t id = (uint32_t)(cbase + r * THREADS + tid);
+        uint32_t kx = 0, ky = 0;
+        for (uint32_t k = 0; k < n[r]; k++) {
+            const uint32_t tile = (y0[r] + ky) * (uint32_t)cam.gx + x0[r] + kx;
+            const uint32_t ls = atomicAdd(&s_cur[tile], 1u);
+            s_stage[ls] = ((unsigned long long)dbits[r] << 32) | id;
+            s_gslot[ls] = ls + s_delta[tile];
+            if (++kx == w[r]) { kx = 0; ++ky; }
+        }
+    }
+    __syncthreads();
+    // ---- copy out: adjacent lanes, adjacent slots of a slice ----
+    for (uint32_t j = tid; j < total; j += THREADS) {
+        const uint32_t gs = s_gslot[j];
+        if (gs < cap) pairs[gs] = s_stage[j];
+    }
 }
 
 // Column-wise exclusive scan of the [chunks][tiles] count matrix, in place: base[c][t] = instances of tile t in the chunks before c;
-// tile_total[t] = the column sum.  32 tiles x 32 row segments per workgroup: lanes read 128 contiguous bytes of a row.
+// tile_total[t] = the column sum.  TW tiles x (1024 / TW) row segments per workgroup (the matrix was just written and sits in L2, so
+// short row pieces are fine; measured at 2 M Gaussians / 1200 tiles: TW = 32: 16.3 us, 16: 11.4, 8: 12.0, 4: 18.7).
+template <int TW>
 __global__ __launch_bounds__(1024) void tile_colscan_kernel(uint32_t* __restrict__ base, int chunks, int tiles, uint32_t* __restrict__ tile_total)
 {
-    __shared__ uint32_t s_sum[32][33];
-    const int l = threadIdx.x & 31, sgm = threadIdx.x >> 5;
-    const int t = blockIdx.x * 32 + l;
-    const int L = (chunks + 31) / 32, r0 = min(chunks, sgm * L), r1 = min(chunks, r0 + L);
+    constexpr int SEG = 1024 / TW;
+    __shared__ uint32_t s_sum[SEG][TW + 1];
+    const int l = threadIdx.x % TW, sgm = threadIdx.x / TW;
+    const int t = blockIdx.x * TW + l;
+    const int L = (chunks + SEG - 1) / SEG, r0 = min(chunks, sgm * L), r1 = min(chunks, r0 + L);
     uint32_t sum = 0;
-    if (t < tiles) for (int r = r0; r < r1; r++) sum += base[(size_t)r * tiles + t];
+    if (t < tiles) {
+#pragma unroll 8
+        for (int r = r0; r < r1; r++) sum += base[(size_t)r * tiles + t];
+    }
     s_sum[sgm][l] = sum;
     __syncthreads();
     uint32_t run = 0;
     for (int q = 0; q < sgm; q++) run += s_sum[q][l];
     if (t < tiles) {
+#pragma unroll 8
         for (int r = r0; r < r1; r++) {
             const size_t idx = (size_t)r * tiles + t;
             const uint32_t v = base[idx];
             base[idx] = run;
             run += v;
         }
-        if (sgm == 31) tile_total[t] = run;          // the last segment ends with the column sum (empty segments pass it through)
+        if (sgm == SEG - 1) tile_total[t] = run;     // the last segment ends with the column sum (empty segments pass it through)
     }
 }
 
@@ -348,9 +457,12 @@ static void bin_config(int P, int& threads, int& chunk)
 
 template <bool SCATTER>
 static void launch_bin(int threads, int nb, hipStream_t st, Cam cam, int P, GeomPtrs gp, int tiles, int chunk,
-                       uint32_t* tile_total, uint32_t* tile_base, const uint2* ranges, unsigned long long* pairs, uint32_t cap)
+                       uint32_t* tile_total, uint32_t* tile_base, const uint2* ranges, unsigned long long* pairs, uint32_t cap,
+                       const uint32_t* flags = nullptr)
 {
-    hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 1024>), dim3(nb), dim3(1024), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs, cap);
+    const int nchunks = nb;
+    if (flags && nb > 64) nb = 64;                       // stride loop: the flagged chunks are few
+    hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 1024>), dim3(nb), dim3(1024), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs, cap, flags, nchunks);
 }
 
 hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,
@@ -360,10 +472,12 @@ hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_
     int threads, chunk; bin_config(P, threads, chunk);
     const int nb = (P + chunk - 1) / chunk;
     if (nb > 0) launch_bin<false>(threads, nb, st, cam, P, gp, tiles, chunk, tile_total, tile_base, nullptr, nullptr, 0u);
-    hipLaunchKernelGGL(tile_colscan_kernel, dim3((tiles + 31) / 32), dim3(1024), 0, st, tile_base, nb, tiles, tile_total);
+    hipLaunchKernelGGL(tile_colscan_kernel<16>, dim3((tiles + 15) / 16), dim3(1024), 0, st, tile_base, nb, tiles, tile_total);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_total, tiles, ranges, d_counts, host_counts);
     return hipGetLastError();
 }
+
+int g_staged_min_chunks = 512;            // gs_set_scatter_staging (development knob)
 
 hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_base, const uint2* ranges,
                                     uint32_t max_tile_instances, unsigned long long* pairs, uint32_t* point_list,
@@ -372,7 +486,23 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
     const int tiles = cam.gx * cam.gy;
     int threads, chunk; bin_config(P, threads, chunk);
     const int nb = (P + chunk - 1) / chunk;
-    if (nb > 0) launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
+    if (nb >= g_staged_min_chunks && chunk == 2048) {
+        // large maps (>= 1 M Gaussians; measured: 2 M 55 -> 42 + 4 us, 500 k 17 -> 14 + 4 us, i.e. no gain there): staged scatter for
+        // the usual chunks, the direct kernel for the ones it flags (large rects, overfull chunks)
+        constexpr int kLdsBudget = 76 * 1024;                                 // two workgroups per CU
+        const int stage_cap = (kLdsBudget - tiles * 8) / 12;
+        if (stage_cap >= 2048) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_scatter_staged_kernel<1024, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+                attr_set = true;
+            }
+            const size_t dyn = (size_t)stage_cap * 12 + (size_t)tiles * 8;
+            hipLaunchKernelGGL((tile_scatter_staged_kernel<1024, 2>), dim3(nb), dim3(1024), dyn, st, cam, P, gp, tiles, tile_base, ranges, pairs, cap,
+                               stage_cap, gp.chunk_flags);
+            launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap, gp.chunk_flags);
+        } else launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
+    } else if (nb > 0) launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
     if (max_tile_instances > 8192) {
         // very long lists (256 x 256 frames over a million Gaussians: ~10 k per tile): 4096-key runs halve the number of runs the
         // rank merge has to search (3 instead of 6 for 11 k keys)

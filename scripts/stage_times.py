@@ -59,7 +59,7 @@ if __name__ == "__main__":
     for var, vals in sweeps:
         for v in vals.split(","):
             os.environ[var] = v
-            wall, st = run(N=N, W=int(os.environ.get("W", 640)), H=int(os.environ.get("H", 480)))
+            wall, st = run(N=N, W=int(os.environ.get("W", 640)), H=int(os.environ.get("H", 480)), backward=os.environ.get("BWD", "1") != "0")
             from activesplat_amd import rasterizer as R
             print(f"{var}={v} N={N} D={R.last_stats['num_rendered']} maxtile={R.last_stats.get('max_tile_instances')} wall_us={wall:.1f} " + " ".join(f"{k}={u:.1f}" for k, u in st.items()), flush=True)
         os.environ.pop(var, None)

@@ -322,9 +322,25 @@ static inline hipError_t hipPeekAtLastError() { return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 
-template <class K, class... A>
-static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t, A... args)
+// dynamic LDS (extern __shared__): one buffer per host worker thread, sized by the launch
+namespace hipemu {
+inline size_t& dyn_bytes() { static size_t b = 0; return b; }
+inline unsigned char* dyn_lds()
 {
+    static thread_local std::vector<unsigned long long> buf;
+    const size_t need = (dyn_bytes() + 7) / 8 + 2;
+    if (buf.size() < need) buf.resize(need);
+    return reinterpret_cast<unsigned char*>(buf.data());
+}
+}  // namespace hipemu
+#define GS_DYNAMIC_LDS(name) unsigned char* name = hipemu::dyn_lds()
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
+
+template <class K, class... A>
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, A... args)
+{
+    hipemu::dyn_bytes() = shmem;
     std::function<void()> body = [=]() { kernel(args...); };
     hipemu::run_grid(grid, block, body);
 }

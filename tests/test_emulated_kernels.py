@@ -144,3 +144,7 @@ def test_emulated_densification_statistics_kernels(emu):
 
 def test_emulated_segmented_forward(emu, oracle32):
     pc.check_segmented_forward(emu, oracle32)
+
+
+def test_staged_scatter_forced_on(emu, oracle32):
+    pc.check_staged_scatter(emu, oracle32)

@@ -194,3 +194,7 @@ def test_random_scene_matches_oracle_on_gpu(hip, oracle32, oracle64, seed):
 
 def test_segmented_forward(hip, oracle32):
     pc.check_segmented_forward(hip, oracle32)
+
+
+def test_staged_scatter_forced_on(hip, oracle32):
+    pc.check_staged_scatter(hip, oracle32)
