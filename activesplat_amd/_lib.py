@@ -40,7 +40,7 @@ class GsAdamTensor(C.Structure):
 
 class GsBinLayout(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "path", "pairs", "keys_unsorted", "vals_unsorted", "keys_sorted",
-                                          "sort_temp", "segments", "seg_T")]
+                                          "sort_temp", "segments", "seg_T", "pairs_alt")]
 
 
 SORT_AUTO, SORT_TILE_LDS, SORT_RADIX = 0, 1, 2

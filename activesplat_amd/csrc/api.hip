@@ -26,7 +26,8 @@ bool g_segments_enabled = true;
 
 int choose_path(int tiles, uint32_t max_tile_instances)
 {
-    const bool fits = tiles <= gs::kMaxLdsTiles && max_tile_instances <= (uint32_t)gs::kSortCapMax;
+    (void)max_tile_instances;                 // any list length: runs beyond the LDS merge are merged pass by pass through global memory
+    const bool fits = tiles <= gs::kMaxLdsTiles;
     if (g_sort_path == GS_SORT_RADIX) return GS_SORT_RADIX;
     return fits ? GS_SORT_TILE_LDS : GS_SORT_RADIX;
 }
@@ -211,6 +212,8 @@ int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t
     uint64_t o = 0;
     if (out->path == GS_SORT_TILE_LDS) {
         out->pairs = o; o = align_up(o + n * 8);
+        // (0xffffffff = "unknown", the radix path's placeholder when the tile path is forced: no second buffer then)
+        if (max_tile_instances > (uint32_t)gs::kSortCapMax && max_tile_instances != 0xffffffffu) { out->pairs_alt = o; o = align_up(o + n * 8); }
     } else {
         out->keys_unsorted = o; o = align_up(o + n * 8);
         out->vals_unsorted = o; o = align_up(o + n * 4);
@@ -315,7 +318,7 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_ti
         if (D > 0) {          // ranges were written by gs_preprocess_forward
             ScopedStage ps(ST_TILE_SCATTER_SORT, st);
             e = gs::launch_tile_scatter_sort(k, P, gp, gp.tile_base, ranges, max_tile_instances,
-                                             (unsigned long long*)(bb + BL.pairs), point_list, (uint32_t)D, st);
+                                             (unsigned long long*)(bb + BL.pairs), (unsigned long long*)(bb + BL.pairs_alt), point_list, (uint32_t)D, st);
             if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: tile scatter/sort %s", hipGetErrorString(e));
         }
     } else {

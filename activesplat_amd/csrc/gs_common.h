@@ -15,7 +15,7 @@ constexpr int kQuad = 8;            // each wavefront owns one 8x8 pixel quadran
 constexpr int kBinChunk = 2048;     // Gaussians per tile-binning workgroup (LDS-private histogram)
 constexpr int kMaxLdsTiles = 8192;  // tile-binning path needs the tile histogram in LDS (32 KiB)
 constexpr int kSortChunk = 2048;    // keys one workgroup bitonic-sorts in LDS
-constexpr int kSortCapMax = 16384;  // largest per-tile list whose sorted chunks are rank-merged in LDS (128 KiB); beyond -> device radix sort
+constexpr int kSortCapMax = 16384;  // largest per-tile list whose sorted chunks are rank-merged in LDS (128 KiB); beyond -> pairwise merge passes
 
 // By-value kernel argument; matrices stay in device memory exactly where the caller's settings
 // tensors put them (uniform loads -> scalar cache).
@@ -302,8 +302,8 @@ hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3
 hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,
                              uint2* ranges, uint32_t* d_counts, uint32_t* host_counts, hipStream_t st);
 hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_base, const uint2* ranges,
-                                    uint32_t max_tile_instances, unsigned long long* pairs, uint32_t* point_list,
-                                    uint32_t cap, hipStream_t st);
+                                    uint32_t max_tile_instances, unsigned long long* pairs, unsigned long long* pairs_alt,
+                                    uint32_t* point_list, uint32_t cap, hipStream_t st);
 extern int g_staged_min_chunks;
 hipError_t launch_emit(const Cam& cam, int P, GeomPtrs gp, uint64_t* keys, uint32_t* vals, hipStream_t st);
 hipError_t launch_ranges(int64_t D, const uint64_t* keys_sorted, uint2* ranges, hipStream_t st);

@@ -357,9 +357,9 @@ __device__ __forceinline__ void bitonic_sort_block(unsigned long long (&k)[E], u
 }
 
 template <int E, int THREADS>
-__device__ __forceinline__ void tile_sort_impl(const uint2 range, uint32_t n, unsigned long long* __restrict__ pairs,
-                                               uint32_t* __restrict__ point_list, unsigned long long* buf0,
-                                               unsigned long long* buf1, int tid)
+__device__ __forceinline__ void tile_sort_impl(const uint2 range, uint32_t n, const unsigned long long* pairs,
+                                               unsigned long long* pairs_out, uint32_t* __restrict__ point_list,
+                                               unsigned long long* buf0, unsigned long long* buf1, int tid)
 {
     unsigned long long k[E];
     const uint32_t base = (uint32_t)tid * E;
@@ -383,17 +383,18 @@ __device__ __forceinline__ void tile_sort_impl(const uint2 range, uint32_t n, un
         const uint32_t e = (uint32_t)i * THREADS + tid;
         if (e < n) {
             const unsigned long long v = buf0[e];
-            pairs[range.x + e] = v;
+            pairs_out[range.x + e] = v;
             point_list[range.x + e] = (uint32_t)v;
         }
     }
 }
 
-// grid = (tiles, chunks): block (t, c) sorts keys [c*CAP, min(n, (c+1)*CAP)) of tile t in place and writes their ids.
-// A tile with n <= CAP is finished by this kernel alone; longer lists are completed by tile_merge_kernel.
+// grid = (tiles, chunks): block (t, c) sorts keys [c*CAP, min(n, (c+1)*CAP)) of tile t (pairs -> pairs_out, which may be the same
+// array) and writes their ids.  A tile with n <= CAP is finished by this kernel alone; longer lists are completed by
+// tile_merge_kernel (up to kSortCapMax keys, in LDS) or by tile_merge_pass_kernel (any length, run by run through global memory).
 template <int CAP, int THREADS>
 __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restrict__ ranges,
-                                                             unsigned long long* __restrict__ pairs,
+                                                             const unsigned long long* pairs, unsigned long long* pairs_out,
                                                              uint32_t* __restrict__ point_list, uint32_t cap)
 {
     __shared__ unsigned long long s_a[CAP];
@@ -406,9 +407,9 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restr
     range.x += start;
     const uint32_t n = min(range.y - range.x, (uint32_t)CAP);
     constexpr int EMAX = CAP / THREADS;                       // 8
-    if (n <= (uint32_t)THREADS * (EMAX / 4)) tile_sort_impl<EMAX / 4, THREADS>(range, n, pairs, point_list, s_a, s_b, tid);
-    else if (n <= (uint32_t)THREADS * (EMAX / 2)) tile_sort_impl<EMAX / 2, THREADS>(range, n, pairs, point_list, s_a, s_b, tid);
-    else tile_sort_impl<EMAX, THREADS>(range, n, pairs, point_list, s_a, s_b, tid);
+    if (n <= (uint32_t)THREADS * (EMAX / 4)) tile_sort_impl<EMAX / 4, THREADS>(range, n, pairs, pairs_out, point_list, s_a, s_b, tid);
+    else if (n <= (uint32_t)THREADS * (EMAX / 2)) tile_sort_impl<EMAX / 2, THREADS>(range, n, pairs, pairs_out, point_list, s_a, s_b, tid);
+    else tile_sort_impl<EMAX, THREADS>(range, n, pairs, pairs_out, point_list, s_a, s_b, tid);
 }
 
 // Tiles with CHUNK < n <= CAP: the CHUNK-sized sorted runs left by tile_sort_kernel are merged by RANK: the whole
@@ -447,6 +448,75 @@ __global__ __launch_bounds__(THREADS) void tile_merge_kernel(const uint2* __rest
     }
 }
 
+// Lists longer than kSortCapMax (the planner's 120 x 150 views of a large map: tens of thousands of records per tile): the sorted
+// runs are merged PAIRWISE, pass by pass, through global memory (src -> dst, run length doubling).  grid = (tiles, output blocks of
+// OUT keys); OUT divides the run length, so a block lies inside one pair of runs (A, B).  Two merge-path searches (first wavefront:
+// start diagonal, second: end diagonal) give the stretches of A and B that make up the block's OUT outputs; they are loaded into LDS,
+// every key finds its rank by a binary search in the other stretch (keys are unique), the block is permuted inside LDS and leaves
+// in list order.  A pair whose B is empty (odd run out, or a tile that was finished passes ago) is copied.
+template <int OUT, int THREADS>
+__global__ __launch_bounds__(THREADS) void tile_merge_pass_kernel(const uint2* __restrict__ ranges, const unsigned long long* __restrict__ src,
+                                                                   unsigned long long* __restrict__ dst, uint32_t* __restrict__ point_list,
+                                                                   uint32_t run, uint32_t cap)
+{
+    __shared__ unsigned long long s_in[OUT];
+    __shared__ unsigned long long s_out[OUT];
+    __shared__ uint32_t s_split[2];
+    const int tid = threadIdx.x;
+    uint2 range = ranges[blockIdx.x];
+    range.x = min(range.x, cap); range.y = min(range.y, cap);
+    const uint32_t n = range.y - range.x;
+    const uint32_t o0 = blockIdx.y * (uint32_t)OUT;
+    if (o0 >= n) return;                                        // uniform
+    const uint32_t o1 = min(n, o0 + (uint32_t)OUT);
+    const uint32_t pair0 = o0 / (2u * run) * (2u * run);
+    const uint32_t lenA = min(run, n - pair0), lenB = min(run, n - pair0 - lenA);
+    const unsigned long long* A = src + range.x + pair0;
+    const unsigned long long* B = A + lenA;
+    if (tid < 2 * kWave) {
+        // merge path: how many of the first d outputs of merge(A, B) come from A = the smallest i in [lo, hi] for which
+        // A[i] < B[d-1-i] no longer holds (it holds for small i, then never again).  64 probes per round instead of one: the
+        // interval shrinks 64-fold per global-memory round trip (a 128 k-key run: 3 rounds instead of 17)
+        const int lane = tid & (kWave - 1);
+        const uint32_t d = (tid < kWave ? o0 : o1) - pair0;
+        uint32_t lo = d > lenB ? d - lenB : 0u, hi = min(d, lenA);
+        while (lo < hi) {                                       // wave-uniform
+            const uint32_t span = hi - lo;
+            const uint32_t q = lo + (uint32_t)(((uint64_t)span * (uint32_t)lane) >> 6);      // lo <= q <= hi - 1, non-decreasing in lane
+            const int c = (int)__popcll(__ballot(A[q] < B[d - 1 - q]));                       // the first c probes hold
+            const uint32_t q_prev = lo + (uint32_t)(((uint64_t)span * (uint32_t)max(c - 1, 0)) >> 6);
+            const uint32_t q_c = lo + (uint32_t)(((uint64_t)span * (uint32_t)min(c, kWave - 1)) >> 6);
+            if (c == 0) hi = lo;
+            else if (c == kWave) lo = q_prev + 1;
+            else { lo = q_prev + 1; hi = q_c; }
+        }
+        if (lane == 0) s_split[tid / kWave] = lo;
+    }
+    __syncthreads();
+    const uint32_t d0 = o0 - pair0, d1 = o1 - pair0;
+    const uint32_t a0 = s_split[0], a1 = s_split[1], b0 = d0 - a0, b1 = d1 - a1;
+    const uint32_t na = a1 - a0, nb = b1 - b0, m = na + nb;     // m = o1 - o0
+    for (uint32_t i = tid; i < m; i += THREADS) s_in[i] = i < na ? A[a0 + i] : B[b0 + (i - na)];
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += THREADS) {
+        const unsigned long long key = s_in[i];
+        const bool in_a = i < na;
+        const uint32_t base = in_a ? na : 0u, len = in_a ? nb : na;
+        uint32_t lo = 0, hi = len;                              // keys of the other stretch below this one
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_in[base + mid] < key) lo = mid + 1; else hi = mid;
+        }
+        s_out[(in_a ? i : i - na) + lo] = key;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += THREADS) {
+        const unsigned long long key = s_out[i];
+        dst[range.x + o0 + i] = key;
+        if (point_list) point_list[range.x + o0 + i] = (uint32_t)key;
+    }
+}
+
 // 1024 threads x kBinChunk Gaussians per workgroup (measured best of 256/512/1024 threads x 1024..4096 Gaussians)
 static void bin_config(int P, int& threads, int& chunk)
 {
@@ -480,8 +550,8 @@ hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_
 int g_staged_min_chunks = 512;            // gs_set_scatter_staging (development knob)
 
 hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_base, const uint2* ranges,
-                                    uint32_t max_tile_instances, unsigned long long* pairs, uint32_t* point_list,
-                                    uint32_t cap, hipStream_t st)
+                                    uint32_t max_tile_instances, unsigned long long* pairs, unsigned long long* pairs_alt,
+                                    uint32_t* point_list, uint32_t cap, hipStream_t st)
 {
     const int tiles = cam.gx * cam.gy;
     int threads, chunk; bin_config(P, threads, chunk);
@@ -503,17 +573,36 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
             launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap, gp.chunk_flags);
         } else launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
     } else if (nb > 0) launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
+    if (max_tile_instances > (uint32_t)kSortCapMax) {
+        // longer than the LDS rank merge holds: 2048-key runs (4096-key runs sort at half the rate), then pairwise merge passes between
+        // `pairs` and `pairs_alt`; the run sort writes into whichever of the two leaves the final pass's output in `pairs`
+        constexpr int kOut = kSortChunk;
+        const unsigned chunks = (max_tile_instances + kSortChunk - 1) / kSortChunk;
+        int passes = 0;
+        for (uint64_t r = kSortChunk; r < max_tile_instances; r <<= 1) passes++;
+        unsigned long long* cur = (passes & 1) ? pairs_alt : pairs;
+        hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, chunks), dim3(256), 0, st, ranges, pairs, cur, point_list, cap);
+        const unsigned blocks = (max_tile_instances + kOut - 1) / kOut;
+        uint64_t r = kSortChunk;
+        for (int p = 0; p < passes; p++, r <<= 1) {
+            unsigned long long* nxt = cur == pairs ? pairs_alt : pairs;
+            hipLaunchKernelGGL((tile_merge_pass_kernel<kOut, 256>), dim3(tiles, blocks), dim3(256), 0, st, ranges, cur, nxt,
+                               p == passes - 1 ? point_list : nullptr, (uint32_t)r, cap);
+            cur = nxt;
+        }
+        return hipGetLastError();
+    }
     if (max_tile_instances > 8192) {
         // very long lists (256 x 256 frames over a million Gaussians: ~10 k per tile): 4096-key runs halve the number of runs the
         // rank merge has to search (3 instead of 6 for 11 k keys)
         constexpr int kBigChunk = 2 * kSortChunk;
         const unsigned chunks = (max_tile_instances + kBigChunk - 1) / kBigChunk;
-        hipLaunchKernelGGL((tile_sort_kernel<kBigChunk, 512>), dim3(tiles, chunks), dim3(512), 0, st, ranges, pairs, point_list, cap);
+        hipLaunchKernelGGL((tile_sort_kernel<kBigChunk, 512>), dim3(tiles, chunks), dim3(512), 0, st, ranges, pairs, pairs, point_list, cap);
         hipLaunchKernelGGL((tile_merge_kernel<kSortCapMax, kBigChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
         return hipGetLastError();
     }
     const unsigned chunks = (max_tile_instances + kSortChunk - 1) / kSortChunk;
-    hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, chunks ? chunks : 1), dim3(256), 0, st, ranges, pairs, point_list, cap);
+    hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, chunks ? chunks : 1), dim3(256), 0, st, ranges, pairs, pairs, point_list, cap);
     if (max_tile_instances > (uint32_t)kSortChunk) {
         // the list sits in LDS: the smallest capacity that holds the longest list keeps the most workgroups resident per CU
         if (max_tile_instances <= 4096)

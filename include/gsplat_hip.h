@@ -96,8 +96,8 @@ typedef struct GsImageLayout {
 } GsImageLayout;
 
 #define GS_SORT_AUTO 0
-#define GS_SORT_TILE_LDS 1   /* count/scatter into tile segments + per-tile LDS bitonic sort */
-#define GS_SORT_RADIX 2      /* duplicate with 64-bit keys + device radix sort (any tile size) */
+#define GS_SORT_TILE_LDS 1   /* count/scatter into tile segments + per-tile LDS bitonic sort (+ merges for lists over 2048 keys); <= 8192 tiles */
+#define GS_SORT_RADIX 2      /* duplicate with 64-bit keys + device radix sort (any image size) */
 
 typedef struct GsBinLayout {
     uint64_t total_bytes;
@@ -109,6 +109,7 @@ typedef struct GsBinLayout {
     uint64_t sort_temp;     /* RADIX: scratch of the sort */
     uint64_t segments;      /* > 1: gs_render_forward composites every tile list in this many parallel segments (few tiles, long lists) */
     uint64_t seg_T;         /* float [tiles][segments][256]: per-segment transmittance of the segmented forward, then uint32 [tiles][4] flag words */
+    uint64_t pairs_alt;     /* TILE_LDS, tile lists longer than 16384: uint64 [D], the second buffer of the pairwise merge passes */
 } GsBinLayout;
 
 /* Multi-view atlas (the planner's look-around: V small views of one map, src/mapper/splatam/__init__.py:707-736): with
@@ -121,7 +122,7 @@ int gs_atlas_layout(int32_t P, int32_t view_width, int32_t num_views, int32_t* v
 int gs_geom_layout(int32_t P, int32_t width, int32_t height, GsGeomLayout* out);
 int gs_image_layout(int32_t width, int32_t height, GsImageLayout* out);
 int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t height, GsBinLayout* out);
-/* Force a binning path (GS_SORT_*; default GS_SORT_AUTO picks TILE_LDS when every tile list fits LDS). */
+/* Force a binning path (GS_SORT_*; default GS_SORT_AUTO picks TILE_LDS whenever the image has at most 8192 tiles). */
 int gs_set_sort_path(int32_t path);
 /* Segmented compositing of long tile lists in images of few tiles (GsBinLayout.segments > 1): on by default; 0 switches it
  * off (every list is then walked by one workgroup, bit-reproducible forward). */

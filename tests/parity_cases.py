@@ -47,9 +47,12 @@ def build_case(name, device):
     elif name == "merge_tiles_large":       # ~12k instances per tile: 16384 variant
         W, H, N = 48, 48, 48000
         mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.02)  # noqa: E731
-    elif name == "radix_fallback":          # > 16384 instances per tile: device radix sort chosen automatically
+    elif name == "merge_passes":            # > 16384 instances per tile: 4096-key runs + pairwise merge passes through global memory (3 passes)
         W, H, N = 32, 32, 40000
         mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.02)  # noqa: E731
+    elif name == "merge_passes_even":       # > 32768 per tile: 4 passes (the run sort starts in the other buffer), ragged last runs
+        W, H, N = 32, 32, 75000
+        mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.01)  # noqa: E731
     elif name == "many_tiles":              # 2064x1104 px = 129 x 69 = 8901 tiles > 8192: no LDS tile histogram -> radix path
         W, H, N = 2064, 1104, 3000
     elif name == "low_opacity":             # many Gaussians below the 1/255 threshold
@@ -80,7 +83,7 @@ def build_case(name, device):
     return rs, rv
 
 
-BIG_TILE_CASES = ["merge_tiles", "merge_tiles_large", "radix_fallback"]
+BIG_TILE_CASES = ["merge_tiles", "merge_tiles_large", "merge_passes", "merge_passes_even"]
 CASES = ["basic", "ragged_image", "tiny_lookaround", "lookaround_intrinsics", "posed_white_bg", "scale_modifier", "behind_camera", "all_culled",
          "huge_gaussians", "dense_overdraw", "low_opacity", "one_gaussian", "not_multiple_of_block", "sh0", "sh1", "sh2",
          "sh3", "sh2_ragged", "sh3_half_culled", "cov3d_precomp"]
