@@ -26,8 +26,9 @@ bool g_segments_enabled = true;
 
 int choose_path(int tiles, uint32_t max_tile_instances)
 {
-    (void)max_tile_instances;                 // any list length: runs beyond the LDS merge are merged pass by pass through global memory
-    const bool fits = tiles <= gs::kMaxLdsTiles;
+    // any list length a grid's y dimension can index in 2048-key blocks (runs beyond the LDS merge are merged pass by pass
+    // through global memory); 0xffffffff = counts unknown (more tiles than the LDS histogram holds)
+    const bool fits = tiles <= gs::kMaxLdsTiles && max_tile_instances <= 65535u * (uint32_t)gs::kSortChunk;
     if (g_sort_path == GS_SORT_RADIX) return GS_SORT_RADIX;
     return fits ? GS_SORT_TILE_LDS : GS_SORT_RADIX;
 }
@@ -212,8 +213,7 @@ int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t
     uint64_t o = 0;
     if (out->path == GS_SORT_TILE_LDS) {
         out->pairs = o; o = align_up(o + n * 8);
-        // (0xffffffff = "unknown", the radix path's placeholder when the tile path is forced: no second buffer then)
-        if (max_tile_instances > (uint32_t)gs::kSortCapMax && max_tile_instances != 0xffffffffu) { out->pairs_alt = o; o = align_up(o + n * 8); }
+        if (max_tile_instances > (uint32_t)gs::kSortCapMax) { out->pairs_alt = o; o = align_up(o + n * 8); }
     } else {
         out->keys_unsorted = o; o = align_up(o + n * 8);
         out->vals_unsorted = o; o = align_up(o + n * 4);
