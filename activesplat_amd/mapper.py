@@ -86,8 +86,15 @@ class SplatMapper:
         self.keyframe_list, self.selected_keyframes, self.gt_w2c_all_frames = [], [], []
         self.rng = np.random.RandomState(self.cfg["seed"])
         self.stats = dict(iters=0, iter_time=0.0, frames=0, frame_time=0.0)
-        self.last_losses = None
+        self._last_losses = None           # device scalars of the most recent iteration (read through `last_losses`)
         self.high_loss_mask = None          # bool [H,W] of the most recent frame (None before the first map exists)
+
+    @property
+    def last_losses(self):
+        """{name: float} of the most recent mapping iteration (None before the first); synchronises with the device."""
+        if self._last_losses is None:
+            return None
+        return {k: float(v.detach()) for k, v in self._last_losses.items()}
 
     # -- helpers ---------------------------------------------------------------------------------
     def _w2c(self, frame_id):
@@ -175,7 +182,7 @@ class SplatMapper:
                     self.params, self.variables = O.densify(self.params, self.variables, self.optimizer, it, mc["densify_dict"])
                 self.optimizer.step()
                 self.optimizer.zero_grad(set_to_none=True)
-            self.last_losses = {k: float(v.detach()) for k, v in losses.items()}
+            self._last_losses = losses                  # converted on access: a float() here would stall the host every iteration
             self.stats["iters"] += 1
             self.stats["iter_time"] += time.perf_counter() - t0
         if iter_per_frame > 0:
