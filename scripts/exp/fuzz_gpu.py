@@ -1,0 +1,36 @@
+"""Development helper (uses the oracle: a checker run, not product code): a wider random sweep of the parity cases on the GPU than the
+test suite holds -- more seeds, larger Gaussian counts (several binning chunks, merged tile lists), the staged scatter forced on."""
+import os, sys, traceback
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.gs_oracle import Oracle
+from activesplat_amd import _lib
+from tests import parity_cases as pc, util
+from tests.test_randomized import _draw
+
+o32, o64 = Oracle("f32"), Oracle("f64")
+lib = _lib.get()
+n0, n1 = int(os.environ.get("SEED0", 20000)), int(os.environ.get("SEED1", 20300))
+bad = []
+for seed in range(n0, n1):
+    r = np.random.RandomState(seed)
+    try:
+        rs, rv = _draw(seed, "cuda")
+        mode = seed % 4
+        if mode == 1:                                   # bigger scene: more chunks, longer lists
+            N = int(r.randint(3000, 30000))
+            W, H = int(r.randint(40, 200)), int(r.randint(40, 160))
+            rs, rv = util.scene(N, W, H, seed=seed, device="cuda", w2c=util.pose(float(r.uniform(-0.4, 0.4)), (0.0, 0.0, float(r.uniform(-1.0, 0.5)))),
+                                sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
+            rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
+            rv["scales"] = rv["scales"] * float(np.exp(r.uniform(-0.5, 1.5)))
+        lib.gs_set_scatter_staging(0 if mode >= 2 else 512)
+        pc.check_forward(rs, rv, o32)
+        if seed % 3 == 0:
+            pc.check_backward(rs, rv, o64, min_frac=0.99, oracle32=o32)
+    except Exception as e:
+        bad.append((seed, repr(e)[:300]))
+        print("FAIL seed", seed, repr(e)[:300], flush=True)
+lib.gs_set_scatter_staging(512)
+print("seeds %d..%d: %d failures" % (n0, n1, len(bad)))
