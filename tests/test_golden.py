@@ -267,13 +267,16 @@ def test_fused_densify_and_prune_equal_the_stepwise_call_pattern(backend, iso):
     """One classification + one gather per tensor (optim.densify / prune_gaussians, fused=True) against the reference's
     clone -> cat -> split -> cat -> remove -> cull -> remove sequence (fused=False) on a map where every branch fires:
     clones, splits, opacity culls, too-big culls (of originals AND of freshly split children), 0/0 gradients."""
+    check_fused_densify_and_prune(backend, iso, 3000, 11)
+
+
+def check_fused_densify_and_prune(backend, iso, N, seed):
     from activesplat_amd import optim as O
-    N = 3000
     ddict = dict(start_after=0, remove_big_after=0, stop_after=100, densify_every=10, grad_thresh=0.0002, num_to_split_into=2,
                  removal_opacity_threshold=0.05, final_removal_opacity_threshold=0.05, reset_opacities=False, reset_opacities_every=3000)
     out = []
     for fused in (True, False):
-        params, var, opt, g = _random_map(backend, N, iso, 11)
+        params, var, opt, g = _random_map(backend, N, iso, seed)
         samples = (torch.randn(2 * N, 3, generator=g) * 0.02).to(backend)      # more rows than any split list: indexed like the reference's
         # how many rows the reference would draw: 2 x number of split parents
         grads = var["means2D_gradient_accum"] + 0.0
@@ -286,7 +289,7 @@ def test_fused_densify_and_prune_equal_the_stepwise_call_pattern(backend, iso):
         out.append((p2, v2, opt))
     (pa, va, oa), (pb, vb, ob) = out
     n = pa["means3D"].shape[0]
-    assert n == pb["means3D"].shape[0] and n != N
+    assert n == pb["means3D"].shape[0] and (n != N or N < 500)
     for k in KEYS[:5]:
         tol = dict(rtol=2e-6, atol=1e-7) if k in ("means3D", "log_scales") else dict(rtol=0, atol=0)
         np.testing.assert_allclose(pa[k].detach().cpu().numpy(), pb[k].detach().cpu().numpy(), err_msg=k, **tol)
@@ -300,10 +303,10 @@ def test_fused_densify_and_prune_equal_the_stepwise_call_pattern(backend, iso):
                  final_removal_opacity_threshold=0.05, reset_opacities=False, reset_opacities_every=500)
     res = []
     for fused in (True, False):
-        params, var, opt, _ = _random_map(backend, N, iso, 12)
+        params, var, opt, _ = _random_map(backend, N, iso, seed + 1)
         res.append(O.prune_gaussians(params, var, opt, 5, pdict, fused=fused) + (opt,))
     (pa, va, oa), (pb, vb, ob) = res
-    assert 0 < pa["means3D"].shape[0] == pb["means3D"].shape[0] < N
+    assert pa["means3D"].shape[0] == pb["means3D"].shape[0] and (0 < pa["means3D"].shape[0] < N or N < 500)
     for k in KEYS[:5]:
         np.testing.assert_array_equal(pa[k].detach().cpu().numpy(), pb[k].detach().cpu().numpy(), err_msg=k)
         np.testing.assert_array_equal(oa.state[pa[k]]["exp_avg"].cpu().numpy(), ob.state[pb[k]]["exp_avg"].cpu().numpy())
