@@ -297,92 +297,169 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restr
     }
 }
 
-// One workgroup per tile: bitonic sort of (depth_bits<<32 | id), REGISTER-BLOCKED: every thread owns E
-// consecutive keys.  All steps with stride < E (and the whole first log2(E) levels) are compare-exchanges
-// between a thread's own registers -- no LDS, no barrier; a step with stride >= E pairs each thread with
-// ONE partner thread (t ^ stride/E): it publishes its E keys to LDS, reads the partner's E keys and keeps
-// the element-wise min or max.  Two LDS buffers alternate, so such a step costs one barrier.  For 2048 keys
-// on 256 threads: 36 barrier steps instead of 66, and 8x fewer LDS accesses.
-__device__ __forceinline__ void cmpswap(unsigned long long& a, unsigned long long& b, bool up)
+// One workgroup per (tile, chunk): bitonic sort of (depth_bits<<32 | id), REGISTER-BLOCKED: every thread owns E consecutive
+// keys.  Steps with stride < E (and the whole first log2(E) levels) are compare-exchanges between a thread's own registers; a
+// step with stride >= E pairs each thread with ONE partner thread (t ^ stride/E), whose E keys it needs.
+//
+// What the first version of this kernel was bound by (2 M Gaussians: 76 us) is the LDS pipe: 36 partner steps, each moving
+// every key through LDS (8 x ds_write_b64 + 8 x ds_read_b64 per thread), and a 64-bit compare + four 32-bit selects per
+// compare-exchange.  Here
+//   * the keys are handled as DOUBLES: the high word is the bit pattern of a positive finite float (the view depth, > 0.2), so
+//     the 64-bit pattern is a positive normal double and doubles order exactly like the unsigned keys; a compare-exchange is
+//     v_min_f64 + v_max_f64 (full rate on this chip) instead of v_cmp_lt_u64 + 4 x v_cndmask.  Padding = the largest finite
+//     double (0x7fefffff ffffffff), which no key reaches;
+//   * a thread that has to keep the LARGER key of each pair holds its keys NEGATED for that step: both partners then do the
+//     same thing, v = min(v, -partner), and the per-thread direction of a level turns into one sign flip (v_xor on the high
+//     word) per key where it changes;
+//   * the partner's keys of the 26 steps with strides 1, 2, 4, 8 come by DPP (quad_perm, row_shl / row_shr with bank masks,
+//     row_ror:8: one or two moves per word); the 7 steps with strides 16 and 32 go through LDS without a workgroup barrier (same
+//     wavefront), only the 3 steps whose partner sits in another wavefront need barriers.
+// (inline assembly: __builtin_fmin / fmax add a v_max_f64 x, x canonicalisation in front of every operand; the host emulator of the
+// tests defines the two macros as std::fmin / std::fmax)
+#ifndef GS_MIN_F64
+#define GS_MIN_F64(a, b) ({ double r_; asm("v_min_f64 %0, %1, %2" : "=v"(r_) : "v"(a), "v"(b)); r_; })
+#define GS_MAX_F64(a, b) ({ double r_; asm("v_max_f64 %0, %1, %2" : "=v"(r_) : "v"(a), "v"(b)); r_; })
+#endif
+constexpr unsigned long long kPadKey = 0x7fefffffffffffffull;
+
+__device__ __forceinline__ double key_to_f64(unsigned long long k) { return __builtin_bit_cast(double, k); }
+__device__ __forceinline__ unsigned long long f64_to_key(double v) { return __builtin_bit_cast(unsigned long long, v); }
+// v with its sign flipped where mask = 0x80000000 (0: unchanged)
+__device__ __forceinline__ double f64_flip(double v, uint32_t mask)
 {
-    const bool sw = (a > b) == up;            // one 64-bit compare, one mask xnor, four 32-bit selects
-    const unsigned long long t = a;
-    a = sw ? b : a;
-    b = sw ? t : b;
+    return __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, v) ^ ((unsigned long long)mask << 32));
+}
+
+// the value lane (lane ^ M) holds, M in {1, 2, 4, 8} (inside a row of 16 lanes): DPP, no LDS
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t x)
+{
+    const int xi = (int)x;
+    // (mov_dpp: no "old" operand to keep alive -- every lane is written, so the result needs no copy of x in front of it)
+    if (M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp(xi, 0xB1, 0xf, 0xf, true);                    // quad_perm [1,0,3,2]
+    if (M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp(xi, 0x4E, 0xf, 0xf, true);                    // quad_perm [2,3,0,1]
+    if (M == 4) {
+        const int t = __builtin_amdgcn_mov_dpp(xi, 0x104, 0xf, 0x5, true);                              // banks 0, 2 read lane + 4
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, xi, 0x114, 0xf, 0xA, false);                    // banks 1, 3 read lane - 4
+    }
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8, "in-row strides only");
+    return (uint32_t)__builtin_amdgcn_mov_dpp(xi, 0x128, 0xf, 0xf, true);                                // row_ror:8
+}
+template <int M>
+__device__ __forceinline__ double lane_xor_f64(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const uint32_t lo = lane_xor_u32<M>((uint32_t)b), hi = lane_xor_u32<M>((uint32_t)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
 template <int E, int THREADS>
-__device__ __forceinline__ void bitonic_sort_block(unsigned long long (&k)[E], unsigned long long* buf0, unsigned long long* buf1, int tid)
+__device__ __forceinline__ void bitonic_sort_block(double (&v)[E], double* buf, int tid)
 {
     const uint32_t base = (uint32_t)tid * E;
-    // levels that fit inside one thread
+    uint32_t neg = 0u;                                            // 0x80000000 while v holds the negated keys
+#define GS_DOMAIN(want_neg)                                                      \
+    {                                                                            \
+        const uint32_t w_ = (want_neg) ? 0x80000000u : 0u, m_ = w_ ^ neg;        \
+        _Pragma("unroll") for (int i = 0; i < E; i++) v[i] = f64_flip(v[i], m_); \
+        neg = w_;                                                                \
+    }
+#define GS_SORT2(a, b)                                      \
+    {                                                       \
+        const double mn_ = GS_MIN_F64(a, b), mx_ = GS_MAX_F64(a, b); \
+        a = mn_; b = mx_;                                   \
+    }
+    // levels that fit inside one thread: the direction of pair (i, i | j) at level kk is ((base + i) & kk) == 0 -- a constant of
+    // the unrolled code for kk < E, per thread for kk == E (negated domain for descending threads)
 #pragma unroll
     for (int kk = 2; kk <= E; kk <<= 1) {
+        if (kk == E) GS_DOMAIN((base & (uint32_t)E) != 0u)
 #pragma unroll
         for (int j = kk >> 1; j > 0; j >>= 1) {
 #pragma unroll
             for (int i = 0; i < E; i++) {
-                if ((i & j) == 0) cmpswap(k[i], k[i | j], ((base + i) & kk) == 0);
+                if ((i & j) != 0) continue;
+                if (kk == E || (i & kk) == 0) GS_SORT2(v[i], v[i | j])
+                else GS_SORT2(v[i | j], v[i])
             }
         }
     }
-    int flip = 0;
     for (uint32_t kk = 2 * E; kk <= (uint32_t)E * THREADS; kk <<= 1) {
+        const bool up = (base & kk) == 0;                         // same for all E keys of a thread (kk >= 2E)
         for (uint32_t j = kk >> 1; j >= (uint32_t)E; j >>= 1) {
-            unsigned long long* buf = flip ? buf1 : buf0;
-            flip ^= 1;
-            // LDS layout is TRANSPOSED ([i][thread]): lane-contiguous 8-byte accesses, no bank conflicts
+            const int m = (int)(j / E);                           // partner thread = tid ^ m
+            const bool lower = (tid & m) == 0;
+            GS_DOMAIN(lower != up)                                // natural domain <=> this thread keeps the smaller key of each pair
+            double p[E];
+            switch (m) {
+#define GS_CASE(M) case M: _Pragma("unroll") for (int i = 0; i < E; i++) p[i] = lane_xor_f64<M>(v[i]); break;
+                GS_CASE(1) GS_CASE(2) GS_CASE(4) GS_CASE(8)
+#undef GS_CASE
+                case 16: case 32:
+                    // same wavefront, other row / half: through the wave's own slots of the exchange buffer (LDS serves a wave in
+                    // order: no workgroup barrier).  The swap instructions would cost two register copies and a select per word
+                    // on the VALU, which is this kernel's bound; the LDS pipe is idle.
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i < E; i++) buf[i * THREADS + tid] = k[i];
-            __syncthreads();
-            const int ptid = tid ^ (int)(j / E);                  // partner thread (j is a multiple of E)
-            const bool lower = (base & j) == 0;
-            const bool up = (base & kk) == 0;                     // same for all E keys of a thread (kk >= 2E)
-            const bool take_min = lower == up;
+                    for (int i = 0; i < E; i++) buf[i * THREADS + tid] = v[i];
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i < E; i++) {
-                const unsigned long long o = buf[i * THREADS + ptid];
-                k[i] = ((k[i] < o) == take_min) ? k[i] : o;
+                    for (int i = 0; i < E; i++) p[i] = buf[i * THREADS + (tid ^ m)];
+                    __builtin_amdgcn_wave_barrier();
+                    break;
+                default:                                          // the partner is in another wavefront: through LDS, transposed
+                    __syncthreads();                              // (lane-contiguous 8-byte accesses, no bank conflicts)
+#pragma unroll
+                    for (int i = 0; i < E; i++) buf[i * THREADS + tid] = v[i];
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < E; i++) p[i] = buf[i * THREADS + (tid ^ m)];
+                    __syncthreads();                              // the slots are rewritten by wave-local steps that follow
             }
+            // the partner is in the opposite domain: -p is its key in this thread's domain
+#pragma unroll
+            for (int i = 0; i < E; i++) v[i] = GS_MIN_F64(v[i], f64_flip(p[i], 0x80000000u));
         }
-        const bool up = (base & kk) == 0;
+        GS_DOMAIN(!up)
 #pragma unroll
         for (int j = E >> 1; j > 0; j >>= 1) {
 #pragma unroll
             for (int i = 0; i < E; i++) {
-                if ((i & j) == 0) cmpswap(k[i], k[i | j], up);
+                if ((i & j) == 0) GS_SORT2(v[i], v[i | j])
             }
         }
     }
+    GS_DOMAIN(false)
+#undef GS_DOMAIN
+#undef GS_SORT2
 }
 
 template <int E, int THREADS>
 __device__ __forceinline__ void tile_sort_impl(const uint2 range, uint32_t n, const unsigned long long* pairs,
                                                unsigned long long* pairs_out, uint32_t* __restrict__ point_list,
-                                               unsigned long long* buf0, unsigned long long* buf1, int tid)
+                                               unsigned long long* buf, int tid)
 {
-    unsigned long long k[E];
+    double k[E];
     const uint32_t base = (uint32_t)tid * E;
     // coalesced global reads, then each thread picks up its E consecutive keys from LDS
 #pragma unroll
     for (int i = 0; i < E; i++) {
         const uint32_t e = (uint32_t)i * THREADS + tid;
-        buf0[e] = e < n ? pairs[range.x + e] : ~0ull;
+        buf[e] = e < n ? pairs[range.x + e] : kPadKey;
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < E; i++) k[i] = buf0[base + i];
-    __syncthreads();
-    bitonic_sort_block<E, THREADS>(k, buf0, buf1, tid);
+    for (int i = 0; i < E; i++) k[i] = key_to_f64(buf[base + i]);
+    bitonic_sort_block<E, THREADS>(k, reinterpret_cast<double*>(buf), tid);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < E; i++) buf0[base + i] = k[i];
+    for (int i = 0; i < E; i++) buf[base + i] = f64_to_key(k[i]);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < E; i++) {
         const uint32_t e = (uint32_t)i * THREADS + tid;
         if (e < n) {
-            const unsigned long long v = buf0[e];
+            const unsigned long long v = buf[e];
             pairs_out[range.x + e] = v;
             point_list[range.x + e] = (uint32_t)v;
         }
@@ -398,7 +475,6 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restr
                                                              uint32_t* __restrict__ point_list, uint32_t cap)
 {
     __shared__ unsigned long long s_a[CAP];
-    __shared__ unsigned long long s_b[CAP];
     const int tid = threadIdx.x;
     uint2 range = ranges[blockIdx.x];
     range.x = min(range.x, cap); range.y = min(range.y, cap);   // workspace capacity (see tile_bin_kernel)
@@ -407,9 +483,9 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restr
     range.x += start;
     const uint32_t n = min(range.y - range.x, (uint32_t)CAP);
     constexpr int EMAX = CAP / THREADS;                       // 8
-    if (n <= (uint32_t)THREADS * (EMAX / 4)) tile_sort_impl<EMAX / 4, THREADS>(range, n, pairs, pairs_out, point_list, s_a, s_b, tid);
-    else if (n <= (uint32_t)THREADS * (EMAX / 2)) tile_sort_impl<EMAX / 2, THREADS>(range, n, pairs, pairs_out, point_list, s_a, s_b, tid);
-    else tile_sort_impl<EMAX, THREADS>(range, n, pairs, pairs_out, point_list, s_a, s_b, tid);
+    if (n <= (uint32_t)THREADS * (EMAX / 4)) tile_sort_impl<EMAX / 4, THREADS>(range, n, pairs, pairs_out, point_list, s_a, tid);
+    else if (n <= (uint32_t)THREADS * (EMAX / 2)) tile_sort_impl<EMAX / 2, THREADS>(range, n, pairs, pairs_out, point_list, s_a, tid);
+    else tile_sort_impl<EMAX, THREADS>(range, n, pairs, pairs_out, point_list, s_a, tid);
 }
 
 // Tiles with CHUNK < n <= CAP: the CHUNK-sized sorted runs left by tile_sort_kernel are merged by RANK: the whole

@@ -1,11 +1,8 @@
 cd /root/repo
-N=200000 PROFILE=1 timeout 300 python scripts/exp/iter_host.py 2>&1 | grep -v amdgpu | head -60
-N=2000 timeout 300 python scripts/exp/iter_host.py 2>&1 | grep -v amdgpu | head -3
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
+timeout 300 python scripts/stage_times.py 2>&1 | tail -1
+N=2000000 SH=3 STEPS=20 timeout 600 python scripts/stage_times.py 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
-N=200000 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/ith -o it -- python /root/repo/scripts/exp/iter_host.py > /dev/null 2>&1
-python - <<'PY'
-import csv
-rows=list(csv.DictReader(open('/root/repo/gpurun_out/ith/it_kernel_stats.csv')))
-tot=sum(float(r['TotalDurationNs']) for r in rows)
-print('kernel time per iteration us', tot/220/1e3, 'launches per iteration', sum(int(r['Calls']) for r in rows)/220)
-PY
+N=2000000 SH=3 STEPS=10 BWD=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/mrg -o m -- python /root/repo/scripts/stage_times.py > /dev/null 2>&1
+STEPS=10 BWD=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/mrg -o c2 -- python /root/repo/scripts/stage_times.py > /dev/null 2>&1
+grep -h "tile_sort" /root/repo/gpurun_out/mrg/m_kernel_stats.csv /root/repo/gpurun_out/mrg/c2_kernel_stats.csv | sed 's/(.*)"/"/'

@@ -334,6 +334,9 @@ inline unsigned char* dyn_lds()
 }
 }  // namespace hipemu
 #define GS_DYNAMIC_LDS(name) unsigned char* name = hipemu::dyn_lds()
+// v_min_f64 / v_max_f64 of the tile sort (inline assembly in the device build)
+#define GS_MIN_F64(a, b) std::fmin(a, b)
+#define GS_MAX_F64(a, b) std::fmax(a, b)
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
 
