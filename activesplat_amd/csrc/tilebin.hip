@@ -441,15 +441,12 @@ __device__ __forceinline__ void tile_sort_impl(const uint2 range, uint32_t n, co
 {
     double k[E];
     const uint32_t base = (uint32_t)tid * E;
-    // coalesced global reads, then each thread picks up its E consecutive keys from LDS
+    // coalesced global reads straight into the registers: which unsorted key starts in which (thread, slot) does not matter
 #pragma unroll
     for (int i = 0; i < E; i++) {
         const uint32_t e = (uint32_t)i * THREADS + tid;
-        buf[e] = e < n ? pairs[range.x + e] : kPadKey;
+        k[i] = key_to_f64(e < n ? pairs[range.x + e] : kPadKey);
     }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < E; i++) k[i] = key_to_f64(buf[base + i]);
     bitonic_sort_block<E, THREADS>(k, reinterpret_cast<double*>(buf), tid);
     __syncthreads();
 #pragma unroll

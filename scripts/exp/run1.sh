@@ -1,5 +1,5 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "matches_oracle or big_tile or 2m" 2>&1 | tail -2
 timeout 300 python scripts/stage_times.py 2>&1 | tail -1
 N=2000000 SH=3 STEPS=20 timeout 600 python scripts/stage_times.py 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
