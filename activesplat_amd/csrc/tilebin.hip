@@ -646,44 +646,37 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
             launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap, gp.chunk_flags);
         } else launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
     } else if (nb > 0) launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
-    if (max_tile_instances > (uint32_t)kSortCapMax) {
-        // longer than the LDS rank merge holds: 2048-key runs (4096-key runs sort at half the rate), then pairwise merge passes between
-        // `pairs` and `pairs_alt`; the run sort writes into whichever of the two leaves the final pass's output in `pairs`
-        constexpr int kOut = kSortChunk;
-        const unsigned chunks = (max_tile_instances + kSortChunk - 1) / kSortChunk;
-        int passes = 0;
-        for (uint64_t r = kSortChunk; r < max_tile_instances; r <<= 1) passes++;
-        unsigned long long* cur = (passes & 1) ? pairs_alt : pairs;
-        hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, chunks), dim3(256), 0, st, ranges, pairs, cur, point_list, cap);
-        const unsigned blocks = (max_tile_instances + kOut - 1) / kOut;
-        uint64_t r = kSortChunk;
-        for (int p = 0; p < passes; p++, r <<= 1) {
-            unsigned long long* nxt = cur == pairs ? pairs_alt : pairs;
-            hipLaunchKernelGGL((tile_merge_pass_kernel<kOut, 256>), dim3(tiles, blocks), dim3(256), 0, st, ranges, cur, nxt,
-                               p == passes - 1 ? point_list : nullptr, (uint32_t)r, cap);
-            cur = nxt;
-        }
+    // Lists of at most 2048 keys: one 2048-key sort per tile.  Longer lists: 4096-key runs sorted with 16 keys per thread (the same 36
+    // partner steps as a 2048-key sort; measured at 2 M Gaussians, lists of ~4000: 53 us + 15 us of merging against 45 + 31 us with
+    // 2048-key runs), then the runs of a tile are merged -- by rank inside LDS up to kSortCapMax keys, pass by pass through global
+    // memory beyond (`pairs` <-> `pairs_alt`; the run sort writes into whichever of the two leaves the final pass's output in `pairs`).
+    constexpr int kBigChunk = 2 * kSortChunk;
+    if (max_tile_instances <= (uint32_t)kSortChunk) {
+        hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, 1), dim3(256), 0, st, ranges, pairs, pairs, point_list, cap);
         return hipGetLastError();
     }
-    if (max_tile_instances > 8192) {
-        // very long lists (256 x 256 frames over a million Gaussians: ~10 k per tile): 4096-key runs halve the number of runs the
-        // rank merge has to search (3 instead of 6 for 11 k keys)
-        constexpr int kBigChunk = 2 * kSortChunk;
-        const unsigned chunks = (max_tile_instances + kBigChunk - 1) / kBigChunk;
-        hipLaunchKernelGGL((tile_sort_kernel<kBigChunk, 512>), dim3(tiles, chunks), dim3(512), 0, st, ranges, pairs, pairs, point_list, cap);
-        hipLaunchKernelGGL((tile_merge_kernel<kSortCapMax, kBigChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
+    const unsigned chunks = (max_tile_instances + kBigChunk - 1) / kBigChunk;
+    if (max_tile_instances <= (uint32_t)kSortCapMax) {
+        hipLaunchKernelGGL((tile_sort_kernel<kBigChunk, 256>), dim3(tiles, chunks), dim3(256), 0, st, ranges, pairs, pairs, point_list, cap);
+        // the list sits in LDS: the smaller capacity keeps two workgroups resident per CU
+        if (max_tile_instances > 8192)
+            hipLaunchKernelGGL((tile_merge_kernel<kSortCapMax, kBigChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
+        else if (max_tile_instances > (uint32_t)kBigChunk)
+            hipLaunchKernelGGL((tile_merge_kernel<8192, kBigChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
         return hipGetLastError();
     }
-    const unsigned chunks = (max_tile_instances + kSortChunk - 1) / kSortChunk;
-    hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, chunks ? chunks : 1), dim3(256), 0, st, ranges, pairs, pairs, point_list, cap);
-    if (max_tile_instances > (uint32_t)kSortChunk) {
-        // the list sits in LDS: the smallest capacity that holds the longest list keeps the most workgroups resident per CU
-        if (max_tile_instances <= 4096)
-            hipLaunchKernelGGL((tile_merge_kernel<4096, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
-        else if (max_tile_instances <= 6144)
-            hipLaunchKernelGGL((tile_merge_kernel<6144, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
-        else
-            hipLaunchKernelGGL((tile_merge_kernel<8192, kSortChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
+    constexpr int kOut = kSortChunk;
+    int passes = 0;
+    for (uint64_t r = kBigChunk; r < max_tile_instances; r <<= 1) passes++;
+    unsigned long long* cur = (passes & 1) ? pairs_alt : pairs;
+    hipLaunchKernelGGL((tile_sort_kernel<kBigChunk, 256>), dim3(tiles, chunks), dim3(256), 0, st, ranges, pairs, cur, point_list, cap);
+    const unsigned blocks = (max_tile_instances + kOut - 1) / kOut;
+    uint64_t r = kBigChunk;
+    for (int p = 0; p < passes; p++, r <<= 1) {
+        unsigned long long* nxt = cur == pairs ? pairs_alt : pairs;
+        hipLaunchKernelGGL((tile_merge_pass_kernel<kOut, 256>), dim3(tiles, blocks), dim3(256), 0, st, ranges, cur, nxt,
+                           p == passes - 1 ? point_list : nullptr, (uint32_t)r, cap);
+        cur = nxt;
     }
     return hipGetLastError();
 }
