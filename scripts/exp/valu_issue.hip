@@ -23,9 +23,11 @@ __global__ __launch_bounds__(256) void k_issue(float* out, float seed)
 {
     float a[8];
     v2f p[8];
+    double dd[8];
     __shared__ __attribute__((aligned(16))) float lds[256 * 20];
     const int tid = threadIdx.x;
-    for (int i = 0; i < 8; i++) { a[i] = seed + i + tid * 1e-3f; p[i] = v2f{a[i], a[i] * 0.5f}; }
+    for (int i = 0; i < 8; i++) { a[i] = seed + i + tid * 1e-3f; p[i] = v2f{a[i], a[i] * 0.5f}; dd[i] = (double)a[i]; }
+    const double dc = 1.0 + (double)seed * 1e-12;
     for (int i = tid; i < 256 * 20; i += 256) lds[i] = seed;
     __syncthreads();
     const float c1 = 0.999f + seed * 1e-9f, c2 = 1e-6f;
@@ -175,6 +177,26 @@ __global__ __launch_bounds__(256) void k_issue(float* out, float seed)
             BODY8(S)
 #undef S
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (KIND == 33) {    // v_min_f64
+#define S(i) asm volatile("v_min_f64 %0, %0, %1" : "+v"(dd[i]) : "v"(dc));
+            BODY8(S)
+#undef S
+        } else if (KIND == 34) {    // v_fma_f64
+#define S(i) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(dd[i]) : "v"(dc));
+            BODY8(S)
+#undef S
+        } else if (KIND == 35) {    // v_cmp_lt_u64 -> sgpr pair
+#define S(i) { unsigned long long m_; asm volatile("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(m_) : "v"(dd[i]), "v"(dc)); acc_mask ^= m_; }
+            BODY8(S)
+#undef S
+        } else if (KIND == 36) {    // v_permlane32_swap_b32
+#define S(i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) & 7]));
+            BODY8(S)
+#undef S
+        } else if (KIND == 37) {    // v_xor_b32
+#define S(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            BODY8(S)
+#undef S
         } else if (KIND == 29) {    // v_fma_f32 with operands spread over register banks: a[i] = a[i] * a[(i+1)&7] + a[(i+2)&7]
 #define S(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
             BODY8(S)
@@ -183,7 +205,7 @@ __global__ __launch_bounds__(256) void k_issue(float* out, float seed)
     }
     if (acc_mask == 0x123456789ull) out[1] = 1.f;
     float s = 0.f;
-    for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y;
+    for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y + (float)dd[i];
     if (s == 12345.678f) out[0] = s + lds[tid];
 }
 
@@ -192,7 +214,8 @@ const char* kNames[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f
                         "ds_read_b32 s17", "v_fma_f32 2 chains", "ds_write_b128", "ds_bpermute_b32",
                         "v_cndmask_e64 sgpr mask", "v_cmp+v_cndmask vcc (pairs)", "v_cmp_e64 -> sgpr", "v_max_f32", "v_fmac_f32", "v_mov_b32", "v_add_f32",
                         "s_nop1+v_mul (pairs)", "v_cndmask vcc (cmp hoisted)", "v_mul_f32 sgpr src", "v_readlane_b32", "v_fma_f32 mixed banks",
-                        "ds_add_u32", "ds_add_rtn_u32", "ds_add_u32 histogram"};
+                        "ds_add_u32", "ds_add_rtn_u32", "ds_add_u32 histogram",
+                        "v_min_f64", "v_fma_f64", "v_cmp_lt_u64 -> sgpr", "v_permlane32_swap_b32", "v_xor_b32"};
 
 template <int KIND>
 void run(float* d_out, int waves_per_simd)
@@ -237,5 +260,6 @@ int main(int argc, char** argv)
     sweep<25>(d_out); sweep<26>(d_out); sweep<27>(d_out); sweep<28>(d_out); sweep<29>(d_out);
     }
     sweep<30>(d_out); sweep<31>(d_out); sweep<32>(d_out);
+    sweep<33>(d_out); sweep<34>(d_out); sweep<35>(d_out); sweep<36>(d_out); sweep<37>(d_out);
     return 0;
 }
