@@ -65,7 +65,13 @@ __global__ __launch_bounds__(THREADS) void tile_bin_kernel(Cam cam, int P, GeomP
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // one chunk per workgroup in the count pass; the direct scatter behind the staged one is launched with a small grid that strides
     // over the chunks and only works on the flagged ones (usually none)
-  for (int cid = blockIdx.x; cid < nchunks; cid += gridDim.x) {
+  // workgroup b runs on XCD b & 7 and takes chunk (b >> 3) of that XCD's contiguous band of chunks: the slices that consecutive
+  // chunks write into a tile's segment are adjacent in memory (a 128-byte line holds ~4 of them), and this way they meet in ONE L2
+  // before the line is written back, instead of leaving four L2s as four partial lines
+  const int cper = (nchunks + 7) >> 3;
+  for (int b = blockIdx.x; b < 8 * cper; b += gridDim.x) {
+    const int cid = SCATTER ? (b & 7) * cper + (b >> 3) : b;      // (the count pass writes whole matrix rows: plain order, measured faster)
+    if (cid >= nchunks) continue;
     uint32_t* my_base = tile_base + (size_t)cid * tiles;
     if (SCATTER && chunk_flags && chunk_flags[cid] == 0u) continue;           // this chunk went through the staged scatter
     __syncthreads();
@@ -152,7 +158,11 @@ __global__ __launch_bounds__(THREADS) void tile_scatter_staged_kernel(Cam cam, i
     __shared__ uint32_t s_w[THREADS / kWave];
     __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cbase = blockIdx.x * THREADS * ROUNDS;
+    // XCD-banded chunk order (see tile_bin_kernel): adjacent slices of a tile segment are written through the same L2
+    const int nchunks = (P + THREADS * ROUNDS - 1) / (THREADS * ROUNDS), cper = (nchunks + 7) >> 3;
+    const int chunk = (int)(blockIdx.x & 7) * cper + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= cper || chunk >= nchunks) return;
+    const int cbase = chunk * THREADS * ROUNDS;
     for (int t = tid; t < tiles; t += THREADS) s_cur[t] = 0u;
     if (tid == 0) s_carry = 0u;
     uint32_t n[ROUNDS], x0[ROUNDS], w[ROUNDS], y0[ROUNDS], dbits[ROUNDS];
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(THREADS) void tile_scatter_staged_kernel(Cam cam, i
         big = big || n[r] > 16u;
     }
     const bool any_big = __syncthreads_or(big) != 0;           // (also orders the zero fill of s_cur before the counting)
-    if (any_big) { if (tid == 0) chunk_flags[blockIdx.x] = 1u; return; }
+    if (any_big) { if (tid == 0) chunk_flags[chunk] = 1u; return; }
     // ---- count ----
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(THREADS) void tile_scatter_staged_kernel(Cam cam, i
     }
     __syncthreads();
     // ---- exclusive scan over the tiles: s_cur[t] = first local slot of tile t, s_delta[t] = (its global slot) - (its local slot) ----
-    const uint32_t* my_base = tile_base + (size_t)blockIdx.x * tiles;
+    const uint32_t* my_base = tile_base + (size_t)chunk * tiles;
     for (int b = 0; b < tiles; b += THREADS) {
         const int t = b + tid;
         const uint32_t v = t < tiles ? s_cur[t] : 0u;
@@ -201,8 +211,8 @@ __global__ __launch_bounds__(THREADS) void tile_scatter_staged_kernel(Cam cam, i
         __syncthreads();
     }
     const uint32_t total = s_carry;
-    if (total > (uint32_t)stage_cap) { if (tid == 0) chunk_flags[blockIdx.x] = 1u; return; }      // uniform
-    if (tid == 0) chunk_flags[blockIdx.x] = 0u;
+    if (total > (uint32_t)stage_cap) { if (tid == 0) chunk_flags[chunk] = 1u; return; }      // uniform
+    if (tid == 0) chunk_flags[chunk] = 0u;
     // ---- place into LDS, sorted by tile ----
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
@@ -604,6 +614,7 @@ static void launch_bin(int threads, int nb, hipStream_t st, Cam cam, int P, Geom
                        const uint32_t* flags = nullptr)
 {
     const int nchunks = nb;
+    nb = 8 * ((nb + 7) / 8);                              // XCD bands of chunks
     if (flags && nb > 64) nb = 64;                       // stride loop: the flagged chunks are few
     hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 1024>), dim3(nb), dim3(1024), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs, cap, flags, nchunks);
 }
@@ -641,7 +652,7 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
                 attr_set = true;
             }
             const size_t dyn = (size_t)stage_cap * 12 + (size_t)tiles * 8;
-            hipLaunchKernelGGL((tile_scatter_staged_kernel<1024, 2>), dim3(nb), dim3(1024), dyn, st, cam, P, gp, tiles, tile_base, ranges, pairs, cap,
+            hipLaunchKernelGGL((tile_scatter_staged_kernel<1024, 2>), dim3(8 * ((nb + 7) / 8)), dim3(1024), dyn, st, cam, P, gp, tiles, tile_base, ranges, pairs, cap,
                                stage_cap, gp.chunk_flags);
             launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap, gp.chunk_flags);
         } else launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
