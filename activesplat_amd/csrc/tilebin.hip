@@ -243,7 +243,10 @@ __global__ __launch_bounds__(1024) void tile_colscan_kernel(uint32_t* __restrict
     constexpr int SEG = 1024 / TW;
     __shared__ uint32_t s_sum[SEG][TW + 1];
     const int l = threadIdx.x % TW, sgm = threadIdx.x / TW;
-    const int t = blockIdx.x * TW + l;
+    // XCD-banded column groups: the two 64-byte halves of a 128-byte matrix line are rewritten through the same L2
+    const int ngroups = (tiles + TW - 1) / TW, gper = (ngroups + 7) >> 3;
+    const int grp = (int)(blockIdx.x & 7) * gper + (int)(blockIdx.x >> 3);
+    const int t = ((int)(blockIdx.x >> 3) < gper && grp < ngroups) ? grp * TW + l : tiles;
     const int L = (chunks + SEG - 1) / SEG, r0 = min(chunks, sgm * L), r1 = min(chunks, r0 + L);
     uint32_t sum = 0;
     if (t < tiles) {
@@ -626,7 +629,7 @@ hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_
     int threads, chunk; bin_config(P, threads, chunk);
     const int nb = (P + chunk - 1) / chunk;
     if (nb > 0) launch_bin<false>(threads, nb, st, cam, P, gp, tiles, chunk, tile_total, tile_base, nullptr, nullptr, 0u);
-    hipLaunchKernelGGL(tile_colscan_kernel<16>, dim3((tiles + 15) / 16), dim3(1024), 0, st, tile_base, nb, tiles, tile_total);
+    hipLaunchKernelGGL(tile_colscan_kernel<16>, dim3(8 * (((tiles + 15) / 16 + 7) / 8)), dim3(1024), 0, st, tile_base, nb, tiles, tile_total);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_total, tiles, ranges, d_counts, host_counts);
     return hipGetLastError();
 }
