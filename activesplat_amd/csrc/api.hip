@@ -79,6 +79,7 @@ bool make_cam(const GsCamera* c, gs::Cam& k)
     k.mod = c->scale_modifier;
     k.sh_degree = c->sh_degree; k.sh_coeffs = c->sh_coeffs;
     k.bg = c->bg; k.view = c->viewmatrix; k.proj = c->projmatrix; k.campos = c->campos;
+    k.half = 0;                                            // decided by the blend launchers
     return true;
 }
 
@@ -147,6 +148,12 @@ int gs_set_sort_path(int32_t path)
 int gs_set_scatter_staging(int32_t min_chunks)
 {
     gs::g_staged_min_chunks = min_chunks < 0 ? 0x7fffffff : min_chunks;
+    return GS_OK;
+}
+
+int gs_set_half_quadrants(int32_t max_tiles)
+{
+    gs::g_half_quadrant_tiles = max_tiles < 0 ? 0 : max_tiles;
     return GS_OK;
 }
 

@@ -36,33 +36,20 @@ struct TileCtx {
     bool inside;
 };
 
-__device__ __forceinline__ bool tile_ctx(const Cam& cam, int wave, int lane, TileCtx& c)
-{
-    const int ntiles = cam.gx * cam.gy, per = (ntiles + 7) >> 3;
-    c.tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);          // XCD-aware band mapping
-    if ((int)(blockIdx.x >> 3) >= per || c.tile >= ntiles) return false;
-    c.tx = c.tile % cam.gx; c.ty = c.tile / cam.gx; c.quad = wave;
-    const int qx = c.tx * kTile + (wave & 1) * kQuad, qy = c.ty * kTile + (wave >> 1) * kQuad;
-    c.px = qx + (lane & 7); c.py = qy + (lane >> 3);
-    c.qx0 = (float)qx; c.qy0 = (float)qy; c.pxf = (float)c.px; c.pyf = (float)c.py;
-    c.inside = c.px < cam.W && c.py < cam.H;
-    return true;
-}
-
-// The same for workgroups of NW < 4 wavefronts (the quadrants of a tile are independent): workgroup b of XCD b & 7 takes
-// quadrant-group (b >> 3) of that XCD's tile band, so a tile's quadrants run on one XCD and its records stay in one L2.
+// Workgroup b runs on XCD b & 7 (round-robin dispatch) and takes entry (b >> 3) of that XCD's contiguous band of tiles (neighbouring
+// tiles share Gaussians: their records are reused in one 4 MiB L2); a tile is NW-wavefront workgroups of quadrant walkers -- four
+// 8 x 8 quadrants, or with cam.half eight 8 x 4 half quadrants (c.quad = 2 * row of halves + column).
 template <int NW>
 __device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, TileCtx& c)
 {
-    if (NW == 4) return tile_ctx(cam, wave, lane, c);
-    constexpr int G = 4 / NW;                               // workgroups per tile
+    const int G = (cam.half ? 8 : 4) / NW;                   // workgroups per tile
     const int ntiles = cam.gx * cam.gy, per = (ntiles + 7) >> 3;
     const int idx = (int)(blockIdx.x >> 3);
     c.tile = (int)(blockIdx.x & 7) * per + idx / G;
     if (idx / G >= per || c.tile >= ntiles) return false;
     const int quad = (idx % G) * NW + wave;
     c.tx = c.tile % cam.gx; c.ty = c.tile / cam.gx; c.quad = quad;
-    const int qx = c.tx * kTile + (quad & 1) * kQuad, qy = c.ty * kTile + (quad >> 1) * kQuad;
+    const int qx = c.tx * kTile + (quad & 1) * kQuad, qy = c.ty * kTile + (quad >> 1) * (cam.half ? kQuad / 2 : kQuad);
     c.px = qx + (lane & 7); c.py = qy + (lane >> 3);
     c.qx0 = (float)qx; c.qy0 = (float)qy; c.pxf = (float)c.px; c.pyf = (float)c.py;
     c.inside = c.px < cam.W && c.py < cam.H;
@@ -70,10 +57,10 @@ __device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, 
 }
 
 // does the record's alpha-visible box overlap the 8x8 quadrant at pixel origin (qx0,qy0)?
-__device__ __forceinline__ bool quadrant_hit(const float4& q0, const float4& q2, float qx0, float qy0)
+__device__ __forceinline__ bool quadrant_hit(const float4& q0, const float4& q2, float qx0, float qy0, float last_row = 7.0f)
 {
     const float ex = q2.z, ey = q2.w;
-    return ex >= 0.0f && (q0.x + ex >= qx0) && (q0.x - ex <= qx0 + 7.0f) && (q0.y + ey >= qy0) && (q0.y - ey <= qy0 + 7.0f);
+    return ex >= 0.0f && (q0.x + ex >= qx0) && (q0.x - ex <= qx0 + 7.0f) && (q0.y + ey >= qy0) && (q0.y - ey <= qy0 + last_row);
 }
 
 // LDS staging form: the conic pre-scaled so that the inner loop is  p = (A dx + B dy) dx + C dy dy ; G = 2^p
@@ -161,7 +148,8 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     // lane -> pixel: stream sid owns block (sid & 1, sid >> 1) of the quadrant
     const int sid = lane / LS, l = lane % LS;
     const int px = (int)c.qx0 + (sid & 1) * 4 + (l & 3), py = (int)c.qy0 + (sid >> 1) * BH + (l >> 2);
-    const bool inside = px < cam.W && py < cam.H;
+    const int ns_live = cam.half ? NS / 2 : NS;            // half quadrants: the upper row of blocks only (lanes 0-31)
+    const bool inside = px < cam.W && py < cam.H && sid < ns_live;
     const float pxf = (float)px, pyf = (float)py;
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
     write_sentinel(s0, s1, s2, lane);
@@ -222,7 +210,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
             if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
 
             const bool live = id_cur != kNoId;
-            if (!__any(live && quadrant_hit(q0, q2, c.qx0, c.qy0))) continue;
+            if (!__any(live && quadrant_hit(q0, q2, c.qx0, c.qy0, cam.half ? 3.0f : 7.0f))) continue;
             stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
             // per-stream lists: sentinel fill (one store per lane covers NS x 64 bytes), then every hit lane drops its index
             {
@@ -236,7 +224,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
 #pragma unroll
             for (int s = 0; s < NS; s++) {
                 const float x0 = c.qx0 + (float)((s & 1) * 4), y0 = c.qy0 + (float)((s >> 1) * BH);
-                const bool hit = live && ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) &&
+                const bool hit = live && s < ns_live && ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) &&
                                  (q0.y - ey <= y0 + (float)(BH - 1));
                 const unsigned long long m = __ballot(hit);
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -359,7 +347,8 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     // phase A role: row (lane>>4) = 4x4 sub-block, (lane&15) = pixel inside it
     const int row = lane >> 4, l16 = lane & 15;
     const int px = (int)c.qx0 + (row & 1) * 4 + (l16 & 3), py = (int)c.qy0 + (row >> 1) * 4 + (l16 >> 2);
-    const bool inside = px < cam.W && py < cam.H;
+    const int rows_live = cam.half ? 2 : 4;                  // half quadrants: blocks 0 and 1 only (lanes 0-31 in phase A)
+    const bool inside = px < cam.W && py < cam.H && row < rows_live;
     const float pxf = (float)px, pyf = (float)py;
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
     write_sentinel(s0, s1, s2, lane);
@@ -392,7 +381,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int x = bxb + (i & 3), y = byb + (i >> 2);
-        const bool in = x < cam.W && y < cam.H;
+        const bool in = x < cam.W && y < cam.H && rb < rows_live;
         const size_t p = (size_t)y * cam.W + x;
         e0[i] = in ? dL_dcolor[p] : 0.f; e1[i] = in ? dL_dcolor[HW + p] : 0.f; e2[i] = in ? dL_dcolor[2 * HW + p] : 0.f;
         ez[i] = (DEPTH_GRAD && in) ? dL_ddepth[p] : 0.f;
@@ -416,7 +405,8 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
 
         const bool live = id_cur != kNoId;
         const bool h0 = live && subblock_hit(q0, q2, c.qx0, c.qy0), h1 = live && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0);
-        const bool h2 = live && subblock_hit(q0, q2, c.qx0, c.qy0 + 4.0f), h3 = live && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0 + 4.0f);
+        const bool lower = live && !cam.half;
+        const bool h2 = lower && subblock_hit(q0, q2, c.qx0, c.qy0 + 4.0f), h3 = lower && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0 + 4.0f);
         const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
         if ((m0 | m1 | m2 | m3) == 0ull) continue;
         stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
@@ -575,13 +565,21 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     }
 }
 
-hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
+// images of at most this many tiles are walked by half-quadrant wavefronts (gs_set_half_quadrants): 256 tiles x 4 quadrants are one
+// wavefront per SIMD of this chip, with every LDS / global round trip exposed; two half-filled wavefronts per SIMD hide each other's.
+// Measured (200 k - 1 M Gaussians): 256 tiles backward 132 -> 122 us / 146 -> 130 us, forward 80 -> 78 / 98 -> 89 us; 80 tiles backward
+// 130 -> 112 us; but 400 tiles (3200 half wavefronts: more than the backward's three slots per SIMD) 134 -> 172 us: hence 256
+int g_half_quadrant_tiles = 256;
+
+hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
                                 uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, uint32_t P, float* zero_fill, hipStream_t st)
 {
     // whole-tile workgroups (NW = 4) here: one-wavefront workgroups measured 85 vs 80 us on configs[1] and the same at 2 M -- the
     // four walkers of a tile gather the same records, and on one CU three of them hit its L1
-    const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
+    Cam cam = cam_in;
+    cam.half = (segments <= 1 || !seg_T) && cam.gx * cam.gy <= g_half_quadrant_tiles;
+    const int nb = (((cam.gx * cam.gy + 7) >> 3) << 3) * (cam.half ? 2 : 1);
 #define GS_FWD(DSQ, SEG, GRID)                                                                                                     \
     hipLaunchKernelGGL((blend_forward_streams_kernel<DSQ, kFwdStreams, SEG, 4>), GRID, dim3(kBlock), 0, st, cam, ranges, point_list, geom, \
                        out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap, seg_T, P, (float4*)zero_fill)
@@ -605,12 +603,14 @@ hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint3
     return hipGetLastError();
 }
 
-hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
+hipError_t launch_blend_backward(const Cam& cam_in, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  const float* dL_ddepth, float* grad2d, hipStream_t st)
 {
-    // one-wavefront workgroups (see blend_backward_kernel): per XCD band ceil(tiles/8) tiles x 4 quadrants
-    const int per = (cam.gx * cam.gy + 7) >> 3;
+    // one-wavefront workgroups (see blend_backward_kernel): per XCD band ceil(tiles/8) tiles x 4 quadrants (8 half quadrants)
+    Cam cam = cam_in;
+    cam.half = cam.gx * cam.gy <= g_half_quadrant_tiles;
+    const int per = ((cam.gx * cam.gy + 7) >> 3) * (cam.half ? 2 : 1);
     if (dL_ddepth)
         hipLaunchKernelGGL((blend_backward_kernel<true, 1>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom,
                            final_T, n_contrib, dL_dcolor, dL_ddepth, grad2d);

@@ -31,6 +31,9 @@ struct Cam {
     const float* view;
     const float* proj;
     const float* campos;
+    // blend kernels, images of few tiles: a wavefront takes HALF a quadrant (8 x 4 pixels on lanes 0-31, lanes 32-63 idle), twice the
+    // wavefronts per tile (set by the blend launchers)
+    int half;
 };
 
 // Per-Gaussian screen-space record, 3 x float4 = 48 B, one gather per tile instance in the blend.
@@ -305,6 +308,7 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
                                     uint32_t max_tile_instances, unsigned long long* pairs, unsigned long long* pairs_alt,
                                     uint32_t* point_list, uint32_t cap, hipStream_t st);
 extern int g_staged_min_chunks;
+extern int g_half_quadrant_tiles;
 hipError_t launch_emit(const Cam& cam, int P, GeomPtrs gp, uint64_t* keys, uint32_t* vals, hipStream_t st);
 hipError_t launch_ranges(int64_t D, const uint64_t* keys_sorted, uint2* ranges, hipStream_t st);
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,

@@ -21,7 +21,7 @@
  *   - return value 0 = success, otherwise a GS_E* code; gs_last_error() gives the message;
  *   - no torch types.  Process-wide state: the last-error string (thread-local), and three development knobs that are NOT
  *     synchronised with rendering calls on other threads -- set them while nothing is in flight: gs_set_sort_path,
- *     gs_set_forward_segments, gs_set_scatter_staging (defaults: automatic path choice, segments on, staging from 1 M Gaussians) and the gs_profile_* event log (off).
+ *     gs_set_forward_segments, gs_set_scatter_staging, gs_set_half_quadrants (defaults: automatic path choice, segments on, staging from 1 M Gaussians) and the gs_profile_* event log (off).
  *
  * Call sequence for one forward:
  *     gs_preprocess_forward(...)            // per-Gaussian stage + tile counting; writes the counts
@@ -130,6 +130,9 @@ int gs_set_forward_segments(int32_t on);
 /* The tile scatter stages a chunk's instances in LDS (sorted by tile, written out slice by slice) when the map has at least
  * min_chunks binning chunks of 2048 Gaussians (default 512 = 1 M Gaussians; 0 = always, negative = never). */
 int gs_set_scatter_staging(int32_t min_chunks);
+/* Images of at most max_tiles tiles (default 256; 0 = never) are blended by wavefronts that take half an 8 x 8 quadrant each (twice the
+ * wavefronts, half their lanes idle): 256 tiles x 4 quadrants are one wavefront per SIMD of an MI355X.  Results are unchanged. */
+int gs_set_half_quadrants(int32_t max_tiles);
 /* bytes of the scratch gs_render_backward needs (per-Gaussian 2-D gradient records) */
 uint64_t gs_backward_scratch_bytes(int32_t P);
 

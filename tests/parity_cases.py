@@ -112,6 +112,26 @@ def check_staged_scatter(device, oracle32):
         _lib.check(lib.gs_set_scatter_staging(512))
 
 
+def check_whole_quadrants_on_small_images(device, oracle32, oracle64):
+    """Images of at most 256 tiles are blended by half-quadrant wavefronts (default), so the small parity cases all run that way: here
+    the same cases with whole quadrants (what larger images use), and both must agree with each other bit for bit in the forward."""
+    from activesplat_amd import _lib
+    lib = _lib.get()
+    try:
+        for name in ("basic", "ragged_image", "posed_white_bg", "dense_overdraw", "huge_gaussians", "sh3", "merge_tiles", "not_multiple_of_block"):
+            rs, rv = build_case(name, device)
+            _lib.check(lib.gs_set_half_quadrants(256))
+            halves = util.run_product(rs, rv)
+            _lib.check(lib.gs_set_half_quadrants(0))
+            got, _ = check_forward(rs, rv, oracle32)
+            for k in ("color", "depth", "opacity"):
+                assert np.array_equal(got[k], halves[k]), (name, k)
+            if name in ("basic", "ragged_image", "dense_overdraw", "sh3"):
+                check_backward(rs, rv, oracle64, oracle32=oracle32)
+    finally:
+        _lib.check(lib.gs_set_half_quadrants(256))
+
+
 def check_forward(rs, rv, oracle32, exact_float=False):
     got = util.run_product(rs, rv)
     art = util.artefacts()
