@@ -29,7 +29,7 @@ class GsGeomLayout(C.Structure):
 
 
 class GsImageLayout(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "ranges", "final_T", "n_contrib")]
+    _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "ranges", "final_T", "n_contrib", "split_state")]
 
 
 class GsAdamTensor(C.Structure):

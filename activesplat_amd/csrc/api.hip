@@ -79,7 +79,7 @@ bool make_cam(const GsCamera* c, gs::Cam& k)
     k.mod = c->scale_modifier;
     k.sh_degree = c->sh_degree; k.sh_coeffs = c->sh_coeffs;
     k.bg = c->bg; k.view = c->viewmatrix; k.proj = c->projmatrix; k.campos = c->campos;
-    k.half = 0;                                            // decided by the blend launchers
+    k.half = 0; k.split = 0;                               // decided by the blend launchers
     return true;
 }
 
@@ -206,6 +206,8 @@ int gs_image_layout(int32_t width, int32_t height, GsImageLayout* out)
     out->ranges = o; o = align_up(o + tiles * 8);
     out->final_T = o; o = align_up(o + hw * 4);
     out->n_contrib = o; o = align_up(o + hw * 4);
+    // (recorded only for images of few tiles: every pixel's state at the cut positions of the two-segment backward)
+    out->split_state = o; o = align_up(o + (tiles <= (uint64_t)gs::kFewTiles ? ((uint64_t)gs::kCutLevels * 5 + 4) * hw + 4 : 4) * 4);
     out->total_bytes = o;
     return GS_OK;
 }
@@ -358,7 +360,9 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_ti
         e = gs::launch_blend_forward(k, ranges, point_list, gp.geom, out_color, out_depth, out_opacity,
                                      (float*)(ib + IL.final_T), (uint32_t*)(ib + IL.n_contrib), out_depth_sq,
                                      BL.path == GS_SORT_TILE_LDS ? (uint32_t)D : 0xffffffffu, (int)BL.segments,
-                                     BL.segments > 1 ? (float*)(bb + BL.seg_T) : nullptr, (uint32_t)P, (float*)backward_scratch, st);
+                                     BL.segments > 1 ? (float*)(bb + BL.seg_T) : nullptr,
+                                     k.gx * k.gy <= gs::kFewTiles ? (float*)(ib + IL.split_state) : nullptr, (uint32_t)P,
+                                     (float*)backward_scratch, st);
     }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: blend %s", hipGetErrorString(e));
     return GS_OK;
@@ -392,7 +396,9 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* m
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_backward: memset %s", hipGetErrorString(e));
     if (D > 0) {
         ScopedStage ps(ST_BLEND_BWD, st);
-        e = gs::launch_blend_backward(k, (const uint2*)(ib + IL.ranges), point_list, gp.geom, (const float*)(ib + IL.final_T),
+        e = gs::launch_blend_backward(k, (const uint2*)(ib + IL.ranges), point_list, gp.geom,
+                                      k.gx * k.gy <= gs::kFewTiles ? (const float*)(ib + IL.split_state) : nullptr,
+                                      (const float*)(ib + IL.final_T),
                                       (const uint32_t*)(ib + IL.n_contrib), dL_dcolor, dL_ddepth, grad2d, st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_backward: blend %s", hipGetErrorString(e));
     }

@@ -31,25 +31,27 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr uint32_t kNoId = 0xffffffffu;
 
 struct TileCtx {
-    int tile, tx, ty, px, py, quad;
+    int tile, tx, ty, px, py, quad, seg;
     float qx0, qy0, pxf, pyf;
     bool inside;
 };
 
 // Workgroup b runs on XCD b & 7 (round-robin dispatch) and takes entry (b >> 3) of that XCD's contiguous band of tiles (neighbouring
 // tiles share Gaussians: their records are reused in one 4 MiB L2); a tile is NW-wavefront workgroups of quadrant walkers -- four
-// 8 x 8 quadrants, or with cam.half eight 8 x 4 half quadrants (c.quad = 2 * row of halves + column).
+// 8 x 8 quadrants, or eight 8 x 4 half quadrants (c.quad = 2 * row of halves + column), or four quadrants x two list segments.
 template <int NW>
-__device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, TileCtx& c)
+__device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, TileCtx& c, bool halves, bool segments = false)
 {
-    const int G = (cam.half ? 8 : 4) / NW;                   // workgroups per tile
+    const int G = ((halves || segments) ? 8 : 4) / NW;       // workgroups per tile
     const int ntiles = cam.gx * cam.gy, per = (ntiles + 7) >> 3;
     const int idx = (int)(blockIdx.x >> 3);
     c.tile = (int)(blockIdx.x & 7) * per + idx / G;
     if (idx / G >= per || c.tile >= ntiles) return false;
-    const int quad = (idx % G) * NW + wave;
+    int quad = (idx % G) * NW + wave;
+    c.seg = segments ? quad >> 2 : 0;                        // (list segments: walkers 0-3 = front segment of the four quadrants, 4-7 = back)
+    if (segments) quad &= 3;
     c.tx = c.tile % cam.gx; c.ty = c.tile / cam.gx; c.quad = quad;
-    const int qx = c.tx * kTile + (quad & 1) * kQuad, qy = c.ty * kTile + (quad >> 1) * (cam.half ? kQuad / 2 : kQuad);
+    const int qx = c.tx * kTile + (quad & 1) * kQuad, qy = c.ty * kTile + (quad >> 1) * (halves ? kQuad / 2 : kQuad);
     c.px = qx + (lane & 7); c.py = qy + (lane >> 3);
     c.qx0 = (float)qx; c.qy0 = (float)qy; c.pxf = (float)c.px; c.pyf = (float)c.py;
     c.inside = c.px < cam.W && c.py < cam.H;
@@ -128,7 +130,8 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ out_depth_sq, uint32_t cap, float* __restrict__ seg_T, uint32_t P, float4* __restrict__ zero_fill)
+    float* __restrict__ out_depth_sq, uint32_t cap, float* __restrict__ seg_T, float* __restrict__ split_state, uint32_t P,
+    float4* __restrict__ zero_fill)
 {
     constexpr int LS = kWave / NS;          // lanes per stream
     constexpr int BH = LS / 4;              // block = 4 x BH pixels
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
         for (size_t z = z0 + tid; z < z1; z += NW * kWave) zero_fill[z] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     TileCtx c;
-    if (!tile_ctx_nw<NW>(cam, wave, lane, c)) return;
+    if (!tile_ctx_nw<NW>(cam, wave, lane, c, cam.half != 0)) return;
     // lane -> pixel: stream sid owns block (sid & 1, sid >> 1) of the quadrant
     const int sid = lane / LS, l = lane % LS;
     const int px = (int)c.qx0 + (sid & 1) * 4 + (l & 3), py = (int)c.qy0 + (sid >> 1) * BH + (l >> 2);
@@ -187,6 +190,15 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     }
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Dq = 0.f;
     uint32_t last = 0;
+    // Two-segment backward of images of few tiles (cam.split, a backward will follow = its scratch was handed over): every pixel's
+    // running state -- T and the four sums -- is recorded where its walk passes the list positions 128 * 2^k, and the totals at the
+    // end.  The backward cuts every quadrant's walk at the largest of those positions below half its depth, and its front walker
+    // starts from (T at the cut, what lies behind the cut = totals - sums) instead of waiting for the back walker.  The word behind
+    // the planes tells the backward whether this forward recorded.
+    const size_t HWs = (size_t)cam.W * cam.H;
+    const bool record = SEG == 0 && cam.split != 0 && zero_fill != nullptr && split_state != nullptr;
+    if (SEG == 0 && split_state && blockIdx.x == 0 && tid == 0)
+        reinterpret_cast<uint32_t*>(split_state + (kCutLevels * 5 + 4) * HWs)[0] = record ? 1u : 0u;
     const bool stopped_at_entry = SEG == 2 && T < kTmin;
     bool done = !inside || stopped_at_entry;
 
@@ -201,6 +213,11 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
         if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
         for (uint32_t base = first; base < n; base += kWave) {
+            if (SEG == 0 && record && base >= (uint32_t)kCutFirst && (base & (base - 1u)) == 0u && inside) {
+                const int k = min(kCutLevels - 1, 31 - __clz((int)base) - 7);                 // 128 -> 0, 256 -> 1, ...
+                float* st = split_state + (size_t)k * 5 * HWs + (size_t)py * cam.W + px;
+                st[0] = T; st[HWs] = C0; st[2 * HWs] = C1; st[3 * HWs] = C2; st[4 * HWs] = Dp;
+            }
             const float4 q0 = r0, q1 = r1, q2 = r2;
             const uint32_t id_cur = id_next;
             id_next = id_next2;
@@ -294,6 +311,10 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
         out_depth[pix] = Dp;
         out_opacity[pix] = 1.0f - T;
         if (DEPTH_SQ) out_depth_sq[pix] = Dq;
+        if (SEG == 0 && record) {
+            float* tot = split_state + (size_t)kCutLevels * 5 * HW + pix;
+            tot[0] = C0; tot[HW] = C1; tot[2 * HW] = C2; tot[3 * HW] = Dp;
+        }
     }
 }
 
@@ -336,14 +357,15 @@ template <bool DEPTH_GRAD, int NW>
 __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, float* __restrict__ grad2d)
+    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, float* __restrict__ grad2d,
+    const float* __restrict__ split_state)
 {
     __shared__ float4 s_rec[NW][3][kWave + 1];           // + the sentinel slot
     __shared__ __attribute__((aligned(16))) uint8_t s_list[NW][4 * kWave + 16];
     __shared__ __attribute__((aligned(16))) float s_m[NW][2][kMPlane];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
-    if (!tile_ctx_nw<NW>(cam, wave, lane, c)) return;
+    if (!tile_ctx_nw<NW>(cam, wave, lane, c, cam.half != 0, cam.split != 0)) return;
     // phase A role: row (lane>>4) = 4x4 sub-block, (lane&15) = pixel inside it
     const int row = lane >> 4, l16 = lane & 15;
     const int px = (int)c.qx0 + (row & 1) * 4 + (l16 & 3), py = (int)c.qy0 + (row >> 1) * 4 + (l16 >> 2);
@@ -362,17 +384,45 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
 
     const float Tf = inside ? final_T[pix] : 0.f;
-    const uint32_t last = inside ? n_contrib[pix] : 0u;
+    uint32_t last = inside ? n_contrib[pix] : 0u;
+    // Two list segments per quadrant (cam.split and the forward recorded): the quadrant's walk, wmax positions deep, is cut at the recorded
+    // position 128 * 2^k nearest (in ratio) to half of it.  The BACK walker (c.seg = 1) replays positions >= m_cut exactly as the
+    // one-walker kernel would; the FRONT walker (c.seg = 0) takes the pixels that contributed past the cut from the recorded state -- T in
+    // front of record m_cut, behind-colour = (totals - sums up to the cut) / T -- and everything else as usual.
+    uint32_t wmax = last;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor(wmax, m));
+    if (wmax == 0) return;
+    uint32_t m_cut = 0;
+    int k_cut = 0;
+    if (cam.split) {
+        const bool recorded = split_state && reinterpret_cast<const uint32_t*>(split_state + (kCutLevels * 5 + 4) * HW)[0] == 1u;
+        if (recorded && wmax >= 2u * kCutFirst) {
+            // the recorded position nearest to half the depth (in ratio): wmax / 2 in [2^j / sqrt2, 2^j sqrt2)  ->  2^j
+            const uint32_t target = (uint32_t)((unsigned long long)wmax * 46341ull >> 16);      // wmax / 2 * sqrt2
+            k_cut = max(0, min(kCutLevels - 1, 31 - __clz((int)target) - 7));
+            m_cut = (uint32_t)kCutFirst << k_cut;
+            if (m_cut >= wmax) m_cut = 0u;
+        }
+        if (m_cut == 0u && c.seg == 1) return;                  // nothing to share: the front walker does the whole list
+    }
+    const bool resumed = m_cut != 0u && c.seg == 0 && last > m_cut;
+    if (m_cut != 0u && c.seg == 0) { last = min(last, m_cut); wmax = min(wmax, m_cut); }
     const float d0 = inside ? dL_dcolor[pix] : 0.f, d1 = inside ? dL_dcolor[HW + pix] : 0.f,
                 d2 = inside ? dL_dcolor[2 * HW + pix] : 0.f;
     const float dz_ = (DEPTH_GRAD && inside) ? dL_ddepth[pix] : 0.f;
     const float tfbg = Tf * (cam.bg[0] * d0 + cam.bg[1] * d1 + cam.bg[2] * d2);    // background term of dL/dalpha
     float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accz = 0.f;
-
-    uint32_t wmax = last;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor(wmax, m));
-    if (wmax == 0) return;
+    if (resumed) {
+        const float* st = split_state + (size_t)k_cut * 5 * HW + pix;
+        const float* tot = split_state + (size_t)kCutLevels * 5 * HW + pix;
+        T = st[0];
+        const float it = 1.0f / T;                               // (T in front of a record that contributed later is >= 1e-4)
+        acc0 = (tot[0] - st[HW]) * it; acc1 = (tot[HW] - st[2 * HW]) * it; acc2 = (tot[2 * HW] - st[3 * HW]) * it;
+        if (DEPTH_GRAD) accz = (tot[3 * HW] - st[4 * HW]) * it;
+    }
+    if (c.seg == 1 && wmax <= m_cut) return;
+    const int cmin = c.seg == 1 ? (int)(m_cut / kWave) : 0;      // the back walker stops at the cut
 
     // phase B role: the block of row rb at list position tb of the batch; its 16 pixels' dL/dcolour stay in registers
     const int tb = lane >> 2, rb = lane & 3;
@@ -392,14 +442,14 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
 
     const int cmax = (int)((wmax - 1) / kWave);
     uint32_t id_next = (uint32_t)cmax * kWave + lane < wmax ? list[cmax * kWave + lane] : kNoId;
-    uint32_t id_next2 = cmax >= 1 ? list[(cmax - 1) * kWave + lane] : kNoId;
+    uint32_t id_next2 = cmax >= cmin + 1 ? list[(cmax - 1) * kWave + lane] : kNoId;
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
     if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
-    for (int ch = cmax; ch >= 0; ch--) {
+    for (int ch = cmax; ch >= cmin; ch--) {
         const float4 q0 = r0, q1 = r1, q2 = r2;
         const uint32_t id_cur = id_next;
         id_next = id_next2;
-        id_next2 = ch >= 2 ? list[(ch - 2) * kWave + lane] : kNoId;
+        id_next2 = ch >= cmin + 2 ? list[(ch - 2) * kWave + lane] : kNoId;
         r2 = make_float4(0.f, 0.f, -1.f, -1.f);
         if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
 
@@ -573,16 +623,18 @@ int g_half_quadrant_tiles = 256;
 
 hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
-                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, uint32_t P, float* zero_fill, hipStream_t st)
+                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, float* split_state, uint32_t P,
+                                float* zero_fill, hipStream_t st)
 {
     // whole-tile workgroups (NW = 4) here: one-wavefront workgroups measured 85 vs 80 us on configs[1] and the same at 2 M -- the
     // four walkers of a tile gather the same records, and on one CU three of them hit its L1
     Cam cam = cam_in;
     cam.half = (segments <= 1 || !seg_T) && cam.gx * cam.gy <= g_half_quadrant_tiles;
+    cam.split = cam.V == 1 && split_state && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles);      // (the backward refuses atlases)
     const int nb = (((cam.gx * cam.gy + 7) >> 3) << 3) * (cam.half ? 2 : 1);
 #define GS_FWD(DSQ, SEG, GRID)                                                                                                     \
     hipLaunchKernelGGL((blend_forward_streams_kernel<DSQ, kFwdStreams, SEG, 4>), GRID, dim3(kBlock), 0, st, cam, ranges, point_list, geom, \
-                       out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap, seg_T, P, (float4*)zero_fill)
+                       out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap, seg_T, split_state, P, (float4*)zero_fill)
     if (segments > 1 && seg_T) {
         // segmented compositing: the sums are added with atomics, so the images start from zero
         const size_t HW = (size_t)cam.W * cam.H;
@@ -593,6 +645,7 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
         if (e == hipSuccess) e = hipMemsetAsync(out_depth, 0, HW * sizeof(float), st);
         if (e == hipSuccess && out_depth_sq) e = hipMemsetAsync(out_depth_sq, 0, HW * sizeof(float), st);
         if (e == hipSuccess) e = hipMemsetAsync(n_contrib, 0, HW * sizeof(uint32_t), st);
+        if (e == hipSuccess && split_state) e = hipMemsetAsync(split_state + (kCutLevels * 5 + 4) * HW, 0, sizeof(uint32_t), st);    // nothing recorded
         if (e != hipSuccess) return e;
         const dim3 grid(nb, segments);
         if (out_depth_sq) { GS_FWD(true, 1, grid); GS_FWD(true, 2, grid); }
@@ -603,20 +656,22 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
     return hipGetLastError();
 }
 
-hipError_t launch_blend_backward(const Cam& cam_in, const uint2* ranges, const uint32_t* point_list, const float4* geom,
+hipError_t launch_blend_backward(const Cam& cam_in, const uint2* ranges, const uint32_t* point_list, const float4* geom, const float* split_state,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  const float* dL_ddepth, float* grad2d, hipStream_t st)
 {
-    // one-wavefront workgroups (see blend_backward_kernel): per XCD band ceil(tiles/8) tiles x 4 quadrants (8 half quadrants)
+    // one-wavefront workgroups (see blend_backward_kernel): per XCD band ceil(tiles/8) tiles x 4 quadrants; images of few tiles: x 2 list
+    // segments (the forward of such an image has recorded the state at the cut; if it has not, the back walkers exit at once)
     Cam cam = cam_in;
-    cam.half = cam.gx * cam.gy <= g_half_quadrant_tiles;
-    const int per = ((cam.gx * cam.gy + 7) >> 3) * (cam.half ? 2 : 1);
+    cam.half = 0;
+    cam.split = split_state != nullptr && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles);
+    const int per = ((cam.gx * cam.gy + 7) >> 3) * (cam.split ? 2 : 1);
     if (dL_ddepth)
         hipLaunchKernelGGL((blend_backward_kernel<true, 1>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom,
-                           final_T, n_contrib, dL_dcolor, dL_ddepth, grad2d);
+                           final_T, n_contrib, dL_dcolor, dL_ddepth, grad2d, split_state);
     else
         hipLaunchKernelGGL((blend_backward_kernel<false, 1>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom,
-                           final_T, n_contrib, dL_dcolor, dL_ddepth, grad2d);
+                           final_T, n_contrib, dL_dcolor, dL_ddepth, grad2d, split_state);
     return hipGetLastError();
 }
 

@@ -34,6 +34,9 @@ struct Cam {
     // blend kernels, images of few tiles: a wavefront takes HALF a quadrant (8 x 4 pixels on lanes 0-31, lanes 32-63 idle), twice the
     // wavefronts per tile (set by the blend launchers)
     int half;
+    // backward blend, images of few tiles: every tile list is walked in TWO segments by two wavefronts per quadrant; the front
+    // one starts from the per-pixel state the forward left at the boundary (set by the blend launchers)
+    int split;
 };
 
 // Per-Gaussian screen-space record, 3 x float4 = 48 B, one gather per tile instance in the blend.
@@ -309,12 +312,19 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
                                     uint32_t* point_list, uint32_t cap, hipStream_t st);
 extern int g_staged_min_chunks;
 extern int g_half_quadrant_tiles;
+// images of few tiles (at most kFewTiles; the knob above can only lower the limit): the forward records every pixel's running state
+// at the list positions 128 * 2^k, k < kCutLevels, for the two-segment backward.  Planes of H*W floats: [k][T, C0, C1, C2, D], then the
+// four totals, then one word "recorded"
+constexpr int kFewTiles = 256;
+constexpr int kCutLevels = 12;
+constexpr int kCutFirst = 128;
 hipError_t launch_emit(const Cam& cam, int P, GeomPtrs gp, uint64_t* keys, uint32_t* vals, hipStream_t st);
 hipError_t launch_ranges(int64_t D, const uint64_t* keys_sorted, uint2* ranges, hipStream_t st);
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
-                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, uint32_t P, float* zero_fill, hipStream_t st);
-hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,
+                                uint32_t* n_contrib, float* out_depth_sq, uint32_t cap, int segments, float* seg_T, float* split_state, uint32_t P, float* zero_fill,
+                                hipStream_t st);
+hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom, const float* split_state,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  const float* dL_ddepth, float* grad2d, hipStream_t st);
 hipError_t launch_adam_multi(int count, const GsAdamTensor* tensors, hipStream_t st);

@@ -93,6 +93,8 @@ typedef struct GsImageLayout {
     uint64_t ranges;        /* uint32 [tiles][2] : [start,end) into point_list */
     uint64_t final_T;       /* float  [H*W] */
     uint64_t n_contrib;     /* uint32 [H*W] : 1-based position in the tile list of the last contributor */
+    uint64_t split_state;   /* images of at most 256 tiles: float [12][5][H*W] + [4][H*W] + 1 word, per-pixel running state at the list
+                             * positions 128 * 2^k, where the backward may cut a quadrant's walk in two */
 } GsImageLayout;
 
 #define GS_SORT_AUTO 0
@@ -130,8 +132,9 @@ int gs_set_forward_segments(int32_t on);
 /* The tile scatter stages a chunk's instances in LDS (sorted by tile, written out slice by slice) when the map has at least
  * min_chunks binning chunks of 2048 Gaussians (default 512 = 1 M Gaussians; 0 = always, negative = never). */
 int gs_set_scatter_staging(int32_t min_chunks);
-/* Images of at most max_tiles tiles (default 256; 0 = never) are blended by wavefronts that take half an 8 x 8 quadrant each (twice the
- * wavefronts, half their lanes idle): 256 tiles x 4 quadrants are one wavefront per SIMD of an MI355X.  Results are unchanged. */
+/* Images of at most max_tiles tiles (default 256; 0 = never) get twice the wavefronts: 256 tiles x 4 quadrants are one wavefront per SIMD of
+ * an MI355X.  The forward's wavefronts take half an 8 x 8 quadrant each (half their lanes idle; results unchanged); the backward walks every
+ * tile list in two segments, the front one from a per-pixel state the forward recorded at the cut (gradients agree to rounding). */
 int gs_set_half_quadrants(int32_t max_tiles);
 /* bytes of the scratch gs_render_backward needs (per-Gaussian 2-D gradient records) */
 uint64_t gs_backward_scratch_bytes(int32_t P);

@@ -18,6 +18,9 @@ data = dict(cam=cam, im=tim.to(dev), depth=tdepth.to(dev), id=0, w2c=torch.eye(4
 opt = O.initialize_optimizer(prm, dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05,
                                        log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0))
 flags = dict(fused=True, fused_loss=True, fused_inputs=True)
+if os.environ.get("HALF"):
+    from activesplat_amd import _lib
+    _lib.get().gs_set_half_quadrants(int(os.environ["HALF"]))
 
 def it():
     loss, _, _ = M.get_loss(prm, data, var, 0, dict(im=0.5, depth=1.0), pose7=[1.0, 0, 0, 0, 0, 0, 0], **flags)
