@@ -125,7 +125,9 @@ __device__ __forceinline__ void write_sentinel(float4* s0, float4* s1, float4* s
 //            product) and adds its colour / depth sums to the zero-initialised images with atomics; the last segment of a
 //            pixel that is not yet stopped at entry writes final_T, opacity and T*bg; n_contrib is an atomic max.
 //   SEG = 0: the whole list in one workgroup (the normal path; its code is untouched by the other two).
-template <bool DEPTH_SQ, int NS, int SEG, int NW>     // DEPTH_SQ: also accumulate sum z^2 alpha T (third channel of the reference's depth/silhouette pass)
+// FEW: the variant for images of few tiles (half quadrants, state recording for the two-segment backward); the code of the other one
+// does not carry any of it (registers: 64 against 70, i.e. 8 against 7 wavefronts per SIMD)
+template <bool DEPTH_SQ, int NS, int SEG, int NW, bool FEW = false>     // DEPTH_SQ: also accumulate sum z^2 alpha T (third channel of the reference's depth/silhouette pass)
 __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -147,11 +149,12 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
         for (size_t z = z0 + tid; z < z1; z += NW * kWave) zero_fill[z] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     TileCtx c;
-    if (!tile_ctx_nw<NW>(cam, wave, lane, c, cam.half != 0)) return;
+    const bool half = FEW && cam.half != 0;
+    if (!tile_ctx_nw<NW>(cam, wave, lane, c, half)) return;
     // lane -> pixel: stream sid owns block (sid & 1, sid >> 1) of the quadrant
     const int sid = lane / LS, l = lane % LS;
     const int px = (int)c.qx0 + (sid & 1) * 4 + (l & 3), py = (int)c.qy0 + (sid >> 1) * BH + (l >> 2);
-    const int ns_live = cam.half ? NS / 2 : NS;            // half quadrants: the upper row of blocks only (lanes 0-31)
+    const int ns_live = half ? NS / 2 : NS;                // half quadrants: the upper row of blocks only (lanes 0-31)
     const bool inside = px < cam.W && py < cam.H && sid < ns_live;
     const float pxf = (float)px, pyf = (float)py;
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     // starts from (T at the cut, what lies behind the cut = totals - sums) instead of waiting for the back walker.  The word behind
     // the planes tells the backward whether this forward recorded.
     const size_t HWs = (size_t)cam.W * cam.H;
-    const bool record = SEG == 0 && cam.split != 0 && zero_fill != nullptr && split_state != nullptr;
-    if (SEG == 0 && split_state && blockIdx.x == 0 && tid == 0)
+    const bool record = FEW && SEG == 0 && cam.split != 0 && zero_fill != nullptr && split_state != nullptr;
+    if (FEW && SEG == 0 && split_state && blockIdx.x == 0 && tid == 0)
         reinterpret_cast<uint32_t*>(split_state + (kCutLevels * 5 + 4) * HWs)[0] = record ? 1u : 0u;
     const bool stopped_at_entry = SEG == 2 && T < kTmin;
     bool done = !inside || stopped_at_entry;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
         if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
         for (uint32_t base = first; base < n; base += kWave) {
-            if (SEG == 0 && record && base >= (uint32_t)kCutFirst && (base & (base - 1u)) == 0u && inside) {
+            if (FEW && SEG == 0 && record && base >= (uint32_t)kCutFirst && (base & (base - 1u)) == 0u && inside) {
                 const int k = min(kCutLevels - 1, 31 - __clz((int)base) - 7);                 // 128 -> 0, 256 -> 1, ...
                 float* st = split_state + (size_t)k * 5 * HWs + (size_t)py * cam.W + px;
                 st[0] = T; st[HWs] = C0; st[2 * HWs] = C1; st[3 * HWs] = C2; st[4 * HWs] = Dp;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
             if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
 
             const bool live = id_cur != kNoId;
-            if (!__any(live && quadrant_hit(q0, q2, c.qx0, c.qy0, cam.half ? 3.0f : 7.0f))) continue;
+            if (!__any(live && quadrant_hit(q0, q2, c.qx0, c.qy0, half ? 3.0f : 7.0f))) continue;
             stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
             // per-stream lists: sentinel fill (one store per lane covers NS x 64 bytes), then every hit lane drops its index
             {
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
         out_depth[pix] = Dp;
         out_opacity[pix] = 1.0f - T;
         if (DEPTH_SQ) out_depth_sq[pix] = Dq;
-        if (SEG == 0 && record) {
+        if (FEW && SEG == 0 && record) {
             float* tot = split_state + (size_t)kCutLevels * 5 * HW + pix;
             tot[0] = C0; tot[HW] = C1; tot[2 * HW] = C2; tot[3 * HW] = Dp;
         }
@@ -353,7 +356,7 @@ constexpr int kMT = kWave + 4;         // floats per position in an exchange pla
 constexpr int kPairStride = 12;        // floats per pair / record slot in the sum exchanges: components 0-4 at [0,5), 5-9 at [6,11)
 constexpr int kMPlane = (kBT - 1) * kMT + kWave;   // floats of one exchange plane
 
-template <bool DEPTH_GRAD, int NW>
+template <bool DEPTH_GRAD, int NW, bool FEW = false>        // FEW: two list segments per quadrant (images of few tiles)
 __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -365,12 +368,12 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     __shared__ __attribute__((aligned(16))) float s_m[NW][2][kMPlane];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
-    if (!tile_ctx_nw<NW>(cam, wave, lane, c, cam.half != 0, cam.split != 0)) return;
+    const bool split = FEW && cam.split != 0;
+    if (!tile_ctx_nw<NW>(cam, wave, lane, c, false, split)) return;
     // phase A role: row (lane>>4) = 4x4 sub-block, (lane&15) = pixel inside it
     const int row = lane >> 4, l16 = lane & 15;
     const int px = (int)c.qx0 + (row & 1) * 4 + (l16 & 3), py = (int)c.qy0 + (row >> 1) * 4 + (l16 >> 2);
-    const int rows_live = cam.half ? 2 : 4;                  // half quadrants: blocks 0 and 1 only (lanes 0-31 in phase A)
-    const bool inside = px < cam.W && py < cam.H && row < rows_live;
+    const bool inside = px < cam.W && py < cam.H;
     const float pxf = (float)px, pyf = (float)py;
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
     write_sentinel(s0, s1, s2, lane);
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     if (wmax == 0) return;
     uint32_t m_cut = 0;
     int k_cut = 0;
-    if (cam.split) {
+    if (split) {
         const bool recorded = split_state && reinterpret_cast<const uint32_t*>(split_state + (kCutLevels * 5 + 4) * HW)[0] == 1u;
         if (recorded && wmax >= 2u * kCutFirst) {
             // the recorded position nearest to half the depth (in ratio): wmax / 2 in [2^j / sqrt2, 2^j sqrt2)  ->  2^j
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int x = bxb + (i & 3), y = byb + (i >> 2);
-        const bool in = x < cam.W && y < cam.H && rb < rows_live;
+        const bool in = x < cam.W && y < cam.H;
         const size_t p = (size_t)y * cam.W + x;
         e0[i] = in ? dL_dcolor[p] : 0.f; e1[i] = in ? dL_dcolor[HW + p] : 0.f; e2[i] = in ? dL_dcolor[2 * HW + p] : 0.f;
         ez[i] = (DEPTH_GRAD && in) ? dL_ddepth[p] : 0.f;
@@ -455,8 +458,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
 
         const bool live = id_cur != kNoId;
         const bool h0 = live && subblock_hit(q0, q2, c.qx0, c.qy0), h1 = live && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0);
-        const bool lower = live && !cam.half;
-        const bool h2 = lower && subblock_hit(q0, q2, c.qx0, c.qy0 + 4.0f), h3 = lower && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0 + 4.0f);
+        const bool h2 = live && subblock_hit(q0, q2, c.qx0, c.qy0 + 4.0f), h3 = live && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0 + 4.0f);
         const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
         if ((m0 | m1 | m2 | m3) == 0ull) continue;
         stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
@@ -632,12 +634,12 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
     cam.half = (segments <= 1 || !seg_T) && cam.gx * cam.gy <= g_half_quadrant_tiles;
     cam.split = cam.V == 1 && split_state && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles);      // (the backward refuses atlases)
     const int nb = (((cam.gx * cam.gy + 7) >> 3) << 3) * (cam.half ? 2 : 1);
-#define GS_FWD(DSQ, SEG, GRID)                                                                                                     \
-    hipLaunchKernelGGL((blend_forward_streams_kernel<DSQ, kFwdStreams, SEG, 4>), GRID, dim3(kBlock), 0, st, cam, ranges, point_list, geom, \
+#define GS_FWD(DSQ, SEG, FEW, GRID)                                                                                                \
+    hipLaunchKernelGGL((blend_forward_streams_kernel<DSQ, kFwdStreams, SEG, 4, FEW>), GRID, dim3(kBlock), 0, st, cam, ranges, point_list, geom, \
                        out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap, seg_T, split_state, P, (float4*)zero_fill)
+    const size_t HW = (size_t)cam.W * cam.H;
     if (segments > 1 && seg_T) {
         // segmented compositing: the sums are added with atomics, so the images start from zero
-        const size_t HW = (size_t)cam.W * cam.H;
         hipError_t e = zero_fill ? hipMemsetAsync(zero_fill, 0, (size_t)P * kGradStride * sizeof(float), st) : hipSuccess;
         if (e == hipSuccess)       // the quadrants' "an earlier segment saturates" flag words behind the transmittances
             e = hipMemsetAsync(seg_T + (size_t)cam.gx * cam.gy * segments * kBlock, 0, (size_t)cam.gx * cam.gy * 4 * sizeof(uint32_t), st);
@@ -648,10 +650,17 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
         if (e == hipSuccess && split_state) e = hipMemsetAsync(split_state + (kCutLevels * 5 + 4) * HW, 0, sizeof(uint32_t), st);    // nothing recorded
         if (e != hipSuccess) return e;
         const dim3 grid(nb, segments);
-        if (out_depth_sq) { GS_FWD(true, 1, grid); GS_FWD(true, 2, grid); }
-        else { GS_FWD(false, 1, grid); GS_FWD(false, 2, grid); }
-    } else if (out_depth_sq) GS_FWD(true, 0, dim3(nb));
-    else GS_FWD(false, 0, dim3(nb));
+        if (out_depth_sq) { GS_FWD(true, 1, false, grid); GS_FWD(true, 2, false, grid); }
+        else { GS_FWD(false, 1, false, grid); GS_FWD(false, 2, false, grid); }
+    } else if (cam.half || cam.split) {
+        if (out_depth_sq) GS_FWD(true, 0, true, dim3(nb)); else GS_FWD(false, 0, true, dim3(nb));
+    } else {
+        if (split_state) {          // a small image with the few-tile paths switched off: "nothing recorded"
+            hipError_t e = hipMemsetAsync(split_state + (kCutLevels * 5 + 4) * HW, 0, sizeof(uint32_t), st);
+            if (e != hipSuccess) return e;
+        }
+        if (out_depth_sq) GS_FWD(true, 0, false, dim3(nb)); else GS_FWD(false, 0, false, dim3(nb));
+    }
 #undef GS_FWD
     return hipGetLastError();
 }
@@ -666,12 +675,12 @@ hipError_t launch_blend_backward(const Cam& cam_in, const uint2* ranges, const u
     cam.half = 0;
     cam.split = split_state != nullptr && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles);
     const int per = ((cam.gx * cam.gy + 7) >> 3) * (cam.split ? 2 : 1);
-    if (dL_ddepth)
-        hipLaunchKernelGGL((blend_backward_kernel<true, 1>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom,
-                           final_T, n_contrib, dL_dcolor, dL_ddepth, grad2d, split_state);
-    else
-        hipLaunchKernelGGL((blend_backward_kernel<false, 1>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom,
-                           final_T, n_contrib, dL_dcolor, dL_ddepth, grad2d, split_state);
+#define GS_BWD(DG, FEW)                                                                                                          \
+    hipLaunchKernelGGL((blend_backward_kernel<DG, 1, FEW>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom, final_T, \
+                       n_contrib, dL_dcolor, dL_ddepth, grad2d, split_state)
+    if (cam.split) { if (dL_ddepth) GS_BWD(true, true); else GS_BWD(false, true); }
+    else { if (dL_ddepth) GS_BWD(true, false); else GS_BWD(false, false); }
+#undef GS_BWD
     return hipGetLastError();
 }
 
