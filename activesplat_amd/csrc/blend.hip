@@ -216,8 +216,9 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
         if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
         for (uint32_t base = first; base < n; base += kWave) {
-            if (FEW && SEG == 0 && record && base >= (uint32_t)kCutFirst && (base & (base - 1u)) == 0u && inside) {
-                const int k = min(kCutLevels - 1, 31 - __clz((int)base) - 7);                 // 128 -> 0, 256 -> 1, ...
+            if (FEW && SEG == 0 && record && base >= (uint32_t)kCutFirst && base < ((uint32_t)kCutFirst << kCutLevels) &&
+                (base & (base - 1u)) == 0u && inside) {
+                const int k = 31 - __clz((int)base) - 7;                                       // 128 -> 0, 256 -> 1, ...
                 float* st = split_state + (size_t)k * 5 * HWs + (size_t)py * cam.W + px;
                 st[0] = T; st[HWs] = C0; st[2 * HWs] = C1; st[3 * HWs] = C2; st[4 * HWs] = Dp;
             }
