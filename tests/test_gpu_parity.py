@@ -202,3 +202,28 @@ def test_staged_scatter_forced_on(hip, oracle32):
 
 def test_whole_quadrants_on_small_images(hip, oracle32, oracle64):
     pc.check_whole_quadrants_on_small_images(hip, oracle32, oracle64)
+
+
+def test_two_segment_backward_at_the_reference_resolution(hip):
+    """256 x 256 (the reference's default frames: 256 tiles), 150 k Gaussians, opaque enough that pixels stop at different depths: the
+    backward that walks every quadrant's list in two segments (default for such images) against the one-walker kernel; forward outputs
+    identical, gradients equal up to the order of the sums."""
+    from activesplat_amd import _lib
+    lib = _lib.get()
+    rs, rv = util.scene(150_000, 256, 256, seed=21, device=hip)
+    rs = rs._replace(debug=False)
+    rv["opacities"] = (rv["opacities"] * 0.5 + 0.3).clamp(0, 0.99)
+    dL = torch.randn(3, 256, 256, generator=torch.Generator().manual_seed(5))
+    try:
+        _lib.check(lib.gs_set_half_quadrants(0))
+        ref = util.run_product(rs, rv, dL)
+        _lib.check(lib.gs_set_half_quadrants(256))
+        got = util.run_product(rs, rv, dL)
+    finally:
+        _lib.check(lib.gs_set_half_quadrants(256))
+    for k in ("color", "depth", "opacity", "radii"):
+        assert np.array_equal(got[k], ref[k]), k
+    for k, g in got["grads"].items():
+        r = ref["grads"][k]
+        assert np.isfinite(g).all(), k
+        assert np.linalg.norm(g.astype(np.float64) - r) <= 2e-5 * max(np.linalg.norm(r), 1e-30), (k, np.linalg.norm(g - r) / np.linalg.norm(r))
