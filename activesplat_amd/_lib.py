@@ -25,7 +25,7 @@ class GsCamera(C.Structure):
 
 class GsGeomLayout(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "geom", "rect", "tiles_touched", "offsets", "block_sums", "clamped",
-                                          "tile_total", "tile_base", "sh_jac", "depth_bits", "chunk_flags")]
+                                          "tile_total", "tile_base", "sh_jac", "depth_bits")]
 
 
 class GsImageLayout(C.Structure):
@@ -48,7 +48,7 @@ SORT_AUTO, SORT_TILE_LDS, SORT_RADIX = 0, 1, 2
 
 # every symbol include/gsplat_hip.h declares (tests check the library exports all of them)
 SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
-           "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_set_scatter_staging", "gs_set_half_quadrants", "gs_preprocess_forward", "gs_render_forward", "gs_render_backward", "gs_adam_step", "gs_adam_step_multi",
+           "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_set_half_quadrants", "gs_preprocess_forward", "gs_render_forward", "gs_render_backward", "gs_adam_step", "gs_adam_step_multi",
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
            "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward",
            "gs_grow_scratch_bytes", "gs_grow_gaussians", "gs_keyframe_overlap", "gs_visibility_stats", "gs_accumulate_grad2d",
@@ -63,8 +63,6 @@ def _bind(lib):
     lib.gs_set_sort_path.argtypes = [i32]
     lib.gs_set_sort_path.restype = C.c_int
     lib.gs_set_forward_segments.argtypes = [i32]
-    lib.gs_set_scatter_staging.argtypes = [i32]
-    lib.gs_set_scatter_staging.restype = C.c_int
     lib.gs_set_half_quadrants.argtypes = [i32]
     lib.gs_set_half_quadrants.restype = C.c_int
     lib.gs_set_forward_segments.restype = C.c_int

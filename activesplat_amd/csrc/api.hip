@@ -102,7 +102,6 @@ gs::GeomPtrs carve_geom(void* base, int32_t P, const gs::Cam& k)
     g.tile_total = (uint32_t*)(b + L.tile_total); g.tile_base = (uint32_t*)(b + L.tile_base);
     g.sh_jac = (float4*)(b + L.sh_jac);
     g.depth_bits = (uint32_t*)(b + L.depth_bits);
-    g.chunk_flags = (uint32_t*)(b + L.chunk_flags);
     return g;
 }
 
@@ -142,12 +141,6 @@ int gs_set_sort_path(int32_t path)
 {
     if (path < GS_SORT_AUTO || path > GS_SORT_RADIX) return fail(GS_EINVAL, "gs_set_sort_path: bad path");
     g_sort_path = path;
-    return GS_OK;
-}
-
-int gs_set_scatter_staging(int32_t min_chunks)
-{
-    gs::g_staged_min_chunks = min_chunks < 0 ? 0x7fffffff : min_chunks;
     return GS_OK;
 }
 
@@ -192,7 +185,6 @@ int gs_geom_layout(int32_t P, int32_t width, int32_t height, GsGeomLayout* out)
     out->tile_base = o; o = align_up(o + (tiles <= (uint64_t)gs::kMaxLdsTiles ? rows * tiles * 4 : 4));
     out->sh_jac = o; o = align_up(o + n * 48);
     out->depth_bits = o; o = align_up(o + n * 4);
-    out->chunk_flags = o; o = align_up(o + rows * 4);
     out->total_bytes = o;
     return GS_OK;
 }

@@ -52,7 +52,6 @@ struct GeomPtrs {
     uint32_t* clamped;   // uchar4 packed
     uint32_t* tile_total;  // [tiles]
     uint32_t* tile_base;   // [ceil(P/kBinChunk)][tiles]
-    uint32_t* chunk_flags; // [ceil(P/1024)]: 1 = this binning chunk is scattered by the direct kernel (large rects / overfull)
     uint32_t* depth_bits;  // [P]: bit pattern of the view-space depth (the binning key), compact copy of geom[.][9] for coalesced reads
     float4* sh_jac;        // [P][3]: d(rgb before the clamp)/d(unit view direction), 3x3 row-major in 9 of 12 floats (SH inputs with a backward to follow)
 };
@@ -310,7 +309,6 @@ hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_
 hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_base, const uint2* ranges,
                                     uint32_t max_tile_instances, unsigned long long* pairs, unsigned long long* pairs_alt,
                                     uint32_t* point_list, uint32_t cap, hipStream_t st);
-extern int g_staged_min_chunks;
 extern int g_half_quadrant_tiles;
 // images of few tiles (at most kFewTiles; the knob above can only lower the limit): the forward records every pixel's running state
 // at the list positions 128 * 2^k, k < kCutLevels, for the two-segment backward.  Planes of H*W floats: [k][T, C0, C1, C2, D], then the

@@ -18,9 +18,6 @@
 //                  the result does not depend on the atomics' arrival order), writes point_list.
 #include "gs_common.h"
 
-#ifndef GS_DYNAMIC_LDS
-#define GS_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
-#endif
 
 namespace gs {
 
@@ -53,8 +50,7 @@ __global__ __launch_bounds__(THREADS) void tile_bin_kernel(Cam cam, int P, GeomP
                                                           uint32_t* __restrict__ tile_total,
                                                           uint32_t* __restrict__ tile_base,
                                                           const uint2* __restrict__ ranges,
-                                                          unsigned long long* __restrict__ pairs, uint32_t cap, const uint32_t* __restrict__ chunk_flags,
-                                                          int nchunks)
+                                                          unsigned long long* __restrict__ pairs, uint32_t cap, int nchunks)
 {
     __shared__ uint32_t s_hist[kMaxLdsTiles];      // count pass: histogram; scatter pass: cursors
     __shared__ uint32_t s_incl[THREADS];
@@ -63,17 +59,17 @@ __global__ __launch_bounds__(THREADS) void tile_bin_kernel(Cam cam, int P, GeomP
     __shared__ uint32_t s_depth[THREADS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // one chunk per workgroup in the count pass; the direct scatter behind the staged one is launched with a small grid that strides
-    // over the chunks and only works on the flagged ones (usually none)
-  // workgroup b runs on XCD b & 7 and takes chunk (b >> 3) of that XCD's contiguous band of chunks: the slices that consecutive
-  // chunks write into a tile's segment are adjacent in memory (a 128-byte line holds ~4 of them), and this way they meet in ONE L2
-  // before the line is written back, instead of leaving four L2s as four partial lines
+  // Scatter pass: workgroup b runs on XCD b & 7 and takes chunk (b >> 3) of that XCD's contiguous band of chunks.  The 8-byte pair
+  // stores of a chunk go to ~1000 tile segments, ~4 instances (32 bytes) each; the slices that CONSECUTIVE chunks write into a tile's
+  // segment are adjacent in memory, so this way the ~4 slices of a 128-byte line meet in ONE write-back L2 and leave it as a whole line,
+  // instead of leaving four L2s as four partial lines (2 M Gaussians: 55 -> 33 us; an LDS-staged variant that ordered a chunk's
+  // instances by tile before writing them reached 42 us in plain chunk order and nothing on top of this one: removed).  The count pass
+  // writes whole matrix rows: plain order (measured faster).
   const int cper = (nchunks + 7) >> 3;
   for (int b = blockIdx.x; b < 8 * cper; b += gridDim.x) {
-    const int cid = SCATTER ? (b & 7) * cper + (b >> 3) : b;      // (the count pass writes whole matrix rows: plain order, measured faster)
+    const int cid = SCATTER ? (b & 7) * cper + (b >> 3) : b;
     if (cid >= nchunks) continue;
     uint32_t* my_base = tile_base + (size_t)cid * tiles;
-    if (SCATTER && chunk_flags && chunk_flags[cid] == 0u) continue;           // this chunk went through the staged scatter
     __syncthreads();
     for (int t = tid; t < tiles; t += THREADS) s_hist[t] = SCATTER ? ranges[t].x + my_base[t] : 0u;
     __syncthreads();
@@ -137,101 +133,6 @@ __global__ __launch_bounds__(THREADS) void tile_bin_kernel(Cam cam, int P, GeomP
         for (int t = tid; t < tiles; t += THREADS) my_base[t] = s_hist[t];
     }
   }
-}
-
-// Scatter, staged: the 8-byte pair stores of the direct scatter above go to ~1000 different tile segments per workgroup, one lane
-// at a time -- 4.8 M separate partial-line writes at 2 M Gaussians, 45 of that kernel's 55 us (with the stores removed it takes
-// 10 us).  Here a workgroup first sorts its chunk's instances by tile INSIDE LDS (count -> exclusive scan -> place, all with LDS
-// integer atomics), then copies them out in that order: the instances of a (chunk, tile) slice are adjacent in LDS and in HBM, so
-// adjacent lanes write adjacent addresses and a slice leaves as one request.  Chunks that hold a large rect (> 16 tiles) or more
-// instances than the staging buffer takes are flagged and left to the direct kernel.
-template <int THREADS, int ROUNDS>
-__global__ __launch_bounds__(THREADS) void tile_scatter_staged_kernel(Cam cam, int P, GeomPtrs gp, int tiles, const uint32_t* __restrict__ tile_base,
-                                                                      const uint2* __restrict__ ranges, unsigned long long* __restrict__ pairs,
-                                                                      uint32_t cap, int stage_cap, uint32_t* __restrict__ chunk_flags)
-{
-    GS_DYNAMIC_LDS(s_dyn);
-    unsigned long long* s_stage = reinterpret_cast<unsigned long long*>(s_dyn);             // [stage_cap]
-    uint32_t* s_gslot = reinterpret_cast<uint32_t*>(s_stage + stage_cap);                      // [stage_cap]
-    uint32_t* s_cur = s_gslot + stage_cap;                                                      // [tiles]: counts, then cursors
-    uint32_t* s_delta = s_cur + tiles;                                                          // [tiles]: global slot - local slot
-    __shared__ uint32_t s_w[THREADS / kWave];
-    __shared__ uint32_t s_carry;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-banded chunk order (see tile_bin_kernel): adjacent slices of a tile segment are written through the same L2
-    const int nchunks = (P + THREADS * ROUNDS - 1) / (THREADS * ROUNDS), cper = (nchunks + 7) >> 3;
-    const int chunk = (int)(blockIdx.x & 7) * cper + (int)(blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= cper || chunk >= nchunks) return;
-    const int cbase = chunk * THREADS * ROUNDS;
-    for (int t = tid; t < tiles; t += THREADS) s_cur[t] = 0u;
-    if (tid == 0) s_carry = 0u;
-    uint32_t n[ROUNDS], x0[ROUNDS], w[ROUNDS], y0[ROUNDS], dbits[ROUNDS];
-    bool big = false;
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        const int i = cbase + r * THREADS + tid;
-        n[r] = 0; x0[r] = 0; w[r] = 1; y0[r] = 0; dbits[r] = 0;
-        if (i < P) {
-            n[r] = gp.tiles[i];
-            if (n[r]) {
-                const uint2 rc = gp.rect[i];
-                x0[r] = rc.x & 0xffffu; w[r] = (rc.x >> 16) - x0[r]; y0[r] = rc.y & 0xffffu;
-                dbits[r] = gp.depth_bits[i];
-            }
-        }
-        big = big || n[r] > 16u;
-    }
-    const bool any_big = __syncthreads_or(big) != 0;           // (also orders the zero fill of s_cur before the counting)
-    if (any_big) { if (tid == 0) chunk_flags[chunk] = 1u; return; }
-    // ---- count ----
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        uint32_t kx = 0, ky = 0;
-        for (uint32_t k = 0; k < n[r]; k++) {
-            atomicAdd(&s_cur[(y0[r] + ky) * (uint32_t)cam.gx + x0[r] + kx], 1u);
-            if (++kx == w[r]) { kx = 0; ++ky; }
-        }
-    }
-    __syncthreads();
-    // ---- exclusive scan over the tiles: s_cur[t] = first local slot of tile t, s_delta[t] = (its global slot) - (its local slot) ----
-    const uint32_t* my_base = tile_base + (size_t)chunk * tiles;
-    for (int b = 0; b < tiles; b += THREADS) {
-        const int t = b + tid;
-        const uint32_t v = t < tiles ? s_cur[t] : 0u;
-        const uint32_t inc = wave_inclusive_scan(v, lane);
-        if (lane == 63) s_w[wave] = inc;
-        __syncthreads();
-        uint32_t wprefix = 0;
-        for (int q = 0; q < wave; q++) wprefix += s_w[q];
-        const uint32_t carry = s_carry;
-        const uint32_t start = carry + wprefix + inc - v;
-        if (t < tiles) { s_cur[t] = start; s_delta[t] = ranges[t].x + my_base[t] - start; }
-        __syncthreads();
-        if (tid == THREADS - 1) s_carry = carry + wprefix + inc;
-        __syncthreads();
-    }
-    const uint32_t total = s_carry;
-    if (total > (uint32_t)stage_cap) { if (tid == 0) chunk_flags[chunk] = 1u; return; }      // uniform
-    if (tid == 0) chunk_flags[chunk] = 0u;
-    // ---- place into LDS, sorted by tile ----
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        const uint32_t id = (uint32_t)(cbase + r * THREADS + tid);
-        uint32_t kx = 0, ky = 0;
-        for (uint32_t k = 0; k < n[r]; k++) {
-            const uint32_t tile = (y0[r] + ky) * (uint32_t)cam.gx + x0[r] + kx;
-            const uint32_t ls = atomicAdd(&s_cur[tile], 1u);
-            s_stage[ls] = ((unsigned long long)dbits[r] << 32) | id;
-            s_gslot[ls] = ls + s_delta[tile];
-            if (++kx == w[r]) { kx = 0; ++ky; }
-        }
-    }
-    __syncthreads();
-    // ---- copy out: adjacent lanes, adjacent slots of a slice ----
-    for (uint32_t j = tid; j < total; j += THREADS) {
-        const uint32_t gs = s_gslot[j];
-        if (gs < cap) pairs[gs] = s_stage[j];
-    }
 }
 
 // Column-wise exclusive scan of the [chunks][tiles] count matrix, in place: base[c][t] = instances of tile t in the chunks before c;
@@ -613,13 +514,11 @@ static void bin_config(int P, int& threads, int& chunk)
 
 template <bool SCATTER>
 static void launch_bin(int threads, int nb, hipStream_t st, Cam cam, int P, GeomPtrs gp, int tiles, int chunk,
-                       uint32_t* tile_total, uint32_t* tile_base, const uint2* ranges, unsigned long long* pairs, uint32_t cap,
-                       const uint32_t* flags = nullptr)
+                       uint32_t* tile_total, uint32_t* tile_base, const uint2* ranges, unsigned long long* pairs, uint32_t cap)
 {
     const int nchunks = nb;
     nb = 8 * ((nb + 7) / 8);                              // XCD bands of chunks
-    if (flags && nb > 64) nb = 64;                       // stride loop: the flagged chunks are few
-    hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 1024>), dim3(nb), dim3(1024), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs, cap, flags, nchunks);
+    hipLaunchKernelGGL((tile_bin_kernel<SCATTER, 1024>), dim3(nb), dim3(1024), 0, st, cam, P, gp, tiles, chunk, tile_total, tile_base, ranges, pairs, cap, nchunks);
 }
 
 hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,
@@ -634,8 +533,6 @@ hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_
     return hipGetLastError();
 }
 
-int g_staged_min_chunks = 512;            // gs_set_scatter_staging (development knob)
-
 hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_base, const uint2* ranges,
                                     uint32_t max_tile_instances, unsigned long long* pairs, unsigned long long* pairs_alt,
                                     uint32_t* point_list, uint32_t cap, hipStream_t st)
@@ -643,23 +540,7 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
     const int tiles = cam.gx * cam.gy;
     int threads, chunk; bin_config(P, threads, chunk);
     const int nb = (P + chunk - 1) / chunk;
-    if (nb >= g_staged_min_chunks && chunk == 2048) {
-        // large maps (>= 1 M Gaussians; measured: 2 M 55 -> 42 + 4 us, 500 k 17 -> 14 + 4 us, i.e. no gain there): staged scatter for
-        // the usual chunks, the direct kernel for the ones it flags (large rects, overfull chunks)
-        constexpr int kLdsBudget = 76 * 1024;                                 // two workgroups per CU
-        const int stage_cap = (kLdsBudget - tiles * 8) / 12;
-        if (stage_cap >= 2048) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_scatter_staged_kernel<1024, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
-                attr_set = true;
-            }
-            const size_t dyn = (size_t)stage_cap * 12 + (size_t)tiles * 8;
-            hipLaunchKernelGGL((tile_scatter_staged_kernel<1024, 2>), dim3(8 * ((nb + 7) / 8)), dim3(1024), dyn, st, cam, P, gp, tiles, tile_base, ranges, pairs, cap,
-                               stage_cap, gp.chunk_flags);
-            launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap, gp.chunk_flags);
-        } else launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
-    } else if (nb > 0) launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
+    if (nb > 0) launch_bin<true>(threads, nb, st, cam, P, gp, tiles, chunk, nullptr, tile_base, ranges, pairs, cap);
     // Lists of at most 2048 keys: one 2048-key sort per tile.  Longer lists: 4096-key runs sorted with 16 keys per thread (the same 36
     // partner steps as a 2048-key sort; measured at 2 M Gaussians, lists of ~4000: 53 us + 15 us of merging against 45 + 31 us with
     // 2048-key runs), then the runs of a tile are merged -- by rank inside LDS up to kSortCapMax keys, pass by pass through global

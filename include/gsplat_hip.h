@@ -21,7 +21,7 @@
  *   - return value 0 = success, otherwise a GS_E* code; gs_last_error() gives the message;
  *   - no torch types.  Process-wide state: the last-error string (thread-local), and three development knobs that are NOT
  *     synchronised with rendering calls on other threads -- set them while nothing is in flight: gs_set_sort_path,
- *     gs_set_forward_segments, gs_set_scatter_staging, gs_set_half_quadrants (defaults: automatic path choice, segments on, staging from 1 M Gaussians) and the gs_profile_* event log (off).
+ *     gs_set_forward_segments, gs_set_half_quadrants (defaults: automatic path choice, segments on, few-tile kernels up to 256 tiles) and the gs_profile_* event log (off).
  *
  * Call sequence for one forward:
  *     gs_preprocess_forward(...)            // per-Gaussian stage + tile counting; writes the counts
@@ -85,7 +85,6 @@ typedef struct GsGeomLayout {
     uint64_t tile_base;     /* uint32 [ceil(P/4096)][tiles]: slice reserved by each binning workgroup */
     uint64_t sh_jac;        /* float [P][12]: 3x3 d(rgb)/d(view direction) of SH inputs (9 used), written when want_backward */
     uint64_t depth_bits;    /* uint32 [P]: float bits of the view-space depth (binning key) */
-    uint64_t chunk_flags;   /* uint32 [ceil(P/1024)]: binning chunks left to the direct scatter kernel */
 } GsGeomLayout;
 
 typedef struct GsImageLayout {
@@ -129,9 +128,6 @@ int gs_set_sort_path(int32_t path);
 /* Segmented compositing of long tile lists in images of few tiles (GsBinLayout.segments > 1): on by default; 0 switches it
  * off (every list is then walked by one workgroup, bit-reproducible forward). */
 int gs_set_forward_segments(int32_t on);
-/* The tile scatter stages a chunk's instances in LDS (sorted by tile, written out slice by slice) when the map has at least
- * min_chunks binning chunks of 2048 Gaussians (default 512 = 1 M Gaussians; 0 = always, negative = never). */
-int gs_set_scatter_staging(int32_t min_chunks);
 /* Images of at most max_tiles tiles (default 256; 0 = never) get twice the wavefronts: 256 tiles x 4 quadrants are one wavefront per SIMD of
  * an MI355X.  The forward's wavefronts take half an 8 x 8 quadrant each (half their lanes idle; results unchanged); the backward walks every
  * tile list in two segments, the front one from a per-pixel state the forward recorded at the cut (gradients agree to rounding). */

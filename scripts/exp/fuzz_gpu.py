@@ -1,5 +1,5 @@
 """Development helper (uses the oracle: a checker run, not product code): a wider random sweep of the parity cases on the GPU than the
-test suite holds -- more seeds, larger Gaussian counts (several binning chunks, merged tile lists), the staged scatter forced on."""
+test suite holds -- more seeds, larger Gaussian counts (several binning chunks, merged tile lists)."""
 import os, sys, traceback
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,12 +25,10 @@ for seed in range(n0, n1):
                                 sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
             rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
             rv["scales"] = rv["scales"] * float(np.exp(r.uniform(-0.5, 1.5)))
-        lib.gs_set_scatter_staging(0 if mode >= 2 else 512)
         pc.check_forward(rs, rv, o32)
         if seed % 3 == 0:
             pc.check_backward(rs, rv, o64, min_frac=0.99, oracle32=o32)
     except Exception as e:
         bad.append((seed, repr(e)[:300]))
         print("FAIL seed", seed, repr(e)[:300], flush=True)
-lib.gs_set_scatter_staging(512)
 print("seeds %d..%d: %d failures" % (n0, n1, len(bad)))

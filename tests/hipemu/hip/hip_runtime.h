@@ -322,28 +322,13 @@ static inline hipError_t hipPeekAtLastError() { return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 
-// dynamic LDS (extern __shared__): one buffer per host worker thread, sized by the launch
-namespace hipemu {
-inline size_t& dyn_bytes() { static size_t b = 0; return b; }
-inline unsigned char* dyn_lds()
-{
-    static thread_local std::vector<unsigned long long> buf;
-    const size_t need = (dyn_bytes() + 7) / 8 + 2;
-    if (buf.size() < need) buf.resize(need);
-    return reinterpret_cast<unsigned char*>(buf.data());
-}
-}  // namespace hipemu
-#define GS_DYNAMIC_LDS(name) unsigned char* name = hipemu::dyn_lds()
 // v_min_f64 / v_max_f64 of the tile sort (inline assembly in the device build)
 #define GS_MIN_F64(a, b) std::fmin(a, b)
 #define GS_MAX_F64(a, b) std::fmax(a, b)
-enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
-static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
 
 template <class K, class... A>
-static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, A... args)
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... args)
 {
-    hipemu::dyn_bytes() = shmem;
     std::function<void()> body = [=]() { kernel(args...); };
     hipemu::run_grid(grid, block, body);
 }

@@ -95,23 +95,6 @@ def set_sort_path(path):
     _lib.check(_lib.get().gs_set_sort_path({"auto": 0, "tile_lds": 1, "radix": 2}[path]))
 
 
-def check_staged_scatter(device, oracle32):
-    """The LDS-staged tile scatter (default: maps of >= 1 M Gaussians) forced on for small cases: ordinary chunks, a chunk flagged for
-    the direct kernel because it holds large rects, overfull chunks (more instances than the staging buffer), ragged images."""
-    from activesplat_amd import _lib
-    lib = _lib.get()
-    _lib.check(lib.gs_set_scatter_staging(0))
-    try:
-        for name in ("basic", "ragged_image", "huge_gaussians", "merge_tiles", "behind_camera", "not_multiple_of_block", "dense_overdraw"):
-            rs, rv = build_case(name, device)
-            check_forward(rs, rv, oracle32)
-        rs, rv = util.scene(30000, 320, 240, seed=4, device=device)            # 15 chunks; a few huge Gaussians flag theirs
-        rv["scales"][::4001] *= 40.0
-        check_forward(rs, rv, oracle32)
-    finally:
-        _lib.check(lib.gs_set_scatter_staging(512))
-
-
 def check_whole_quadrants_on_small_images(device, oracle32, oracle64):
     """Images of at most 256 tiles are blended by half-quadrant wavefronts (default), so the small parity cases all run that way: here
     the same cases with whole quadrants (what larger images use), and both must agree with each other bit for bit in the forward."""

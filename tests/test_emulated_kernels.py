@@ -146,9 +146,6 @@ def test_emulated_segmented_forward(emu, oracle32):
     pc.check_segmented_forward(emu, oracle32)
 
 
-def test_staged_scatter_forced_on(emu, oracle32):
-    pc.check_staged_scatter(emu, oracle32)
-
 
 def test_whole_quadrants_on_small_images(emu, oracle32, oracle64):
     pc.check_whole_quadrants_on_small_images(emu, oracle32, oracle64)

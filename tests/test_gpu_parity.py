@@ -196,9 +196,6 @@ def test_segmented_forward(hip, oracle32):
     pc.check_segmented_forward(hip, oracle32)
 
 
-def test_staged_scatter_forced_on(hip, oracle32):
-    pc.check_staged_scatter(hip, oracle32)
-
 
 def test_whole_quadrants_on_small_images(hip, oracle32, oracle64):
     pc.check_whole_quadrants_on_small_images(hip, oracle32, oracle64)
