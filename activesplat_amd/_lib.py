@@ -38,6 +38,12 @@ class GsAdamTensor(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class GsRowTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("grad", C.c_void_p),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("width", C.c_int32),
+                ("step", C.c_int32)]
+
+
 class GsBinLayout(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("total_bytes", "path", "pairs", "keys_unsorted", "vals_unsorted", "keys_sorted",
                                           "sort_temp", "segments", "seg_T", "pairs_alt")]
@@ -52,7 +58,8 @@ SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_sc
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
            "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward",
            "gs_grow_scratch_bytes", "gs_grow_gaussians", "gs_keyframe_overlap", "gs_visibility_stats", "gs_accumulate_grad2d",
-           "gs_gather_rows_zero_tail", "gs_densify_classify", "gs_densify_children", "gs_atlas_layout")
+           "gs_gather_rows_zero_tail", "gs_densify_classify", "gs_densify_children", "gs_atlas_layout",
+           "gs_pack_columns", "gs_adam_rows", "gs_unpack_columns")
 
 
 def _bind(lib):
@@ -114,6 +121,12 @@ def _bind(lib):
     lib.gs_accumulate_grad2d.argtypes = [i32, vp, vp, vp, vp, vp]
     lib.gs_accumulate_grad2d.restype = C.c_int
     lib.gs_adam_step_multi.restype = C.c_int
+    lib.gs_pack_columns.argtypes = [i32, C.POINTER(GsRowTensor), i64, i64, vp, vp]
+    lib.gs_pack_columns.restype = C.c_int
+    lib.gs_adam_rows.argtypes = [i32, C.POINTER(GsRowTensor), i64, i64, i64, vp, vp, vp]
+    lib.gs_adam_rows.restype = C.c_int
+    lib.gs_unpack_columns.argtypes = [i32, C.POINTER(GsRowTensor), i64, vp, vp]
+    lib.gs_unpack_columns.restype = C.c_int
     for n in ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_preprocess_forward", "gs_render_forward",
               "gs_render_backward", "gs_adam_step"):
         getattr(lib, n).restype = C.c_int

@@ -10,15 +10,6 @@
 
 namespace gs {
 
-__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float one_m_b1, float b2, float one_m_b2,
-                                          float step_size, float inv_bc2s, float eps)
-{
-    m = m + one_m_b1 * (g - m);
-    v = b2 * v + one_m_b2 * g * g;
-    const float denom = sqrtf(v) * inv_bc2s + eps;
-    p = p - step_size * (m / denom);
-}
-
 __global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v, float one_m_b1,
                                                        float b2, float one_m_b2, float step_size, float inv_bc2s, float eps)

@@ -435,6 +435,49 @@ int gs_adam_step_multi(int32_t count, const GsAdamTensor* tensors, gs_stream_t s
     return GS_OK;
 }
 
+static int rows_args_ok(int32_t count, const GsRowTensor* t, int mode)
+{
+    if (count < 1 || count > gs::kAdamMaxTensors || !t) return 0;
+    int G = 0;
+    for (int i = 0; i < count; ++i) {
+        if (t[i].width < 1 || t[i].width > 64) return 0;
+        G += t[i].width;
+        if (mode != 0 && !t[i].param) return 0;
+        if (mode == 2 && (!t[i].exp_avg || !t[i].exp_avg_sq || t[i].step < 1)) return 0;
+    }
+    return G <= 64;
+}
+
+int gs_pack_columns(int32_t count, const GsRowTensor* tensors, int64_t n, int64_t n_padded, float* flat, gs_stream_t stream)
+{
+    if (!rows_args_ok(count, tensors, 0) || n < 0 || n_padded < n || (n_padded > 0 && !flat)) return fail(GS_EINVAL, "gs_pack_columns: bad argument");
+    hipError_t e = gs::launch_rows(0, count, tensors, 0, n, n_padded, nullptr, flat, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_pack_columns: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_adam_rows(int32_t count, const GsRowTensor* tensors, int64_t row_lo, int64_t n_valid, int64_t n_rows, const float* grad_shard,
+                 float* out_shard, gs_stream_t stream)
+{
+    if (!rows_args_ok(count, tensors, 2) || row_lo < 0 || n_valid < 0 || n_rows < n_valid || (n_rows > 0 && !grad_shard))
+        return fail(GS_EINVAL, "gs_adam_rows: bad argument");
+    hipError_t e;
+    {
+        ScopedStage sc(ST_ADAM, (hipStream_t)stream);
+        e = gs::launch_rows(2, count, tensors, row_lo, n_valid, n_rows, grad_shard, out_shard, (hipStream_t)stream);
+    }
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_adam_rows: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_unpack_columns(int32_t count, const GsRowTensor* tensors, int64_t n, const float* flat, gs_stream_t stream)
+{
+    if (!rows_args_ok(count, tensors, 1) || n < 0 || (n > 0 && !flat)) return fail(GS_EINVAL, "gs_unpack_columns: bad argument");
+    hipError_t e = gs::launch_rows(1, count, tensors, 0, n, n, flat, nullptr, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_unpack_columns: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
 int gs_activate_forward(int32_t P, int32_t isotropic, const float* h_pose7, const float* means3D, const float* unnorm_rotations,
                         const float* logit_opacities, const float* log_scales, float* out_means3D, float* out_rotations,
                         float* out_opacities, float* out_scales, gs_stream_t stream)

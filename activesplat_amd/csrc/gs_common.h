@@ -293,6 +293,16 @@ __device__ __forceinline__ void sh_direction_jacobian(int deg, float x, float y,
 }
 #undef GS_SHJ
 
+// One Adam update (torch's single-tensor arithmetic; adam.hip and rows.hip share it so that the keyframe-sharded step is the full step to the bit)
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float one_m_b1, float b2, float one_m_b2,
+                                          float step_size, float inv_bc2s, float eps)
+{
+    m = m + one_m_b1 * (g - m);
+    v = b2 * v + one_m_b2 * g * g;
+    const float denom = sqrtf(v) * inv_bc2s + eps;
+    p = p - step_size * (m / denom);
+}
+
 // ---- launchers implemented in the individual translation units -------------------------------------
 hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D, const float* shs,
                                      const float* colors, const float* opac, const float* scales,
@@ -326,6 +336,8 @@ hipError_t launch_blend_backward(const Cam& cam, const uint2* ranges, const uint
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  const float* dL_ddepth, float* grad2d, hipStream_t st);
 hipError_t launch_adam_multi(int count, const GsAdamTensor* tensors, hipStream_t st);
+hipError_t launch_rows(int mode, int count, const GsRowTensor* t, int64_t row0, int64_t n_valid, int64_t n_rows, const float* in, float* out,
+                       hipStream_t st);
 hipError_t launch_adam(int64_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2,
                        double eps, int step, hipStream_t st);
 

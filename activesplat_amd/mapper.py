@@ -182,7 +182,7 @@ class SplatMapper:
                     self.params, self.variables = O.densify(self.params, self.variables, self.optimizer, it, mc["densify_dict"])
                 self.optimizer.step()
                 self.optimizer.zero_grad(set_to_none=True)
-            self._last_losses = losses                  # converted on access: a float() here would stall the host every iteration
+            self._last_losses = {k: v.detach() for k, v in losses.items()}   # (no graph kept alive) converted on access: a float() here would stall the host every iteration
             self.stats["iters"] += 1
             self.stats["iter_time"] += time.perf_counter() - t0
         if iter_per_frame > 0:

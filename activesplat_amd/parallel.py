@@ -24,37 +24,87 @@ def shard_keyframes(num_keyframes: int, rank: int, world: int) -> range:
     return range(start, start + base + (1 if rank < extra else 0))
 
 
-class FlatGradBuffer:
-    """One contiguous [N, G] fp32 buffer that the per-key gradients are packed into for a single collective."""
+#: what the most recent gradient exchange of this process actually ran (bench.py prints it): backend, the collectives, and -- with
+#: `timing=True` -- CUDA events around exchange + Adam
+last_exchange = {}
 
-    def __init__(self, params, keys=GRAD_KEYS):
+
+def _backend(group=None) -> str:
+    return str(dist.get_backend(group)).lower()
+
+
+def _stream(t):
+    import ctypes as C
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else C.c_void_p(0)
+
+
+def _row_tensors(params, keys, optimizer=None, target="param"):
+    """HOST descriptor array of the per-key tensors for the gs_pack_columns / gs_adam_rows / gs_unpack_columns launches.
+    target="param": rows are read/written in the parameters; target="grad": in their .grad tensors (all-reduce path)."""
+    from . import _lib
+    arr = (_lib.GsRowTensor * len(keys))()
+    keep = []
+    groups = {g["name"]: g for g in optimizer.param_groups} if optimizer is not None else {}
+    for i, k in enumerate(keys):
+        p = params[k]
+        if not p.is_contiguous() or p.dtype != torch.float32:
+            raise RuntimeError("keyframe-sharded step needs contiguous fp32 parameters")
+        g = p.grad
+        if g is not None and (not g.is_contiguous() or g.dtype != torch.float32):
+            g = g.contiguous().float()
+        keep.append(g)
+        t = arr[i]
+        t.width = int(p.shape[1])
+        t.grad = g.data_ptr() if g is not None else None
+        t.param = (g.data_ptr() if g is not None else None) if target == "grad" else p.data_ptr()
+        t.step = 1
+        if optimizer is not None:
+            grp, st = groups[k], optimizer.state[p]
+            b1, b2 = grp["betas"]
+            t.exp_avg, t.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            t.lr, t.beta1, t.beta2, t.eps, t.step = float(grp["lr"]), float(b1), float(b2), float(grp["eps"]), int(st["step"].item())
+    return arr, keep
+
+
+class FlatGradBuffer:
+    """One contiguous [N_padded, G] fp32 buffer that the per-key gradients are packed into for a single collective
+    (gs_pack_columns: ONE launch writes gradients, zero columns of keys without a gradient and the zero padding rows)."""
+
+    def __init__(self, params, keys=GRAD_KEYS, pad_to=1):
         self.keys = [k for k in keys if k in params]
         self.widths = [params[k].shape[1] for k in self.keys]
-        n = params[self.keys[0]].shape[0]
-        self.flat = torch.zeros(n, sum(self.widths), dtype=torch.float32, device=params[self.keys[0]].device)
+        self.n = int(params[self.keys[0]].shape[0])
+        self.n_padded = (self.n + pad_to - 1) // pad_to * pad_to
+        dev = params[self.keys[0]].device
+        self.padded = torch.empty(self.n_padded, sum(self.widths), dtype=torch.float32, device=dev)
+        self.flat = self.padded[:self.n]
 
     def pack(self, params):
-        col = 0
-        for k, w in zip(self.keys, self.widths):
-            g = params[k].grad
-            self.flat[:, col:col + w] = 0 if g is None else g
-            col += w
+        from . import _lib
+        arr, keep = _row_tensors(params, self.keys)
+        _lib.check(_lib.get().gs_pack_columns(len(self.keys), arr, self.n, self.n_padded, self.padded.data_ptr(), _stream(self.padded)))
         return self.flat
 
     def unpack(self, params):
-        col = 0
-        for k, w in zip(self.keys, self.widths):
-            params[k].grad = self.flat[:, col:col + w].contiguous()
-            col += w
+        """flat -> the keys' .grad tensors (in place where a gradient tensor exists), one launch."""
+        from . import _lib
+        for k in self.keys:
+            if params[k].grad is None or not params[k].grad.is_contiguous():
+                params[k].grad = torch.empty_like(params[k])
+        arr, keep = _row_tensors(params, self.keys, target="grad")
+        _lib.check(_lib.get().gs_unpack_columns(len(self.keys), arr, self.n, self.padded.data_ptr(), _stream(self.padded)))
 
 
-def all_reduce_gradients(params, buf: FlatGradBuffer | None = None, group=None):
-    """Sum the locally accumulated .grad of every per-Gaussian tensor over all ranks (one all-reduce)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def all_reduce_gradients(params, buf: FlatGradBuffer | None = None, group=None, force=False):
+    """Sum the locally accumulated .grad of every per-Gaussian tensor over all ranks (one all-reduce of the flat [N, 14] buffer).
+    A one-rank group is a no-op unless force=True (the collective then really runs: RCCL's first contact in the 1-GPU tests)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return buf
-    buf = FlatGradBuffer(params) if buf is None else buf
+    if buf is None or buf.n != int(params[buf.keys[0]].shape[0]):
+        buf = FlatGradBuffer(params)
     dist.all_reduce(buf.pack(params), op=dist.ReduceOp.SUM, group=group)
     buf.unpack(params)
+    last_exchange.update(backend=_backend(group), reduce="all_reduce", gather=None, bytes=buf.flat.numel() * 4)
     return buf
 
 
@@ -69,7 +119,7 @@ def all_reduce_statistics(variables, group=None):
 
 
 def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank=None, world=None, buf=None,
-                          sharded_adam=False, streams=1, densify_statistics=False):
+                          sharded_adam=False, streams=1, densify_statistics=False, timing=False):
     """One optimiser step over a batch of keyframes sharded across ranks.
     loss_fn(params, keyframe, variables) -> (loss, variables).  Returns the local loss sum.
 
@@ -131,7 +181,7 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
     if world <= 1 or not on:
         optimizer.step()                         # one rank (or a caller that overrides rank/world to run the batch alone): no collective
     elif sharded_adam:
-        reduce_scatter_adam_step(params, optimizer)
+        reduce_scatter_adam_step(params, optimizer, timing=timing)
     else:
         buf = all_reduce_gradients(params, buf)
         optimizer.step()
@@ -149,59 +199,75 @@ def _row_block(n: int, rank: int, world: int):
     return rows, min(rank * rows, n), min((rank + 1) * rows, n)
 
 
-def _reduce_scatter_rows(flat_padded, rows, rank, group):
-    out = torch.empty(rows, flat_padded.shape[1], dtype=flat_padded.dtype, device=flat_padded.device)
-    try:
+def _reduce_scatter_rows(flat_padded, out, rank, group):
+    """out[rows, G] = this rank's row block of the sum over ranks.  RCCL: reduce_scatter_tensor; gloo (CPU tests, the same-device
+    development knob of bench.py) has no reduce-scatter: all-reduce, then the row block.  The branch is decided by the BACKEND --
+    a collective that fails raises."""
+    rows = out.shape[0]
+    if _backend(group) == "nccl":
         dist.reduce_scatter_tensor(out, flat_padded, op=dist.ReduceOp.SUM, group=group)
-    except (RuntimeError, NotImplementedError):          # gloo (CPU tests) has no reduce-scatter
-        dist.all_reduce(flat_padded, op=dist.ReduceOp.SUM, group=group)
-        out.copy_(flat_padded[rank * rows:(rank + 1) * rows])
-    return out
+        return "reduce_scatter_tensor"
+    dist.all_reduce(flat_padded, op=dist.ReduceOp.SUM, group=group)
+    out.copy_(flat_padded[rank * rows:(rank + 1) * rows])
+    return "all_reduce+slice"
 
 
 def _all_gather_rows(full_padded, mine, group):
-    try:
+    if _backend(group) == "nccl":
         dist.all_gather_into_tensor(full_padded, mine, group=group)
-    except (RuntimeError, NotImplementedError):
-        parts = list(full_padded.chunk(dist.get_world_size(group), dim=0))
-        dist.all_gather(parts, mine, group=group)
-    return full_padded
+        return "all_gather_into_tensor"
+    parts = list(full_padded.chunk(dist.get_world_size(group), dim=0))
+    dist.all_gather(parts, mine, group=group)
+    return "all_gather(list)"
 
 
-def reduce_scatter_adam_step(params, optimizer, group=None):
-    """Replaces `all_reduce_gradients(...); optimizer.step()` when every rank holds replicated parameters."""
-    from . import _lib, optim as O
+def reduce_scatter_adam_step(params, optimizer, group=None, timing=False):
+    """Replaces `all_reduce_gradients(...); optimizer.step()` when every rank holds replicated parameters:
+    pack (1 launch) -> reduce-scatter -> fused Adam on the rank's row block of all keys (1 launch, writes the all-gather's send
+    buffer) -> all-gather -> unpack (1 launch).  The buffers live on the optimizer and are reused from step to step."""
+    from . import _lib
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    buf = FlatGradBuffer(params)
-    n, G = buf.flat.shape
-    rows, lo, hi = _row_block(n, rank, world)
-    padded = torch.zeros(rows * world, G, dtype=torch.float32, device=buf.flat.device)
-    padded[:n] = buf.pack(params)
-    gshard = _reduce_scatter_rows(padded, rows, rank, group)
+    keys = [k for k in GRAD_KEYS if k in params]
+    n = int(params[keys[0]].shape[0])
+    plan = getattr(optimizer, "_shard_plan", None)
+    if plan is None or plan["n"] != n or plan["world"] != world or plan["buf"].padded.device != params[keys[0]].device:
+        rows, lo, hi = _row_block(n, rank, world)
+        buf = FlatGradBuffer(params, pad_to=rows * world)          # whole row blocks: rows * world >= n
+        G = buf.padded.shape[1]
+        plan = optimizer._shard_plan = dict(n=n, world=world, rows=rows, lo=lo, hi=hi, buf=buf,
+                                            gshard=torch.empty(rows, G, dtype=torch.float32, device=buf.padded.device),
+                                            pshard=torch.empty(rows, G, dtype=torch.float32, device=buf.padded.device))
+    buf, rows, lo, hi = plan["buf"], plan["rows"], plan["lo"], plan["hi"]
     lib = _lib.get()
-    pshard = torch.zeros(rows, G, dtype=torch.float32, device=buf.flat.device)
-    groups = {g["name"]: g for g in optimizer.param_groups}
-    col = 0
+    ev = None
+    if timing and buf.padded.is_cuda:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+    buf.pack(params)
+    how_r = _reduce_scatter_rows(buf.padded, plan["gshard"], rank, group)
     with torch.no_grad():
-        for k, w in zip(buf.keys, buf.widths):
-            p, g = params[k], groups[k]
+        for k in keys:
+            p = params[k]
             st = optimizer.state.get(p)
             if st is None or len(st) == 0:
                 st = optimizer.state[p] = {"step": torch.tensor(0.0), "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
             st["step"] = st["step"] + 1
-            if hi > lo:
-                grad = gshard[:hi - lo, col:col + w].contiguous()
-                b1, b2 = g["betas"]
-                _lib.check(lib.gs_adam_step((hi - lo) * w, p.data[lo:hi].data_ptr(), grad.data_ptr(), st["exp_avg"][lo:hi].data_ptr(),
-                                            st["exp_avg_sq"][lo:hi].data_ptr(), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
-                                            int(st["step"].item()), O._stream(p)))
-                pshard[:hi - lo, col:col + w] = p.data[lo:hi]
-            col += w
-        full = _all_gather_rows(padded, pshard, group)     # reuse the padded buffer for the updated rows
-        col = 0
-        for k, w in zip(buf.keys, buf.widths):
-            params[k].data.copy_(full[:n, col:col + w])
-            col += w
+        arr, keep = _row_tensors(params, keys, optimizer)
+        _lib.check(lib.gs_adam_rows(len(keys), arr, lo, hi - lo, rows, plan["gshard"].data_ptr(), plan["pshard"].data_ptr(), _stream(buf.padded)))
+        how_g = _all_gather_rows(buf.padded, plan["pshard"], group)      # the send buffer of the reduce-scatter takes the updated rows
+        _lib.check(lib.gs_unpack_columns(len(keys), arr, n, buf.padded.data_ptr(), _stream(buf.padded)))
+    if ev is not None:
+        ev[1].record()
+    last_exchange.update(backend=_backend(group), reduce=how_r, gather=how_g, bytes=buf.padded.numel() * 4, events=ev)
+
+
+def exchange_ms():
+    """Milliseconds of the most recent timed exchange + sharded Adam (reduce_scatter_adam_step(timing=True)); None if not timed."""
+    ev = last_exchange.get("events")
+    if not ev:
+        return None
+    ev[1].synchronize()
+    return float(ev[0].elapsed_time(ev[1]))
 
 
 def gather_moments(params, optimizer, group=None):
@@ -217,5 +283,6 @@ def gather_moments(params, optimizer, group=None):
             t = st[name].reshape(n, -1)
             mine = torch.zeros(rows, t.shape[1], dtype=t.dtype, device=t.device)
             mine[:hi - lo] = t[lo:hi]
-            full = _all_gather_rows(torch.empty(rows * world, t.shape[1], dtype=t.dtype, device=t.device), mine, group)
+            full = torch.empty(rows * world, t.shape[1], dtype=t.dtype, device=t.device)
+            _all_gather_rows(full, mine, group)
             st[name].copy_(full[:n].reshape(st[name].shape))

@@ -230,7 +230,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         scratch, clean = ctx.scratch, ctx.scratch_clean
         if scratch is None:
             scratch, clean = torch.empty(int(lib.gs_backward_scratch_bytes(P)), dtype=torch.uint8, device=device), False
-        ctx.scratch_clean = False                        # a second backward through the same graph finds it dirty
+        ctx.scratch, ctx.scratch_clean = None, False     # released with this launch (64 B x P); a second backward through the same graph
+                                                         # takes a fresh buffer plus a memset
         _lib.check(lib.gs_render_backward(
             C.byref(cam), P, ctx.D, _ptr(means3D), _ptr(shs if has_sh else None), _ptr(colors if has_col else None),
             _ptr(scales if has_sc else None), _ptr(rots if has_rot else None), _ptr(cov3Dp if has_cov else None),
@@ -293,19 +294,23 @@ def render_views(settings_list, means3D, opacities, shs=None, colors_precomp=Non
     scale modifier and SH degree and differ in their view / projection matrices and camera centre.  The per-Gaussian stage runs
     once over V x P virtual Gaussians; binning, sorting and blending see ONE atlas image (GsCamera.num_views, gs_atlas_layout) --
     one set of launches and one host read of the counters instead of V.
-    -> list of (color [3,H,W], radii [P] int32, depth [1,H,W], opacity [1,H,W]) per view (views of the atlas tensors);
+    -> list of (color [3,H,W], radii [P] int32, depth [1,H,W], opacity [1,H,W]) per view (views of the atlas tensors; `radii` is the
+       view's first P rows of the padded virtual layout -- each view owns ceil(P/256)*256 rows, the padding rows are never returned);
     return_atlas=True: (color [3,H,AW], depth [1,H,AW], opacity [1,H,AW], view_stride) -- view v is columns [v stride, v stride + W).
     Settings whose tensors live on the host (setup_camera(device="cpu")) cost ONE host-to-device copy for all views."""
     lib = _lib.get()
     V = len(settings_list)
     rs0 = settings_list[0]
     if V == 1:
-        return [GaussianRasterizer(rs0)(means3D=means3D, means2D=None, opacities=opacities, shs=shs, colors_precomp=colors_precomp,
-                                        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)]
+        one = GaussianRasterizer(rs0)(means3D=means3D, means2D=None, opacities=opacities, shs=shs, colors_precomp=colors_precomp,
+                                      scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        return (one[0], one[2], one[3], int(rs0.image_width)) if return_atlas else [one]
+    bg0 = [float(x) for x in rs0.bg.reshape(-1).tolist()]
     for rs in settings_list[1:]:
         if (rs.image_width, rs.image_height, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.sh_degree) != \
-                (rs0.image_width, rs0.image_height, rs0.tanfovx, rs0.tanfovy, rs0.scale_modifier, rs0.sh_degree):
-            raise Exception("render_views: the views must share size, field of view, scale modifier and SH degree")
+                (rs0.image_width, rs0.image_height, rs0.tanfovx, rs0.tanfovy, rs0.scale_modifier, rs0.sh_degree) or \
+                (rs.bg is not rs0.bg and [float(x) for x in rs.bg.reshape(-1).tolist()] != bg0):
+            raise Exception("render_views: the views must share size, field of view, scale modifier, SH degree and background")
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
     device = means3D.device

@@ -1,0 +1,73 @@
+"""Synthetic WORKLOADS of the BASELINE configurations that more than one caller runs (bench.py legs, tests, scripts/)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import rasterizer as R
+from . import synthetic as syn
+from .camera import setup_camera
+
+
+def configs2_optimise_loop(N, iters, device, fused_densify=True, densify_every=50, sh_degree=3, W=640, H=480, seed=0, time_it=False):
+    """BASELINE configs[2]: N Gaussians with SH coefficients, one 640x480 target, `iters` iterations of
+    fused activations -> single-pass RGB-D render -> fused loss -> backward -> densify (every `densify_every`) -> fused Adam.
+    Returns dict(losses=[first, last], counts=[N after every densify event], seconds)."""
+    import time
+    from activesplat_amd import mapping as M, optim as O
+    dev = torch.device(device)
+    p = syn.make_params(N, W, H, seed=seed, sh_degree=sh_degree)
+    params = {k: torch.nn.Parameter(p[k].to(dev)) for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales")}
+    params["shs"] = torch.nn.Parameter(p["shs"].to(dev))
+    params["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([1.0, 0, 0, 0], device=dev).reshape(1, 4, 1))
+    params["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 1, device=dev))
+    lrs = dict(means3D=1e-4, shs=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
+    opt = O.initialize_optimizer(params, lrs)
+    variables = {k: torch.zeros(N, device=dev) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+    variables["scene_radius"] = torch.tensor(4.0 / 3.0, device=dev)
+    cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=dev, sh_degree=sh_degree)
+    gt_im, gt_depth = (t.to(dev) for t in syn.make_targets(W, H))
+    ddict = dict(start_after=0, remove_big_after=0, stop_after=iters, densify_every=densify_every, grad_thresh=0.0002, num_to_split_into=2,
+                 removal_opacity_threshold=0.005, final_removal_opacity_threshold=0.005, reset_opacities=False, reset_opacities_every=3000)
+    state = dict(params=params, variables=variables)
+    counts, losses, densify_s = [], [], []
+
+    def one_iter(it, densify=True):
+        params, variables = state["params"], state["variables"]
+        rv = M.fused_rendervar(dict(params, rgb_colors=params["shs"]), 0, [1.0, 0, 0, 0, 0, 0, 0])
+        rv.pop("colors_precomp")
+        rv["means2D"].retain_grad()
+        im, radius, depth, sil, dsq = R.render_rgbd(cam, shs=params["shs"], **rv)
+        loss, _ = M.fused_mapping_loss(im, depth, dsq, gt_im, gt_depth, dict(im=0.5, depth=1.0))
+        loss.backward()
+        variables["means2D"], variables["seen"] = rv["means2D"], radius > 0
+        variables["max_2D_radius"] = torch.maximum(variables["max_2D_radius"], radius.float())
+        with torch.no_grad():
+            if it > 0 and densify:
+                n0 = params["means3D"].shape[0]
+                event = it % densify_every == 0
+                if event and time_it:
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                params, variables = O.densify(params, variables, opt, it, ddict, fused=fused_densify)
+                if event and time_it:
+                    torch.cuda.synchronize(); densify_s.append(time.perf_counter() - t1)
+                if params["means3D"].shape[0] != n0:
+                    counts.append(int(params["means3D"].shape[0]))
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        state["params"], state["variables"] = params, variables
+        return loss
+
+    if time_it:
+        for _ in range(3):
+            one_iter(0)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(iters):
+        loss = one_iter(it)
+        if it in (0, iters - 1):
+            losses.append(float(loss.detach()))
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    return dict(losses=losses, counts=counts, seconds=time.perf_counter() - t0, densify_seconds=densify_s, final_N=int(state["params"]["means3D"].shape[0]))

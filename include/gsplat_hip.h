@@ -216,10 +216,32 @@ typedef struct GsAdamTensor {
     float* exp_avg_sq;
     double lr, beta1, beta2, eps;
     int32_t step;
-    int32_t num_views;      /* 0/1: one view.  V > 1: multi-view ATLAS (forward only, see gs_atlas_layout): viewmatrix / projmatrix /
-                             * campos hold V consecutive blocks; image_width is the width of ONE view */
+    int32_t reserved;       /* padding; set to 0 */
 } GsAdamTensor;
 int gs_adam_step_multi(int32_t count, const GsAdamTensor* tensors, gs_stream_t stream);
+
+/* Keyframe-sharded optimiser step (activesplat_amd/parallel.py; SURVEY.md section 8e -- new capability, the reference steps one
+ * keyframe on one GPU, src/mapper/splatam/__init__.py:450-480): glue between the K per-key tensors ([N, width] fp32, K <= 8,
+ * sum of widths <= 64) and ONE flat [rows, G] buffer, G = sum of widths.  `tensors` is a HOST array.
+ *   gs_pack_columns  : flat[r][.] = the keys' `grad` rows (NULL grad = zeros) for r < n, zeros for n <= r < n_padded
+ *                      (the send buffer of the reduce-scatter / all-reduce);
+ *   gs_adam_rows     : Adam (arithmetic of gs_adam_step) on rows [row_lo, row_lo + n_valid) of every key, gradient from
+ *                      grad_shard[r - row_lo][.]; the updated rows are also written to out_shard (may be NULL), rows
+ *                      n_valid..n_rows-1 of it zero (the send buffer of the all-gather);
+ *   gs_unpack_columns: the keys' `param` rows r < n = flat[r][.]. */
+typedef struct GsRowTensor {
+    float* param;
+    float* exp_avg;
+    float* exp_avg_sq;
+    const float* grad;
+    double lr, beta1, beta2, eps;
+    int32_t width;
+    int32_t step;
+} GsRowTensor;
+int gs_pack_columns(int32_t count, const GsRowTensor* tensors, int64_t n, int64_t n_padded, float* flat, gs_stream_t stream);
+int gs_adam_rows(int32_t count, const GsRowTensor* tensors, int64_t row_lo, int64_t n_valid, int64_t n_rows, const float* grad_shard,
+                 float* out_shard, gs_stream_t stream);
+int gs_unpack_columns(int32_t count, const GsRowTensor* tensors, int64_t n, const float* flat, gs_stream_t stream);
 
 /* Fused frame transform + activations (replaces transform_to_frame + transformed_params2rendervar,
  * src/mapper/splatam/utils/slam_helpers.py:252-304,124-139).  h_pose7 is a HOST array {qw,qx,qy,qz,tx,ty,tz}: the

@@ -51,3 +51,15 @@ def hip():
     assert torch.cuda.is_available(), "GPU test without a GPU"
     _lib.get()
     return "cuda"
+
+
+def pytest_terminal_summary(terminalreporter):
+    """How often check_backward's fp32 escape hatch decided a gradient comparison (tests/parity_cases.py)."""
+    try:
+        from tests import parity_cases as pc
+    except Exception:
+        return
+    h = pc.HATCH
+    if h["keys_checked"]:
+        terminalreporter.write_line(f"check_backward: {h['keys_checked']} gradient tensors compared with the fp64 oracle at the stated tolerance; "
+                                    f"fp32 escape hatch fired {h['fired']} time(s)" + (": " + ", ".join(f"{k} rel={r:.2e} frac={f:.4f} P={n}" for k, r, f, n in h["where"][:12]) if h["fired"] else ""))

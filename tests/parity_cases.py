@@ -115,6 +115,10 @@ def check_whole_quadrants_on_small_images(device, oracle32, oracle64):
         _lib.check(lib.gs_set_half_quadrants(256))
 
 
+#: tally of check_backward's fp32 escape hatch over the session (printed by tests/conftest.py)
+HATCH = {"keys_checked": 0, "fired": 0, "where": []}
+
+
 def check_forward(rs, rv, oracle32, exact_float=False):
     got = util.run_product(rs, rv)
     art = util.artefacts()
@@ -176,7 +180,12 @@ def check_backward(rs, rv, oracle64, seed=0, min_frac=0.995, oracle32=None):
         assert np.isfinite(g).all(), k
         frac = util.close_frac(g, r, GRAD_RTOL, 1e-6 * gmax)
         rel = np.linalg.norm(g.astype(np.float64) - r) / np.linalg.norm(r)
+        HATCH["keys_checked"] += 1
         if (frac < min_frac or rel >= 1e-3) and oracle32 is not None:
+            # logged: how often the stated tolerance is missed and the fp32-oracle comparison decides instead (conftest prints the tally)
+            HATCH["fired"] += 1
+            HATCH["where"].append((k, float(rel), float(frac), int(g.shape[0])))
+            print(f"check_backward: fp32 escape hatch for {k}: rel {rel:.3e}, frac {frac:.5f} (P = {g.shape[0]})")
             ref32 = util.run_oracle(oracle32, rs, rv, dL) if ref32 is None else ref32
             o = ref32["grads"][k].reshape(g.shape).astype(np.float64)
             rel32 = np.linalg.norm(o - r) / np.linalg.norm(r)

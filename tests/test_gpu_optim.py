@@ -165,7 +165,7 @@ def test_look_around_fused_equals_reference_pattern_on_gpu(hip):
     assert float(((a["rgb"].int() - b["rgb"].int()).abs() > 1).float().mean()) < 1e-3
     assert abs(LA.local_invisibility(params, c2w) - float((1 - b["opacity"]).sum())) <= 1e-3 * 150 * 360
     # the multi-view atlas (one raster pass for the three views) against one pass per view, on a map whose tile lists are far beyond
-    # the LDS sort capacity (radix path, segmented compositing)
+    # the LDS sort capacity (pairwise merge passes, segmented compositing)
     params = {k: v.to(hip) for k, v in syn.shell_scene(1_000_000, seed=3, W=LA.LOOK_W, H=LA.LOOK_H).items()}
     a, c = LA.look_around(params, c2w, fused=True, batched=True), LA.look_around(params, c2w, fused=True, batched=False)
     assert torch.allclose(a["opacity"], c["opacity"], atol=1e-4)

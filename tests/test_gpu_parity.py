@@ -37,19 +37,53 @@ def test_midsize_scene_forward_backward(hip, oracle32, oracle64):
     pc.check_backward(rs, rv, oracle64)
 
 
-def test_full_size_config1_against_oracle(hip, oracle32):
-    """BASELINE configs[1]: 500k Gaussians, 640x480, SH-0 -- forward vs the fp32 oracle (integers exact),
-    backward vs the fp32 oracle build (same decisions), a few seconds of CPU."""
-    rs, rv = util.scene(500_000, 640, 480, seed=0, device=hip)
-    got, ref = pc.check_forward(rs, rv, oracle32)
-    dL = torch.randn(3, 480, 640, generator=torch.Generator().manual_seed(1))
+def _full_size_gradients_vs_fp64(rs, rv, got_ref32, oracle64, H, W):
+    """SURVEY 8(d)'s stated bar at full size: gradients vs the **fp64** oracle, rtol 1e-3 / atol 1e-6 |g|_inf on >= 99.5 % of the
+    elements and relative L2 error < 1e-3 (the oracle's OpenMP threads are raised for this one call: fp64 sums do not care)."""
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
     g = util.run_product(rs, rv, dL)["grads"]
-    r = oracle32.backward(ref, dL.numpy())
+    oracle64.set_threads(16)
+    try:
+        r = util.run_oracle(oracle64, rs, rv, dL)["grads"]
+    finally:
+        oracle64.set_threads(1)
     for k, a in g.items():
         b = r[k].reshape(a.shape)
-        rel = np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64))
-        assert rel < 2e-3, (k, rel)
-        assert util.close_frac(a, b, 5e-3, 1e-5 * float(np.abs(b).max())) > 0.99, k
+        rel = np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b)
+        frac = util.close_frac(a, b, pc.GRAD_RTOL, 1e-6 * float(np.abs(b).max()))
+        print(f"full-size gradient {k}: rel L2 {rel:.3e}, within tolerance {frac:.5f}")
+        assert rel < 1e-3, (k, rel)
+        assert frac >= 0.995, (k, frac)
+    return g
+
+
+def test_full_size_config1_against_oracle(hip, oracle32, oracle64):
+    """BASELINE configs[1]: 500k Gaussians, 640x480, SH-0 -- forward vs the fp32 oracle (integers exact),
+    backward vs the fp64 oracle at the stated tolerance."""
+    rs, rv = util.scene(500_000, 640, 480, seed=0, device=hip)
+    got, ref = pc.check_forward(rs, rv, oracle32)
+    _full_size_gradients_vs_fp64(rs, rv, ref, oracle64, 480, 640)
+
+
+def test_configs0_hip_forward_vs_cpu_pytorch_render(hip):
+    """BASELINE configs[0]: 10k random Gaussians, one 640x480 view, forward only -- the HIP forward against the plain CPU PyTorch
+    render of the same scene (oracle/dense_torch.render_dense(tiled=True), independent of the C oracle)."""
+    from oracle import dense_torch as DT
+    rs, rv = util.scene(10_000, 640, 480, seed=0, device="cpu")
+    with torch.no_grad():
+        ref = DT.render_dense(util.cam_dict(rs), rv["means3D"], rv["opacities"], colors=rv["colors_precomp"], scales=rv["scales"],
+                              rotations=rv["rotations"], tiled=True)
+    rs_d, rv_d = util.scene(10_000, 640, 480, seed=0, device=hip)
+    got = util.run_product(rs_d, rv_d)
+    for k_got, k_ref in (("color", "color"), ("depth", "depth"), ("opacity", "opacity")):
+        a, b = got[k_got].reshape(-1), ref[k_ref].detach().cpu().numpy().astype(np.float32).reshape(-1)
+        scale = max(1.0, float(np.abs(b).max()))
+        assert util.close_frac(a, b, pc.FWD_RTOL, pc.FWD_ATOL * scale) >= 0.999, k_got
+        assert np.abs(a - b).max() <= 0.02 * scale, k_got
+    assert util.psnr(got["color"], ref["color"].detach().cpu().numpy()) >= 60.0
+    live = ref["radii"].cpu().numpy() > 0 if "radii" in ref else None
+    if live is not None:
+        assert np.array_equal(got["radii"] > 0, live)
 
 
 def test_full_size_properties(hip):
@@ -158,7 +192,7 @@ def test_optimistic_launch_hit_and_miss_equal_exact_launch(hip):
     pc.check_optimistic_tile_list_growth(hip)
 
 
-def test_full_size_config2_sh3_against_oracle_and_properties(hip, oracle32):
+def test_full_size_config2_sh3_against_oracle_and_properties(hip, oracle32, oracle64):
     """BASELINE configs[2]'s render: 2 M Gaussians, SH degree 3, 640x480 -- forward vs the fp32 oracle (integer artefacts
     exact), gradients vs the oracle's fp32 build, plus permutation invariance (a shuffled scene renders the same
     image; radii and gradients follow the permutation)."""
@@ -167,12 +201,7 @@ def test_full_size_config2_sh3_against_oracle_and_properties(hip, oracle32):
     got, ref = pc.check_forward(rs, rv, oracle32)
     assert util.artefacts()["path"] == 1                       # tile lists of a few thousand: chunk sort + LDS merge
     dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
-    g = util.run_product(rs, rv, dL)["grads"]
-    r = oracle32.backward(ref, dL.numpy())
-    for k, a in g.items():
-        b = r[k].reshape(a.shape)
-        rel = np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64))
-        assert rel < 2e-3, (k, rel)
+    g = _full_size_gradients_vs_fp64(rs, rv, ref, oracle64, H, W)          # fp64 oracle, SURVEY 8(d)'s stated tolerance
     perm = torch.randperm(N, generator=torch.Generator().manual_seed(5)).to(hip)
     rv_p = {k: v[perm].contiguous() for k, v in rv.items()}
     gp = util.run_product(rs, rv_p, dL)

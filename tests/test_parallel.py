@@ -196,10 +196,12 @@ def test_two_stream_keyframe_batch_equals_serial_batch(hip):
 
 
 @pytest.mark.gpu
-def test_bench_configs3_workload_two_ranks_on_one_device(hip):
+@pytest.mark.parametrize("n_gauss,kf", [(200_000, 8), (2_000_000, 64)], ids=["200k-8kf", "configs3-2M-64kf"])
+def test_bench_configs3_workload_two_ranks_on_one_device(hip, n_gauss, kf):
     """`bench.py --gpus 2` = BASELINE configs[3] (keyframe batch sharded over the ranks, reduce-scatter -> sharded Adam -> all-gather),
     launched the way the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment) -- with the
-    development knobs that put both ranks on the one GPU of the test box and exchange through gloo."""
+    development knobs that put both ranks on the one GPU of the test box and exchange through gloo.  The second case is configs[3]'s
+    workload at size: 2 M Gaussians, 64 keyframes per optimiser step."""
     import json
     import subprocess
     import sys
@@ -210,12 +212,77 @@ def test_bench_configs3_workload_two_ranks_on_one_device(hip):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    BENCH_SAME_DEVICE="1", BENCH_BACKEND="gloo")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                                       "--c4-gaussians", "200000", "--keyframes", "8"], env=env, stdout=subprocess.PIPE,
+                                       "--c4-gaussians", str(n_gauss), "--keyframes", str(kf)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=600) for p in procs]
+    outs = [p.communicate(timeout=900) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
     line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "configs[3]" in d["config"]["workload"]
-    assert d["config"]["keyframes_per_rank_per_step"] == 4 and d["value"] > 0 and d["single_gpu_same_workload_fps"] > 0
+    assert d["config"]["keyframes_per_rank_per_step"] == kf // 2 and d["value"] > 0 and d["single_gpu_same_workload_fps"] > 0
+    assert d["config"]["gaussians"] == n_gauss and d["config"]["grad_exchange"]["backend"] == "gloo"
+    assert d["config"]["grad_exchange"]["reduce"] == "all_reduce+slice"             # what actually ran (gloo has no reduce-scatter)
+    assert d["exchange_plus_adam_ms"] > 0
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]          # only rank 0 prints
+
+
+def _worker_nccl_one_rank(port, q):
+    """RCCL itself, on the one GPU of the test box: a ONE-rank "nccl" process group runs the very collectives of the 8-GPU step
+    (reduce_scatter_tensor, all_gather_into_tensor, all_reduce) on configs[3]'s buffer: [2 M, 14] fp32 = 112 MB."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from activesplat_amd import _lib, optim as O, parallel as PL
+        _lib.get()
+        assert str(dist.get_backend()).lower() == "nccl"
+        n = 2_000_000
+        widths = dict(means3D=3, rgb_colors=3, unnorm_rotations=4, logit_opacities=1, log_scales=3)
+        lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3)
+        g0 = torch.Generator(device=dev).manual_seed(5)
+        init = {k: torch.randn(n, w, generator=g0, device=dev) for k, w in widths.items()}
+        grads = [{k: torch.randn(n, w, generator=g0, device=dev) for k, w in widths.items()} for _ in range(2)]
+        runs = []
+        for mode in ("full", "sharded"):
+            params = {k: torch.nn.Parameter(v.clone()) for k, v in init.items()}
+            opt = O.initialize_optimizer(params, lrs)
+            for g in grads:
+                for k in widths:
+                    params[k].grad = g[k].clone()
+                if mode == "full":
+                    opt.step()                                     # the unsharded GaussianAdam step
+                else:
+                    PL.reduce_scatter_adam_step(params, opt, timing=True)
+            runs.append({k: (params[k].detach().clone(), opt.state[params[k]]["exp_avg"].clone(), opt.state[params[k]]["exp_avg_sq"].clone())
+                         for k in widths})
+        same = all(torch.equal(a, b) for k in widths for a, b in zip(runs[0][k], runs[1][k]))
+        ex = dict(PL.last_exchange); ms = PL.exchange_ms(); ex.pop("events", None)
+        # the all-reduce variant: one rank's sum is its own gradient, and the collective must really have run
+        params = {k: torch.nn.Parameter(v.clone()) for k, v in init.items()}
+        for k in widths:
+            params[k].grad = grads[0][k].clone()
+        buf = PL.all_reduce_gradients(params, force=True)
+        ar_same = buf is not None and tuple(buf.flat.shape) == (n, 14) and all(torch.equal(params[k].grad, grads[0][k]) for k in widths)
+        ar = dict(PL.last_exchange); ar.pop("events", None)
+        stats = PL.all_reduce_statistics({"max_2D_radius": torch.full((4,), 3.0, device=dev), "denom": torch.ones(4, device=dev)})
+        torch.cuda.synchronize()
+        q.put((same, ex, ms, ar_same, ar, float(stats["max_2D_radius"][0])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_group_runs_the_sharded_step_at_configs3_size(hip):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_nccl_one_rank, args=(_free_port(), q))
+    p.start()
+    same, ex, ms, ar_same, ar, mx = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert same, "reduce-scatter -> sharded Adam -> all-gather differs from the unsharded GaussianAdam step"
+    assert ex["backend"] == "nccl" and ex["reduce"] == "reduce_scatter_tensor" and ex["gather"] == "all_gather_into_tensor"
+    assert ex["bytes"] == 2_000_000 * 14 * 4 and ms is not None and ms > 0
+    print(f"RCCL 1-rank exchange + sharded Adam at [2M,14]: {ms:.3f} ms")
+    assert ar_same and ar["backend"] == "nccl" and ar["reduce"] == "all_reduce" and mx == 3.0
