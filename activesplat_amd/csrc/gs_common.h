@@ -3,10 +3,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/gsplat_hip.h"
 
 namespace gs {
+
+// development knob: integer environment variable read at every launch (kernel-variant experiments; the shipped default is `dflt`)
+static inline int env_knob(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
 
 constexpr int kTile = GS_TILE;      // 16x16 pixel tile = one 256-thread workgroup = 4 wavefronts
 constexpr int kBlock = 256;
@@ -191,6 +199,44 @@ __device__ __forceinline__ void sh48_half_to_lds(float* slab, const float4 (&v)[
     }
 }
 
+// 16-coefficient rows (48 floats) in slabs with a 52-float row stride: rows stay 16-byte aligned, so a 16-byte piece of a row moves with ONE
+// ds_write_b128 / ds_read_b128 (the 49-float stride needs four scalar LDS operations per piece), and lane = row accesses are conflict-free
+// (52 r mod 64 takes 16 distinct multiples of 4 over the lanes a 128-bit LDS access serves together).
+constexpr int kShPad4 = 52;
+__device__ __forceinline__ void sh48_half_to_lds4(float* slab, const float4 (&v)[6], int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const int q = lane + kWave * j, r = q / 12, c = q - 12 * r;
+        *reinterpret_cast<float4*>(slab + r * kShPad4 + 4 * c) = v[j];
+    }
+}
+// any number of rows (<= kShHalf) with a row mask: the last wavefront of the array, and rows that are not needed
+__device__ __forceinline__ void sh48_rows_to_lds4(float* slab, const float* __restrict__ src, int row0, int nrows, int lane, uint32_t row_mask = 0xffffffffu)
+{
+    const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)row0 * 48);
+    for (int q = lane; q < nrows * 12; q += kWave) {
+        const int r = q / 12, c = q - 12 * r;
+        if ((row_mask >> r) & 1u) *reinterpret_cast<float4*>(slab + r * kShPad4 + 4 * c) = load_stream(&s4[q]);
+    }
+}
+__device__ __forceinline__ void sh48_rows_from_lds4(const float* slab, float* __restrict__ dst, int row0, int nrows, int lane)
+{
+    float4* d4 = reinterpret_cast<float4*>(dst + (size_t)row0 * 48);
+    if (nrows == kShHalf) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const int q = lane + kWave * j, r = q / 12, c = q - 12 * r;
+            store_stream(&d4[q], *reinterpret_cast<const float4*>(slab + r * kShPad4 + 4 * c));
+        }
+    } else {
+        for (int q = lane; q < nrows * 12; q += kWave) {
+            const int r = q / 12, c = q - 12 * r;
+            store_stream(&d4[q], *reinterpret_cast<const float4*>(slab + r * kShPad4 + 4 * c));
+        }
+    }
+}
+
 template <int KC = 0>
 __device__ __forceinline__ void sh_wave_rows_from_lds(const float* slab, float* __restrict__ dst, int row0, int nrows, int Krt, int lane)
 {
@@ -297,11 +343,91 @@ __device__ __forceinline__ void sh_direction_jacobian(int deg, float x, float y,
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float one_m_b1, float b2, float one_m_b2,
                                           float step_size, float inv_bc2s, float eps)
 {
+    // no FMA contraction here: which products the compiler fuses would otherwise depend on the kernel the function is inlined into
+#pragma clang fp contract(off)
     m = m + one_m_b1 * (g - m);
-    v = b2 * v + one_m_b2 * g * g;
+    v = b2 * v + (one_m_b2 * g) * g;
     const float denom = sqrtf(v) * inv_bc2s + eps;
     p = p - step_size * (m / denom);
 }
+
+// Colour sums and (optionally) the direction Jacobian of ONE 16-coefficient row that sits 16-byte aligned in LDS: the row is read four
+// coefficients (three ds_read_b128) at a time and consumed at once, in the order of the scalar formulation above (colour: k ascending, one
+// FMA per channel; Jacobian: sh_direction_jacobian's sequence) -- same results to the bit, a dozen live registers instead of 48.
+#define GS_SHC(j, k)                                                                                                           \
+    do {                                                                                                                        \
+        acc[0] = fmaf(b[k], f[3 * (j)], acc[0]); acc[1] = fmaf(b[k], f[3 * (j) + 1], acc[1]); acc[2] = fmaf(b[k], f[3 * (j) + 2], acc[2]);    \
+    } while (0)
+#define GS_SHJ4(j, gx, gy, gz)                                                                                                 \
+    do {                                                                                                                        \
+        const float c0_ = f[3 * (j)], c1_ = f[3 * (j) + 1], c2_ = f[3 * (j) + 2];                                               \
+        const float gx_ = (gx), gy_ = (gy), gz_ = (gz);                                                                         \
+        J[0] = fmaf(c0_, gx_, J[0]); J[1] = fmaf(c0_, gy_, J[1]); J[2] = fmaf(c0_, gz_, J[2]);                                  \
+        J[3] = fmaf(c1_, gx_, J[3]); J[4] = fmaf(c1_, gy_, J[4]); J[5] = fmaf(c1_, gz_, J[5]);                                  \
+        J[6] = fmaf(c2_, gx_, J[6]); J[7] = fmaf(c2_, gy_, J[7]); J[8] = fmaf(c2_, gz_, J[8]);                                  \
+    } while (0)
+#define GS_SHLOAD(g)                                                                                                           \
+    const float4 q0_##g = row4[3 * (g)], q1_##g = row4[3 * (g) + 1], q2_##g = row4[3 * (g) + 2];                              \
+    const float f[12] = {q0_##g.x, q0_##g.y, q0_##g.z, q0_##g.w, q1_##g.x, q1_##g.y, q1_##g.z, q1_##g.w, q2_##g.x, q2_##g.y, q2_##g.z, q2_##g.w}
+__device__ __forceinline__ void sh48_color_and_jacobian(int deg, float x, float y, float z, const float (&b)[16], const float* row, bool want_j,
+                                                        float (&acc)[3], float (&J)[9])
+{
+    const float4* row4 = reinterpret_cast<const float4*>(row);
+#pragma unroll
+    for (int q = 0; q < 9; q++) J[q] = 0.0f;
+    acc[0] = acc[1] = acc[2] = 0.0f;
+    const float C1 = 0.4886025119029199f;
+    const float c20 = 1.0925484305920792f, c21 = -1.0925484305920792f, c22 = 0.31539156525252005f, c23 = -1.0925484305920792f,
+                c24 = 0.5462742152960396f;
+    const float c30 = -0.5900435899266435f, c31 = 2.890611442640554f, c32 = -0.4570457994644658f, c33 = 0.3731763325901154f,
+                c34 = -0.4570457994644658f, c35 = 1.445305721320277f, c36 = -0.5900435899266435f;
+    const float xx = x * x, yy = y * y, zz = z * z;
+    {
+        GS_SHLOAD(0);
+        GS_SHC(0, 0);
+        if (deg < 1) return;
+        GS_SHC(1, 1); GS_SHC(2, 2); GS_SHC(3, 3);
+        if (want_j) { GS_SHJ4(1, 0.f, -C1, 0.f); GS_SHJ4(2, 0.f, 0.f, C1); GS_SHJ4(3, -C1, 0.f, 0.f); }
+    }
+    if (deg < 2) return;
+    {
+        GS_SHLOAD(1);
+        GS_SHC(0, 4); GS_SHC(1, 5); GS_SHC(2, 6); GS_SHC(3, 7);
+        if (want_j) {
+            GS_SHJ4(0, c20 * y, c20 * x, 0.f);
+            GS_SHJ4(1, 0.f, c21 * z, c21 * y);
+            GS_SHJ4(2, c22 * (-2.f * x), c22 * (-2.f * y), c22 * (4.f * z));
+            GS_SHJ4(3, c23 * z, 0.f, c23 * x);
+        }
+    }
+    {
+        GS_SHLOAD(2);
+        GS_SHC(0, 8);
+        if (want_j) GS_SHJ4(0, c24 * (2.f * x), c24 * (-2.f * y), 0.f);
+        if (deg >= 3) {
+            GS_SHC(1, 9); GS_SHC(2, 10); GS_SHC(3, 11);
+            if (want_j) {
+                GS_SHJ4(1, c30 * (6.f * x * y), c30 * (3.f * xx - 3.f * yy), 0.f);
+                GS_SHJ4(2, c31 * y * z, c31 * x * z, c31 * x * y);
+                GS_SHJ4(3, c32 * (-2.f * x * y), c32 * (4.f * zz - xx - 3.f * yy), c32 * (8.f * y * z));
+            }
+        }
+    }
+    if (deg < 3) return;
+    {
+        GS_SHLOAD(3);
+        GS_SHC(0, 12); GS_SHC(1, 13); GS_SHC(2, 14); GS_SHC(3, 15);
+        if (want_j) {
+            GS_SHJ4(0, c33 * (-6.f * x * z), c33 * (-6.f * y * z), c33 * (6.f * zz - 3.f * xx - 3.f * yy));
+            GS_SHJ4(1, c34 * (4.f * zz - 3.f * xx - yy), c34 * (-2.f * x * y), c34 * (8.f * x * z));
+            GS_SHJ4(2, c35 * (2.f * x * z), c35 * (-2.f * y * z), c35 * (xx - yy));
+            GS_SHJ4(3, c36 * (3.f * xx - 3.f * yy), c36 * (-6.f * x * y), 0.f);
+        }
+    }
+}
+#undef GS_SHC
+#undef GS_SHJ4
+#undef GS_SHLOAD
 
 // ---- launchers implemented in the individual translation units -------------------------------------
 hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D, const float* shs,

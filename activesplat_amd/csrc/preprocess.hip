@@ -47,6 +47,132 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
+// The per-Gaussian geometry of one lane (bit-level spec): projection, EWA covariance, radius, tile rect, the 48-byte
+// record.  Inputs come from the workgroup's LDS staging (means; scales + rotations or the covariance; colours for the no-SH case).
+// Returns the number of tiles the Gaussian touches.
+template <bool HAS_SH>
+__device__ __forceinline__ uint32_t project_gaussian(const Cam& cam, int P, int view, int i, int io, int tid, const float* s_mean,
+                                                     const float* s_scale, const float* s_rot, const float* s_cov, const float* s_col,
+                                                     bool has_cov, float o, const float (&sh_rgb)[3], uint32_t sh_clamp,
+                                                     int32_t* __restrict__ radii, const GeomPtrs& gp)
+{
+    uint32_t ntiles = 0;
+    if (i < P) {
+        const float* m = cam.view + 16 * view;
+        const float* q = cam.proj + 16 * view;
+        const float px = s_mean[tid * 3], py = s_mean[tid * 3 + 1], pz = s_mean[tid * 3 + 2];
+        const float tx = ((m[0] * px + m[4] * py) + m[8] * pz) + m[12];
+        const float ty = ((m[1] * px + m[5] * py) + m[9] * pz) + m[13];
+        const float tz = ((m[2] * px + m[6] * py) + m[10] * pz) + m[14];
+        int radius = 0;
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+        uint2 rc = make_uint2(0u, 0u);
+        uint32_t clampbits = 0;
+        if (tz > 0.2f) {                              // near cull only -- no far plane (SURVEY App. A.1)
+            const float hx = ((q[0] * px + q[4] * py) + q[8] * pz) + q[12];
+            const float hy = ((q[1] * px + q[5] * py) + q[9] * pz) + q[13];
+            const float hw = ((q[3] * px + q[7] * py) + q[11] * pz) + q[15];
+            const float pw = 1.0f / (hw + 1e-7f);
+            const float ndcx = hx * pw, ndcy = hy * pw;
+            float c0, c1, c2, c3, c4, c5;             // 3-D covariance (upper triangle)
+            if (has_cov) {
+                c0 = s_cov[tid * 6]; c1 = s_cov[tid * 6 + 1]; c2 = s_cov[tid * 6 + 2];
+                c3 = s_cov[tid * 6 + 3]; c4 = s_cov[tid * 6 + 4]; c5 = s_cov[tid * 6 + 5];
+            } else {
+                const float sx = cam.mod * s_scale[tid * 3], sy = cam.mod * s_scale[tid * 3 + 1], sz = cam.mod * s_scale[tid * 3 + 2];
+                const float4 rq = reinterpret_cast<const float4*>(s_rot)[tid];
+                const float r = rq.x, x = rq.y, y = rq.z, z = rq.w;
+                const float R00 = 1.0f - 2.0f * (y * y + z * z), R01 = 2.0f * (x * y - r * z), R02 = 2.0f * (x * z + r * y);
+                const float R10 = 2.0f * (x * y + r * z), R11 = 1.0f - 2.0f * (x * x + z * z), R12 = 2.0f * (y * z - r * x);
+                const float R20 = 2.0f * (x * z - r * y), R21 = 2.0f * (y * z + r * x), R22 = 1.0f - 2.0f * (x * x + y * y);
+                const float M00 = R00 * sx, M01 = R01 * sy, M02 = R02 * sz;
+                const float M10 = R10 * sx, M11 = R11 * sy, M12 = R12 * sz;
+                const float M20 = R20 * sx, M21 = R21 * sy, M22 = R22 * sz;
+                c0 = (M00 * M00 + M01 * M01) + M02 * M02;
+                c1 = (M00 * M10 + M01 * M11) + M02 * M12;
+                c2 = (M00 * M20 + M01 * M21) + M02 * M22;
+                c3 = (M10 * M10 + M11 * M11) + M12 * M12;
+                c4 = (M10 * M20 + M11 * M21) + M12 * M22;
+                c5 = (M20 * M20 + M21 * M21) + M22 * M22;
+            }
+            // EWA projection of the covariance
+            const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+            const float txtz = tx / tz, tytz = ty / tz;
+            const float cx_ = fminf(limx, fmaxf(-limx, txtz)) * tz;
+            const float cy_ = fminf(limy, fmaxf(-limy, tytz)) * tz;
+            const float J00 = cam.fx / tz, J02 = -(cam.fx * cx_) / (tz * tz);
+            const float J11 = cam.fy / tz, J12 = -(cam.fy * cy_) / (tz * tz);
+            const float T00 = J00 * m[0] + J02 * m[2], T01 = J00 * m[4] + J02 * m[6], T02 = J00 * m[8] + J02 * m[10];
+            const float T10 = J11 * m[1] + J12 * m[2], T11 = J11 * m[5] + J12 * m[6], T12 = J11 * m[9] + J12 * m[10];
+            const float v00 = (c0 * T00 + c1 * T01) + c2 * T02;
+            const float v01 = (c1 * T00 + c3 * T01) + c4 * T02;
+            const float v02 = (c2 * T00 + c4 * T01) + c5 * T02;
+            const float v10 = (c0 * T10 + c1 * T11) + c2 * T12;
+            const float v11 = (c1 * T10 + c3 * T11) + c4 * T12;
+            const float v12 = (c2 * T10 + c4 * T11) + c5 * T12;
+            const float k00 = ((T00 * v00 + T01 * v01) + T02 * v02) + 0.3f;
+            const float k01 = (T10 * v00 + T11 * v01) + T12 * v02;
+            const float k11 = ((T10 * v10 + T11 * v11) + T12 * v12) + 0.3f;
+            const float det = k00 * k11 - k01 * k01;
+            if (det > 0.0f) {
+                const float det_inv = 1.0f / det;
+                const float mid = 0.5f * (k00 + k11);
+                const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lam = fmaxf(mid + sq, mid - sq);
+                float rf = ceilf(3.0f * sqrtf(lam));
+                rf = fminf(rf, 16777216.0f);
+                const float pxv = ((ndcx + 1.0f) * (float)cam.Wv - 1.0f) * 0.5f;     // pixel x inside this view
+                const float pyy = ((ndcy + 1.0f) * (float)cam.H - 1.0f) * 0.5f;
+                // the tile rect is clamped to the view's own columns, then moved to the view's slot of the atlas
+                const int xs = view * cam.gxv;
+                const int x0 = clamp_tile((pxv - rf) / 16.0f, cam.gxv) + xs, x1 = clamp_tile(((pxv + rf) + 15.0f) / 16.0f, cam.gxv) + xs;
+                const float pxx = cam.V > 1 ? pxv + (float)(xs * kTile) : pxv;
+                const int y0 = clamp_tile((pyy - rf) / 16.0f, cam.gy), y1 = clamp_tile(((pyy + rf) + 15.0f) / 16.0f, cam.gy);
+                const int area = (x1 - x0) * (y1 - y0);
+                if (area > 0) {
+                    radius = (int)rf;
+                    ntiles = (uint32_t)area;
+                    rc = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+                    float cr, cg, cb;
+                    if (HAS_SH) {
+                        clampbits = sh_clamp;
+                        cr = sh_rgb[0]; cg = sh_rgb[1]; cb = sh_rgb[2];
+                    } else {
+                        cr = s_col[tid * 3]; cg = s_col[tid * 3 + 1]; cb = s_col[tid * 3 + 2];
+                    }
+                    // work-skipping extents: alpha >= 1/255 needs power >= -ln(255 o); the ellipse
+                    // {d : d^T conic d <= 2 tau} has half-extents sqrt(2 tau cov_xx), sqrt(2 tau cov_yy).
+                    // tau carries a 0.02 slack (>> any fp32 rounding of conic / exp); o*255 <= 1 -> never visible.
+                    float ex = -1.0f, ey = -1.0f;
+                    const float o255 = o * 255.0f;
+                    if (o255 > 1.0f) {
+                        const float tau2 = 2.0f * (__logf(o255) + 0.02f);
+                        ex = sqrtf(tau2 * k00) + 0.01f;
+                        ey = sqrtf(tau2 * k11) + 0.01f;
+                    }
+                    g0 = make_float4(pxx, pyy, k11 * det_inv, -k01 * det_inv);
+                    g1 = make_float4(k00 * det_inv, o, cr, cg);
+                    g2 = make_float4(cb, tz, ex, ey);
+                }
+            }
+        }
+        radii[io] = radius;
+        gp.geom[(size_t)io * 3] = g0; gp.geom[(size_t)io * 3 + 1] = g1; gp.geom[(size_t)io * 3 + 2] = g2;
+        gp.rect[io] = rc;
+        gp.tiles[io] = ntiles;
+        gp.depth_bits[io] = __float_as_uint(g2.y);
+        if (HAS_SH) gp.clamped[io] = clampbits;
+    } else if (cam.V > 1) {                            // padding rows of a view's last block: never visible
+        radii[io] = 0;
+        gp.geom[(size_t)io * 3] = gp.geom[(size_t)io * 3 + 1] = gp.geom[(size_t)io * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gp.rect[io] = make_uint2(0u, 0u);
+        gp.tiles[io] = 0u;
+        gp.depth_bits[io] = 0u;
+        if (HAS_SH) gp.clamped[io] = 0u;
+    }
+    return ntiles;
+}
+
 // SH: 0 = colours given, 1 = coefficient rows of any width through per-wave LDS slabs, 3 = the same for 16-coefficient rows
 // (row width 48 known at compile time: the copy loops' element -> (row, column) divisions fold away)
 template <int SH>
@@ -79,6 +205,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     // the per-tile instance counters of the binning stage are zeroed here (saves a memset launch)
     if (vbase + tid < cam.gx * cam.gy) gp.tile_total[vbase + tid] = 0u;
     const int i = base + tid, io = vbase + tid;
+    const float o_in = i < P ? opac[i] : 0.0f;                 // requested up front: not a dependent load inside the visible branch
     stage_rows<3>(s_mean, means3D, base, nrows, tid);
     if (!SLAB) {
         if (cov3Dp) stage_rows<6>(s_cov, cov3Dp, base, nrows, tid);
@@ -140,124 +267,84 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
         else { stage_rows<3>(s_scale, scales, base, nrows, tid); stage_rows<4>(s_rot, rots, base, nrows, tid); }
         __syncthreads();
     }
-    uint32_t ntiles = 0;
-    if (i < P) {
-        const float* m = cam.view + 16 * view;
-        const float* q = cam.proj + 16 * view;
-        const float px = s_mean[tid * 3], py = s_mean[tid * 3 + 1], pz = s_mean[tid * 3 + 2];
-        const float tx = ((m[0] * px + m[4] * py) + m[8] * pz) + m[12];
-        const float ty = ((m[1] * px + m[5] * py) + m[9] * pz) + m[13];
-        const float tz = ((m[2] * px + m[6] * py) + m[10] * pz) + m[14];
-        int radius = 0;
-        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
-        uint2 rc = make_uint2(0u, 0u);
-        uint32_t clampbits = 0;
-        if (tz > 0.2f) {                              // near cull only -- no far plane (SURVEY App. A.1)
-            const float hx = ((q[0] * px + q[4] * py) + q[8] * pz) + q[12];
-            const float hy = ((q[1] * px + q[5] * py) + q[9] * pz) + q[13];
-            const float hw = ((q[3] * px + q[7] * py) + q[11] * pz) + q[15];
-            const float pw = 1.0f / (hw + 1e-7f);
-            const float ndcx = hx * pw, ndcy = hy * pw;
-            float c0, c1, c2, c3, c4, c5;             // 3-D covariance (upper triangle)
-            if (cov3Dp) {
-                c0 = s_cov[tid * 6]; c1 = s_cov[tid * 6 + 1]; c2 = s_cov[tid * 6 + 2];
-                c3 = s_cov[tid * 6 + 3]; c4 = s_cov[tid * 6 + 4]; c5 = s_cov[tid * 6 + 5];
-            } else {
-                const float sx = cam.mod * s_scale[tid * 3], sy = cam.mod * s_scale[tid * 3 + 1], sz = cam.mod * s_scale[tid * 3 + 2];
-                const float4 rq = reinterpret_cast<const float4*>(s_rot)[tid];
-                const float r = rq.x, x = rq.y, y = rq.z, z = rq.w;
-                const float R00 = 1.0f - 2.0f * (y * y + z * z), R01 = 2.0f * (x * y - r * z), R02 = 2.0f * (x * z + r * y);
-                const float R10 = 2.0f * (x * y + r * z), R11 = 1.0f - 2.0f * (x * x + z * z), R12 = 2.0f * (y * z - r * x);
-                const float R20 = 2.0f * (x * z - r * y), R21 = 2.0f * (y * z + r * x), R22 = 1.0f - 2.0f * (x * x + y * y);
-                const float M00 = R00 * sx, M01 = R01 * sy, M02 = R02 * sz;
-                const float M10 = R10 * sx, M11 = R11 * sy, M12 = R12 * sz;
-                const float M20 = R20 * sx, M21 = R21 * sy, M22 = R22 * sz;
-                c0 = (M00 * M00 + M01 * M01) + M02 * M02;
-                c1 = (M00 * M10 + M01 * M11) + M02 * M12;
-                c2 = (M00 * M20 + M01 * M21) + M02 * M22;
-                c3 = (M10 * M10 + M11 * M11) + M12 * M12;
-                c4 = (M10 * M20 + M11 * M21) + M12 * M22;
-                c5 = (M20 * M20 + M21 * M21) + M22 * M22;
-            }
-            // EWA projection of the covariance
-            const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
-            const float txtz = tx / tz, tytz = ty / tz;
-            const float cx_ = fminf(limx, fmaxf(-limx, txtz)) * tz;
-            const float cy_ = fminf(limy, fmaxf(-limy, tytz)) * tz;
-            const float J00 = cam.fx / tz, J02 = -(cam.fx * cx_) / (tz * tz);
-            const float J11 = cam.fy / tz, J12 = -(cam.fy * cy_) / (tz * tz);
-            const float T00 = J00 * m[0] + J02 * m[2], T01 = J00 * m[4] + J02 * m[6], T02 = J00 * m[8] + J02 * m[10];
-            const float T10 = J11 * m[1] + J12 * m[2], T11 = J11 * m[5] + J12 * m[6], T12 = J11 * m[9] + J12 * m[10];
-            const float v00 = (c0 * T00 + c1 * T01) + c2 * T02;
-            const float v01 = (c1 * T00 + c3 * T01) + c4 * T02;
-            const float v02 = (c2 * T00 + c4 * T01) + c5 * T02;
-            const float v10 = (c0 * T10 + c1 * T11) + c2 * T12;
-            const float v11 = (c1 * T10 + c3 * T11) + c4 * T12;
-            const float v12 = (c2 * T10 + c4 * T11) + c5 * T12;
-            const float k00 = ((T00 * v00 + T01 * v01) + T02 * v02) + 0.3f;
-            const float k01 = (T10 * v00 + T11 * v01) + T12 * v02;
-            const float k11 = ((T10 * v10 + T11 * v11) + T12 * v12) + 0.3f;
-            const float det = k00 * k11 - k01 * k01;
-            if (det > 0.0f) {
-                const float det_inv = 1.0f / det;
-                const float mid = 0.5f * (k00 + k11);
-                const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
-                const float lam = fmaxf(mid + sq, mid - sq);
-                float rf = ceilf(3.0f * sqrtf(lam));
-                rf = fminf(rf, 16777216.0f);
-                const float pxv = ((ndcx + 1.0f) * (float)cam.Wv - 1.0f) * 0.5f;     // pixel x inside this view
-                const float pyy = ((ndcy + 1.0f) * (float)cam.H - 1.0f) * 0.5f;
-                // the tile rect is clamped to the view's own columns, then moved to the view's slot of the atlas
-                const int xs = view * cam.gxv;
-                const int x0 = clamp_tile((pxv - rf) / 16.0f, cam.gxv) + xs, x1 = clamp_tile(((pxv + rf) + 15.0f) / 16.0f, cam.gxv) + xs;
-                const float pxx = cam.V > 1 ? pxv + (float)(xs * kTile) : pxv;
-                const int y0 = clamp_tile((pyy - rf) / 16.0f, cam.gy), y1 = clamp_tile(((pyy + rf) + 15.0f) / 16.0f, cam.gy);
-                const int area = (x1 - x0) * (y1 - y0);
-                if (area > 0) {
-                    radius = (int)rf;
-                    ntiles = (uint32_t)area;
-                    rc = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
-                    const float o = opac[i];
-                    float cr, cg, cb;
-                    if (HAS_SH) {
-                        clampbits = sh_clamp;
-                        cr = sh_rgb[0]; cg = sh_rgb[1]; cb = sh_rgb[2];
-                    } else {
-                        cr = s_col[tid * 3]; cg = s_col[tid * 3 + 1]; cb = s_col[tid * 3 + 2];
-                    }
-                    // work-skipping extents: alpha >= 1/255 needs power >= -ln(255 o); the ellipse
-                    // {d : d^T conic d <= 2 tau} has half-extents sqrt(2 tau cov_xx), sqrt(2 tau cov_yy).
-                    // tau carries a 0.02 slack (>> any fp32 rounding of conic / exp); o*255 <= 1 -> never visible.
-                    float ex = -1.0f, ey = -1.0f;
-                    const float o255 = o * 255.0f;
-                    if (o255 > 1.0f) {
-                        const float tau2 = 2.0f * (__logf(o255) + 0.02f);
-                        ex = sqrtf(tau2 * k00) + 0.01f;
-                        ey = sqrtf(tau2 * k11) + 0.01f;
-                    }
-                    g0 = make_float4(pxx, pyy, k11 * det_inv, -k01 * det_inv);
-                    g1 = make_float4(k00 * det_inv, o, cr, cg);
-                    g2 = make_float4(cb, tz, ex, ey);
-                }
-            }
-        }
-        radii[io] = radius;
-        gp.geom[(size_t)io * 3] = g0; gp.geom[(size_t)io * 3 + 1] = g1; gp.geom[(size_t)io * 3 + 2] = g2;
-        gp.rect[io] = rc;
-        gp.tiles[io] = ntiles;
-        gp.depth_bits[io] = __float_as_uint(g2.y);
-        if (HAS_SH) gp.clamped[io] = clampbits;
-    } else if (cam.V > 1) {                            // padding rows of a view's last block: never visible
-        radii[io] = 0;
-        gp.geom[(size_t)io * 3] = gp.geom[(size_t)io * 3 + 1] = gp.geom[(size_t)io * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        gp.rect[io] = make_uint2(0u, 0u);
-        gp.tiles[io] = 0u;
-        gp.depth_bits[io] = 0u;
-        if (HAS_SH) gp.clamped[io] = 0u;
-    }
+    const uint32_t ntiles = project_gaussian<HAS_SH>(cam, P, view, i, io, tid, s_mean, s_scale, s_rot, s_cov, s_col, cov3Dp != nullptr, o_in,
+                                                     sh_rgb, sh_clamp, radii, gp);
     // per-block tile count -> block_sums (scanned by scan_block_sums_kernel)
     const uint32_t ws = wave_sum_u32(ntiles);
     if ((tid & 63) == 0) s_wsum[tid >> 6] = ws;
+    __syncthreads();
+    if (tid == 0) gp.block_sums[blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+}
+
+// 16-coefficient SH rows, second design (GS_PRE_FWD=1): ONE workgroup barrier instead of three and one memory round trip in front of it --
+// the first half's coefficient loads, the opacity and the staging of means / scales / rotations are all issued before anything waits; the
+// second half's loads are issued as soon as the first half sits in the slab and fly during its arithmetic (the same 24 registers: 128 VGPRs,
+// four workgroups per CU instead of three); slabs with 16-byte aligned rows (gs_common.h: kShPad4), i.e. 128-bit LDS accesses.
+// Arithmetic and results are those of preprocess_forward_kernel<3>, to the bit.
+__global__ __launch_bounds__(kBlock, 4) void preprocess_forward_sh48_kernel(
+    Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ opac,
+    const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov3Dp, int32_t* __restrict__ radii, GeomPtrs gp)
+{
+    __shared__ __attribute__((aligned(16))) float s_mean[kBlock * 3];
+    __shared__ __attribute__((aligned(16))) float s_geo[kBlock * 7];
+    __shared__ __attribute__((aligned(16))) float s_sh[(kBlock / kWave) * kShHalf * kShPad4];
+    __shared__ uint32_t s_wsum[kBlock / kWave];
+    float* const s_scale = s_geo;
+    float* const s_rot = s_geo + kBlock * 3;
+    float* const s_cov = s_geo;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int vbase = blockIdx.x * kBlock;
+    const int view = cam.V > 1 ? (int)blockIdx.x / cam.nbv : 0;
+    const int base = (cam.V > 1 ? (int)blockIdx.x - view * cam.nbv : (int)blockIdx.x) * kBlock;
+    const int nrows = max(0, min(kBlock, P - base));
+    if (vbase + tid < cam.gx * cam.gy) gp.tile_total[vbase + tid] = 0u;
+    const int i = base + tid, io = vbase + tid;
+    const int row_w = base + wave * kWave;
+    const bool full = row_w + kWave <= P;
+    float4 va[6];
+    if (full) sh48_half_load(va, shs, row_w, lane);
+    const float o_in = i < P ? opac[i] : 0.0f;
+    stage_rows<3>(s_mean, means3D, base, nrows, tid);
+    if (cov3Dp) stage_rows<6>(s_cov, cov3Dp, base, nrows, tid);
+    else { stage_rows<3>(s_scale, scales, base, nrows, tid); stage_rows<4>(s_rot, rots, base, nrows, tid); }
+    __syncthreads();
+
+    float sh_rgb[3] = {0.f, 0.f, 0.f};
+    uint32_t sh_clamp = 0;
+    float* slab = s_sh + wave * kShHalf * kShPad4;
+    for (int h = 0; h < kWave / kShHalf; h++) {
+        const int row0 = row_w + h * kShHalf;
+        if (row0 >= P) break;                                  // wave-uniform
+        __builtin_amdgcn_wave_barrier();
+        if (full) {
+            sh48_half_to_lds4(slab, va, lane);
+            if (h == 0) sh48_half_load(va, shs, row_w + kShHalf, lane);
+        } else {
+            sh48_rows_to_lds4(slab, shs, row0, min(kShHalf, P - row0), lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if ((lane >> 5) == h && i < P) {
+            const float* cp = cam.campos + 3 * view;
+            const float dx = s_mean[tid * 3] - cp[0], dy = s_mean[tid * 3 + 1] - cp[1], dz = s_mean[tid * 3 + 2] - cp[2];
+            const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+            float b[16];
+            sh_basis(cam.sh_degree, dx * inv, dy * inv, dz * inv, b);
+            float acc[3], J[9];
+            sh48_color_and_jacobian(cam.sh_degree, dx * inv, dy * inv, dz * inv, b, slab + (lane & 31) * kShPad4, gp.sh_jac != nullptr, acc, J);
+            if (gp.sh_jac) {
+                float4* jo = gp.sh_jac + (size_t)io * 3;
+                jo[0] = make_float4(J[0], J[1], J[2], J[3]); jo[1] = make_float4(J[4], J[5], J[6], J[7]); jo[2] = make_float4(J[8], 0.f, 0.f, 0.f);
+            }
+            acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
+            sh_clamp = (acc[0] < 0.f ? 1u : 0u) | (acc[1] < 0.f ? 0x100u : 0u) | (acc[2] < 0.f ? 0x10000u : 0u);
+            sh_rgb[0] = fmaxf(acc[0], 0.f); sh_rgb[1] = fmaxf(acc[1], 0.f); sh_rgb[2] = fmaxf(acc[2], 0.f);
+        }
+    }
+    const uint32_t ntiles = project_gaussian<true>(cam, P, view, i, io, tid, s_mean, s_scale, s_rot, s_cov, nullptr, cov3Dp != nullptr, o_in,
+                                                   sh_rgb, sh_clamp, radii, gp);
+    const uint32_t ws = wave_sum_u32(ntiles);
+    if (lane == 0) s_wsum[wave] = ws;
     __syncthreads();
     if (tid == 0) gp.block_sums[blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
 }
@@ -293,7 +380,9 @@ hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D
                                      uint32_t* d_num_rendered, hipStream_t st)
 {
     const int nb = cam.V > 1 ? cam.V * cam.nbv : (P + kBlock - 1) / kBlock;
-    if (nb > 0 && shs && cam.sh_coeffs == 16)
+    if (nb > 0 && shs && cam.sh_coeffs == 16 && env_knob("GS_PRE_FWD", 0) == 1)
+        hipLaunchKernelGGL(preprocess_forward_sh48_kernel, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, opac, scales, rots, cov3Dp, radii, gp);
+    else if (nb > 0 && shs && cam.sh_coeffs == 16)
         hipLaunchKernelGGL(preprocess_forward_kernel<3>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
                            scales, rots, cov3Dp, radii, gp);
     else if (nb > 0 && shs)

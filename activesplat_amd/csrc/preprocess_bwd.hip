@@ -11,7 +11,8 @@
 namespace gs {
 
 // SH: 0 = colours given, 1 = coefficient rows of any width through per-wave LDS slabs, 3 = the same for 16-coefficient rows
-// (row width 48 known at compile time)
+// (row width 48 known at compile time), 4 = 16-coefficient rows in slabs with 16-byte aligned rows (gs_common.h: kShPad4): a lane's 48
+// gradient values leave as twelve ds_write_b128 and the copy-out reads ds_read_b128 (GS_PRE_BWD=1)
 template <int SH>
 __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -23,8 +24,9 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
 {
     // per-wave slabs: 32 coefficient rows in, their gradients written back IN PLACE (each element is read before it is overwritten)
     constexpr bool HAS_SH = SH != 0;
-    constexpr bool SLAB = SH == 1 || SH == 3;
-    __shared__ __attribute__((aligned(16))) float s_sh[SLAB ? (kBlock / kWave) * kShHalf * kShPad : 1];
+    constexpr bool SLAB = SH == 1 || SH == 3 || SH == 4;
+    constexpr bool PAD4 = SH == 4;
+    __shared__ __attribute__((aligned(16))) float s_sh[SLAB ? (kBlock / kWave) * kShHalf * (PAD4 ? kShPad4 : kShPad) : 1];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kBlock + tid;
     const bool in_range = i < P;
@@ -40,13 +42,27 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
     float o_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float px = means3D[3 * ic], py = means3D[3 * ic + 1], pz = means3D[3 * ic + 2];
     const float drgb[3] = {gb.z, gb.w, gc.x};
+    // every other per-Gaussian input is requested here as well, whether or not the lane turns out to need it: ONE memory round trip
+    // per wavefront instead of three dependent ones (the compiler does not move loads out of the `live` branches below)
+    const uint32_t cl_in = HAS_SH ? clamped[ic] : 0u;
+    float4 j0 = make_float4(0.f, 0.f, 0.f, 0.f), j1 = j0, j2 = j0;
+    if (HAS_SH && sh_jac) { j0 = sh_jac[(size_t)ic * 3]; j1 = sh_jac[(size_t)ic * 3 + 1]; j2 = sh_jac[(size_t)ic * 3 + 2]; }
+    float sc_in[3] = {0.f, 0.f, 0.f};
+    float4 rq_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cov_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (cov3Dp) {
+        for (int c = 0; c < 6; c++) cov_in[c] = cov3Dp[(size_t)ic * 6 + c];
+    } else {
+        sc_in[0] = scales[3 * ic]; sc_in[1] = scales[3 * ic + 1]; sc_in[2] = scales[3 * ic + 2];
+        rq_in = reinterpret_cast<const float4*>(rots)[ic];
+    }
     // ---- colour / SH: one wavefront's 64 coefficient rows per LDS pass, coalesced global traffic by all threads ----
     if (SLAB) {
-        constexpr int KC = SH == 3 ? 48 : 0;
+        constexpr int KC = SH >= 3 ? 48 : 0;
         const int deg = cam.sh_degree, nb = (deg + 1) * (deg + 1), M = KC ? 16 : cam.sh_coeffs, K = M * 3;
-        const int stride = sh_row_stride(K);
+        const int stride = PAD4 ? kShPad4 : sh_row_stride(K);
         const int lane = tid & 63, wave = tid >> 6;
-        float* slab = s_sh + wave * kShHalf * kShPad;
+        float* slab = s_sh + wave * kShHalf * (PAD4 ? kShPad4 : kShPad);
         for (int h = 0; h < kWave / kShHalf; h++) {
             const int row0 = blockIdx.x * kBlock + wave * kWave + h * kShHalf;
             if (row0 >= P) break;                                  // wave-uniform
@@ -56,7 +72,10 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
             // 3x3 block per Gaussian (sh_jac), so the coefficient rows -- 192 B per Gaussian at 16 coefficients -- are NOT read again;
             // without it (a forward that was not told a backward follows) only live Gaussians read their rows
             const uint32_t live_rows = (uint32_t)(__ballot(live) >> (h * kShHalf));
-            if (!sh_jac) sh_wave_rows_to_lds<KC>(slab, shs, row0, nrows, K, lane, live_rows);
+            if (!sh_jac) {
+                if (PAD4) sh48_rows_to_lds4(slab, shs, row0, nrows, lane, live_rows);
+                else sh_wave_rows_to_lds<KC>(slab, shs, row0, nrows, K, lane, live_rows);
+            }
             __builtin_amdgcn_wave_barrier();
             if ((lane >> 5) == h && in_range) {
                 float* dsh = slab + (lane & 31) * stride;
@@ -66,16 +85,32 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
                     const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
                     float b[16], bx[16], by[16], bz[16];
                     sh_basis_and_grad(deg, ux, uy, uz, b, bx, by, bz);
-                    const uint32_t cl = clamped[i];
+                    const uint32_t cl = cl_in;
                     float du[3] = {0.f, 0.f, 0.f};
                     if (sh_jac) {
-                        const float4 j0 = sh_jac[(size_t)i * 3], j1 = sh_jac[(size_t)i * 3 + 1], j2 = sh_jac[(size_t)i * 3 + 2];
                         const float jr[3][3] = {{j0.x, j0.y, j0.z}, {j0.w, j1.x, j1.y}, {j1.z, j1.w, j2.x}};
+                        float gch[3];
                         for (int ch = 0; ch < 3; ch++) {
                             const float g = ((cl >> (8 * ch)) & 1u) ? 0.f : drgb[ch];
+                            gch[ch] = g;
                             du[0] += g * jr[ch][0]; du[1] += g * jr[ch][1]; du[2] += g * jr[ch][2];
-                            for (int k = 0; k < nb; k++) dsh[3 * k + ch] = g * b[k];
-                            for (int k = nb; k < M; k++) dsh[3 * k + ch] = 0.f;
+                            if (!PAD4) {
+                                for (int k = 0; k < nb; k++) dsh[3 * k + ch] = g * b[k];
+                                for (int k = nb; k < M; k++) dsh[3 * k + ch] = 0.f;
+                            }
+                        }
+                        if (PAD4) {                                 // the row as twelve 16-byte pieces: flat element e = 3 k + ch
+                            float4* d4 = reinterpret_cast<float4*>(dsh);
+#pragma unroll
+                            for (int q = 0; q < 12; q++) {
+                                float v[4];
+#pragma unroll
+                                for (int t = 0; t < 4; t++) {
+                                    const int e = 4 * q + t, k = e / 3, ch = e - 3 * k;
+                                    v[t] = k < nb ? gch[ch] * b[k] : 0.f;
+                                }
+                                d4[q] = make_float4(v[0], v[1], v[2], v[3]);
+                            }
                         }
                     } else {
                         for (int ch = 0; ch < 3; ch++) {
@@ -90,12 +125,17 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
                     }
                     const float dot = ux * du[0] + uy * du[1] + uz * du[2];
                     dmean[0] += (du[0] - ux * dot) * inv; dmean[1] += (du[1] - uy * dot) * inv; dmean[2] += (du[2] - uz * dot) * inv;
+                } else if (PAD4) {
+                    float4* d4 = reinterpret_cast<float4*>(dsh);
+#pragma unroll
+                    for (int q = 0; q < 12; q++) d4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
                     for (int k = 0; k < K; k++) dsh[k] = 0.f;
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            sh_wave_rows_from_lds<KC>(slab, dshs, row0, nrows, K, lane);
+            if (PAD4) sh48_rows_from_lds4(slab, dshs, row0, nrows, lane);
+            else sh_wave_rows_from_lds<KC>(slab, dshs, row0, nrows, K, lane);
         }
         if (!in_range) return;
     }
@@ -120,12 +160,12 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
         float Rm[3][3], s3[3] = {0.f, 0.f, 0.f};
         float r = 0.f, x = 0.f, y = 0.f, z = 0.f;
         if (cov3Dp) {
-            const float* c = cov3Dp + (size_t)i * 6;
+            const float* c = cov_in;
             S[0][0] = c[0]; S[0][1] = c[1]; S[0][2] = c[2]; S[1][0] = c[1]; S[1][1] = c[3]; S[1][2] = c[4];
             S[2][0] = c[2]; S[2][1] = c[4]; S[2][2] = c[5];
         } else {
-            s3[0] = cam.mod * scales[3 * i]; s3[1] = cam.mod * scales[3 * i + 1]; s3[2] = cam.mod * scales[3 * i + 2];
-            const float4 rq = reinterpret_cast<const float4*>(rots)[i];
+            s3[0] = cam.mod * sc_in[0]; s3[1] = cam.mod * sc_in[1]; s3[2] = cam.mod * sc_in[2];
+            const float4 rq = rq_in;
             r = rq.x; x = rq.y; y = rq.z; z = rq.w;
             Rm[0][0] = 1.f - 2.f * (y * y + z * z); Rm[0][1] = 2.f * (x * y - r * z); Rm[0][2] = 2.f * (x * z + r * y);
             Rm[1][0] = 2.f * (x * y + r * z); Rm[1][1] = 1.f - 2.f * (x * x + z * z); Rm[1][2] = 2.f * (y * z - r * x);
@@ -223,7 +263,10 @@ hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3
                                       float* dscales, float* drots, float* dcov3D, hipStream_t st)
 {
     const int nb = (P + kBlock - 1) / kBlock;
-    if (nb > 0 && shs && cam.sh_coeffs == 16)
+    if (nb > 0 && shs && cam.sh_coeffs == 16 && env_knob("GS_PRE_BWD", 0) == 1)
+        hipLaunchKernelGGL(preprocess_backward_kernel<4>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
+                           cov3Dp, radii, clamped, sh_jac, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
+    else if (nb > 0 && shs && cam.sh_coeffs == 16)
         hipLaunchKernelGGL(preprocess_backward_kernel<3>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
                            cov3Dp, radii, clamped, sh_jac, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
     else if (nb > 0 && shs)

@@ -383,14 +383,14 @@ __device__ __forceinline__ void tile_sort_impl(const uint2 range, uint32_t n, co
 template <int CAP, int THREADS>
 __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restrict__ ranges,
                                                              const unsigned long long* pairs, unsigned long long* pairs_out,
-                                                             uint32_t* __restrict__ point_list, uint32_t cap)
+                                                             uint32_t* __restrict__ point_list, uint32_t cap, uint32_t skip_le)
 {
     __shared__ unsigned long long s_a[CAP];
     const int tid = threadIdx.x;
     uint2 range = ranges[blockIdx.x];
     range.x = min(range.x, cap); range.y = min(range.y, cap);   // workspace capacity (see tile_bin_kernel)
     const uint32_t start = blockIdx.y * (uint32_t)CAP;
-    if (range.y - range.x <= start) return;                    // uniform (also n == 0)
+    if (range.y - range.x <= start || range.y - range.x <= skip_le) return;        // uniform (also n == 0; skip_le: lists the bucket kernel sorts)
     range.x += start;
     const uint32_t n = min(range.y - range.x, (uint32_t)CAP);
     constexpr int EMAX = CAP / THREADS;                       // 8
@@ -399,20 +399,201 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restr
     else tile_sort_impl<EMAX, THREADS>(range, n, pairs, pairs_out, point_list, s_a, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Bucket sort of a whole tile list of at most kBucketCap keys in ONE workgroup (lists beyond that: the run sort + merges above).
+//
+// The keys are (view depth bits << 32 | id); a tile's depths lie in a narrow interval [zlo, zhi], so a LINEAR map of the depth onto
+// kBuckets bins is a monotone coarse key for free (three VALU operations per key -- no comparison network):
+//   1. every thread loads its E keys into registers; workgroup min / max of the depths;
+//   2. bin = floor((z - zlo) * scale): one returning LDS integer atomic per key counts the bin and hands the key its arrival index
+//      inside the bin (LDS integer atomics: 4-5 clk per 64-lane instruction);
+//   3. exclusive scan of the kBuckets counts -> every bin's slice of the sorted list;
+//   4. the keys are scattered into LDS, grouped by bin (bins in depth order, arrival order inside a bin);
+//   5. thread p takes position p of that array: its bin's slice holds a handful of keys (n / kBuckets ~ 1 ... 5 on average), the key's
+//      rank inside the slice is the number of smaller keys in it (keys are unique), and the key's ID leaves for its final position in
+//      point_list (the sorted 64-bit pairs themselves are not written back: nothing downstream reads them -- 20 -> 12 bytes per key).
+//      The lanes of a wavefront sit in the same or neighbouring bins: the LDS reads are broadcasts and the stores land in the same few
+//      lines.
+// Work per key: ~25 VALU + ~10 LDS operations, against 78 compare-exchange stages of the bitonic network (2 M Gaussians, lists of ~4000:
+// sort + merge 69 us -> see profiles/README.md).  The result is THE sorted order (unique keys): identical to the network's.
+// Clustered depths (a wall at constant depth and one far outlier in the same tile) crowd a bin and the quadratic rank step with it:
+// a tile whose fullest bin exceeds kBucketRankMax keys is sorted by the bitonic network instead -- same kernel, keys already in
+// registers: runs of 4096 (and the rest) + a rank merge in LDS -- i.e. never slower than the path above by more than the counting.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int kBucketCap = 5632;          // keys per tile list the bucket kernel takes (44 KB of LDS: three workgroups per CU)
+constexpr int kBuckets = 2048;           // 16-bit counters, two per LDS word (a list holds < 65536 keys)
+constexpr int kBucketThreads = 512;
+constexpr int kBucketRankMax = 64;
+
+template <int E>
+__device__ __forceinline__ void bucket_sort_impl(const uint2 range, uint32_t n, const unsigned long long* __restrict__ pairs,
+                                                 uint32_t* __restrict__ point_list, unsigned long long* s_keys, uint32_t* s_cnt, uint16_t* s_off,
+                                                 float* s_redf, uint32_t* s_redu, int tid)
+{
+    constexpr int T = kBucketThreads;
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned long long k[E];
+    float zmin = 3.0e38f, zmax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const uint32_t e = (uint32_t)i * T + tid;
+        k[i] = e < n ? pairs[range.x + e] : kPadKey;
+        if (e < n) {
+            const float z = __uint_as_float((uint32_t)(k[i] >> 32));
+            zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
+        }
+    }
+    // short lists use fewer bins (fixed cost of zeroing and scanning them): ~2 keys per bin either way
+    const int nbins = n <= 1024u ? kBuckets / 4 : (n <= 2560u ? kBuckets / 2 : kBuckets);
+    for (int b = tid; b < nbins / 2; b += T) s_cnt[b] = 0u;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { zmin = fminf(zmin, __shfl_xor(zmin, m)); zmax = fmaxf(zmax, __shfl_xor(zmax, m)); }
+    if (lane == 0) { s_redf[wave] = zmin; s_redf[T / kWave + wave] = zmax; }
+    __syncthreads();
+    float zlo = s_redf[0], zhi = s_redf[T / kWave];
+#pragma unroll
+    for (int w = 1; w < T / kWave; w++) { zlo = fminf(zlo, s_redf[w]); zhi = fmaxf(zhi, s_redf[T / kWave + w]); }
+    // bin = min(kBuckets - 1, (uint)((z - zlo) * scale)): monotone in z whatever the rounding (subtraction, product and conversion are)
+    const float span = zhi - zlo;
+    const float scale = span > 0.0f ? (float)nbins / span : 0.0f;
+    const uint32_t last_bin = (uint32_t)nbins - 1u;
+#define GS_BIN(key) min(last_bin, (uint32_t)((__uint_as_float((uint32_t)((key) >> 32)) - zlo) * scale))
+    uint32_t br[E];                                             // bin << 16 | arrival index inside the bin
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const uint32_t e = (uint32_t)i * T + tid;
+        br[i] = 0u;
+        if (e < n) {
+            const uint32_t b = GS_BIN(k[i]);
+            const uint32_t sh = (b & 1u) * 16u;
+            br[i] = (b << 16) | ((atomicAdd(&s_cnt[b >> 1], 1u << sh) >> sh) & 0xffffu);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the counts (kBuckets / T consecutive bins per thread) and the fullest bin
+    constexpr int PB = kBuckets / T;
+    static_assert(PB % 2 == 0, "a thread scans whole counter words");
+    uint32_t c[PB], sum = 0, cmax = 0;
+#pragma unroll
+    for (int j = 0; j < PB; j++) { c[j] = tid * PB < nbins ? (s_cnt[(tid * PB + j) >> 1] >> (16 * (j & 1))) & 0xffffu : 0u; sum += c[j]; cmax = max(cmax, c[j]); }
+    const uint32_t incl = wave_inclusive_scan(sum, lane);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor(cmax, m));
+    if (lane == 63) s_redu[wave] = incl;
+    if (lane == 0) s_redu[T / kWave + wave] = cmax;
+    __syncthreads();
+    uint32_t run = incl - sum, fullest = 0;
+#pragma unroll
+    for (int w = 0; w < T / kWave; w++) { if (w < wave) run += s_redu[w]; fullest = max(fullest, s_redu[T / kWave + w]); }
+    if (tid * PB < nbins) {
+#pragma unroll
+        for (int j = 0; j < PB; j++) { s_off[tid * PB + j] = (uint16_t)run; run += c[j]; }
+        if (tid * PB + PB == nbins) s_off[nbins] = (uint16_t)run;
+    }
+    __syncthreads();
+    if (fullest <= (uint32_t)kBucketRankMax) {
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const uint32_t e = (uint32_t)i * T + tid;
+            if (e < n) s_keys[s_off[br[i] >> 16] + (br[i] & 0xffffu)] = k[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const uint32_t p = (uint32_t)i * T + tid;
+            if (p < n) {
+                const unsigned long long key = s_keys[p];
+                const uint32_t b = GS_BIN(key);
+                const uint32_t lo = s_off[b], hi = s_off[b + 1];
+                uint32_t rank = lo;
+                for (uint32_t j = lo; j < hi; j++) rank += s_keys[j] < key ? 1u : 0u;
+                point_list[range.x + rank] = (uint32_t)key;
+            }
+        }
+        return;
+    }
+#undef GS_BIN
+    // ---- crowded bins: the comparison network on the keys in the registers (uniform branch) ----
+    constexpr int EA = E > 8 ? 8 : E;                              // run A: slots [0, EA * T) of the load order; run B: the rest (E = 11 only)
+    double va[EA];
+#pragma unroll
+    for (int i = 0; i < EA; i++) va[i] = key_to_f64(k[i]);
+    bitonic_sort_block<EA, T>(va, reinterpret_cast<double*>(s_keys), tid);
+    const uint32_t nA = min(n, (uint32_t)(EA * T));
+    if (E <= 8) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < EA; i++) s_keys[(uint32_t)tid * EA + i] = f64_to_key(va[i]);
+        __syncthreads();
+        for (uint32_t e = tid; e < n; e += T) {
+            const unsigned long long v = s_keys[e];
+            point_list[range.x + e] = (uint32_t)v;
+        }
+        return;
+    }
+    constexpr int EB = 4;                                          // (kBucketCap - 8 T) / T = 3 keys per thread, as a power of two
+    static_assert(kBucketCap <= (8 + EB) * T && E <= 8 + EB, "run B holds the keys beyond run A");
+    double vb[EB];
+#pragma unroll
+    for (int i = 0; i < EB; i++) vb[i] = key_to_f64((EA + i) < E ? k[(EA + i) < E ? (EA + i) : 0] : kPadKey);
+    __syncthreads();                                               // run A is in the registers: its exchange buffer is free again
+    bitonic_sort_block<EB, T>(vb, reinterpret_cast<double*>(s_keys), tid);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < EA; i++) s_keys[(uint32_t)tid * EA + i] = f64_to_key(va[i]);
+#pragma unroll
+    for (int i = 0; i < EB; i++) if ((uint32_t)(EA * T + tid * EB + i) < (uint32_t)kBucketCap) s_keys[EA * T + (uint32_t)tid * EB + i] = f64_to_key(vb[i]);
+    __syncthreads();
+    // rank merge of the two sorted runs A = s_keys[0, nA), B = s_keys[EA T, EA T + nB): keys are unique
+    const uint32_t nB = n - nA;
+    for (uint32_t e = tid; e < n; e += T) {
+        const bool in_a = e < nA;
+        const unsigned long long key = in_a ? s_keys[e] : s_keys[EA * T + (e - nA)];
+        const uint32_t base = in_a ? (uint32_t)(EA * T) : 0u, len = in_a ? nB : nA;
+        uint32_t lo = 0, hi = len;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_keys[base + mid] < key) lo = mid + 1; else hi = mid;
+        }
+        const uint32_t rank = (in_a ? e : e - nA) + lo;
+        point_list[range.x + rank] = (uint32_t)key;
+    }
+}
+
+__global__ __launch_bounds__(kBucketThreads) void tile_bucket_sort_kernel(const uint2* __restrict__ ranges, const unsigned long long* __restrict__ pairs,
+                                                                           uint32_t* __restrict__ point_list, uint32_t cap)
+{
+    __shared__ unsigned long long s_keys[kBucketCap];
+    __shared__ uint32_t s_cnt[kBuckets / 2];
+    __shared__ uint16_t s_off[kBuckets + 2];
+    __shared__ float s_redf[2 * kBucketThreads / kWave];
+    __shared__ uint32_t s_redu[2 * kBucketThreads / kWave];
+    const int tid = threadIdx.x;
+    uint2 range = ranges[blockIdx.x];
+    range.x = min(range.x, cap); range.y = min(range.y, cap);   // workspace capacity (see tile_bin_kernel)
+    const uint32_t n = range.y - range.x;
+    if (n == 0 || n > (uint32_t)kBucketCap) return;             // uniform
+    constexpr int T = kBucketThreads;
+    if (n <= 2u * T) bucket_sort_impl<2>(range, n, pairs, point_list, s_keys, s_cnt, s_off, s_redf, s_redu, tid);
+    else if (n <= 4u * T) bucket_sort_impl<4>(range, n, pairs, point_list, s_keys, s_cnt, s_off, s_redf, s_redu, tid);
+    else if (n <= 8u * T) bucket_sort_impl<8>(range, n, pairs, point_list, s_keys, s_cnt, s_off, s_redf, s_redu, tid);
+    else bucket_sort_impl<11>(range, n, pairs, point_list, s_keys, s_cnt, s_off, s_redf, s_redu, tid);
+}
+
 // Tiles with CHUNK < n <= CAP: the CHUNK-sized sorted runs left by tile_sort_kernel are merged by RANK: the whole
 // list sits in LDS, every key adds to its index inside its own run the number of smaller keys in each other run
 // (binary search in LDS; keys are unique) and is written straight to its final position.
 template <int CAP, int CHUNK, int THREADS>
 __global__ __launch_bounds__(THREADS) void tile_merge_kernel(const uint2* __restrict__ ranges,
                                                               unsigned long long* __restrict__ pairs,
-                                                              uint32_t* __restrict__ point_list, uint32_t cap)
+                                                              uint32_t* __restrict__ point_list, uint32_t cap, uint32_t skip_le)
 {
     __shared__ unsigned long long s_k[CAP];
     const int tid = threadIdx.x;
     uint2 range = ranges[blockIdx.x];
     range.x = min(range.x, cap); range.y = min(range.y, cap);
     const uint32_t n = range.y - range.x;
-    if (n <= (uint32_t)CHUNK || n > (uint32_t)CAP) return;     // uniform: already final / longer than the caller assumed
+    if (n <= (uint32_t)CHUNK || n > (uint32_t)CAP || n <= skip_le) return;     // uniform: already final / longer than the caller assumed / bucket-sorted
     for (uint32_t i = tid; i < n; i += THREADS) s_k[i] = pairs[range.x + i];
     __syncthreads();
     const uint32_t nruns = (n + CHUNK - 1) / CHUNK;
@@ -546,25 +727,33 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
     // 2048-key runs), then the runs of a tile are merged -- by rank inside LDS up to kSortCapMax keys, pass by pass through global
     // memory beyond (`pairs` <-> `pairs_alt`; the run sort writes into whichever of the two leaves the final pass's output in `pairs`).
     constexpr int kBigChunk = 2 * kSortChunk;
+    // Lists of at most kBucketCap keys: the bucket sort, one workgroup per tile.  The choice is made PER TILE on the device (the caller's
+    // max_tile_instances may be the capacity guess of an optimistic launch): when longer lists are possible the run sort + merges below
+    // are launched as well and skip the tiles the bucket kernel took.
+    const uint32_t skip_le = max_tile_instances <= (uint32_t)kSortCapMax && env_knob("GS_SORT_BUCKET", 1) != 0 ? (uint32_t)kBucketCap : 0u;
+    if (skip_le) {
+        hipLaunchKernelGGL(tile_bucket_sort_kernel, dim3(tiles), dim3(kBucketThreads), 0, st, ranges, pairs, point_list, cap);
+        if (max_tile_instances <= (uint32_t)kBucketCap) return hipGetLastError();
+    }
     if (max_tile_instances <= (uint32_t)kSortChunk) {
-        hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, 1), dim3(256), 0, st, ranges, pairs, pairs, point_list, cap);
+        hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, 1), dim3(256), 0, st, ranges, pairs, pairs, point_list, cap, 0u);
         return hipGetLastError();
     }
     const unsigned chunks = (max_tile_instances + kBigChunk - 1) / kBigChunk;
     if (max_tile_instances <= (uint32_t)kSortCapMax) {
-        hipLaunchKernelGGL((tile_sort_kernel<kBigChunk, 256>), dim3(tiles, chunks), dim3(256), 0, st, ranges, pairs, pairs, point_list, cap);
+        hipLaunchKernelGGL((tile_sort_kernel<kBigChunk, 256>), dim3(tiles, chunks), dim3(256), 0, st, ranges, pairs, pairs, point_list, cap, skip_le);
         // the list sits in LDS: the smaller capacity keeps two workgroups resident per CU
         if (max_tile_instances > 8192)
-            hipLaunchKernelGGL((tile_merge_kernel<kSortCapMax, kBigChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
+            hipLaunchKernelGGL((tile_merge_kernel<kSortCapMax, kBigChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap, skip_le);
         else if (max_tile_instances > (uint32_t)kBigChunk)
-            hipLaunchKernelGGL((tile_merge_kernel<8192, kBigChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap);
+            hipLaunchKernelGGL((tile_merge_kernel<8192, kBigChunk, 1024>), dim3(tiles), dim3(1024), 0, st, ranges, pairs, point_list, cap, skip_le);
         return hipGetLastError();
     }
     constexpr int kOut = kSortChunk;
     int passes = 0;
     for (uint64_t r = kBigChunk; r < max_tile_instances; r <<= 1) passes++;
     unsigned long long* cur = (passes & 1) ? pairs_alt : pairs;
-    hipLaunchKernelGGL((tile_sort_kernel<kBigChunk, 256>), dim3(tiles, chunks), dim3(256), 0, st, ranges, pairs, cur, point_list, cap);
+    hipLaunchKernelGGL((tile_sort_kernel<kBigChunk, 256>), dim3(tiles, chunks), dim3(256), 0, st, ranges, pairs, cur, point_list, cap, 0u);
     const unsigned blocks = (max_tile_instances + kOut - 1) / kOut;
     uint64_t r = kBigChunk;
     for (int p = 0; p < passes; p++, r <<= 1) {

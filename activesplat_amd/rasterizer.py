@@ -187,7 +187,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             old = _capacity.get(key, (0, 0))                    # monotone: views that alternate settle on the largest
             if len(_capacity) >= 64 and key not in _capacity:   # P changes with every densify / growth step: keep the table small
                 _capacity.pop(next(iter(_capacity)))
-            _capacity[key] = (max(old[0], int(D * 1.25) + 4096), max(old[1], int(max_tile * 1.25) + 64))
+            # (the tile-list bound only selects kernels and LDS variants: a tight margin keeps a 2 M-Gaussian frame -- lists of up to 4.8 k keys --
+            # inside the one-workgroup bucket sort's 5632-key class; a list that outgrows it costs one exact re-launch)
+            _capacity[key] = (max(old[0], int(D * 1.25) + 4096), max(old[1], max_tile + max_tile // 16 + 64))
         last_stats["num_rendered"], last_stats["P"], last_stats["max_tile_instances"] = D, P, max_tile
         ctx.rs, ctx.D, ctx.keep, ctx.fused, ctx.cam = rs, D, keep, fused, cam      # the backward reuses the camera block
         ctx.scratch, ctx.scratch_clean, ctx.sh_jac = scratch, scratch is not None, want_bwd

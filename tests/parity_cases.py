@@ -53,6 +53,21 @@ def build_case(name, device):
     elif name == "merge_passes_even":       # > 32768 per tile: 4 passes (the run sort starts in the other buffer), ragged last runs
         W, H, N = 32, 32, 75000
         mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.01)  # noqa: E731
+    elif name in ("bucket_lists", "bucket_lists_long", "crowded_depth", "crowded_depth_long"):
+        # tile lists of ~3.5 k / ~4.6 k keys (one bucket-sort workgroup per tile, 8 / 10 keys per thread); "crowded": every depth but a
+        # few outliers inside 1e-4 of each other, so one bin of the bucket sort holds the whole list -> its comparison-network branch
+        # (one run / two runs + merge)
+        W, H, N = 48, 48, {"bucket_lists": 14000, "bucket_lists_long": 18000, "crowded_depth": 11000, "crowded_depth_long": 15500}[name]
+
+        def mutate(rv, crowded=name.startswith("crowded")):
+            upd = dict(opacities=rv["opacities"] * 0.05)
+            if crowded:
+                g = torch.Generator().manual_seed(7)
+                m = rv["means3D"]
+                znew = 2.0 + 1e-4 * torch.rand(m.shape[0], generator=g).to(m.device)
+                znew[:3] = 0.6; znew[3:6] = 3.9
+                upd["means3D"] = (m * (znew / m[:, 2])[:, None]).contiguous()
+            rv.update(upd)
     elif name == "many_tiles":              # 2064x1104 px = 129 x 69 = 8901 tiles > 8192: no LDS tile histogram -> radix path
         W, H, N = 2064, 1104, 3000
     elif name == "low_opacity":             # many Gaussians below the 1/255 threshold
@@ -83,7 +98,8 @@ def build_case(name, device):
     return rs, rv
 
 
-BIG_TILE_CASES = ["merge_tiles", "merge_tiles_large", "merge_passes", "merge_passes_even"]
+BIG_TILE_CASES = ["merge_tiles", "merge_tiles_large", "merge_passes", "merge_passes_even", "bucket_lists", "bucket_lists_long", "crowded_depth",
+                  "crowded_depth_long"]
 CASES = ["basic", "ragged_image", "tiny_lookaround", "lookaround_intrinsics", "posed_white_bg", "scale_modifier", "behind_camera", "all_culled",
          "huge_gaussians", "dense_overdraw", "low_opacity", "one_gaussian", "not_multiple_of_block", "sh0", "sh1", "sh2",
          "sh3", "sh2_ragged", "sh3_half_culled", "cov3d_precomp"]

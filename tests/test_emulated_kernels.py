@@ -19,7 +19,8 @@ def test_emulated_forward_matches_oracle(emu, oracle32, case):
     assert util.artefacts()["path"] == 1        # tile-binning + LDS sort path
 
 
-@pytest.mark.parametrize("case,path", [("merge_tiles", 1), ("merge_passes", 1), ("merge_passes_even", 1)])
+@pytest.mark.parametrize("case,path", [("merge_tiles", 1), ("merge_passes", 1), ("merge_passes_even", 1), ("bucket_lists", 1), ("bucket_lists_long", 1),
+                                       ("crowded_depth", 1), ("crowded_depth_long", 1)])
 def test_emulated_big_tile_lists(emu, oracle32, case, path):
     """tile lists beyond one sort chunk: sorted chunks + LDS rank-merge; beyond the LDS capacity: pairwise merge passes."""
     rs, rv = pc.build_case(case, emu)

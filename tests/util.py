@@ -78,11 +78,12 @@ def artefacts():
                point_list=d["point_list"].cpu().numpy()[:D].astype(np.uint32), ranges=ranges,
                final_T=view(image, il.final_T, np.float32, W * H).reshape(H, W),
                n_contrib=view(image, il.n_contrib, np.uint32, W * H).reshape(H, W))
-    if bl.path == 1:      # GS_SORT_TILE_LDS: pairs = (depth_bits << 32 | id), tile-major; rebuild the 64-bit keys
-        pairs = view(binning, bl.pairs, np.uint64, D)
+    if bl.path == 1:      # GS_SORT_TILE_LDS: the sorted list is point_list (ids, tile-major); the 64-bit keys (tile << 32 | depth bits) are
+        # rebuilt from it and the per-Gaussian depth bits (the bucket sort does not write sorted pairs back)
+        depth_bits = view(geom, gl.depth_bits, np.uint32, P).astype(np.uint64)
         tile_of = np.repeat(np.arange(tiles, dtype=np.uint64), (ranges[:, 1] - ranges[:, 0]).astype(np.int64))
-        out["keys_sorted"] = (tile_of << np.uint64(32)) | (pairs >> np.uint64(32))
-        out["pairs_ids"] = (pairs & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        out["keys_sorted"] = (tile_of << np.uint64(32)) | depth_bits[out["point_list"].astype(np.int64)]
+        out["pairs_ids"] = out["point_list"]
         out["offsets"] = None
     else:
         out["keys_sorted"] = view(binning, bl.keys_sorted, np.uint64, D)
