@@ -141,16 +141,21 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     // NS rows of 64 entries per wave (+16 bytes so that the look-ahead read behind the last row stays inside the wave's slab)
     __shared__ __attribute__((aligned(16))) uint8_t s_list[NW][NS * kWave + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // side job (SEG = 0 only): this workgroup's slice of the backward's gradient records is zero-filled here -- plain
-    // fire-and-forget 16-byte stores next to an arithmetic-bound loop instead of a separate fill launch before the backward
+    // side job (SEG = 0 only): this workgroup's slice of the backward's gradient records is zero-filled here instead of by a fill launch
+    // in front of the backward -- plain fire-and-forget 16-byte stores, kFillPerStep of them per trip of the chunk loop below.  (Issued
+    // all at once at the top of the kernel -- the first version -- they are a 128 MB memset at 2 M Gaussians that every CU's store
+    // queue has to drain BEFORE its wavefronts get to blend: ~25 us of the forward; interleaved they ride along.)  What is left when a
+    // wavefront's walk ends is stored then.
+    constexpr int kFillPerStep = 2;
+    size_t zf = 0, zf_end = 0;
     if (SEG == 0 && zero_fill) {
         const size_t total = (size_t)P * (kGradStride / 4), per = (total + gridDim.x - 1) / gridDim.x;
-        const size_t z0 = (size_t)blockIdx.x * per, z1 = min(total, z0 + per);
-        for (size_t z = z0 + tid; z < z1; z += NW * kWave) zero_fill[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+        zf = (size_t)blockIdx.x * per + tid; zf_end = min(total, (size_t)blockIdx.x * per + per);
     }
+#define GS_FILL_REST() if (SEG == 0) { for (; zf < zf_end; zf += NW * kWave) zero_fill[zf] = make_float4(0.f, 0.f, 0.f, 0.f); }
     TileCtx c;
     const bool half = FEW && cam.half != 0;
-    if (!tile_ctx_nw<NW>(cam, wave, lane, c, half)) return;
+    if (!tile_ctx_nw<NW>(cam, wave, lane, c, half)) { GS_FILL_REST(); return; }
     // lane -> pixel: stream sid owns block (sid & 1, sid >> 1) of the quadrant
     const int sid = lane / LS, l = lane % LS;
     const int px = (int)c.qx0 + (sid & 1) * 4 + (l & 3), py = (int)c.qy0 + (sid >> 1) * BH + (l >> 2);
@@ -216,6 +221,11 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
         if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
         for (uint32_t base = first; base < n; base += kWave) {
+            if (SEG == 0) {
+#pragma unroll
+                for (int f = 0; f < kFillPerStep; f++)
+                    if (zf < zf_end) { zero_fill[zf] = make_float4(0.f, 0.f, 0.f, 0.f); zf += NW * kWave; }
+            }
             if (FEW && SEG == 0 && record && base >= (uint32_t)kCutFirst && base < ((uint32_t)kCutFirst << kCutLevels) &&
                 (base & (base - 1u)) == 0u && inside) {
                 const int k = 31 - __clz((int)base) - 7;                                       // 128 -> 0, 256 -> 1, ...
@@ -242,10 +252,15 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
             __builtin_amdgcn_wave_barrier();
             int ntrips = 0;
             const float ex = q2.z, ey = q2.w;
+            // a stream whose pixels have ALL stopped gets an empty list: the walk's trip count is the longest list of the streams that
+            // still blend (pixels of a quadrant saturate at different depths: at 2 M Gaussians the mean stop is at position ~900, the
+            // last pixel of a quadrant stops around 1400)
+            const unsigned long long going = SEG == 1 ? ~0ull : ~__ballot(done);
 #pragma unroll
             for (int s = 0; s < NS; s++) {
                 const float x0 = c.qx0 + (float)((s & 1) * 4), y0 = c.qy0 + (float)((s >> 1) * BH);
-                const bool hit = live && s < ns_live && ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) &&
+                const bool stream_going = ((going >> (s * LS)) & ((1ull << LS) - 1ull)) != 0ull;
+                const bool hit = live && s < ns_live && stream_going && ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) &&
                                  (q0.y - ey <= y0 + (float)(BH - 1));
                 const unsigned long long m = __ballot(hit);
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -286,6 +301,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
             if (SEG == 1 && __all(!inside || T < kTmin)) break;      // every pixel is below the stop threshold: the rest cannot matter
         }
     }
+    GS_FILL_REST();
     if (SEG == 1) {
         my_seg_T[0] = T;
         if (__all(!inside || T < kTmin) && lane == 0) atomicOr(seg_flag, 1u << blockIdx.y);
@@ -322,6 +338,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     }
 }
 
+#undef GS_FILL_REST
 // ---------------------------------------------------------------------------------------------------
 // Backward: back-to-front replay in two phases per batch of list positions.  Same independent-quadrant walk and the same four
 // record streams as the forward (one per 16-lane row = 4x4 pixel block of the quadrant), lists built deepest-first.
@@ -427,6 +444,13 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     }
     if (c.seg == 1 && wmax <= m_cut) return;
     const int cmin = c.seg == 1 ? (int)(m_cut / kWave) : 0;      // the back walker stops at the cut
+    // the deepest contributing position of every 4x4 block (row of 16 lanes): the walk starts at the quadrant's deepest contributor, but a
+    // block takes part only from its own -- above that its list stays empty and the trip count is set by the blocks that do contribute
+    uint32_t rmax = last;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) rmax = max(rmax, (uint32_t)__shfl_xor(rmax, m));
+    const uint32_t rm0 = (uint32_t)__builtin_amdgcn_readlane((int)rmax, 0), rm1 = (uint32_t)__builtin_amdgcn_readlane((int)rmax, 16);
+    const uint32_t rm2 = (uint32_t)__builtin_amdgcn_readlane((int)rmax, 32), rm3 = (uint32_t)__builtin_amdgcn_readlane((int)rmax, 48);
 
     // phase B role: the block of row rb at list position tb of the batch; its 16 pixels' dL/dcolour stay in registers
     const int tb = lane >> 2, rb = lane & 3;
@@ -458,8 +482,9 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
         if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
 
         const bool live = id_cur != kNoId;
-        const bool h0 = live && subblock_hit(q0, q2, c.qx0, c.qy0), h1 = live && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0);
-        const bool h2 = live && subblock_hit(q0, q2, c.qx0, c.qy0 + 4.0f), h3 = live && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0 + 4.0f);
+        const uint32_t cpos = (uint32_t)ch * kWave;                  // first list position of this chunk
+        const bool h0 = live && cpos < rm0 && subblock_hit(q0, q2, c.qx0, c.qy0), h1 = live && cpos < rm1 && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0);
+        const bool h2 = live && cpos < rm2 && subblock_hit(q0, q2, c.qx0, c.qy0 + 4.0f), h3 = live && cpos < rm3 && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0 + 4.0f);
         const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
         if ((m0 | m1 | m2 | m3) == 0ull) continue;
         stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);

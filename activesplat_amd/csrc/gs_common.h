@@ -184,21 +184,6 @@ __device__ __forceinline__ void sh48_half_load(float4 (&v)[6], const float* __re
 #pragma unroll
     for (int j = 0; j < 6; j++) v[j] = load_stream(&s4[lane + kWave * j]);
 }
-__device__ __forceinline__ void sh48_half_to_lds(float* slab, const float4 (&v)[6], int lane)
-{
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-        const int e = (lane + kWave * j) << 2;
-        int r = e / 48, c = e - r * 48;
-        const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            slab[r * kShPad + c] = vv[t];
-            if (++c == 48) { c = 0; ++r; }
-        }
-    }
-}
-
 // 16-coefficient rows (48 floats) in slabs with a 52-float row stride: rows stay 16-byte aligned, so a 16-byte piece of a row moves with ONE
 // ds_write_b128 / ds_read_b128 (the 49-float stride needs four scalar LDS operations per piece), and lane = row accesses are conflict-free
 // (52 r mod 64 takes 16 distinct multiples of 4 over the lanes a 128-bit LDS access serves together).
@@ -220,23 +205,6 @@ __device__ __forceinline__ void sh48_rows_to_lds4(float* slab, const float* __re
         if ((row_mask >> r) & 1u) *reinterpret_cast<float4*>(slab + r * kShPad4 + 4 * c) = load_stream(&s4[q]);
     }
 }
-__device__ __forceinline__ void sh48_rows_from_lds4(const float* slab, float* __restrict__ dst, int row0, int nrows, int lane)
-{
-    float4* d4 = reinterpret_cast<float4*>(dst + (size_t)row0 * 48);
-    if (nrows == kShHalf) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const int q = lane + kWave * j, r = q / 12, c = q - 12 * r;
-            store_stream(&d4[q], *reinterpret_cast<const float4*>(slab + r * kShPad4 + 4 * c));
-        }
-    } else {
-        for (int q = lane; q < nrows * 12; q += kWave) {
-            const int r = q / 12, c = q - 12 * r;
-            store_stream(&d4[q], *reinterpret_cast<const float4*>(slab + r * kShPad4 + 4 * c));
-        }
-    }
-}
-
 template <int KC = 0>
 __device__ __forceinline__ void sh_wave_rows_from_lds(const float* slab, float* __restrict__ dst, int row0, int nrows, int Krt, int lane)
 {

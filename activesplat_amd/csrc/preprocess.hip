@@ -173,8 +173,8 @@ __device__ __forceinline__ uint32_t project_gaussian(const Cam& cam, int P, int 
     return ntiles;
 }
 
-// SH: 0 = colours given, 1 = coefficient rows of any width through per-wave LDS slabs, 3 = the same for 16-coefficient rows
-// (row width 48 known at compile time: the copy loops' element -> (row, column) divisions fold away)
+// SH: 0 = colours given, 1 = coefficient rows of any width through per-wave LDS slabs (16-coefficient rows, the layout every caller of
+// the reference uses, take preprocess_forward_sh48_kernel below)
 template <int SH>
 __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     // LDS: means | one pool that holds, in turn, the per-wave SH slabs (HAS_SH, first phase) and the staged
     // scale+rotation (or covariance) rows and colours (second phase)
     constexpr bool HAS_SH = SH != 0;
-    constexpr bool SLAB = SH == 1 || SH == 3;
+    constexpr bool SLAB = SH == 1;
     constexpr int kGeoFloats = kBlock * 7, kColFloats = SLAB ? 0 : kBlock * 3;
     constexpr int kSlabFloats = SLAB ? (kBlock / kWave) * kShHalf * kShPad : 0;
     constexpr int kPoolFloats = (kGeoFloats + kColFloats) > kSlabFloats ? (kGeoFloats + kColFloats) : kSlabFloats;
@@ -219,21 +219,15 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     float sh_rgb[3] = {0.f, 0.f, 0.f};
     uint32_t sh_clamp = 0;
     if (SLAB) {
-        constexpr int KC = SH == 3 ? 48 : 0;
-        const int M = KC ? 16 : cam.sh_coeffs, K = M * 3, nbasis = (cam.sh_degree + 1) * (cam.sh_degree + 1);
+        const int M = cam.sh_coeffs, K = M * 3, nbasis = (cam.sh_degree + 1) * (cam.sh_degree + 1);
         const int stride = sh_row_stride(K);
         const int lane = tid & 63, wave = tid >> 6;
         float* slab = s_sh + wave * kShHalf * kShPad;
-        // a wavefront whose 64 rows all exist (every one but the last of the array) loads both halves up front
-        const bool pre = KC == 48 && base + wave * kWave + kWave <= P;
-        float4 va[6], vb[6];
-        if (pre) { sh48_half_load(va, shs, base + wave * kWave, lane); sh48_half_load(vb, shs, base + wave * kWave + kShHalf, lane); }
         for (int h = 0; h < kWave / kShHalf; h++) {
             const int row0 = base + wave * kWave + h * kShHalf;
             if (row0 >= P) break;                                  // wave-uniform
             __builtin_amdgcn_wave_barrier();
-            if (pre) { if (h == 0) sh48_half_to_lds(slab, va, lane); else sh48_half_to_lds(slab, vb, lane); }
-            else sh_wave_rows_to_lds<KC>(slab, shs, row0, min(kShHalf, P - row0), K, lane);
+            sh_wave_rows_to_lds<0>(slab, shs, row0, min(kShHalf, P - row0), K, lane);
             __builtin_amdgcn_wave_barrier();
             if ((lane >> 5) == h && base + tid < P) {
                 const float* cp = cam.campos + 3 * view;
@@ -276,11 +270,12 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     if (tid == 0) gp.block_sums[blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
 }
 
-// 16-coefficient SH rows, second design (GS_PRE_FWD=1): ONE workgroup barrier instead of three and one memory round trip in front of it --
+// 16-coefficient SH rows: ONE workgroup barrier instead of the generic kernel's three and one memory round trip in front of it --
 // the first half's coefficient loads, the opacity and the staging of means / scales / rotations are all issued before anything waits; the
 // second half's loads are issued as soon as the first half sits in the slab and fly during its arithmetic (the same 24 registers: 128 VGPRs,
 // four workgroups per CU instead of three); slabs with 16-byte aligned rows (gs_common.h: kShPad4), i.e. 128-bit LDS accesses.
-// Arithmetic and results are those of preprocess_forward_kernel<3>, to the bit.
+// Measured at 2 M Gaussians against the generic design with compile-time row width (three barriers, both halves' loads held in 48
+// registers: 167 VGPRs, three workgroups per CU, 49-float slab rows): 155 -> 131 us; same arithmetic, same results to the bit.
 __global__ __launch_bounds__(kBlock, 4) void preprocess_forward_sh48_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ opac,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov3Dp, int32_t* __restrict__ radii, GeomPtrs gp)
@@ -380,11 +375,8 @@ hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D
                                      uint32_t* d_num_rendered, hipStream_t st)
 {
     const int nb = cam.V > 1 ? cam.V * cam.nbv : (P + kBlock - 1) / kBlock;
-    if (nb > 0 && shs && cam.sh_coeffs == 16 && env_knob("GS_PRE_FWD", 0) == 1)
+    if (nb > 0 && shs && cam.sh_coeffs == 16)
         hipLaunchKernelGGL(preprocess_forward_sh48_kernel, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, opac, scales, rots, cov3Dp, radii, gp);
-    else if (nb > 0 && shs && cam.sh_coeffs == 16)
-        hipLaunchKernelGGL(preprocess_forward_kernel<3>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
-                           scales, rots, cov3Dp, radii, gp);
     else if (nb > 0 && shs)
         hipLaunchKernelGGL(preprocess_forward_kernel<1>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
                            scales, rots, cov3Dp, radii, gp);

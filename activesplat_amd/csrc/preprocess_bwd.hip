@@ -11,8 +11,8 @@
 namespace gs {
 
 // SH: 0 = colours given, 1 = coefficient rows of any width through per-wave LDS slabs, 3 = the same for 16-coefficient rows
-// (row width 48 known at compile time), 4 = 16-coefficient rows in slabs with 16-byte aligned rows (gs_common.h: kShPad4): a lane's 48
-// gradient values leave as twelve ds_write_b128 and the copy-out reads ds_read_b128 (GS_PRE_BWD=1)
+// (row width 48 known at compile time).  (Slabs with 16-byte aligned rows and 128-bit LDS
+// accesses, as the forward uses them, measured slower here: the wider stores' registers spill next to the hoisted loads.)
 template <int SH>
 __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -24,9 +24,8 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
 {
     // per-wave slabs: 32 coefficient rows in, their gradients written back IN PLACE (each element is read before it is overwritten)
     constexpr bool HAS_SH = SH != 0;
-    constexpr bool SLAB = SH == 1 || SH == 3 || SH == 4;
-    constexpr bool PAD4 = SH == 4;
-    __shared__ __attribute__((aligned(16))) float s_sh[SLAB ? (kBlock / kWave) * kShHalf * (PAD4 ? kShPad4 : kShPad) : 1];
+    constexpr bool SLAB = SH == 1 || SH == 3;
+    __shared__ __attribute__((aligned(16))) float s_sh[SLAB ? (kBlock / kWave) * kShHalf * kShPad : 1];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kBlock + tid;
     const bool in_range = i < P;
@@ -58,11 +57,11 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
     }
     // ---- colour / SH: one wavefront's 64 coefficient rows per LDS pass, coalesced global traffic by all threads ----
     if (SLAB) {
-        constexpr int KC = SH >= 3 ? 48 : 0;
+        constexpr int KC = SH == 3 ? 48 : 0;
         const int deg = cam.sh_degree, nb = (deg + 1) * (deg + 1), M = KC ? 16 : cam.sh_coeffs, K = M * 3;
-        const int stride = PAD4 ? kShPad4 : sh_row_stride(K);
+        const int stride = sh_row_stride(K);
         const int lane = tid & 63, wave = tid >> 6;
-        float* slab = s_sh + wave * kShHalf * (PAD4 ? kShPad4 : kShPad);
+        float* slab = s_sh + wave * kShHalf * kShPad;
         for (int h = 0; h < kWave / kShHalf; h++) {
             const int row0 = blockIdx.x * kBlock + wave * kWave + h * kShHalf;
             if (row0 >= P) break;                                  // wave-uniform
@@ -72,10 +71,7 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
             // 3x3 block per Gaussian (sh_jac), so the coefficient rows -- 192 B per Gaussian at 16 coefficients -- are NOT read again;
             // without it (a forward that was not told a backward follows) only live Gaussians read their rows
             const uint32_t live_rows = (uint32_t)(__ballot(live) >> (h * kShHalf));
-            if (!sh_jac) {
-                if (PAD4) sh48_rows_to_lds4(slab, shs, row0, nrows, lane, live_rows);
-                else sh_wave_rows_to_lds<KC>(slab, shs, row0, nrows, K, lane, live_rows);
-            }
+            if (!sh_jac) sh_wave_rows_to_lds<KC>(slab, shs, row0, nrows, K, lane, live_rows);
             __builtin_amdgcn_wave_barrier();
             if ((lane >> 5) == h && in_range) {
                 float* dsh = slab + (lane & 31) * stride;
@@ -89,28 +85,11 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
                     float du[3] = {0.f, 0.f, 0.f};
                     if (sh_jac) {
                         const float jr[3][3] = {{j0.x, j0.y, j0.z}, {j0.w, j1.x, j1.y}, {j1.z, j1.w, j2.x}};
-                        float gch[3];
                         for (int ch = 0; ch < 3; ch++) {
                             const float g = ((cl >> (8 * ch)) & 1u) ? 0.f : drgb[ch];
-                            gch[ch] = g;
                             du[0] += g * jr[ch][0]; du[1] += g * jr[ch][1]; du[2] += g * jr[ch][2];
-                            if (!PAD4) {
-                                for (int k = 0; k < nb; k++) dsh[3 * k + ch] = g * b[k];
-                                for (int k = nb; k < M; k++) dsh[3 * k + ch] = 0.f;
-                            }
-                        }
-                        if (PAD4) {                                 // the row as twelve 16-byte pieces: flat element e = 3 k + ch
-                            float4* d4 = reinterpret_cast<float4*>(dsh);
-#pragma unroll
-                            for (int q = 0; q < 12; q++) {
-                                float v[4];
-#pragma unroll
-                                for (int t = 0; t < 4; t++) {
-                                    const int e = 4 * q + t, k = e / 3, ch = e - 3 * k;
-                                    v[t] = k < nb ? gch[ch] * b[k] : 0.f;
-                                }
-                                d4[q] = make_float4(v[0], v[1], v[2], v[3]);
-                            }
+                            for (int k = 0; k < nb; k++) dsh[3 * k + ch] = g * b[k];
+                            for (int k = nb; k < M; k++) dsh[3 * k + ch] = 0.f;
                         }
                     } else {
                         for (int ch = 0; ch < 3; ch++) {
@@ -125,17 +104,12 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
                     }
                     const float dot = ux * du[0] + uy * du[1] + uz * du[2];
                     dmean[0] += (du[0] - ux * dot) * inv; dmean[1] += (du[1] - uy * dot) * inv; dmean[2] += (du[2] - uz * dot) * inv;
-                } else if (PAD4) {
-                    float4* d4 = reinterpret_cast<float4*>(dsh);
-#pragma unroll
-                    for (int q = 0; q < 12; q++) d4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
                     for (int k = 0; k < K; k++) dsh[k] = 0.f;
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (PAD4) sh48_rows_from_lds4(slab, dshs, row0, nrows, lane);
-            else sh_wave_rows_from_lds<KC>(slab, dshs, row0, nrows, K, lane);
+            sh_wave_rows_from_lds<KC>(slab, dshs, row0, nrows, K, lane);
         }
         if (!in_range) return;
     }
@@ -263,10 +237,7 @@ hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3
                                       float* dscales, float* drots, float* dcov3D, hipStream_t st)
 {
     const int nb = (P + kBlock - 1) / kBlock;
-    if (nb > 0 && shs && cam.sh_coeffs == 16 && env_knob("GS_PRE_BWD", 0) == 1)
-        hipLaunchKernelGGL(preprocess_backward_kernel<4>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
-                           cov3Dp, radii, clamped, sh_jac, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
-    else if (nb > 0 && shs && cam.sh_coeffs == 16)
+    if (nb > 0 && shs && cam.sh_coeffs == 16)
         hipLaunchKernelGGL(preprocess_backward_kernel<3>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
                            cov3Dp, radii, clamped, sh_jac, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
     else if (nb > 0 && shs)
