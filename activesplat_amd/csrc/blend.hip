@@ -433,14 +433,17 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
                 d2 = inside ? dL_dcolor[2 * HW + pix] : 0.f;
     const float dz_ = (DEPTH_GRAD && inside) ? dL_ddepth[pix] : 0.f;
     const float tfbg = Tf * (cam.bg[0] * d0 + cam.bg[1] * d1 + cam.bg[2] * d2);    // background term of dL/dalpha
-    float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accz = 0.f;
+    // The colour blended BEHIND the current record enters the replay only through its product with this pixel's dL/dcolour (and
+    // dL/ddepth): one scalar S = behind . dL instead of a three- (four-) component accumulator -- dot = c . dL - S, S += alpha dot
+    // (four vector operations per record less than the component-wise form)
+    float T = Tf, S = 0.f;
     if (resumed) {
         const float* st = split_state + (size_t)k_cut * 5 * HW + pix;
         const float* tot = split_state + (size_t)kCutLevels * 5 * HW + pix;
         T = st[0];
         const float it = 1.0f / T;                               // (T in front of a record that contributed later is >= 1e-4)
-        acc0 = (tot[0] - st[HW]) * it; acc1 = (tot[HW] - st[2 * HW]) * it; acc2 = (tot[2 * HW] - st[3 * HW]) * it;
-        if (DEPTH_GRAD) accz = (tot[3 * HW] - st[4 * HW]) * it;
+        S = ((tot[0] - st[HW]) * it) * d0 + ((tot[HW] - st[2 * HW]) * it) * d1 + ((tot[2 * HW] - st[3 * HW]) * it) * d2;
+        if (DEPTH_GRAD) S += ((tot[3 * HW] - st[4 * HW]) * it) * dz_;
     }
     if (c.seg == 1 && wmax <= m_cut) return;
     const int cmin = c.seg == 1 ? (int)(m_cut / kWave) : 0;      // the back walker stops at the cut
@@ -533,15 +536,11 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
                     const float G_eff = ok[u] ? G[u] : 0.0f;
                     const float rcp = __builtin_amdgcn_rcpf(1.0f - a_eff);
                     T = T * rcp;                                      // transmittance in front of this record
-                    const float df0 = a1[u].z - acc0, df1 = a1[u].w - acc1, df2 = a2[u].x - acc2;
-                    float dot = df0 * d0 + df1 * d1 + df2 * d2;
-                    if (DEPTH_GRAD) {
-                        const float dfz = a2[u].y - accz;
-                        dot += dfz * dz_;
-                        accz += a_eff * dfz;
-                    }
+                    float cd = a1[u].z * d0 + a1[u].w * d1 + a2[u].x * d2;
+                    if (DEPTH_GRAD) cd += a2[u].y * dz_;
+                    const float dot = cd - S;                         // (colour of this record - colour behind it) . dL
                     const float dL_dalpha = dot * T - tfbg * rcp;
-                    acc0 += a_eff * df0; acc1 += a_eff * df1; acc2 += a_eff * df2;
+                    S += a_eff * dot;
                     const float GdA = G_eff * dL_dalpha;
                     w1[u * kMT] = GdA;                                // (Z = G dL/dG = opacity x GdA is formed in phase B)
                     w2[u * kMT] = a_eff * T;                          // blend weight
