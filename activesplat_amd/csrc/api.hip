@@ -100,7 +100,7 @@ gs::GeomPtrs carve_geom(void* base, int32_t P, const gs::Cam& k)
     g.offsets = (uint32_t*)(b + L.offsets); g.block_sums = (uint32_t*)(b + L.block_sums);
     g.clamped = (uint32_t*)(b + L.clamped);
     g.tile_total = (uint32_t*)(b + L.tile_total); g.tile_base = (uint32_t*)(b + L.tile_base);
-    g.sh_jac = (float4*)(b + L.sh_jac);
+    g.sh_jac = (float2*)(b + L.sh_jac);
     g.depth_bits = (uint32_t*)(b + L.depth_bits);
     return g;
 }
@@ -183,7 +183,7 @@ int gs_geom_layout(int32_t P, int32_t width, int32_t height, GsGeomLayout* out)
     out->clamped = o; o = align_up(o + n * 4);
     out->tile_total = o; o = align_up(o + tiles * 4);
     out->tile_base = o; o = align_up(o + (tiles <= (uint64_t)gs::kMaxLdsTiles ? rows * tiles * 4 : 4));
-    out->sh_jac = o; o = align_up(o + n * 48);
+    out->sh_jac = o; o = align_up(o + n * gs::kShJacFloats * 4);
     out->depth_bits = o; o = align_up(o + n * 4);
     out->total_bytes = o;
     return GS_OK;

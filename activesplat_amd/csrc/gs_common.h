@@ -61,7 +61,8 @@ struct GeomPtrs {
     uint32_t* tile_total;  // [tiles]
     uint32_t* tile_base;   // [ceil(P/kBinChunk)][tiles]
     uint32_t* depth_bits;  // [P]: bit pattern of the view-space depth (the binning key), compact copy of geom[.][9] for coalesced reads
-    float4* sh_jac;        // [P][3]: d(rgb before the clamp)/d(unit view direction), 3x3 row-major in 9 of 12 floats (SH inputs with a backward to follow)
+    float2* sh_jac;        // [P][5]: d(rgb before the clamp)/d(unit view direction), 3x3 row-major, and the colour clamp flags in the tenth word
+                           // (SH inputs with a backward to follow): 40 B per Gaussian
 };
 
 // ---- wave-64 helpers ---------------------------------------------------------------------------
@@ -397,6 +398,22 @@ __device__ __forceinline__ void sh48_color_and_jacobian(int deg, float x, float 
 #undef GS_SHJ4
 #undef GS_SHLOAD
 
+// the saved SH Jacobian record: nine floats + the clamp flags (what `clamped` holds), five 8-byte pieces
+constexpr int kShJacFloats = 10;
+__device__ __forceinline__ void store_sh_jac(float2* base, size_t i, const float (&J)[9], uint32_t clamp_bits)
+{
+    float2* o = base + i * (kShJacFloats / 2);
+    o[0] = make_float2(J[0], J[1]); o[1] = make_float2(J[2], J[3]); o[2] = make_float2(J[4], J[5]); o[3] = make_float2(J[6], J[7]);
+    o[4] = make_float2(J[8], __uint_as_float(clamp_bits));
+}
+__device__ __forceinline__ void load_sh_jac(const float2* base, size_t i, float (&J)[9], uint32_t& clamp_bits)
+{
+    const float2* o = base + i * (kShJacFloats / 2);
+    const float2 a = o[0], b = o[1], c = o[2], d = o[3], e = o[4];
+    J[0] = a.x; J[1] = a.y; J[2] = b.x; J[3] = b.y; J[4] = c.x; J[5] = c.y; J[6] = d.x; J[7] = d.y; J[8] = e.x;
+    clamp_bits = __float_as_uint(e.y);
+}
+
 // ---- launchers implemented in the individual translation units -------------------------------------
 hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D, const float* shs,
                                      const float* colors, const float* opac, const float* scales,
@@ -405,7 +422,7 @@ hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D
 hipError_t launch_scan_block_sums(int P, GeomPtrs gp, uint32_t* d_total, hipStream_t st);
 hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3D, const float* shs,
                                       const float* scales, const float* rots, const float* cov3Dp,
-                                      const int32_t* radii, const uint32_t* clamped, const float4* sh_jac, const float* grad2d,
+                                      const int32_t* radii, const uint32_t* clamped, const float2* sh_jac, const float* grad2d,
                                       float* dmeans2D, float* dmeans3D, float* dopac, float* dcolors, float* dshs,
                                       float* dscales, float* drots, float* dcov3D, hipStream_t st);
 hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,

@@ -161,7 +161,7 @@ __device__ __forceinline__ uint32_t project_gaussian(const Cam& cam, int P, int 
         gp.rect[io] = rc;
         gp.tiles[io] = ntiles;
         gp.depth_bits[io] = __float_as_uint(g2.y);
-        if (HAS_SH) gp.clamped[io] = clampbits;
+        if (HAS_SH && !gp.sh_jac) gp.clamped[io] = clampbits;     // (with a saved Jacobian the flags travel in its record)
     } else if (cam.V > 1) {                            // padding rows of a view's last block: never visible
         radii[io] = 0;
         gp.geom[(size_t)io * 3] = gp.geom[(size_t)io * 3 + 1] = gp.geom[(size_t)io * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -241,16 +241,12 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
                 for (int k = 0; k < nbasis; k++) {
                     acc[0] = fmaf(b[k], sh[3 * k], acc[0]); acc[1] = fmaf(b[k], sh[3 * k + 1], acc[1]); acc[2] = fmaf(b[k], sh[3 * k + 2], acc[2]);
                 }
-                if (gp.sh_jac) {
-                    // for the backward: J[ch] = sum_k coef[k][ch] grad b_k (3x3), so that it need not read the coefficient rows again
-                    float J[9];
-                    sh_direction_jacobian(cam.sh_degree, dx * inv, dy * inv, dz * inv, sh, J);
-                    float4* jo = gp.sh_jac + (size_t)io * 3;
-                    jo[0] = make_float4(J[0], J[1], J[2], J[3]); jo[1] = make_float4(J[4], J[5], J[6], J[7]); jo[2] = make_float4(J[8], 0.f, 0.f, 0.f);
-                }
+                float J[9];
+                if (gp.sh_jac) sh_direction_jacobian(cam.sh_degree, dx * inv, dy * inv, dz * inv, sh, J);   // for the backward: it need not read the coefficient rows again
                 acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
                 sh_clamp = (acc[0] < 0.f ? 1u : 0u) | (acc[1] < 0.f ? 0x100u : 0u) | (acc[2] < 0.f ? 0x10000u : 0u);
                 sh_rgb[0] = fmaxf(acc[0], 0.f); sh_rgb[1] = fmaxf(acc[1], 0.f); sh_rgb[2] = fmaxf(acc[2], 0.f);
+                if (gp.sh_jac) store_sh_jac(gp.sh_jac, (size_t)io, J, sh_clamp);
             }
         }
     }
@@ -327,12 +323,9 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_forward_sh48_kernel(
             sh_basis(cam.sh_degree, dx * inv, dy * inv, dz * inv, b);
             float acc[3], J[9];
             sh48_color_and_jacobian(cam.sh_degree, dx * inv, dy * inv, dz * inv, b, slab + (lane & 31) * kShPad4, gp.sh_jac != nullptr, acc, J);
-            if (gp.sh_jac) {
-                float4* jo = gp.sh_jac + (size_t)io * 3;
-                jo[0] = make_float4(J[0], J[1], J[2], J[3]); jo[1] = make_float4(J[4], J[5], J[6], J[7]); jo[2] = make_float4(J[8], 0.f, 0.f, 0.f);
-            }
             acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
             sh_clamp = (acc[0] < 0.f ? 1u : 0u) | (acc[1] < 0.f ? 0x100u : 0u) | (acc[2] < 0.f ? 0x10000u : 0u);
+            if (gp.sh_jac) store_sh_jac(gp.sh_jac, (size_t)io, J, sh_clamp);
             sh_rgb[0] = fmaxf(acc[0], 0.f); sh_rgb[1] = fmaxf(acc[1], 0.f); sh_rgb[2] = fmaxf(acc[2], 0.f);
         }
     }

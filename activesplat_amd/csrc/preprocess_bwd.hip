@@ -17,7 +17,7 @@ template <int SH>
 __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov3Dp,
-    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const float4* __restrict__ sh_jac,
+    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const float2* __restrict__ sh_jac,
     const float* __restrict__ grad2d, float* __restrict__ dmeans2D, float* __restrict__ dmeans3D, float* __restrict__ dopac,
     float* __restrict__ dcolors, float* __restrict__ dshs, float* __restrict__ dscales,
     float* __restrict__ drots, float* __restrict__ dcov3D)
@@ -43,9 +43,10 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
     const float drgb[3] = {gb.z, gb.w, gc.x};
     // every other per-Gaussian input is requested here as well, whether or not the lane turns out to need it: ONE memory round trip
     // per wavefront instead of three dependent ones (the compiler does not move loads out of the `live` branches below)
-    const uint32_t cl_in = HAS_SH ? clamped[ic] : 0u;
-    float4 j0 = make_float4(0.f, 0.f, 0.f, 0.f), j1 = j0, j2 = j0;
-    if (HAS_SH && sh_jac) { j0 = sh_jac[(size_t)ic * 3]; j1 = sh_jac[(size_t)ic * 3 + 1]; j2 = sh_jac[(size_t)ic * 3 + 2]; }
+    uint32_t cl_in = 0u;
+    float jac[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (HAS_SH && sh_jac) load_sh_jac(sh_jac, (size_t)ic, jac, cl_in);       // (the clamp flags travel in the Jacobian record)
+    else if (HAS_SH) cl_in = clamped[ic];
     float sc_in[3] = {0.f, 0.f, 0.f};
     float4 rq_in = make_float4(0.f, 0.f, 0.f, 0.f);
     float cov_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
                     const uint32_t cl = cl_in;
                     float du[3] = {0.f, 0.f, 0.f};
                     if (sh_jac) {
-                        const float jr[3][3] = {{j0.x, j0.y, j0.z}, {j0.w, j1.x, j1.y}, {j1.z, j1.w, j2.x}};
+                        const float jr[3][3] = {{jac[0], jac[1], jac[2]}, {jac[3], jac[4], jac[5]}, {jac[6], jac[7], jac[8]}};
                         for (int ch = 0; ch < 3; ch++) {
                             const float g = ((cl >> (8 * ch)) & 1u) ? 0.f : drgb[ch];
                             du[0] += g * jr[ch][0]; du[1] += g * jr[ch][1]; du[2] += g * jr[ch][2];
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
 
 hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3D, const float* shs,
                                       const float* scales, const float* rots, const float* cov3Dp,
-                                      const int32_t* radii, const uint32_t* clamped, const float4* sh_jac, const float* grad2d,
+                                      const int32_t* radii, const uint32_t* clamped, const float2* sh_jac, const float* grad2d,
                                       float* dmeans2D, float* dmeans3D, float* dopac, float* dcolors, float* dshs,
                                       float* dscales, float* drots, float* dcov3D, hipStream_t st)
 {
