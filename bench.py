@@ -271,6 +271,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--streams", type=int, default=2, help="N > 1 (configs[3]): HIP streams a rank's keyframes are issued on in turn")
     ap.add_argument("--no-extras", action="store_true", help="skip every leg but the timed region")
+    ap.add_argument("--prep-seconds", type=float, default=0.5, help="untimed preparation in front of the warm-up steps (clock ramp, allocator)")
     ap.add_argument("--cpu-threads", type=int, default=64, help="upper bound on the host threads of the cpu_baseline leg")
     ap.add_argument("--c4-gaussians", type=int, default=2_000_000, help="configs[3]: Gaussians of the replicated map")
     ap.add_argument("--keyframes", type=int, default=64, help="configs[3]: keyframes per optimiser step, sharded over the ranks")
@@ -308,9 +309,14 @@ def main():
     W, H, N = args.width, args.height, args.gaussians
     deg = args.sh_degree if args.sh_degree >= 0 else None
     wl = RenderWorkload(N, W, H, dev, sh_degree=deg)
-    # untimed preparation: code-object loads, the caching allocator's pools, the optimistic launch's capacity guess
-    for _ in range(4):
-        wl.step()
+    # untimed preparation in front of the W warm-up steps: code-object loads, the caching allocator's pools, the optimistic launch's
+    # capacity guess -- and the device's clocks: a fresh process' first ~0.3 s of kernels run below the sustained clock (the same frames
+    # measure 5 % slower there than a second later; scripts/exp/wall_vs_events.py)
+    t_prep = time.perf_counter()
+    while time.perf_counter() - t_prep < args.prep_seconds:
+        for _ in range(8):
+            wl.step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         wl.step()
     torch.cuda.synchronize()
