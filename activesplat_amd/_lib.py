@@ -59,7 +59,7 @@ SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_sc
            "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward",
            "gs_grow_scratch_bytes", "gs_grow_gaussians", "gs_keyframe_overlap", "gs_visibility_stats", "gs_accumulate_grad2d",
            "gs_gather_rows_zero_tail", "gs_densify_classify", "gs_densify_children", "gs_atlas_layout",
-           "gs_pack_columns", "gs_adam_rows", "gs_unpack_columns")
+           "gs_pack_columns", "gs_adam_rows", "gs_unpack_columns", "gs_compact3_scratch_bytes", "gs_compact_index3")
 
 
 def _bind(lib):
@@ -108,7 +108,11 @@ def _bind(lib):
     lib.gs_gather_rows_zero_tail.restype = C.c_int
     lib.gs_densify_classify.argtypes = [i32, i32, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp, vp, vp, vp]
     lib.gs_densify_classify.restype = C.c_int
-    lib.gs_densify_children.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.gs_densify_children.argtypes = [i32, i32, i32, vp, vp, C.c_uint64, vp, vp, vp]
+    lib.gs_compact3_scratch_bytes.argtypes = [i64]
+    lib.gs_compact3_scratch_bytes.restype = C.c_uint64
+    lib.gs_compact_index3.argtypes = [i64, vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.gs_compact_index3.restype = C.c_int
     lib.gs_densify_children.restype = C.c_int
     lib.gs_grow_scratch_bytes.argtypes = [i32, i32]
     lib.gs_grow_scratch_bytes.restype = C.c_uint64

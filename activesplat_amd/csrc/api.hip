@@ -540,6 +540,19 @@ int gs_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32
     return GS_OK;
 }
 
+uint64_t gs_compact3_scratch_bytes(int64_t n) { return align_up(gs::compact3_scratch_bytes(n > 0 ? n : 1)); }
+
+int gs_compact_index3(int64_t n, const uint8_t* keep_a, const uint8_t* keep_b, const uint8_t* keep_c, int32_t repeat_c, uint32_t* src_index,
+                      uint32_t* d_counts, void* scratch, gs_stream_t stream)
+{
+    if (n < 0 || repeat_c < 1 || !d_counts || !scratch || (n > 0 && (!keep_a || !keep_b || !keep_c || !src_index)))
+        return fail(GS_EINVAL, "gs_compact_index3: bad argument");
+    if (n * (2 + (int64_t)repeat_c) >= (int64_t)1 << 32) return fail(GS_ECAPACITY, "gs_compact_index3: more than 2^32 rows");
+    hipError_t e = gs::launch_compact_index3(n, keep_a, keep_b, keep_c, repeat_c, src_index, d_counts, scratch, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_compact_index3: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
 int gs_gather_rows(int64_t n_out, int32_t row_floats, const uint32_t* src_index, const float* src, float* dst, gs_stream_t stream)
 {
     if (n_out < 0 || row_floats <= 0 || (n_out > 0 && (!src_index || !src || !dst))) return fail(GS_EINVAL, "gs_gather_rows: bad argument");
@@ -574,12 +587,12 @@ int gs_densify_classify(int32_t N, int32_t scale_dim, const float* log_scales, c
 }
 
 int gs_densify_children(int32_t n_child, int32_t scale_dim, int32_t num_to_split_into, const float* unnorm_rotations, const float* samples,
-                        float* means3D, float* log_scales, gs_stream_t stream)
+                        uint64_t seed, float* means3D, float* log_scales, gs_stream_t stream)
 {
     if (n_child < 0 || (scale_dim != 1 && scale_dim != 3) || num_to_split_into < 1 ||
-        (n_child > 0 && (!unnorm_rotations || !samples || !means3D || !log_scales)))
+        (n_child > 0 && (!unnorm_rotations || !means3D || !log_scales)))
         return fail(GS_EINVAL, "gs_densify_children: bad argument");
-    hipError_t e = gs::launch_densify_children(n_child, scale_dim, num_to_split_into, unnorm_rotations, samples, means3D, log_scales,
+    hipError_t e = gs::launch_densify_children(n_child, scale_dim, num_to_split_into, unnorm_rotations, samples, seed, means3D, log_scales,
                                                (hipStream_t)stream);
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_densify_children: %s", hipGetErrorString(e));
     return GS_OK;

@@ -504,6 +504,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
         if (h3) s_list[wave][3 * kWave + p3] = (uint8_t)lane;
 #undef GS_RANK
         float racc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    // this record's moments, summed over rows and batches
+        const int rel_last = (int)min(last, (uint32_t)(ch + 1) * kWave) - ch * kWave;   // this pixel's contributors end before slot rel_last of the chunk (<= 0: none)
         const int ntrips = max(max(n0, n1), max(n2, n3));
         __builtin_amdgcn_wave_barrier();
         for (int t0 = 0; t0 < ntrips; t0 += kBT) {
@@ -521,12 +522,11 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
                 for (int u = 0; u < 2; u++) { a0[u] = s0[jj[u]]; a1[u] = s1[jj[u]]; a2[u] = s2[jj[u]]; }
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    const uint32_t pos = (uint32_t)ch * kWave + (uint32_t)jj[u];       // 0-based position in the tile list
                     dx[u] = a0[u].x - pxf; dy[u] = a0[u].y - pyf;
                     const float p = (a0[u].z * dx[u] + a0[u].w * dy[u]) * dx[u] + (a1[u].x * dy[u]) * dy[u];
                     G[u] = __builtin_amdgcn_exp2f(p);
                     alpha[u] = fminf(0.99f, a1[u].y * G[u]);
-                    ok[u] = pos < last && p <= 0.0f && alpha[u] >= kAlphaMin;
+                    ok[u] = jj[u] < rel_last && p <= 0.0f && alpha[u] >= kAlphaMin;     // (list position ch * 64 + jj below this pixel's last contributor)
                 }
                 float* w1 = m1p + (t * kMT + lane); float* w2 = m2p + (t * kMT + lane);
 #pragma unroll

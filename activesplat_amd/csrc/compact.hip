@@ -28,10 +28,12 @@ __global__ __launch_bounds__(kCompactBlock) void compact_count_kernel(int64_t n,
     }
 }
 
+// (workgroup b scans list b of a multi-list compaction: its nb counts start at block_counts + b * nb, its total goes to d_count[b])
 __global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t* __restrict__ block_counts, int nb, uint32_t* __restrict__ d_count)
 {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
+    block_counts += (size_t)blockIdx.x * nb; d_count += blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_carry = 0;
     __syncthreads();
@@ -68,6 +70,49 @@ __global__ __launch_bounds__(kCompactBlock) void compact_write_kernel(int64_t n,
     if (k) src_index[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
 }
 
+// ---- three masks -> ONE index list in one count / scan / write sequence (the densify event: surviving originals | surviving clones |
+// n_rep blocks of surviving split parents = the rows of the children, slam_external.py:216, :232, :236).  The three-list layout needs the
+// totals of the first two lists before anything can be written, so the scan kernel leaves them in d_counts and the write kernel reads
+// them there; the host reads d_counts once, afterwards, to size the new tensors.
+__global__ __launch_bounds__(kCompactBlock) void compact3_count_kernel(int64_t n, const uint8_t* __restrict__ ka, const uint8_t* __restrict__ kb,
+                                                                       const uint8_t* __restrict__ kc, uint32_t* __restrict__ block_counts, int nb)
+{
+    __shared__ uint32_t s_w[3][kCompactBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kCompactBlock + tid;
+    const unsigned long long ma = __ballot(i < n && ka[i] != 0), mb = __ballot(i < n && kb[i] != 0), mc = __ballot(i < n && kc[i] != 0);
+    if (lane == 0) { s_w[0][wave] = (uint32_t)__popcll(ma); s_w[1][wave] = (uint32_t)__popcll(mb); s_w[2][wave] = (uint32_t)__popcll(mc); }
+    __syncthreads();
+    if (tid < 3) {
+        uint32_t c = 0;
+        for (int w = 0; w < kCompactBlock / kWave; w++) c += s_w[tid][w];
+        block_counts[(size_t)tid * nb + blockIdx.x] = c;
+    }
+}
+
+__global__ __launch_bounds__(kCompactBlock) void compact3_write_kernel(int64_t n, const uint8_t* __restrict__ ka, const uint8_t* __restrict__ kb,
+                                                                       const uint8_t* __restrict__ kc, const uint32_t* __restrict__ block_offsets, int nb,
+                                                                       const uint32_t* __restrict__ d_counts, int n_rep, uint32_t* __restrict__ src_index)
+{
+    __shared__ uint32_t s_w[3][kCompactBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kCompactBlock + tid;
+    const bool a = i < n && ka[i] != 0, b = i < n && kb[i] != 0, c = i < n && kc[i] != 0;
+    const unsigned long long ma = __ballot(a), mb = __ballot(b), mc = __ballot(c);
+    if (lane == 0) { s_w[0][wave] = (uint32_t)__popcll(ma); s_w[1][wave] = (uint32_t)__popcll(mb); s_w[2][wave] = (uint32_t)__popcll(mc); }
+    __syncthreads();
+    uint32_t oa = block_offsets[blockIdx.x], ob = block_offsets[(size_t)nb + blockIdx.x], oc = block_offsets[2 * (size_t)nb + blockIdx.x];
+    for (int w = 0; w < wave; w++) { oa += s_w[0][w]; ob += s_w[1][w]; oc += s_w[2][w]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t na = d_counts[0], nbb = d_counts[1], nc = d_counts[2];
+    if (a) src_index[oa + (uint32_t)__popcll(ma & below)] = (uint32_t)i;
+    if (b) src_index[na + ob + (uint32_t)__popcll(mb & below)] = (uint32_t)i;
+    if (c) {
+        const uint32_t r = oc + (uint32_t)__popcll(mc & below);
+        for (int k = 0; k < n_rep; k++) src_index[(size_t)na + nbb + (size_t)k * nc + r] = (uint32_t)i;
+    }
+}
+
 // rows [0, n_copy) are gathered, rows [n_copy, n_out) zero-filled (the Adam moments of appended Gaussians start from zero:
 // slam_external.py:131-134)
 __global__ __launch_bounds__(kBlock) void gather_rows_kernel(int64_t total, int row_floats, const uint32_t* __restrict__ src_index,
@@ -101,6 +146,19 @@ hipError_t launch_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_in
     if (nb > 0) hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(kCompactBlock), 0, st, n, keep, bc);
     hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, bc, nb, d_count);
     if (nb > 0) hipLaunchKernelGGL(compact_write_kernel, dim3(nb), dim3(kCompactBlock), 0, st, n, keep, bc, src_index);
+    return hipGetLastError();
+}
+
+uint64_t compact3_scratch_bytes(int64_t n) { return 3 * compact_scratch_bytes(n); }
+
+hipError_t launch_compact_index3(int64_t n, const uint8_t* ka, const uint8_t* kb, const uint8_t* kc, int n_rep, uint32_t* src_index,
+                                 uint32_t* d_counts, void* scratch, hipStream_t st)
+{
+    const int nb = (int)((n + kCompactBlock - 1) / kCompactBlock);
+    uint32_t* bc = (uint32_t*)scratch;
+    if (nb > 0) hipLaunchKernelGGL(compact3_count_kernel, dim3(nb), dim3(kCompactBlock), 0, st, n, ka, kb, kc, bc, nb);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(3), dim3(1024), 0, st, bc, nb, d_counts);
+    if (nb > 0) hipLaunchKernelGGL(compact3_write_kernel, dim3(nb), dim3(kCompactBlock), 0, st, n, ka, kb, kc, bc, nb, d_counts, n_rep, src_index);
     return hipGetLastError();
 }
 

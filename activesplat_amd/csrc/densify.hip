@@ -49,18 +49,47 @@ __global__ __launch_bounds__(kBlock) void densify_classify_kernel(
     if (split_mask) split_mask[i] = split ? 1 : 0;
 }
 
+// counter-based generator of the split offsets: splitmix64 of (seed, child row, draw) -> uniforms -> Box-Muller.  Stateless: a child's
+// sample depends on the event's seed and its row only (no generator state on the device, no extra launches)
+__device__ __forceinline__ uint32_t mix_u32(uint64_t seed, uint64_t ctr)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+__device__ __forceinline__ void normal_pair(uint64_t seed, uint64_t ctr, float& n0, float& n1)
+{
+    const float u1 = ((float)mix_u32(seed, 2 * ctr) + 1.0f) * 2.3283064365386963e-10f;          // (0, 1]
+    const float u2 = (float)mix_u32(seed, 2 * ctr + 1) * 2.3283064365386963e-10f;
+    const float rad = sqrtf(-2.0f * logf(u1)), ang = 6.283185307179586f * u2;
+    n0 = rad * cosf(ang); n1 = rad * sinf(ang);
+}
+
 // children rows [0, n_child) of the output tail: means3D += R(unnorm_rotation) * sample, log_scale = log(exp(log_scale) / (0.8 n))
-// (slam_external.py:224-230; the quaternion is normalised inside build_rotation, slam_helpers.py:41-60)
+// (slam_external.py:224-230; the quaternion is normalised inside build_rotation, slam_helpers.py:41-60).  samples == NULL: the
+// N(0, scale) offsets (slam_external.py:221-224: torch.normal(mean = 0, std = the parent's scale)) are drawn here.
 __global__ __launch_bounds__(kBlock) void densify_children_kernel(int n_child, int scale_dim, int n_split, const float* __restrict__ rots,
-                                                                   const float* __restrict__ samples, float* __restrict__ means3D,
-                                                                   float* __restrict__ log_scales)
+                                                                   const float* __restrict__ samples, unsigned long long seed,
+                                                                   float* __restrict__ means3D, float* __restrict__ log_scales)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_child) return;
     const float4 q = reinterpret_cast<const float4*>(rots)[i];
     const float inv = 1.0f / sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
     const float r = q.x * inv, x = q.y * inv, y = q.z * inv, z = q.w * inv;
-    const float sx = samples[3 * i], sy = samples[3 * i + 1], sz = samples[3 * i + 2];
+    float sx, sy, sz;
+    if (samples) {
+        sx = samples[3 * i]; sy = samples[3 * i + 1]; sz = samples[3 * i + 2];
+    } else {
+        float n0, n1, n2, n3;
+        normal_pair(seed, 2ull * (unsigned)i, n0, n1);
+        normal_pair(seed, 2ull * (unsigned)i + 1ull, n2, n3);
+        const float s0 = expf(log_scales[(size_t)i * scale_dim]);
+        const float s1 = scale_dim == 3 ? expf(log_scales[(size_t)i * scale_dim + 1]) : s0;       // anisotropic: per-axis scales
+        const float s2 = scale_dim == 3 ? expf(log_scales[(size_t)i * scale_dim + 2]) : s0;
+        sx = n0 * s0; sy = n1 * s1; sz = n2 * s2;
+    }
     const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
     const float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
     const float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
@@ -85,12 +114,12 @@ hipError_t launch_densify_classify(int N, int scale_dim, const float* log_scales
     return hipGetLastError();
 }
 
-hipError_t launch_densify_children(int n_child, int scale_dim, int n_split, const float* rots, const float* samples, float* means3D,
-                                   float* log_scales, hipStream_t st)
+hipError_t launch_densify_children(int n_child, int scale_dim, int n_split, const float* rots, const float* samples, uint64_t seed,
+                                   float* means3D, float* log_scales, hipStream_t st)
 {
     if (n_child <= 0) return hipSuccess;
     hipLaunchKernelGGL(densify_children_kernel, dim3((n_child + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n_child, scale_dim, n_split, rots,
-                       samples, means3D, log_scales);
+                       samples, (unsigned long long)seed, means3D, log_scales);
     return hipGetLastError();
 }
 

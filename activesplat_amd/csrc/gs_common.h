@@ -475,8 +475,11 @@ hipError_t launch_densify_classify(int N, int scale_dim, const float* log_scales
                                    const float* denom, const float* scene_radius, float grad_thresh, float opacity_thresh,
                                    int remove_big, int n_split, uint8_t* keep_orig, uint8_t* keep_clone, uint8_t* keep_child,
                                    uint8_t* split_mask, hipStream_t st);
-hipError_t launch_densify_children(int n_child, int scale_dim, int n_split, const float* rots, const float* samples, float* means3D,
-                                   float* log_scales, hipStream_t st);
+hipError_t launch_densify_children(int n_child, int scale_dim, int n_split, const float* rots, const float* samples, uint64_t seed,
+                                   float* means3D, float* log_scales, hipStream_t st);
+uint64_t compact3_scratch_bytes(int64_t n);
+hipError_t launch_compact_index3(int64_t n, const uint8_t* ka, const uint8_t* kb, const uint8_t* kc, int n_rep, uint32_t* src_index,
+                                 uint32_t* d_counts, void* scratch, hipStream_t st);
 
 // sort backend (sort_rocprim.hip): stable ascending radix sort of (key64, val32) pairs on bits [0,end_bit)
 size_t sort_temp_bytes(int64_t D, int end_bit);

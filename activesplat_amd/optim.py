@@ -313,30 +313,37 @@ def _densify_fused(params, variables, optimizer, iter, densify_dict, samples):
     thr = densify_dict["final_removal_opacity_threshold"] if iter == densify_dict["stop_after"] \
         else densify_dict["removal_opacity_threshold"]
     masks = _classify(params, variables, thr, iter >= densify_dict["remove_big_after"], (densify_dict["grad_thresh"], n_split))
-    (i_orig, c_orig), (i_clone, c_clone), (i_child, c_child) = _index_of(masks[0]), _index_of(masks[1]), _index_of(masks[2])
-    n_orig, n_clone, n_child = (int(v) for v in torch.cat((c_orig, c_clone, c_child)).tolist())     # the event's one host read
-    index = torch.cat((i_orig[:n_orig], i_clone[:n_clone], i_child[:n_child].repeat(n_split)))
+    # the three masks -> ONE index list [originals | clones | n_split blocks of split parents] in one count / scan / write sequence
+    N, dev = int(masks.shape[1]), masks.device
+    idx = torch.empty(max(N, 1) * (2 + n_split), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(3, dtype=torch.int32, device=dev)
+    scratch = torch.empty(int(lib.gs_compact3_scratch_bytes(N)), dtype=torch.uint8, device=dev)
+    _lib.check(lib.gs_compact_index3(N, masks[0].data_ptr(), masks[1].data_ptr(), masks[2].data_ptr(), n_split, idx.data_ptr(), cnt.data_ptr(),
+                                     scratch.data_ptr(), _stream(masks)))
+    n_orig, n_clone, n_child = (int(v) for v in cnt.tolist())                                        # the event's one host read
+    index = idx[:n_orig + n_clone + n_child * n_split]
     params, variables = _apply_index(index, n_orig, params, variables, optimizer, zero_stats=True)
     n_kids = n_child * n_split
     if n_kids:
-        dev = index.device
         base = n_orig + n_clone
         ls = params["log_scales"].detach()
         kid_ls = ls[base:]
+        kid_samples, seed = None, 0
         if samples is None:
-            stds = torch.exp(kid_ls)
-            stds = stds.repeat(1, 3) if stds.shape[1] == 1 else stds          # anisotropic: per-axis
-            kid_samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
+            # drawn inside the kernel (counter-based): the event's seed comes from torch's CPU generator, so torch.manual_seed makes a run
+            # repeatable; no sample tensor, no torch.normal / exp / repeat launches
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         else:
             # injected offsets are indexed like the reference's un-culled split list: block c, rank of the parent among ALL split parents
             rank = torch.cumsum(masks[3].to(torch.int64), 0) - 1
             n_all = int(masks[3].sum().item())
-            parents = i_child[:n_child].to(torch.int64)
+            parents = index[base:base + n_child].to(torch.int64)
             rows = torch.cat([c * n_all + rank[parents] for c in range(n_split)])
             kid_samples = samples.to(dev).float()[rows].contiguous()
         means, rots = params["means3D"].detach(), params["unnorm_rotations"].detach()
         kid_rots = rots[base:].contiguous()
-        _lib.check(lib.gs_densify_children(n_kids, int(ls.shape[1]), n_split, kid_rots.data_ptr(), kid_samples.contiguous().data_ptr(),
+        _lib.check(lib.gs_densify_children(n_kids, int(ls.shape[1]), n_split, kid_rots.data_ptr(),
+                                           None if kid_samples is None else kid_samples.data_ptr(), seed,
                                            means[base:].data_ptr(), kid_ls.data_ptr(), _stream(means)))
     return params, variables
 

@@ -295,9 +295,18 @@ int gs_densify_classify(int32_t N, int32_t scale_dim, const float* log_scales, c
                         float opacity_thresh, int32_t remove_big, int32_t num_to_split_into, uint8_t* keep_orig,
                         uint8_t* keep_clone, uint8_t* keep_child, uint8_t* split_mask, gs_stream_t stream);
 /* Split children (a contiguous block of rows): means3D += R(normalised unnorm_rotation) * sample, log_scale = log(exp(log_scale) /
- * (0.8 n)) in place (slam_external.py:224-230).  samples [n_child,3] are the N(0, scale) offsets. */
+ * (0.8 n)) in place (slam_external.py:224-230).  samples [n_child,3] are the N(0, scale) offsets (slam_external.py:221-224:
+ * torch.normal(0, the parent's scale)); samples == NULL: they are drawn inside the kernel by a counter-based generator
+ * (splitmix64 of (seed, child row, draw) -> Box-Muller; per-axis scales when scale_dim = 3): no sample tensor, no extra launches. */
 int gs_densify_children(int32_t n_child, int32_t scale_dim, int32_t num_to_split_into, const float* unnorm_rotations,
-                        const float* samples, float* means3D, float* log_scales, gs_stream_t stream);
+                        const float* samples, uint64_t seed, float* means3D, float* log_scales, gs_stream_t stream);
+/* The densify event's ONE index list from its three masks in one count / scan / write sequence:
+ *   src_index = [ rows with keep_a | rows with keep_b | repeat_c blocks of the rows with keep_c ]   (each ascending)
+ * d_counts[0..2] = the three totals (device; the host reads them once, afterwards, to size the new tensors).  src_index must hold
+ * n * (2 + repeat_c) entries in the worst case.  Replaces three gs_compact_index passes, a torch.cat and a repeat. */
+uint64_t gs_compact3_scratch_bytes(int64_t n);
+int gs_compact_index3(int64_t n, const uint8_t* keep_a, const uint8_t* keep_b, const uint8_t* keep_c, int32_t repeat_c,
+                      uint32_t* src_index, uint32_t* d_counts, void* scratch, gs_stream_t stream);
 
 /* Densification statistics, one launch each.
  * gs_visibility_stats : seen[i] = radii[i] > 0 (uint8, nullable); max_2D_radius[i] = max(max_2D_radius[i], radii[i]) (nullable)

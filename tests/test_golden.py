@@ -455,3 +455,32 @@ def test_fused_rendervar_kernel_matches_reference_transform(backend, tag):
     sum((rv2[k] * w[k]).sum() for k in w).backward()
     for k in got:
         np.testing.assert_allclose(got[k].cpu().numpy(), p2[k].grad.cpu().numpy(), atol=2e-6 * float(p2[k].grad.abs().max()), rtol=1e-4, err_msg=k)
+
+
+def test_split_offsets_drawn_in_the_kernel_are_standard_normal_times_scale(backend):
+    """gs_densify_children with samples == NULL: counter-based N(0, scale) offsets (slam_external.py:221-224 draws them with
+    torch.normal): moments of 300 k draws per axis, per-axis scales, independence of the axes, and repeatability per seed."""
+    import ctypes as C
+    from activesplat_amd import _lib, optim as O
+    lib = _lib.get()
+    n = 300_000
+    rots = torch.zeros(n, 4); rots[:, 0] = 1.0                     # identity rotation: the offset IS the sample
+    scales = torch.tensor([0.5, 2.0, 0.1])
+
+    def draw(seed, dim):
+        means = torch.zeros(n, 3, device=backend)
+        ls = (torch.log(scales[:dim]).repeat(n, 1)).contiguous().to(backend)
+        r = rots.to(backend)
+        _lib.check(lib.gs_densify_children(n, dim, 2, r.data_ptr(), None, seed, means.data_ptr(), ls.data_ptr(), O._stream(means)))
+        np.testing.assert_allclose(ls.cpu().numpy(), np.log(scales[:dim].numpy() / 1.6)[None].repeat(n, 0), rtol=1e-5, atol=1e-6)
+        return means.cpu().double()
+    a = draw(1234, 3)
+    for ax in range(3):
+        x = a[:, ax] / float(scales[ax])
+        assert abs(float(x.mean())) < 0.01 and abs(float(x.std()) - 1.0) < 0.01, (ax, float(x.mean()), float(x.std()))
+        assert abs(float((x ** 4).mean()) - 3.0) < 0.1 and abs(float((x ** 3).mean())) < 0.05          # kurtosis / skewness of a normal
+    c = np.corrcoef((a / scales.double()).numpy().T)
+    assert np.abs(c - np.eye(3)).max() < 0.01
+    assert torch.equal(a, draw(1234, 3)) and not torch.equal(a, draw(1235, 3))
+    iso = draw(77, 1)                                               # isotropic: the one scale on all three axes
+    assert all(abs(float((iso[:, ax] / 0.5).std()) - 1.0) < 0.01 for ax in range(3))
