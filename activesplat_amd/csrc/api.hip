@@ -237,12 +237,6 @@ int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t
         if (S > 32) S = 32;
         if (S >= 2) { out->segments = S; out->seg_T = o; o = align_up(o + (uint64_t)tiles * S * gs::kBlock * 4 + (uint64_t)tiles * 16); }
     }
-    {   // development knob: force S segments (experiments on the few-tile forward)
-        const int force = gs::env_knob("GS_SEGMENTS", 0);
-        if (force >= 2 && out->path == GS_SORT_TILE_LDS && max_tile_instances != 0xffffffffu && out->segments == 1) {
-            out->segments = (uint64_t)force; out->seg_T = o; o = align_up(o + (uint64_t)tiles * force * gs::kBlock * 4 + (uint64_t)tiles * 16);
-        }
-    }
     out->total_bytes = o;
     return GS_OK;
 }

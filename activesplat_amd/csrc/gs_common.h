@@ -3,18 +3,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "../../include/gsplat_hip.h"
 
 namespace gs {
-
-// development knob: integer environment variable read at every launch (kernel-variant experiments; the shipped default is `dflt`)
-static inline int env_knob(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
 
 constexpr int kTile = GS_TILE;      // 16x16 pixel tile = one 256-thread workgroup = 4 wavefronts
 constexpr int kBlock = 256;

@@ -730,7 +730,7 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
     // Lists of at most kBucketCap keys: the bucket sort, one workgroup per tile.  The choice is made PER TILE on the device (the caller's
     // max_tile_instances may be the capacity guess of an optimistic launch): when longer lists are possible the run sort + merges below
     // are launched as well and skip the tiles the bucket kernel took.
-    const uint32_t skip_le = max_tile_instances <= (uint32_t)kSortCapMax && env_knob("GS_SORT_BUCKET", 1) != 0 ? (uint32_t)kBucketCap : 0u;
+    const uint32_t skip_le = max_tile_instances <= (uint32_t)kSortCapMax ? (uint32_t)kBucketCap : 0u;
     if (skip_le) {
         hipLaunchKernelGGL(tile_bucket_sort_kernel, dim3(tiles), dim3(kBucketThreads), 0, st, ranges, pairs, point_list, cap);
         if (max_tile_instances <= (uint32_t)kBucketCap) return hipGetLastError();

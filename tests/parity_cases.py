@@ -68,6 +68,12 @@ def build_case(name, device):
                 znew[:3] = 0.6; znew[3:6] = 3.9
                 upd["means3D"] = (m * (znew / m[:, 2])[:, None]).contiguous()
             rv.update(upd)
+    elif name == "equal_depth":             # every Gaussian at exactly the same view depth: the keys differ in the id only (index tie-break);
+        W, H, N = 48, 48, 9000              # the bucket sort sees zero depth span (one bin) -> comparison-network branch
+
+        def mutate(rv):
+            m = rv["means3D"]
+            rv.update(means3D=(m * (2.0 / m[:, 2])[:, None]).contiguous(), opacities=rv["opacities"] * 0.05)
     elif name == "many_tiles":              # 2064x1104 px = 129 x 69 = 8901 tiles > 8192: no LDS tile histogram -> radix path
         W, H, N = 2064, 1104, 3000
     elif name == "low_opacity":             # many Gaussians below the 1/255 threshold
@@ -99,7 +105,7 @@ def build_case(name, device):
 
 
 BIG_TILE_CASES = ["merge_tiles", "merge_tiles_large", "merge_passes", "merge_passes_even", "bucket_lists", "bucket_lists_long", "crowded_depth",
-                  "crowded_depth_long"]
+                  "crowded_depth_long", "equal_depth"]
 CASES = ["basic", "ragged_image", "tiny_lookaround", "lookaround_intrinsics", "posed_white_bg", "scale_modifier", "behind_camera", "all_culled",
          "huge_gaussians", "dense_overdraw", "low_opacity", "one_gaussian", "not_multiple_of_block", "sh0", "sh1", "sh2",
          "sh3", "sh2_ragged", "sh3_half_culled", "cov3d_precomp"]
