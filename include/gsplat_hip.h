@@ -83,7 +83,8 @@ typedef struct GsGeomLayout {
     uint64_t clamped;       /* uint8  [P][4]: SH colour clamp flags (r,g,b,pad) */
     uint64_t tile_total;    /* uint32 [tiles]: instances per tile */
     uint64_t tile_base;     /* uint32 [ceil(P/4096)][tiles]: slice reserved by each binning workgroup */
-    uint64_t sh_jac;        /* float [P][12]: 3x3 d(rgb)/d(view direction) of SH inputs (9 used), written when want_backward */
+    uint64_t sh_jac;        /* float [P][10]: 3x3 d(rgb)/d(view direction) of SH inputs + the colour clamp flags in the tenth word, written when
+                             * want_backward (the `clamped` array is then not written) */
     uint64_t depth_bits;    /* uint32 [P]: float bits of the view-space depth (binning key) */
 } GsGeomLayout;
 
@@ -103,7 +104,8 @@ typedef struct GsImageLayout {
 typedef struct GsBinLayout {
     uint64_t total_bytes;
     uint64_t path;          /* GS_SORT_TILE_LDS or GS_SORT_RADIX: what gs_render_forward will run */
-    uint64_t pairs;         /* TILE_LDS: uint64 [D] : (float_bits(view depth) << 32) | Gaussian index, tile-major, sorted */
+    uint64_t pairs;         /* TILE_LDS: uint64 [D] : (float_bits(view depth) << 32) | Gaussian index, tile-major -- scratch: as the scatter pass
+                             * left them for tile lists of <= 5632 keys (the bucket sort writes point_list only), sorted in place for longer lists */
     uint64_t keys_unsorted; /* RADIX: uint64 [D] : (tile << 32) | float_bits(view depth) */
     uint64_t vals_unsorted; /* RADIX: uint32 [D] : Gaussian index */
     uint64_t keys_sorted;   /* RADIX: uint64 [D] */
