@@ -38,11 +38,11 @@ struct TileCtx {
 
 // Workgroup b runs on XCD b & 7 (round-robin dispatch) and takes entry (b >> 3) of that XCD's contiguous band of tiles (neighbouring
 // tiles share Gaussians: their records are reused in one 4 MiB L2); a tile is NW-wavefront workgroups of quadrant walkers -- four
-// 8 x 8 quadrants, or eight 8 x 4 half quadrants (c.quad = 2 * row of halves + column), or four quadrants x two list segments.
+// 8 x 8 quadrants, or four quadrants x two list segments (the few-tile backward).
 template <int NW>
-__device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, TileCtx& c, bool halves, bool segments = false)
+__device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, TileCtx& c, bool segments = false)
 {
-    const int G = ((halves || segments) ? 8 : 4) / NW;       // workgroups per tile
+    const int G = (segments ? 8 : 4) / NW;                   // workgroups per tile
     const int ntiles = cam.gx * cam.gy, per = (ntiles + 7) >> 3;
     const int idx = (int)(blockIdx.x >> 3);
     c.tile = (int)(blockIdx.x & 7) * per + idx / G;
@@ -51,7 +51,7 @@ __device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, 
     c.seg = segments ? quad >> 2 : 0;                        // (list segments: walkers 0-3 = front segment of the four quadrants, 4-7 = back)
     if (segments) quad &= 3;
     c.tx = c.tile % cam.gx; c.ty = c.tile / cam.gx; c.quad = quad;
-    const int qx = c.tx * kTile + (quad & 1) * kQuad, qy = c.ty * kTile + (quad >> 1) * (halves ? kQuad / 2 : kQuad);
+    const int qx = c.tx * kTile + (quad & 1) * kQuad, qy = c.ty * kTile + (quad >> 1) * kQuad;
     c.px = qx + (lane & 7); c.py = qy + (lane >> 3);
     c.qx0 = (float)qx; c.qy0 = (float)qy; c.pxf = (float)c.px; c.pyf = (float)c.py;
     c.inside = c.px < cam.W && c.py < cam.H;
@@ -59,10 +59,10 @@ __device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, 
 }
 
 // does the record's alpha-visible box overlap the 8x8 quadrant at pixel origin (qx0,qy0)?
-__device__ __forceinline__ bool quadrant_hit(const float4& q0, const float4& q2, float qx0, float qy0, float last_row = 7.0f)
+__device__ __forceinline__ bool quadrant_hit(const float4& q0, const float4& q2, float qx0, float qy0)
 {
     const float ex = q2.z, ey = q2.w;
-    return ex >= 0.0f && (q0.x + ex >= qx0) && (q0.x - ex <= qx0 + 7.0f) && (q0.y + ey >= qy0) && (q0.y - ey <= qy0 + last_row);
+    return ex >= 0.0f && (q0.x + ex >= qx0) && (q0.x - ex <= qx0 + 7.0f) && (q0.y + ey >= qy0) && (q0.y - ey <= qy0 + 7.0f);
 }
 
 // LDS staging form: the conic pre-scaled so that the inner loop is  p = (A dx + B dy) dx + C dy dy ; G = 2^p
@@ -125,9 +125,8 @@ __device__ __forceinline__ void write_sentinel(float4* s0, float4* s1, float4* s
 //            product) and adds its colour / depth sums to the zero-initialised images with atomics; the last segment of a
 //            pixel that is not yet stopped at entry writes final_T, opacity and T*bg; n_contrib is an atomic max.
 //   SEG = 0: the whole list in one workgroup (the normal path; its code is untouched by the other two).
-// FEW: the variant for images of few tiles (half quadrants, state recording for the two-segment backward); the code of the other one
-// does not carry any of it (registers: 64 against 70, i.e. 8 against 7 wavefronts per SIMD)
-template <bool DEPTH_SQ, int NS, int SEG, int NW, bool FEW = false>     // DEPTH_SQ: also accumulate sum z^2 alpha T (third channel of the reference's depth/silhouette pass)
+// (images of at most 256 tiles take blend_forward_pc_kernel below, which also records the state the two-segment backward resumes from)
+template <bool DEPTH_SQ, int NS, int SEG, int NW>     // DEPTH_SQ: also accumulate sum z^2 alpha T (third channel of the reference's depth/silhouette pass)
 __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -154,13 +153,11 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     }
 #define GS_FILL_REST() if (SEG == 0) { for (; zf < zf_end; zf += NW * kWave) zero_fill[zf] = make_float4(0.f, 0.f, 0.f, 0.f); }
     TileCtx c;
-    const bool half = FEW && cam.half != 0;
-    if (!tile_ctx_nw<NW>(cam, wave, lane, c, half)) { GS_FILL_REST(); return; }
+    if (!tile_ctx_nw<NW>(cam, wave, lane, c)) { GS_FILL_REST(); return; }
     // lane -> pixel: stream sid owns block (sid & 1, sid >> 1) of the quadrant
     const int sid = lane / LS, l = lane % LS;
     const int px = (int)c.qx0 + (sid & 1) * 4 + (l & 3), py = (int)c.qy0 + (sid >> 1) * BH + (l >> 2);
-    const int ns_live = half ? NS / 2 : NS;                // half quadrants: the upper row of blocks only (lanes 0-31)
-    const bool inside = px < cam.W && py < cam.H && sid < ns_live;
+    const bool inside = px < cam.W && py < cam.H;
     const float pxf = (float)px, pyf = (float)py;
     float4* s0 = s_rec[wave][0]; float4* s1 = s_rec[wave][1]; float4* s2 = s_rec[wave][2];
     write_sentinel(s0, s1, s2, lane);
@@ -198,15 +195,6 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     }
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Dq = 0.f;
     uint32_t last = 0;
-    // Two-segment backward of images of few tiles (cam.split, a backward will follow = its scratch was handed over): every pixel's
-    // running state -- T and the four sums -- is recorded where its walk passes the list positions 128 * 2^k, and the totals at the
-    // end.  The backward cuts every quadrant's walk at the largest of those positions below half its depth, and its front walker
-    // starts from (T at the cut, what lies behind the cut = totals - sums) instead of waiting for the back walker.  The word behind
-    // the planes tells the backward whether this forward recorded.
-    const size_t HWs = (size_t)cam.W * cam.H;
-    const bool record = FEW && SEG == 0 && cam.split != 0 && zero_fill != nullptr && split_state != nullptr;
-    if (FEW && SEG == 0 && split_state && blockIdx.x == 0 && tid == 0)
-        reinterpret_cast<uint32_t*>(split_state + (kCutLevels * 5 + 4) * HWs)[0] = record ? 1u : 0u;
     const bool stopped_at_entry = SEG == 2 && T < kTmin;
     bool done = !inside || stopped_at_entry;
 
@@ -226,12 +214,6 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
                 for (int f = 0; f < kFillPerStep; f++)
                     if (zf < zf_end) { zero_fill[zf] = make_float4(0.f, 0.f, 0.f, 0.f); zf += NW * kWave; }
             }
-            if (FEW && SEG == 0 && record && base >= (uint32_t)kCutFirst && base < ((uint32_t)kCutFirst << kCutLevels) &&
-                (base & (base - 1u)) == 0u && inside) {
-                const int k = 31 - __clz((int)base) - 7;                                       // 128 -> 0, 256 -> 1, ...
-                float* st = split_state + (size_t)k * 5 * HWs + (size_t)py * cam.W + px;
-                st[0] = T; st[HWs] = C0; st[2 * HWs] = C1; st[3 * HWs] = C2; st[4 * HWs] = Dp;
-            }
             const float4 q0 = r0, q1 = r1, q2 = r2;
             const uint32_t id_cur = id_next;
             id_next = id_next2;
@@ -241,7 +223,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
             if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
 
             const bool live = id_cur != kNoId;
-            if (!__any(live && quadrant_hit(q0, q2, c.qx0, c.qy0, half ? 3.0f : 7.0f))) continue;
+            if (!__any(live && quadrant_hit(q0, q2, c.qx0, c.qy0))) continue;
             stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
             // per-stream lists: sentinel fill (one store per lane covers NS x 64 bytes), then every hit lane drops its index
             {
@@ -260,7 +242,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
             for (int s = 0; s < NS; s++) {
                 const float x0 = c.qx0 + (float)((s & 1) * 4), y0 = c.qy0 + (float)((s >> 1) * BH);
                 const bool stream_going = ((going >> (s * LS)) & ((1ull << LS) - 1ull)) != 0ull;
-                const bool hit = live && s < ns_live && stream_going && ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) &&
+                const bool hit = live && stream_going && ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) &&
                                  (q0.y - ey <= y0 + (float)(BH - 1));
                 const unsigned long long m = __ballot(hit);
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -331,14 +313,224 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
         out_depth[pix] = Dp;
         out_opacity[pix] = 1.0f - T;
         if (DEPTH_SQ) out_depth_sq[pix] = Dq;
-        if (FEW && SEG == 0 && record) {
+    }
+}
+
+#undef GS_FILL_REST
+
+// ---------------------------------------------------------------------------------------------------
+// Forward for images of FEW tiles (at most 256: the reference's 256 x 256 frames, the planner's views): producer / consumer pairs.
+// 256 tiles x 4 quadrants are one walker per SIMD of this chip, and a walker's trip through a 64-record chunk is one serial chain --
+// alpha (12 VALU + exp) and the compositing step (T, stop test, four sums: 12 more) for every list entry, one entry after the other.
+// The two halves do not depend on each other in the same way: alpha needs nothing from the walk, the compositing step needs alpha.
+// So a tile is ONE 8-wavefront workgroup, one per CU: per quadrant a PRODUCER wavefront (box tests, per-stream lists, alpha of every
+// list entry of chunk i -> an LDS plane [trip][lane]) and a CONSUMER wavefront (composites chunk i-1 from the plane; the four consumers
+// also fetch the tile's records from memory -- ids three chunks ahead, records two -- and stage chunk i+1's for the whole tile: one gather
+// per tile instead of four).  One
+// workgroup barrier per chunk; alpha planes and lists double-buffered, staged records triple-buffered (written at step i, read by the
+// producers at i+1 and by the consumers at i+2).  Same arithmetic per entry as blend_forward_streams_kernel: identical images.
+// LDS: 4 x 2 x 16 KB planes + lists + 3 x 3 KB records = 140 KB: one workgroup per CU, which is what a 256-tile image offers anyway.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kPcWaves = 8;
+template <bool DEPTH_SQ>
+__global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
+    Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ geom,
+    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_opacity, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib, float* __restrict__ out_depth_sq, uint32_t cap, float* __restrict__ split_state, uint32_t P,
+    float4* __restrict__ zero_fill)
+{
+    __shared__ float4 s_rec[3][3][kWave + 1];                                         // [buffer][q0', q1', q2'][slot]; slot 64 = sentinel
+    __shared__ float s_alpha[4][2][kWave * kWave];                                    // [pair][buffer][trip * 64 + lane]
+    __shared__ __attribute__((aligned(16))) uint8_t s_list[4][2][4 * kWave + 16];     // [pair][buffer][stream * 64 + position]
+    __shared__ int s_ntrips[4][2];
+    __shared__ unsigned long long s_going[4];                                         // lanes of the pair's quadrant that still blend
+    __shared__ int s_done[2][4];                                                      // [step parity][pair]: every pixel of the quadrant has stopped
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = wave & 3;
+    const bool consumer = wave >= 4;
+    const int ntiles = cam.gx * cam.gy, per = (ntiles + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    // the backward's gradient records: this workgroup's slice, a few 16-byte stores per step of the loop below
+    size_t zf = 0, zf_end = 0;
+    if (zero_fill) {
+        const size_t total = (size_t)P * (kGradStride / 4), pw = (total + gridDim.x - 1) / gridDim.x;
+        zf = (size_t)blockIdx.x * pw + tid; zf_end = min(total, (size_t)blockIdx.x * pw + pw);
+    }
+    const size_t HWs = (size_t)cam.W * cam.H;
+    const bool record = cam.split != 0 && zero_fill != nullptr && split_state != nullptr;
+    if (split_state && blockIdx.x == 0 && tid == 0) reinterpret_cast<uint32_t*>(split_state + (kCutLevels * 5 + 4) * HWs)[0] = record ? 1u : 0u;
+    if ((int)(blockIdx.x >> 3) >= per || tile >= ntiles) {                             // (uniform for the workgroup)
+        for (; zf < zf_end; zf += kPcWaves * kWave) zero_fill[zf] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    const float qx0 = (float)(tx * kTile + (pair & 1) * kQuad), qy0 = (float)(ty * kTile + (pair >> 1) * kQuad);
+    const int sid = lane >> 4, l = lane & 15;
+    const int px = (int)qx0 + (sid & 1) * 4 + (l & 3), py = (int)qy0 + (sid >> 1) * 4 + (l >> 2);
+    const bool inside = px < cam.W && py < cam.H;
+    const float pxf = (float)px, pyf = (float)py;
+    uint2 range = ranges[tile];
+    range.x = min(range.x, cap); range.y = min(range.y, cap);
+    const uint32_t n = range.y - range.x;
+    const uint32_t* list = point_list + range.x;
+    const int nchunks = (int)((n + kWave - 1) / kWave);
+    if (tid < 3) { s_rec[tid][0][kWave] = make_float4(0.f, 0.f, 0.f, 0.f); s_rec[tid][1][kWave] = make_float4(0.f, 0.f, 0.f, 0.f); s_rec[tid][2][kWave] = make_float4(0.f, 0.f, -1.f, -1.f); }
+    if (tid < 4) { s_going[tid] = ~0ull; s_done[0][tid] = 0; s_done[1][tid] = 0; s_ntrips[tid][0] = 0; s_ntrips[tid][1] = 0; }
+
+    // Record `lane + 16 * pair` of a chunk is fetched by lanes 0-15 of consumer wavefront `pair` and staged in the blend form (conic
+    // pre-scaled for 2^p: see stage_record; the last word pair holds the alpha-visible half extents here).  The fetch is a chain of two
+    // dependent memory reads (id, then record), so it runs ahead of the walk: ids THREE chunks ahead, records TWO, staging one.
+    auto fetch_id = [&](int chunk) -> uint32_t {
+        const uint32_t e = (uint32_t)chunk * kWave + (uint32_t)(pair * 16 + lane);
+        uint32_t id = kNoId;
+        if (lane < 16 && chunk < nchunks && e < n) id = list[e];
+        return id < P ? id : kNoId;                                                   // (an id that is no Gaussian index: no record)
+    };
+    auto fetch_rec = [&](uint32_t id, float4 (&g)[3]) {
+        g[0] = make_float4(0.f, 0.f, 0.f, 0.f); g[1] = g[0]; g[2] = make_float4(0.f, 0.f, -1.f, -1.f);
+        if (id != kNoId) { g[0] = geom[(size_t)id * 3]; g[1] = geom[(size_t)id * 3 + 1]; g[2] = geom[(size_t)id * 3 + 2]; }
+    };
+    auto stage = [&](int chunk, const float4 (&g)[3]) {
+        if (lane < 16 && chunk < nchunks) {
+            const int b = chunk % 3, slot = pair * 16 + lane;
+            s_rec[b][0][slot] = make_float4(g[0].x, g[0].y, -0.5f * kLog2e * g[0].z, -kLog2e * g[0].w);
+            s_rec[b][1][slot] = make_float4(-0.5f * kLog2e * g[1].x, g[1].y, g[1].z, g[1].w);
+            s_rec[b][2][slot] = g[2];                                                 // (b, depth, ext_x, ext_y)
+        }
+    };
+    float4 held[3], flying[3];                       // records of chunk it + 1 (arrived, staged at the end of step it) / of chunk it + 2 (in flight)
+    uint32_t id_ahead = kNoId;                       // this lane's id of chunk it + 2 at the top of step it
+    if (consumer) {
+        fetch_rec(fetch_id(0), held); stage(0, held);
+        fetch_rec(fetch_id(1), held);
+        id_ahead = fetch_id(2);
+    }
+    __syncthreads();
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Dq = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+    for (int it = 0; it <= nchunks; it++) {
+        for (int f = 0; f < 2; f++)
+            if (zf < zf_end) { zero_fill[zf] = make_float4(0.f, 0.f, 0.f, 0.f); zf += kPcWaves * kWave; }
+        if (!consumer) {
+            // ---- producer: lists and alpha of chunk `it` ----
+            if (it < nchunks && !s_done[(it + 1) & 1][pair]) {
+                const int ab = it & 1, rb = it % 3;
+                const float4 q0 = s_rec[rb][0][lane], q2 = s_rec[rb][2][lane];
+                const float ex = q2.z, ey = q2.w;
+                int ntrips = 0;
+                const bool qhit = ex >= 0.0f && (q0.x + ex >= qx0) && (q0.x - ex <= qx0 + 7.0f) && (q0.y + ey >= qy0) && (q0.y - ey <= qy0 + 7.0f);
+                if (__any(qhit)) {
+                    reinterpret_cast<uint32_t*>(s_list[pair][ab])[lane] = 0x40404040u;          // sentinel fill: 4 x 64 bytes
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned long long going = s_going[pair];
+#pragma unroll
+                    for (int st = 0; st < 4; st++) {
+                        const float x0 = qx0 + (float)((st & 1) * 4), y0 = qy0 + (float)((st >> 1) * 4);
+                        const bool stream_going = ((going >> (st * 16)) & 0xffffull) != 0ull;
+                        const bool hit = stream_going && ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) && (q0.y - ey <= y0 + 3.0f);
+                        const unsigned long long m = __ballot(hit);
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (hit) s_list[pair][ab][st * kWave + rank] = (uint8_t)lane;
+                        ntrips = max(ntrips, (int)__popcll(m));
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const uint8_t* my_list = s_list[pair][ab] + sid * kWave;
+                    float* plane = s_alpha[pair][ab] + lane;
+                    const float4* s0 = s_rec[rb][0]; const float4* s1 = s_rec[rb][1];
+                    // four list entries per trip (one 32-bit list read, fetched a trip ahead): the entries are independent here, so
+                    // the eight record reads of a trip are in flight together (entries behind the list's end are the sentinel: alpha 0)
+                    uint32_t jj4_next = *reinterpret_cast<const uint32_t*>(my_list);
+                    for (int t = 0; t < ntrips; t += 4) {
+                        const uint32_t jj4 = jj4_next;
+                        jj4_next = *reinterpret_cast<const uint32_t*>(my_list + ((t + 4) & 63));
+                        float4 a0[4], a1[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { const int j = (int)((jj4 >> (8 * u)) & 0xffu); a0[u] = s0[j]; a1[u] = s1[j]; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const float dx = a0[u].x - pxf, dy = a0[u].y - pyf;
+                            const float p = (a0[u].z * dx + a0[u].w * dy) * dx + (a1[u].x * dy) * dy;
+                            const float alpha = fminf(0.99f, a1[u].y * __builtin_amdgcn_exp2f(p));
+                            plane[(t + u) * kWave] = (p <= 0.0f && alpha >= kAlphaMin) ? alpha : 0.0f;   // 0 = this pixel does not see the record
+                        }
+                    }
+                }
+                if (lane == 0) s_ntrips[pair][ab] = ntrips;
+            }
+        } else {
+            // ---- consumer: fetch chunk it + 1, composite chunk it - 1, stage chunk it + 1 ----
+            const uint32_t id_next = fetch_id(it + 3);
+            fetch_rec(id_ahead, flying);                                              // chunk it + 2
+            if (it >= 1 && !__all(done)) {
+                const int ab = (it - 1) & 1, rb = (it - 1) % 3;
+                const uint32_t base = (uint32_t)(it - 1) * kWave;
+                if (record && base >= (uint32_t)kCutFirst && base < ((uint32_t)kCutFirst << kCutLevels) && (base & (base - 1u)) == 0u && inside) {
+                    const int k = 31 - __clz((int)base) - 7;                                   // 128 -> 0, 256 -> 1, ...
+                    float* stt = split_state + (size_t)k * 5 * HWs + (size_t)py * cam.W + px;
+                    stt[0] = T; stt[HWs] = C0; stt[2 * HWs] = C1; stt[3 * HWs] = C2; stt[4 * HWs] = Dp;
+                }
+                const int ntrips = s_ntrips[pair][ab];
+                const uint8_t* my_list = s_list[pair][ab] + sid * kWave;
+                const float* plane = s_alpha[pair][ab] + lane;
+                const float4* s1 = s_rec[rb][1]; const float4* s2 = s_rec[rb][2];
+                uint32_t jj4_next = *reinterpret_cast<const uint32_t*>(my_list);
+                for (int t = 0; t < ntrips; t += 4) {
+                    const uint32_t jj4 = jj4_next;
+                    jj4_next = *reinterpret_cast<const uint32_t*>(my_list + ((t + 4) & 63));
+                    float al[4];
+                    float4 b1[4], b2[4];
+                    int jj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { jj[u] = (int)((jj4 >> (8 * u)) & 0xffu); al[u] = plane[(t + u) * kWave]; b1[u] = s1[jj[u]]; b2[u] = s2[jj[u]]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float alpha = al[u];
+                        const float4 a1 = b1[u];
+                        const float4 a2 = b2[u];
+                        const float test_T = T * (1.0f - alpha);
+                        const bool vis = !done && alpha > 0.0f;
+                        const bool ok = vis && test_T >= kTmin;
+                        done = done || (vis && !ok);
+                        const float w = ok ? alpha * T : 0.0f;
+                        C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w; Dp += a2.y * w;
+                        if (DEPTH_SQ) Dq += a2.y * a2.y * w;
+                        T = ok ? test_T : T;
+                        last = ok ? base + (uint32_t)jj[u] + 1u : last;
+                    }
+                }
+                const unsigned long long going = ~__ballot(done);
+                if (lane == 0) s_going[pair] = going;
+            }
+            const bool all_done = __all(done);                     // (a wave vote: outside of the one-lane store below)
+            if (lane == 0) s_done[it & 1][pair] = all_done ? 1 : 0;
+            stage(it + 1, held);
+#pragma unroll
+            for (int q = 0; q < 3; q++) held[q] = flying[q];
+            id_ahead = id_next;
+        }
+        __syncthreads();
+        if (s_done[it & 1][0] && s_done[it & 1][1] && s_done[it & 1][2] && s_done[it & 1][3]) break;      // (uniform: written before the barrier)
+    }
+    for (; zf < zf_end; zf += kPcWaves * kWave) zero_fill[zf] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (consumer && inside) {
+        const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = C0 + T * cam.bg[0];
+        out_color[HW + pix] = C1 + T * cam.bg[1];
+        out_color[2 * HW + pix] = C2 + T * cam.bg[2];
+        out_depth[pix] = Dp;
+        out_opacity[pix] = 1.0f - T;
+        if (DEPTH_SQ) out_depth_sq[pix] = Dq;
+        if (record) {
             float* tot = split_state + (size_t)kCutLevels * 5 * HW + pix;
             tot[0] = C0; tot[HW] = C1; tot[2 * HW] = C2; tot[3 * HW] = Dp;
         }
     }
 }
 
-#undef GS_FILL_REST
 // ---------------------------------------------------------------------------------------------------
 // Backward: back-to-front replay in two phases per batch of list positions.  Same independent-quadrant walk and the same four
 // record streams as the forward (one per 16-lane row = 4x4 pixel block of the quadrant), lists built deepest-first.
@@ -387,7 +579,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
     const bool split = FEW && cam.split != 0;
-    if (!tile_ctx_nw<NW>(cam, wave, lane, c, false, split)) return;
+    if (!tile_ctx_nw<NW>(cam, wave, lane, c, split)) return;
     // phase A role: row (lane>>4) = 4x4 sub-block, (lane&15) = pixel inside it
     const int row = lane >> 4, l16 = lane & 15;
     const int px = (int)c.qx0 + (row & 1) * 4 + (l16 & 3), py = (int)c.qy0 + (row >> 1) * 4 + (l16 >> 2);
@@ -642,10 +834,11 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     }
 }
 
-// images of at most this many tiles are walked by half-quadrant wavefronts (gs_set_half_quadrants): 256 tiles x 4 quadrants are one
-// wavefront per SIMD of this chip, with every LDS / global round trip exposed; two half-filled wavefronts per SIMD hide each other's.
-// Measured (200 k - 1 M Gaussians): 256 tiles backward 132 -> 122 us / 146 -> 130 us, forward 80 -> 78 / 98 -> 89 us; 80 tiles backward
-// 130 -> 112 us; but 400 tiles (3200 half wavefronts: more than the backward's three slots per SIMD) 134 -> 172 us: hence 256
+// images of at most this many tiles (gs_set_half_quadrants; the name dates from the first few-tile variant) take the few-tile kernels:
+// 256 tiles x 4 quadrants are one walker per SIMD of this chip and every walker's chunk-by-chunk chain is exposed.  Forward: producer /
+// consumer workgroups (blend_forward_pc_kernel: 256 x 256, 200 k Gaussians 80 -> 65 us, 1 M 87 -> 74 us; 120 x 150 76 -> 68 us); backward:
+// two list segments per quadrant from the state that forward records (134 -> 88 us).  Above 256 tiles the plain kernels win (400 tiles:
+// backward 134 -> 172 us with the few-tile variant): hence 256
 int g_half_quadrant_tiles = 256;
 
 hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const uint32_t* point_list, const float4* geom,
@@ -656,11 +849,11 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
     // whole-tile workgroups (NW = 4) here: one-wavefront workgroups measured 85 vs 80 us on configs[1] and the same at 2 M -- the
     // four walkers of a tile gather the same records, and on one CU three of them hit its L1
     Cam cam = cam_in;
-    cam.half = (segments <= 1 || !seg_T) && cam.gx * cam.gy <= g_half_quadrant_tiles;
+    cam.half = (segments <= 1 || !seg_T) && cam.gx * cam.gy <= g_half_quadrant_tiles;          // few tiles: the producer / consumer forward
     cam.split = cam.V == 1 && split_state && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles);      // (the backward refuses atlases)
-    const int nb = (((cam.gx * cam.gy + 7) >> 3) << 3) * (cam.half ? 2 : 1);
-#define GS_FWD(DSQ, SEG, FEW, GRID)                                                                                                \
-    hipLaunchKernelGGL((blend_forward_streams_kernel<DSQ, kFwdStreams, SEG, 4, FEW>), GRID, dim3(kBlock), 0, st, cam, ranges, point_list, geom, \
+    const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
+#define GS_FWD(DSQ, SEG, GRID)                                                                                                     \
+    hipLaunchKernelGGL((blend_forward_streams_kernel<DSQ, kFwdStreams, SEG, 4>), GRID, dim3(kBlock), 0, st, cam, ranges, point_list, geom, \
                        out_color, out_depth, out_opacity, final_T, n_contrib, out_depth_sq, cap, seg_T, split_state, P, (float4*)zero_fill)
     const size_t HW = (size_t)cam.W * cam.H;
     if (segments > 1 && seg_T) {
@@ -675,16 +868,23 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
         if (e == hipSuccess && split_state) e = hipMemsetAsync(split_state + (kCutLevels * 5 + 4) * HW, 0, sizeof(uint32_t), st);    // nothing recorded
         if (e != hipSuccess) return e;
         const dim3 grid(nb, segments);
-        if (out_depth_sq) { GS_FWD(true, 1, false, grid); GS_FWD(true, 2, false, grid); }
-        else { GS_FWD(false, 1, false, grid); GS_FWD(false, 2, false, grid); }
+        if (out_depth_sq) { GS_FWD(true, 1, grid); GS_FWD(true, 2, grid); }
+        else { GS_FWD(false, 1, grid); GS_FWD(false, 2, grid); }
     } else if (cam.half || cam.split) {
-        if (out_depth_sq) GS_FWD(true, 0, true, dim3(nb)); else GS_FWD(false, 0, true, dim3(nb));
+        // images of few tiles: one producer / consumer workgroup per tile
+        const dim3 grid(((cam.gx * cam.gy + 7) >> 3) << 3), block(kPcWaves * kWave);
+        if (out_depth_sq)
+            hipLaunchKernelGGL((blend_forward_pc_kernel<true>), grid, block, 0, st, cam, ranges, point_list, geom, out_color, out_depth, out_opacity,
+                               final_T, n_contrib, out_depth_sq, cap, split_state, P, (float4*)zero_fill);
+        else
+            hipLaunchKernelGGL((blend_forward_pc_kernel<false>), grid, block, 0, st, cam, ranges, point_list, geom, out_color, out_depth, out_opacity,
+                               final_T, n_contrib, out_depth_sq, cap, split_state, P, (float4*)zero_fill);
     } else {
         if (split_state) {          // a small image with the few-tile paths switched off: "nothing recorded"
             hipError_t e = hipMemsetAsync(split_state + (kCutLevels * 5 + 4) * HW, 0, sizeof(uint32_t), st);
             if (e != hipSuccess) return e;
         }
-        if (out_depth_sq) GS_FWD(true, 0, false, dim3(nb)); else GS_FWD(false, 0, false, dim3(nb));
+        if (out_depth_sq) GS_FWD(true, 0, dim3(nb)); else GS_FWD(false, 0, dim3(nb));
     }
 #undef GS_FWD
     return hipGetLastError();

@@ -31,8 +31,7 @@ struct Cam {
     const float* view;
     const float* proj;
     const float* campos;
-    // blend kernels, images of few tiles: a wavefront takes HALF a quadrant (8 x 4 pixels on lanes 0-31, lanes 32-63 idle), twice the
-    // wavefronts per tile (set by the blend launchers)
+    // forward blend, images of few tiles: the producer / consumer kernel (set by the blend launchers)
     int half;
     // backward blend, images of few tiles: every tile list is walked in TWO segments by two wavefronts per quadrant; the front
     // one starts from the per-pixel state the forward left at the boundary (set by the blend launchers)
