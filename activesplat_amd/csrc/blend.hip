@@ -319,19 +319,24 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
 #undef GS_FILL_REST
 
 // ---------------------------------------------------------------------------------------------------
-// Forward for images of FEW tiles (at most 256: the reference's 256 x 256 frames, the planner's views): producer / consumer pairs.
+// Forward for images of FEW tiles (at most 256: the reference's 256 x 256 frames, the planner's views): a three-stage pipeline per quadrant.
 // 256 tiles x 4 quadrants are one walker per SIMD of this chip, and a walker's trip through a 64-record chunk is one serial chain --
-// alpha (12 VALU + exp) and the compositing step (T, stop test, four sums: 12 more) for every list entry, one entry after the other.
-// The two halves do not depend on each other in the same way: alpha needs nothing from the walk, the compositing step needs alpha.
-// So a tile is ONE 8-wavefront workgroup, one per CU: per quadrant a PRODUCER wavefront (box tests, per-stream lists, alpha of every
-// list entry of chunk i -> an LDS plane [trip][lane]) and a CONSUMER wavefront (composites chunk i-1 from the plane; the four consumers
-// also fetch the tile's records from memory -- ids three chunks ahead, records two -- and stage chunk i+1's for the whole tile: one gather
-// per tile instead of four).  One
-// workgroup barrier per chunk; alpha planes and lists double-buffered, staged records triple-buffered (written at step i, read by the
-// producers at i+1 and by the consumers at i+2).  Same arithmetic per entry as blend_forward_streams_kernel: identical images.
-// LDS: 4 x 2 x 16 KB planes + lists + 3 x 3 KB records = 140 KB: one workgroup per CU, which is what a 256-tile image offers anyway.
+// gather + stage + lists, then alpha (12 VALU + exp) and the compositing step (T, stop test, four sums: 12 more) for every list entry.
+// The stages do not depend on each other in the same way: alpha needs nothing from the walk, the compositing step needs alpha, the
+// lists need neither.  So a tile is ONE 12-wavefront workgroup, one per CU, with three wavefronts per quadrant:
+//   LISTER   : fetches the tile's records (ids four chunks ahead, records three; the four listers share the gather: 16 records each, one
+//              gather per tile instead of four), stages chunk i+2, and builds the per-stream lists of chunk i+1;
+//   PRODUCER : alpha of every list entry of chunk i -> an LDS plane [trip][lane];
+//   CONSUMER : composites chunk i-1 from the plane (and records the state the two-segment backward resumes from).
+// One workgroup barrier per chunk; alpha planes double-buffered, lists triple-buffered, staged records in four buffers (written at step
+// i-2, read by the lister at i-1, the producer at i, the consumer at i+1).  Same arithmetic per entry as blend_forward_streams_kernel:
+// identical images.  LDS: 4 x 2 x 16 KB planes + lists + 4 x 3 KB records = 147 KB: one workgroup per CU, which is what a 256-tile image
+// offers anyway.  Measured (256 x 256, 200 k Gaussians): one walker per (half) quadrant 80 us; here 65 us (1 M Gaussians: 87 -> 73 us).  What is
+// left is instruction issue: the three wavefronts of a quadrant share one SIMD (256 tiles x 4 quadrants = the chip's 1024 SIMDs), ~1500
+// instructions per 64-record chunk between them -- splitting the stages hides their latencies, it does not add issue slots (a two-stage
+// version, and 64-bit / 128-bit variants of the LDS traffic, measured the same 65 us: profiles/README.md).
 // ---------------------------------------------------------------------------------------------------
-constexpr int kPcWaves = 8;
+constexpr int kPcWaves = 12;
 template <bool DEPTH_SQ>
 __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ geom,
@@ -339,15 +344,17 @@ __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_depth_sq, uint32_t cap, float* __restrict__ split_state, uint32_t P,
     float4* __restrict__ zero_fill)
 {
-    __shared__ float4 s_rec[3][3][kWave + 1];                                         // [buffer][q0', q1', q2'][slot]; slot 64 = sentinel
-    __shared__ float s_alpha[4][2][kWave * kWave];                                    // [pair][buffer][trip * 64 + lane]
-    __shared__ __attribute__((aligned(16))) uint8_t s_list[4][2][4 * kWave + 16];     // [pair][buffer][stream * 64 + position]
-    __shared__ int s_ntrips[4][2];
-    __shared__ unsigned long long s_going[4];                                         // lanes of the pair's quadrant that still blend
-    __shared__ int s_done[2][4];                                                      // [step parity][pair]: every pixel of the quadrant has stopped
+    // staged records, split by reader: [0] = (x, y, A', B') and [1] = (C', opacity, ext_x, ext_y) for the lister and the producer,
+    // [2] = (r, g, b, depth) for the consumer: one 128-bit read per entry there, 128 + 64 bits for alpha (the kernel is bound by the CU's
+    // LDS pipe: one workgroup, twelve wavefronts, every list entry read by two of them)
+    __shared__ float4 s_rec[4][3][kWave + 1];                                         // [buffer][part][slot]; slot 64 = sentinel
+    __shared__ float4 s_alpha[4][2][(kWave / 4) * kWave];                             // [pair][buffer][(trip / 4) * 64 + lane]: four trips' alpha
+    __shared__ __attribute__((aligned(16))) uint8_t s_list[4][3][4 * kWave + 16];     // [pair][buffer][stream * 64 + position]
+    __shared__ int s_ntrips[4][3];
+    __shared__ unsigned long long s_going[4];                                         // lanes of the quadrant that still blend
+    __shared__ int s_done[2][4];                                                      // [step parity][quadrant]: every pixel has stopped
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pair = wave & 3;
-    const bool consumer = wave >= 4;
+    const int pair = wave & 3, role = wave >> 2;                                      // role 0: lister, 1: producer, 2: consumer
     const int ntiles = cam.gx * cam.gy, per = (ntiles + 7) >> 3;
     const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     // the backward's gradient records: this workgroup's slice, a few 16-byte stores per step of the loop below
@@ -374,12 +381,14 @@ __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
     const uint32_t n = range.y - range.x;
     const uint32_t* list = point_list + range.x;
     const int nchunks = (int)((n + kWave - 1) / kWave);
-    if (tid < 3) { s_rec[tid][0][kWave] = make_float4(0.f, 0.f, 0.f, 0.f); s_rec[tid][1][kWave] = make_float4(0.f, 0.f, 0.f, 0.f); s_rec[tid][2][kWave] = make_float4(0.f, 0.f, -1.f, -1.f); }
-    if (tid < 4) { s_going[tid] = ~0ull; s_done[0][tid] = 0; s_done[1][tid] = 0; s_ntrips[tid][0] = 0; s_ntrips[tid][1] = 0; }
+    if (tid < 4) {
+        s_rec[tid][0][kWave] = make_float4(0.f, 0.f, 0.f, 0.f); s_rec[tid][1][kWave] = make_float4(0.f, 0.f, -1.f, -1.f); s_rec[tid][2][kWave] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_going[tid] = ~0ull; s_done[0][tid] = 0; s_done[1][tid] = 0; s_ntrips[tid][0] = 0; s_ntrips[tid][1] = 0; s_ntrips[tid][2] = 0;
+    }
 
-    // Record `lane + 16 * pair` of a chunk is fetched by lanes 0-15 of consumer wavefront `pair` and staged in the blend form (conic
-    // pre-scaled for 2^p: see stage_record; the last word pair holds the alpha-visible half extents here).  The fetch is a chain of two
-    // dependent memory reads (id, then record), so it runs ahead of the walk: ids THREE chunks ahead, records TWO, staging one.
+    // Record `lane + 16 * pair` of a chunk is fetched by lanes 0-15 of lister `pair` and staged in the blend form (conic pre-scaled for
+    // 2^p: see stage_record; the last word pair holds the alpha-visible half extents here).  The fetch is a chain of two dependent memory
+    // reads (id, then record), so it runs ahead of the walk.
     auto fetch_id = [&](int chunk) -> uint32_t {
         const uint32_t e = (uint32_t)chunk * kWave + (uint32_t)(pair * 16 + lane);
         uint32_t id = kNoId;
@@ -392,19 +401,49 @@ __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
     };
     auto stage = [&](int chunk, const float4 (&g)[3]) {
         if (lane < 16 && chunk < nchunks) {
-            const int b = chunk % 3, slot = pair * 16 + lane;
+            const int b = chunk & 3, slot = pair * 16 + lane;
             s_rec[b][0][slot] = make_float4(g[0].x, g[0].y, -0.5f * kLog2e * g[0].z, -kLog2e * g[0].w);
-            s_rec[b][1][slot] = make_float4(-0.5f * kLog2e * g[1].x, g[1].y, g[1].z, g[1].w);
-            s_rec[b][2][slot] = g[2];                                                 // (b, depth, ext_x, ext_y)
+            s_rec[b][1][slot] = make_float4(-0.5f * kLog2e * g[1].x, g[1].y, g[2].z, g[2].w);
+            s_rec[b][2][slot] = make_float4(g[1].z, g[1].w, g[2].x, g[2].y);
         }
     };
-    float4 held[3], flying[3];                       // records of chunk it + 1 (arrived, staged at the end of step it) / of chunk it + 2 (in flight)
-    uint32_t id_ahead = kNoId;                       // this lane's id of chunk it + 2 at the top of step it
-    if (consumer) {
+    // the per-stream lists of one chunk (lane = staged record): hits of the alpha-visible box on the quadrant's four 4x4 blocks
+    auto build_lists = [&](int chunk) {
+        if (chunk >= nchunks) return;
+        const int lb = chunk % 3, rb = chunk & 3;
+        const float2 q0 = *reinterpret_cast<const float2*>(&s_rec[rb][0][lane]);                       // (x, y)
+        const float2 q2 = *(reinterpret_cast<const float2*>(&s_rec[rb][1][lane]) + 1);                 // (ext_x, ext_y)
+        const float ex = q2.x, ey = q2.y;
+        int ntrips = 0;
+        const bool qhit = ex >= 0.0f && (q0.x + ex >= qx0) && (q0.x - ex <= qx0 + 7.0f) && (q0.y + ey >= qy0) && (q0.y - ey <= qy0 + 7.0f);
+        if (__any(qhit)) {
+            reinterpret_cast<uint32_t*>(s_list[pair][lb])[lane] = 0x40404040u;        // sentinel fill: 4 x 64 bytes
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long going = s_going[pair];
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const float x0 = qx0 + (float)((st & 1) * 4), y0 = qy0 + (float)((st >> 1) * 4);
+                const bool stream_going = ((going >> (st * 16)) & 0xffffull) != 0ull;
+                const bool hit = stream_going && ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) && (q0.y - ey <= y0 + 3.0f);
+                const unsigned long long m = __ballot(hit);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (hit) s_list[pair][lb][st * kWave + rank] = (uint8_t)lane;
+                ntrips = max(ntrips, (int)__popcll(m));
+            }
+        }
+        if (lane == 0) s_ntrips[pair][lb] = ntrips;
+    };
+    float4 held[3], flying[3];                       // lister: records of chunk it + 2 (arrived, staged during step it) / of chunk it + 3 (in flight)
+    uint32_t id_ahead = kNoId;                       // lister: this lane's id of chunk it + 3 at the top of step it
+    __syncthreads();                                 // (sentinels and flags)
+    if (role == 0) {
         fetch_rec(fetch_id(0), held); stage(0, held);
-        fetch_rec(fetch_id(1), held);
-        id_ahead = fetch_id(2);
+        fetch_rec(fetch_id(1), held); stage(1, held);
+        fetch_rec(fetch_id(2), held);
+        id_ahead = fetch_id(3);
     }
+    __syncthreads();
+    if (role == 0) build_lists(0);
     __syncthreads();
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Dq = 0.f;
@@ -413,89 +452,80 @@ __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
     for (int it = 0; it <= nchunks; it++) {
         for (int f = 0; f < 2; f++)
             if (zf < zf_end) { zero_fill[zf] = make_float4(0.f, 0.f, 0.f, 0.f); zf += kPcWaves * kWave; }
-        if (!consumer) {
-            // ---- producer: lists and alpha of chunk `it` ----
-            if (it < nchunks && !s_done[(it + 1) & 1][pair]) {
-                const int ab = it & 1, rb = it % 3;
-                const float4 q0 = s_rec[rb][0][lane], q2 = s_rec[rb][2][lane];
-                const float ex = q2.z, ey = q2.w;
-                int ntrips = 0;
-                const bool qhit = ex >= 0.0f && (q0.x + ex >= qx0) && (q0.x - ex <= qx0 + 7.0f) && (q0.y + ey >= qy0) && (q0.y - ey <= qy0 + 7.0f);
-                if (__any(qhit)) {
-                    reinterpret_cast<uint32_t*>(s_list[pair][ab])[lane] = 0x40404040u;          // sentinel fill: 4 x 64 bytes
-                    __builtin_amdgcn_wave_barrier();
-                    const unsigned long long going = s_going[pair];
+        const bool quad_done = s_done[(it + 1) & 1][pair] != 0;                         // as of the end of step it - 1
+        if (role == 0) {
+            // ---- lister: records of chunk it + 3 requested, lists of chunk it + 1, chunk it + 2 staged ----
+            const uint32_t id_next = fetch_id(it + 4);
+            fetch_rec(id_ahead, flying);
+            if (!quad_done) build_lists(it + 1);
+            stage(it + 2, held);
 #pragma unroll
-                    for (int st = 0; st < 4; st++) {
-                        const float x0 = qx0 + (float)((st & 1) * 4), y0 = qy0 + (float)((st >> 1) * 4);
-                        const bool stream_going = ((going >> (st * 16)) & 0xffffull) != 0ull;
-                        const bool hit = stream_going && ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) && (q0.y - ey <= y0 + 3.0f);
-                        const unsigned long long m = __ballot(hit);
-                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        if (hit) s_list[pair][ab][st * kWave + rank] = (uint8_t)lane;
-                        ntrips = max(ntrips, (int)__popcll(m));
+            for (int q = 0; q < 3; q++) held[q] = flying[q];
+            id_ahead = id_next;
+        } else if (role == 1) {
+            // ---- producer: alpha of chunk it ----
+            if (it < nchunks && !quad_done) {
+                const int ab = it & 1, lb = it % 3, rb = it & 3;
+                const int ntrips = s_ntrips[pair][lb];
+                const uint8_t* my_list = s_list[pair][lb] + sid * kWave;
+                float4* plane = s_alpha[pair][ab] + lane;
+                const float4* s0 = s_rec[rb][0]; const float4* s1 = s_rec[rb][1];
+                // four list entries per trip (one 32-bit list read, fetched a trip ahead): the entries are independent here, so the
+                // eight record reads of a trip are in flight together (entries behind the list's end are the sentinel: alpha 0)
+                uint32_t jj4_next = ntrips > 0 ? *reinterpret_cast<const uint32_t*>(my_list) : 0x40404040u;
+                for (int t = 0; t < ntrips; t += 4) {
+                    const uint32_t jj4 = jj4_next;
+                    jj4_next = *reinterpret_cast<const uint32_t*>(my_list + ((t + 4) & 63));
+                    float4 a0[4];
+                    float2 a1[4];
+                    float al[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int j = (int)((jj4 >> (8 * u)) & 0xffu); a0[u] = s0[j]; a1[u] = *reinterpret_cast<const float2*>(&s1[j]); }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float dx = a0[u].x - pxf, dy = a0[u].y - pyf;
+                        const float p = (a0[u].z * dx + a0[u].w * dy) * dx + (a1[u].x * dy) * dy;
+                        const float alpha = fminf(0.99f, a1[u].y * __builtin_amdgcn_exp2f(p));
+                        al[u] = (p <= 0.0f && alpha >= kAlphaMin) ? alpha : 0.0f;                        // 0 = this pixel does not see the record
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    const uint8_t* my_list = s_list[pair][ab] + sid * kWave;
-                    float* plane = s_alpha[pair][ab] + lane;
-                    const float4* s0 = s_rec[rb][0]; const float4* s1 = s_rec[rb][1];
-                    // four list entries per trip (one 32-bit list read, fetched a trip ahead): the entries are independent here, so
-                    // the eight record reads of a trip are in flight together (entries behind the list's end are the sentinel: alpha 0)
-                    uint32_t jj4_next = *reinterpret_cast<const uint32_t*>(my_list);
-                    for (int t = 0; t < ntrips; t += 4) {
-                        const uint32_t jj4 = jj4_next;
-                        jj4_next = *reinterpret_cast<const uint32_t*>(my_list + ((t + 4) & 63));
-                        float4 a0[4], a1[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) { const int j = (int)((jj4 >> (8 * u)) & 0xffu); a0[u] = s0[j]; a1[u] = s1[j]; }
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const float dx = a0[u].x - pxf, dy = a0[u].y - pyf;
-                            const float p = (a0[u].z * dx + a0[u].w * dy) * dx + (a1[u].x * dy) * dy;
-                            const float alpha = fminf(0.99f, a1[u].y * __builtin_amdgcn_exp2f(p));
-                            plane[(t + u) * kWave] = (p <= 0.0f && alpha >= kAlphaMin) ? alpha : 0.0f;   // 0 = this pixel does not see the record
-                        }
-                    }
+                    plane[(t >> 2) * kWave] = make_float4(al[0], al[1], al[2], al[3]);
                 }
-                if (lane == 0) s_ntrips[pair][ab] = ntrips;
             }
         } else {
-            // ---- consumer: fetch chunk it + 1, composite chunk it - 1, stage chunk it + 1 ----
-            const uint32_t id_next = fetch_id(it + 3);
-            fetch_rec(id_ahead, flying);                                              // chunk it + 2
+            // ---- consumer: composite chunk it - 1 ----
             if (it >= 1 && !__all(done)) {
-                const int ab = (it - 1) & 1, rb = (it - 1) % 3;
+                const int ab = (it - 1) & 1, lb = (it - 1) % 3, rb = (it - 1) & 3;
                 const uint32_t base = (uint32_t)(it - 1) * kWave;
                 if (record && base >= (uint32_t)kCutFirst && base < ((uint32_t)kCutFirst << kCutLevels) && (base & (base - 1u)) == 0u && inside) {
                     const int k = 31 - __clz((int)base) - 7;                                   // 128 -> 0, 256 -> 1, ...
                     float* stt = split_state + (size_t)k * 5 * HWs + (size_t)py * cam.W + px;
                     stt[0] = T; stt[HWs] = C0; stt[2 * HWs] = C1; stt[3 * HWs] = C2; stt[4 * HWs] = Dp;
                 }
-                const int ntrips = s_ntrips[pair][ab];
-                const uint8_t* my_list = s_list[pair][ab] + sid * kWave;
-                const float* plane = s_alpha[pair][ab] + lane;
-                const float4* s1 = s_rec[rb][1]; const float4* s2 = s_rec[rb][2];
-                uint32_t jj4_next = *reinterpret_cast<const uint32_t*>(my_list);
+                const int ntrips = s_ntrips[pair][lb];
+                const uint8_t* my_list = s_list[pair][lb] + sid * kWave;
+                const float4* plane = s_alpha[pair][ab] + lane;
+                const float4* s2 = s_rec[rb][2];
+                uint32_t jj4_next = ntrips > 0 ? *reinterpret_cast<const uint32_t*>(my_list) : 0x40404040u;
                 for (int t = 0; t < ntrips; t += 4) {
                     const uint32_t jj4 = jj4_next;
                     jj4_next = *reinterpret_cast<const uint32_t*>(my_list + ((t + 4) & 63));
-                    float al[4];
-                    float4 b1[4], b2[4];
+                    const float4 al4 = plane[(t >> 2) * kWave];
+                    const float al[4] = {al4.x, al4.y, al4.z, al4.w};
+                    float4 b2[4];
                     int jj[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { jj[u] = (int)((jj4 >> (8 * u)) & 0xffu); al[u] = plane[(t + u) * kWave]; b1[u] = s1[jj[u]]; b2[u] = s2[jj[u]]; }
+                    for (int u = 0; u < 4; u++) { jj[u] = (int)((jj4 >> (8 * u)) & 0xffu); b2[u] = s2[jj[u]]; }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const float alpha = al[u];
-                        const float4 a1 = b1[u];
-                        const float4 a2 = b2[u];
+                        const float4 cc = b2[u];                                 // (r, g, b, depth)
                         const float test_T = T * (1.0f - alpha);
                         const bool vis = !done && alpha > 0.0f;
                         const bool ok = vis && test_T >= kTmin;
                         done = done || (vis && !ok);
                         const float w = ok ? alpha * T : 0.0f;
-                        C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w; Dp += a2.y * w;
-                        if (DEPTH_SQ) Dq += a2.y * a2.y * w;
+                        C0 += cc.x * w; C1 += cc.y * w; C2 += cc.z * w; Dp += cc.w * w;
+                        if (DEPTH_SQ) Dq += cc.w * cc.w * w;
                         T = ok ? test_T : T;
                         last = ok ? base + (uint32_t)jj[u] + 1u : last;
                     }
@@ -505,16 +535,12 @@ __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
             }
             const bool all_done = __all(done);                     // (a wave vote: outside of the one-lane store below)
             if (lane == 0) s_done[it & 1][pair] = all_done ? 1 : 0;
-            stage(it + 1, held);
-#pragma unroll
-            for (int q = 0; q < 3; q++) held[q] = flying[q];
-            id_ahead = id_next;
         }
         __syncthreads();
         if (s_done[it & 1][0] && s_done[it & 1][1] && s_done[it & 1][2] && s_done[it & 1][3]) break;      // (uniform: written before the barrier)
     }
     for (; zf < zf_end; zf += kPcWaves * kWave) zero_fill[zf] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (consumer && inside) {
+    if (role == 2 && inside) {
         const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
         final_T[pix] = T;
         n_contrib[pix] = last;
