@@ -44,7 +44,7 @@ def overlap_counts(pts, keyframe_list, intrinsics, width, height, edge=20):
     counts = torch.zeros(n_kf, dtype=torch.int32, device=dev)
     K = np.asarray(intrinsics.detach().cpu() if torch.is_tensor(intrinsics) else intrinsics, dtype=np.float64).reshape(-1)
     k9 = (C.c_float * 9)(*[float(v) for v in K])
-    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+    st = _lib.stream_ptr(dev)
     _lib.check(lib.gs_keyframe_overlap(int(p.shape[0]), C.c_void_p(p.data_ptr()), n_kf, C.c_void_p(w2c.data_ptr()), k9, int(width),
                                        int(height), int(edge), C.c_void_p(counts.data_ptr()), st))
     return counts.cpu().tolist()

@@ -174,7 +174,7 @@ class _FusedRendervars(torch.autograd.Function):
         om, orr = torch.empty(P, 3, device=dev), torch.empty(P, 4, device=dev)
         oo, os_ = torch.empty(P, 1, device=dev), torch.empty(P, 3, device=dev)
         pose = (C.c_float * 7)(*[float(v) for v in pose7])
-        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        st = _lib.stream_ptr(dev)
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         _lib.check(lib.gs_activate_forward(P, iso, pose, p(m), p(r), p(o), p(s), p(om), p(orr), p(oo), p(os_), st))
         ctx.save_for_backward(r, oo, os_)
@@ -193,7 +193,7 @@ class _FusedRendervars(torch.autograd.Function):
         dm, dr = torch.empty(P, 3, device=dev), torch.empty(P, 4, device=dev)
         dl, ds = torch.empty(P, 1, device=dev), torch.empty(P, 1 if ctx.iso else 3, device=dev)
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        st = _lib.stream_ptr(dev)
         _lib.check(lib.gs_activate_backward(P, ctx.iso, ctx.pose, p(r), p(oo), p(os_), p(gm), p(gr), p(go), p(gs_), p(dm), p(dr),
                                             p(dl), p(ds), st))
         return dm, dr, dl, ds, None
@@ -209,9 +209,10 @@ def fused_rendervar(params, time_idx, pose7=None):
     m, r, o, s = _FusedRendervars.apply(params["means3D"], params["unnorm_rotations"], params["logit_opacities"],
                                         params["log_scales"], pose7)
     # means2D only exists to receive the screen-space gradient: a fresh LEAF (autograd hands it the rasteriser's gradient
-    # tensor as .grad without a copy; the reference's `zeros + 0` non-leaf costs an add and a retain_grad clone)
+    # tensor as .grad without a copy; the reference's `zeros + 0` non-leaf costs an add and a retain_grad clone).  Its VALUES are
+    # never read -- the rasteriser takes the tensor as a gradient carrier only -- so it is not filled either (one launch less)
     return {"means3D": m, "colors_precomp": params["rgb_colors"], "rotations": r, "opacities": o, "scales": s,
-            "means2D": torch.zeros_like(params["means3D"], requires_grad=True)}
+            "means2D": torch.empty_like(params["means3D"], requires_grad=True)}
 
 
 class _FusedMappingLoss(torch.autograd.Function):
@@ -230,7 +231,7 @@ class _FusedMappingLoss(torch.autograd.Function):
         grads = torch.empty(4, H, W, dtype=torch.float32, device=dev)    # dL/dim [3,H,W] and dL/ddepth [1,H,W] in ONE buffer
         d_im, d_depth = grads[:3], grads[3:]
         scratch = torch.empty(int(lib.gs_mapping_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
-        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+        st = _lib.stream_ptr(dev)
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
         _lib.check(lib.gs_mapping_loss(W, H, p(im_), p(gt_), p(depth_), p(dsq_), p(gtd_), float(w_im), float(w_depth), p(buf),
                                        p(d_im), p(d_depth), p(scratch), st))
@@ -405,7 +406,7 @@ def grow_rows(render_depth, silhouette, gt_depth, color, intrinsics, c2w, sil_th
     k4 = (C.c_float * 4)(K[0][0], K[1][1], K[0][2], K[1][2])
     c2w = np.asarray(c2w.detach().cpu() if torch.is_tensor(c2w) else c2w, dtype=np.float64)
     m12 = (C.c_float * 12)(*[float(v) for v in c2w[:3, :4].reshape(-1)])
-    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
+    st = _lib.stream_ptr(dev)
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     _lib.check(lib.gs_grow_gaussians(W, H, p(rd), p(sil), p(gt), p(col), k4, m12, float(sil_thres), 1 if iso else 0, p(out["means3D"]),
                                      p(out["rgb_colors"]), p(out["unnorm_rotations"]), p(out["logit_opacities"]), p(out["log_scales"]),

@@ -35,7 +35,8 @@ def _backend(group=None) -> str:
 
 def _stream(t):
     import ctypes as C
-    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else C.c_void_p(0)
+    from . import _lib as L
+    return L.stream_ptr(t.device)
 
 
 def _row_tensors(params, keys, optimizer=None, target="param"):
@@ -62,7 +63,7 @@ def _row_tensors(params, keys, optimizer=None, target="param"):
             grp, st = groups[k], optimizer.state[p]
             b1, b2 = grp["betas"]
             t.exp_avg, t.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-            t.lr, t.beta1, t.beta2, t.eps, t.step = float(grp["lr"]), float(b1), float(b2), float(grp["eps"]), int(st["step"].item())
+            t.lr, t.beta1, t.beta2, t.eps, t.step = float(grp["lr"]), float(b1), float(b2), float(grp["eps"]), int(st["step"])
     return arr, keep
 
 
@@ -250,8 +251,8 @@ def reduce_scatter_adam_step(params, optimizer, group=None, timing=False):
             p = params[k]
             st = optimizer.state.get(p)
             if st is None or len(st) == 0:
-                st = optimizer.state[p] = {"step": torch.tensor(0.0), "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
-            st["step"] = st["step"] + 1
+                st = optimizer.state[p] = {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+            st["step"] = int(st["step"]) + 1
         arr, keep = _row_tensors(params, keys, optimizer)
         _lib.check(lib.gs_adam_rows(len(keys), arr, lo, hi - lo, rows, plan["gshard"].data_ptr(), plan["pshard"].data_ptr(), _stream(buf.padded)))
         how_g = _all_gather_rows(buf.padded, plan["pshard"], group)      # the send buffer of the reduce-scatter takes the updated rows

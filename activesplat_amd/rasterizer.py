@@ -63,11 +63,11 @@ _tls = threading.local()
 _capacity_lock = threading.Lock()
 
 
-def _host_counters(device):
+def _host_counters(device, stream_handle):
     pool = getattr(_tls, "pinned", None)
     if pool is None:
         pool = _tls.pinned = {}
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, stream_handle)
     buf = pool.get(key)
     if buf is None:
         if len(pool) >= 64:                              # short-lived streams: do not grow without bound
@@ -91,7 +91,23 @@ def _f32(t, device):
 
 
 def _stream(device):
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else C.c_void_p(0)
+    return _lib.stream_ptr(device)
+
+
+#: the two size-only layouts of a (P, W, H) frame: asked from the library once, not per frame
+_layouts = {}
+
+
+def _frame_layouts(lib, P, W, H):
+    key = (P, W, H)
+    hit = _layouts.get(key)
+    if hit is None:
+        gl = _lib.GsGeomLayout(); _lib.check(lib.gs_geom_layout(P, W, H, C.byref(gl)))
+        il = _lib.GsImageLayout(); _lib.check(lib.gs_image_layout(W, H, C.byref(il)))
+        if len(_layouts) >= 64:                          # P changes with every densify / growth step
+            _layouts.pop(next(iter(_layouts)))
+        hit = _layouts[key] = (gl, il, int(lib.gs_backward_scratch_bytes(P)))
+    return hit
 
 
 def _camera(rs: GaussianRasterizationSettings, device, sh_coeffs: int):
@@ -125,15 +141,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         M = 0 if shs is None else int(shs.shape[1])
         cam, keep = _camera(rs, device, M)
         W, H = int(rs.image_width), int(rs.image_height)
-        st = _stream(device)
+        cur = torch.cuda.current_stream(device) if device.type == "cuda" else None     # ONE lookup per call (~6 us each)
+        st_handle = int(cur.cuda_stream) if cur is not None else 0
+        st = C.c_void_p(st_handle)
 
-        gl = _lib.GsGeomLayout(); _lib.check(lib.gs_geom_layout(P, W, H, C.byref(gl)))
-        il = _lib.GsImageLayout(); _lib.check(lib.gs_image_layout(W, H, C.byref(il)))
+        gl, il, scratch_bytes = _frame_layouts(lib, P, W, H)
         geom = torch.empty(gl.total_bytes, dtype=torch.uint8, device=device)
         image = torch.empty(il.total_bytes, dtype=torch.uint8, device=device)
         radii = torch.empty(P, dtype=torch.int32, device=device)
         d_num = torch.empty(2, dtype=torch.int32, device=device)
-        h_num = _host_counters(device) if device.type == "cuda" else torch.zeros(2, dtype=torch.int32)
+        h_num = _host_counters(device, st_handle) if device.type == "cuda" else torch.zeros(2, dtype=torch.int32)
         want_bwd = 1 if any(ctx.needs_input_grad[:8]) else 0
         _lib.check(lib.gs_preprocess_forward(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
                                              _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
@@ -146,7 +163,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # forward zero-fills them as a side job instead of a fill launch in front of the backward
         scratch = None
         if any(ctx.needs_input_grad[:8]) and P > 0:
-            scratch = torch.empty(int(lib.gs_backward_scratch_bytes(P)), dtype=torch.uint8, device=device)
+            scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=device)
 
         def render(cap_d, cap_tile):
             bl_ = _lib.GsBinLayout(); _lib.check(lib.gs_bin_layout(cap_d, cap_tile, W, H, C.byref(bl_)))
@@ -167,14 +184,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         if guess is not None:
             if device.type == "cuda":
                 ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(device))
+                ev.record(cur)
             bl_g = _lib.GsBinLayout(); _lib.check(lib.gs_bin_layout(guess[0], guess[1], W, H, C.byref(bl_g)))
             if bl_g.path == 1:
                 done = render(*guess)
             if device.type == "cuda":
                 ev.synchronize()                                # counters are on the host; the render is still in flight
         elif device.type == "cuda":
-            torch.cuda.current_stream(device).synchronize()      # first frame of a stream: D sizes the binning buffers
+            cur.synchronize()                                    # first frame of a stream: D sizes the binning buffers
         D = int(h_num[0].item()) & 0xFFFFFFFF
         max_tile = int(h_num[1].item()) & 0xFFFFFFFF
         if done is not None and D <= guess[0] and max_tile <= guess[1]:
@@ -338,14 +355,15 @@ def render_views(settings_list, means3D, opacities, shs=None, colors_precomp=Non
     pv, aw, stride = C.c_int32(), C.c_int32(), C.c_int32()
     _lib.check(lib.gs_atlas_layout(P, W, V, C.byref(pv), C.byref(aw), C.byref(stride)))
     Pv, AW, S = pv.value, aw.value, stride.value
-    st = _stream(device)
+    st_handle = _lib.stream_handle(device)
+    st = C.c_void_p(st_handle)
     gl = _lib.GsGeomLayout(); _lib.check(lib.gs_geom_layout(Pv, AW, H, C.byref(gl)))
     il = _lib.GsImageLayout(); _lib.check(lib.gs_image_layout(AW, H, C.byref(il)))
     geom = torch.empty(gl.total_bytes, dtype=torch.uint8, device=device)
     image = torch.empty(il.total_bytes, dtype=torch.uint8, device=device)
     radii = torch.empty(max(Pv, 1), dtype=torch.int32, device=device)
     d_num = torch.empty(2, dtype=torch.int32, device=device)
-    h_num = _host_counters(device) if device.type == "cuda" else torch.zeros(2, dtype=torch.int32)
+    h_num = _host_counters(device, st_handle) if device.type == "cuda" else torch.zeros(2, dtype=torch.int32)
     _lib.check(lib.gs_preprocess_forward(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
                                          _ptr(rotations), _ptr(cov3D_precomp), _ptr(radii), _ptr(geom), _ptr(image), _ptr(d_num), _ptr(h_num), 0, st))
     if device.type == "cuda":

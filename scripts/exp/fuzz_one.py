@@ -1,0 +1,34 @@
+"""Development helper (checker run): one seed of scripts/exp/fuzz_gpu.py in detail -- where the product's gradient differs from the
+fp64 oracle, next to the fp32 oracle's own difference.  usage: SEED=50310 python scripts/exp/fuzz_one.py"""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.gs_oracle import Oracle
+from tests import util
+from tests.test_randomized import _draw
+
+seed = int(os.environ.get("SEED", 50310))
+o32, o64 = Oracle("f32"), Oracle("f64")
+r = np.random.RandomState(seed)
+rs, rv = _draw(seed, "cuda")
+if seed % 4 == 1:
+    N = int(r.randint(3000, 30000)); W, H = int(r.randint(40, 200)), int(r.randint(40, 160))
+    rs, rv = util.scene(N, W, H, seed=seed, device="cuda", w2c=util.pose(float(r.uniform(-0.4, 0.4)), (0.0, 0.0, float(r.uniform(-1.0, 0.5)))),
+                        sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
+    rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
+    rv["scales"] = rv["scales"] * float(np.exp(r.uniform(-0.5, 1.5)))
+H, W = int(rs.image_height), int(rs.image_width)
+dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(0))
+got = util.run_product(rs, rv, dL)
+art = util.artefacts()
+r64 = util.run_oracle(o64, rs, rv, dL); r32 = util.run_oracle(o32, rs, rv, dL)
+print("P", rv["means3D"].shape[0], "WxH", W, H, "D", got["D"])
+print("n_contrib equal to fp32 oracle:", np.array_equal(art["n_contrib"], r32["n_contrib"].reshape(H, W)) if "n_contrib" in r32 else "n/a")
+for k, g in got["grads"].items():
+    a = r64["grads"][k].reshape(g.shape); b = r32["grads"][k].reshape(g.shape).astype(np.float64)
+    d = np.abs(g - a).reshape(g.shape[0], -1).max(1); d32 = np.abs(b - a).reshape(g.shape[0], -1).max(1)
+    top = np.argsort(-d)[:4]
+    print(k, "rel", np.linalg.norm(g - a) / np.linalg.norm(a), "rel32", np.linalg.norm(b - a) / np.linalg.norm(a), "|g|max", np.abs(a).max())
+    for i in top:
+        print("   gaussian", i, "err", d[i], "fp32-oracle err", d32[i], "radius", got["radii"][i])

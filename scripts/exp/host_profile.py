@@ -2,7 +2,7 @@
 negligible).  GPU box: python scripts/exp/host_profile.py"""
 import cProfile, os, pstats, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.environ.get("PKG_ROOT") or os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from activesplat_amd import GaussianRasterizer, setup_camera
 from activesplat_amd import synthetic as syn
 
