@@ -98,7 +98,8 @@ typedef struct GsImageLayout {
 } GsImageLayout;
 
 #define GS_SORT_AUTO 0
-#define GS_SORT_TILE_LDS 1   /* count/scatter into tile segments + per-tile LDS bitonic sort (+ merges for lists over 2048 keys); <= 8192 tiles */
+#define GS_SORT_TILE_LDS 1   /* count/scatter into tile segments + per-tile sort in LDS / registers (bucket sort for lists of <= 5632 keys, else bitonic
+                              * runs + merges); <= 8192 tiles */
 #define GS_SORT_RADIX 2      /* duplicate with 64-bit keys + device radix sort (any image size) */
 
 typedef struct GsBinLayout {
