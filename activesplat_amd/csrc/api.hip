@@ -150,6 +150,14 @@ int gs_set_half_quadrants(int32_t max_tiles)
     return GS_OK;
 }
 
+int gs_set_backward_chain(int32_t pieces, int32_t min_tiles)
+{
+    if (pieces < 1 || pieces > gs::kChainPieces) return fail(GS_EINVAL, "gs_set_backward_chain: pieces out of range");
+    gs::g_chain_pieces = pieces;
+    gs::g_chain_min_tiles = min_tiles < 0 ? gs::kChainMinTiles : min_tiles;
+    return GS_OK;
+}
+
 int gs_set_forward_segments(int32_t on)
 {
     g_segments_enabled = on != 0;
@@ -199,7 +207,9 @@ int gs_image_layout(int32_t width, int32_t height, GsImageLayout* out)
     out->final_T = o; o = align_up(o + hw * 4);
     out->n_contrib = o; o = align_up(o + hw * 4);
     // (recorded only for images of few tiles: every pixel's state at the cut positions of the two-segment backward)
-    out->split_state = o; o = align_up(o + (tiles <= (uint64_t)gs::kFewTiles ? ((uint64_t)gs::kCutLevels * 5 + 4) * hw + 4 : 4) * 4);
+    // (images of many tiles: the hand-over state of the chained backward walks lives at the same offset)
+    out->split_state = o; o = align_up(o + (tiles <= (uint64_t)gs::kFewTiles ? ((uint64_t)gs::kCutLevels * 5 + 4) * hw + 4
+                                             : (uint64_t)gs::chain_state_words(tiles)) * 4);
     out->total_bytes = o;
     return GS_OK;
 }
@@ -353,7 +363,7 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_ti
                                      (float*)(ib + IL.final_T), (uint32_t*)(ib + IL.n_contrib), out_depth_sq,
                                      BL.path == GS_SORT_TILE_LDS ? (uint32_t)D : 0xffffffffu, (int)BL.segments,
                                      BL.segments > 1 ? (float*)(bb + BL.seg_T) : nullptr,
-                                     k.gx * k.gy <= gs::kFewTiles ? (float*)(ib + IL.split_state) : nullptr, (uint32_t)P,
+                                     (float*)(ib + IL.split_state), (uint32_t)P,
                                      (float*)backward_scratch, st);
     }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_forward: blend %s", hipGetErrorString(e));
@@ -389,7 +399,7 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* m
     if (D > 0) {
         ScopedStage ps(ST_BLEND_BWD, st);
         e = gs::launch_blend_backward(k, (const uint2*)(ib + IL.ranges), point_list, gp.geom,
-                                      k.gx * k.gy <= gs::kFewTiles ? (const float*)(ib + IL.split_state) : nullptr,
+                                      (const float*)(ib + IL.split_state),
                                       (const float*)(ib + IL.final_T),
                                       (const uint32_t*)(ib + IL.n_contrib), dL_dcolor, dL_ddepth, grad2d, st);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_backward: blend %s", hipGetErrorString(e));

@@ -20,6 +20,7 @@
 //     given the contiguous band of tiles [x*ceil(T/8), (x+1)*ceil(T/8)) and neighbouring tiles (which
 //     share Gaussians) reuse records in one 4 MiB L2.
 #include "gs_common.h"
+#include <atomic>
 
 namespace gs {
 
@@ -40,12 +41,12 @@ struct TileCtx {
 // tiles share Gaussians: their records are reused in one 4 MiB L2); a tile is NW-wavefront workgroups of quadrant walkers -- four
 // 8 x 8 quadrants, or four quadrants x two list segments (the few-tile backward).
 template <int NW>
-__device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, TileCtx& c, bool segments = false)
+__device__ __forceinline__ bool tile_ctx_at(const Cam& cam, unsigned block, int wave, int lane, TileCtx& c, bool segments = false)
 {
     const int G = (segments ? 8 : 4) / NW;                   // workgroups per tile
     const int ntiles = cam.gx * cam.gy, per = (ntiles + 7) >> 3;
-    const int idx = (int)(blockIdx.x >> 3);
-    c.tile = (int)(blockIdx.x & 7) * per + idx / G;
+    const int idx = (int)(block >> 3);
+    c.tile = (int)(block & 7) * per + idx / G;
     if (idx / G >= per || c.tile >= ntiles) return false;
     int quad = (idx % G) * NW + wave;
     c.seg = segments ? quad >> 2 : 0;                        // (list segments: walkers 0-3 = front segment of the four quadrants, 4-7 = back)
@@ -56,6 +57,12 @@ __device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, 
     c.qx0 = (float)qx; c.qy0 = (float)qy; c.pxf = (float)c.px; c.pyf = (float)c.py;
     c.inside = c.px < cam.W && c.py < cam.H;
     return true;
+}
+
+template <int NW>
+__device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, TileCtx& c, bool segments = false)
+{
+    return tile_ctx_at<NW>(cam, blockIdx.x, wave, lane, c, segments);
 }
 
 // does the record's alpha-visible box overlap the 8x8 quadrant at pixel origin (qx0,qy0)?
@@ -154,6 +161,9 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
 #define GS_FILL_REST() if (SEG == 0) { for (; zf < zf_end; zf += NW * kWave) zero_fill[zf] = make_float4(0.f, 0.f, 0.f, 0.f); }
     TileCtx c;
     if (!tile_ctx_nw<NW>(cam, wave, lane, c)) { GS_FILL_REST(); return; }
+    // chained backward walks: the quadrant's hand-over flags start from zero with every forward (the backward's epoch is never zero)
+    if (SEG == 0 && cam.chain > 1 && split_state && lane < kChainPieces - 1)
+        reinterpret_cast<uint32_t*>(split_state)[(size_t)cam.gx * cam.gy * 4 * kChainStateFloats + (size_t)(c.tile * 4 + c.quad) * (kChainPieces - 1) + lane] = 0u;
     // lane -> pixel: stream sid owns block (sid & 1, sid >> 1) of the quadrant
     const int sid = lane / LS, l = lane % LS;
     const int px = (int)c.qx0 + (sid & 1) * 4 + (l & 3), py = (int)c.qy0 + (sid >> 1) * BH + (l >> 2);
@@ -587,6 +597,9 @@ __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
 // LDS 11.8 KB per wave; the wavefronts share nothing, so a workgroup is ONE wavefront (NW = 1): LDS and CU slots are handed out at
 // that granularity and 4800 small workgroups drain more evenly than 1200 whole-tile ones.
 // ---------------------------------------------------------------------------------------------------
+#ifndef GS_WAIT_VMEM
+#define GS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")      // (the host emulator of the tests defines it empty)
+#endif
 constexpr int kBT = 16;                // list positions per batch: 16 x 4 rows = one (row, position) pair per lane in phase B
 constexpr int kMT = kWave + 4;         // floats per position in an exchange plane: +4 makes phase B's b128 reads conflict-free
 constexpr int kPairStride = 12;        // floats per pair / record slot in the sum exchanges: components 0-4 at [0,5), 5-9 at [6,11)
@@ -605,7 +618,16 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
     const bool split = FEW && cam.split != 0;
-    if (!tile_ctx_nw<NW>(cam, wave, lane, c, split)) return;
+    // Chained walks (images of more quadrants than resident walkers; never together with `split`): the grid is cam.chain groups of
+    // workgroups, group p walks piece p of every quadrant (piece 0 = the deepest third of the chunks).  A quadrant's pieces form a serial
+    // chain -- piece p starts from the (T, S) piece p - 1 ends with -- but 3 x 4800 short items pack the chip's 3072 walker slots far
+    // better than 4800 long ones: a wavefront's pace does not depend on how many share its SIMD (the walk is a latency chain), so with one
+    // walker per quadrant the kernel lasts two full walks (3072 + 1728 walkers) for 1.56 walks' worth of work.  Workgroups are dispatched in
+    // index order and a piece only ever waits for a LOWER index (same XCD: the group size is a multiple of 8), so the wait cannot deadlock.
+    const int pieces = (!FEW && cam.chain > 1) ? cam.chain : 1;
+    const unsigned group = gridDim.x / (unsigned)pieces;
+    const int piece = pieces > 1 ? (int)(blockIdx.x / group) : 0;
+    if (!tile_ctx_at<NW>(cam, pieces > 1 ? blockIdx.x - (unsigned)piece * group : blockIdx.x, wave, lane, c, split)) return;
     // phase A role: row (lane>>4) = 4x4 sub-block, (lane&15) = pixel inside it
     const int row = lane >> 4, l16 = lane & 15;
     const int px = (int)c.qx0 + (row & 1) * 4 + (l16 & 3), py = (int)c.qy0 + (row >> 1) * 4 + (l16 >> 2);
@@ -664,7 +686,18 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
         if (DEPTH_GRAD) S += ((tot[3 * HW] - st[4 * HW]) * it) * dz_;
     }
     if (c.seg == 1 && wmax <= m_cut) return;
-    const int cmin = c.seg == 1 ? (int)(m_cut / kWave) : 0;      // the back walker stops at the cut
+    int cmin = c.seg == 1 ? (int)(m_cut / kWave) : 0;            // the back walker stops at the cut
+    int ctop = (int)((wmax - 1) / kWave);                        // first (deepest) chunk of this walker
+    // (wave-uniform values, kept in scalar registers: the kernel sits at its register budget)
+    const int chain_q = __builtin_amdgcn_readfirstlane(c.tile * 4 + c.quad);
+    float* const chain_st = const_cast<float*>(split_state) + (size_t)chain_q * kChainStateFloats;
+    uint32_t* const chain_fl = reinterpret_cast<uint32_t*>(const_cast<float*>(split_state) + (size_t)cam.gx * cam.gy * 4 * kChainStateFloats) +
+                               (size_t)chain_q * (kChainPieces - 1);
+    if (pieces > 1) {
+        // piece p of n chunks: chunks [n - b(p+1), n - b(p)), b(p) = n p / pieces (the quadrant's pieces all derive this from the same n_contrib)
+        const int n = __builtin_amdgcn_readfirstlane(ctop + 1);
+        ctop = n - (n * piece) / pieces - 1; cmin = n - (n * (piece + 1)) / pieces;
+    }
     // the deepest contributing position of every 4x4 block (row of 16 lanes): the walk starts at the quadrant's deepest contributor, but a
     // block takes part only from its own -- above that its list stays empty and the trip count is set by the blocks that do contribute
     uint32_t rmax = last;
@@ -689,11 +722,21 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     const int m_rd = tb * kMT + rb * 16;                         // phase B read offset inside a plane
     const uint8_t* list_b = s_list[wave] + rb * kWave + tb;
 
-    const int cmax = (int)((wmax - 1) / kWave);
-    uint32_t id_next = (uint32_t)cmax * kWave + lane < wmax ? list[cmax * kWave + lane] : kNoId;
+    const int cmax = ctop;
+    uint32_t id_next = (cmax >= cmin && (uint32_t)cmax * kWave + lane < wmax) ? list[cmax * kWave + lane] : kNoId;
     uint32_t id_next2 = cmax >= cmin + 1 ? list[(cmax - 1) * kWave + lane] : kNoId;
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
     if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
+    if (pieces > 1 && piece > 0) {
+        // (as late as possible: this walker's own loads are in flight while the piece in front of it finishes)
+        // (state and flag travel as device-scope atomics, which bypass the non-coherent cache levels: no acquire on the poll -- a cache
+        // invalidate per poll of thousands of waiting wavefronts costs everybody's record gathers their hits)
+        while (__hip_atomic_load(chain_fl + piece - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cam.chain_epoch) __builtin_amdgcn_s_sleep(16);
+        GS_WAIT_VMEM();
+        const float* in = chain_st + (piece - 1) * 2 * kWave;
+        T = __hip_atomic_load(in + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        S = __hip_atomic_load(in + kWave + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     for (int ch = cmax; ch >= cmin; ch--) {
         const float4 q0 = r0, q1 = r1, q2 = r2;
         const uint32_t id_cur = id_next;
@@ -858,6 +901,14 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (pieces > 1 && piece < pieces - 1) {            // hand the state on (no exit between the range set-up above and this point)
+        float* out = chain_st + piece * 2 * kWave;
+        __hip_atomic_store(out + lane, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(out + kWave + lane, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        GS_WAIT_VMEM();                                // the state has arrived before the flag leaves
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(chain_fl + piece, cam.chain_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // images of at most this many tiles (gs_set_half_quadrants; the name dates from the first few-tile variant) take the few-tile kernels:
@@ -866,6 +917,9 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
 // two list segments per quadrant from the state that forward records (134 -> 88 us).  Above 256 tiles the plain kernels win (400 tiles:
 // backward 134 -> 172 us with the few-tile variant): hence 256
 int g_half_quadrant_tiles = 256;
+// pieces of a chained backward walk (images of more than kChainMinTiles tiles); 1 switches the chaining off (tests, A/B measurements)
+int g_chain_pieces = kChainPieces;
+int g_chain_min_tiles = kChainMinTiles;
 
 hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
@@ -877,6 +931,7 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
     Cam cam = cam_in;
     cam.half = (segments <= 1 || !seg_T) && cam.gx * cam.gy <= g_half_quadrant_tiles;          // few tiles: the producer / consumer forward
     cam.split = cam.V == 1 && split_state && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles);      // (the backward refuses atlases)
+    cam.chain = (cam.V == 1 && split_state && cam.gx * cam.gy > max(g_chain_min_tiles, kFewTiles) && g_chain_pieces > 1) ? g_chain_pieces : 0;
     const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
 #define GS_FWD(DSQ, SEG, GRID)                                                                                                     \
     hipLaunchKernelGGL((blend_forward_streams_kernel<DSQ, kFwdStreams, SEG, 4>), GRID, dim3(kBlock), 0, st, cam, ranges, point_list, geom, \
@@ -891,7 +946,10 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
         if (e == hipSuccess) e = hipMemsetAsync(out_depth, 0, HW * sizeof(float), st);
         if (e == hipSuccess && out_depth_sq) e = hipMemsetAsync(out_depth_sq, 0, HW * sizeof(float), st);
         if (e == hipSuccess) e = hipMemsetAsync(n_contrib, 0, HW * sizeof(uint32_t), st);
-        if (e == hipSuccess && split_state) e = hipMemsetAsync(split_state + (kCutLevels * 5 + 4) * HW, 0, sizeof(uint32_t), st);    // nothing recorded
+        if (e == hipSuccess && split_state && cam.gx * cam.gy <= kFewTiles)
+            e = hipMemsetAsync(split_state + (kCutLevels * 5 + 4) * HW, 0, sizeof(uint32_t), st);    // nothing recorded
+        if (e == hipSuccess && cam.chain > 1)      // (the segmented kernels do not clear the chained backward's hand-over flags)
+            e = hipMemsetAsync(split_state + (size_t)cam.gx * cam.gy * 4 * kChainStateFloats, 0, (size_t)cam.gx * cam.gy * 4 * (kChainPieces - 1) * sizeof(uint32_t), st);
         if (e != hipSuccess) return e;
         const dim3 grid(nb, segments);
         if (out_depth_sq) { GS_FWD(true, 1, grid); GS_FWD(true, 2, grid); }
@@ -906,7 +964,7 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
             hipLaunchKernelGGL((blend_forward_pc_kernel<false>), grid, block, 0, st, cam, ranges, point_list, geom, out_color, out_depth, out_opacity,
                                final_T, n_contrib, out_depth_sq, cap, split_state, P, (float4*)zero_fill);
     } else {
-        if (split_state) {          // a small image with the few-tile paths switched off: "nothing recorded"
+        if (split_state && cam.gx * cam.gy <= kFewTiles) {          // a small image with the few-tile paths switched off: "nothing recorded"
             hipError_t e = hipMemsetAsync(split_state + (kCutLevels * 5 + 4) * HW, 0, sizeof(uint32_t), st);
             if (e != hipSuccess) return e;
         }
@@ -925,7 +983,10 @@ hipError_t launch_blend_backward(const Cam& cam_in, const uint2* ranges, const u
     Cam cam = cam_in;
     cam.half = 0;
     cam.split = split_state != nullptr && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles);
-    const int per = ((cam.gx * cam.gy + 7) >> 3) * (cam.split ? 2 : 1);
+    cam.chain = (cam.V == 1 && split_state && cam.gx * cam.gy > max(g_chain_min_tiles, kFewTiles) && g_chain_pieces > 1) ? g_chain_pieces : 0;
+    static std::atomic<unsigned> epoch{0};
+    do { cam.chain_epoch = ++epoch; } while (cam.chain_epoch == 0u);          // (the forward leaves zero in the hand-over flags)
+    const int per = ((cam.gx * cam.gy + 7) >> 3) * (cam.split ? 2 : cam.chain > 1 ? cam.chain : 1);
 #define GS_BWD(DG, FEW)                                                                                                          \
     hipLaunchKernelGGL((blend_backward_kernel<DG, 1, FEW>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom, final_T, \
                        n_contrib, dL_dcolor, dL_ddepth, grad2d, split_state)

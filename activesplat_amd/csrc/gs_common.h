@@ -36,6 +36,11 @@ struct Cam {
     // backward blend, images of few tiles: every tile list is walked in TWO segments by two wavefronts per quadrant; the front
     // one starts from the per-pixel state the forward left at the boundary (set by the blend launchers)
     int split;
+    // backward blend, images of MORE quadrants than the chip holds walkers (3 wavefronts x 1024 SIMDs): every quadrant's walk is cut into
+    // `chain` consecutive pieces run by `chain` workgroups in dispatch order, the running state handed on through memory (set by the blend
+    // launchers; 0 / 1: one walker per quadrant)
+    int chain;
+    unsigned chain_epoch;
 };
 
 // Per-Gaussian screen-space record, 3 x float4 = 48 B, one gather per tile instance in the blend.
@@ -422,10 +427,18 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
                                     uint32_t max_tile_instances, unsigned long long* pairs, unsigned long long* pairs_alt,
                                     uint32_t* point_list, uint32_t cap, hipStream_t st);
 extern int g_half_quadrant_tiles;
+extern int g_chain_pieces;
+extern int g_chain_min_tiles;
 // images of few tiles (at most kFewTiles; the knob above can only lower the limit): the forward records every pixel's running state
 // at the list positions 128 * 2^k, k < kCutLevels, for the two-segment backward.  Planes of H*W floats: [k][T, C0, C1, C2, D], then the
 // four totals, then one word "recorded"
 constexpr int kFewTiles = 256;
+// chained backward walks (images of more than kChainMinTiles tiles): pieces per quadrant, and what the image workspace holds for them behind
+// `split_state`'s offset -- [quadrant][piece boundary][T, S][64 lanes] floats, then one flag word per (quadrant, piece boundary)
+constexpr int kChainPieces = 3;
+constexpr int kChainMinTiles = 768;                       // default threshold: 3072 resident walkers / 4 quadrants (gs_set_backward_chain lowers it for tests)
+constexpr int kChainStateFloats = (kChainPieces - 1) * 2 * kWave;
+inline size_t chain_state_words(size_t tiles) { return tiles * 4 * (kChainStateFloats + (kChainPieces - 1)); }
 constexpr int kCutLevels = 12;
 constexpr int kCutFirst = 128;
 hipError_t launch_emit(const Cam& cam, int P, GeomPtrs gp, uint64_t* keys, uint32_t* vals, hipStream_t st);

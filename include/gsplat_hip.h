@@ -21,7 +21,7 @@
  *   - return value 0 = success, otherwise a GS_E* code; gs_last_error() gives the message;
  *   - no torch types.  Process-wide state: the last-error string (thread-local), and three development knobs that are NOT
  *     synchronised with rendering calls on other threads -- set them while nothing is in flight: gs_set_sort_path,
- *     gs_set_forward_segments, gs_set_half_quadrants (defaults: automatic path choice, segments on, few-tile kernels up to 256 tiles) and the gs_profile_* event log (off).
+ *     gs_set_forward_segments, gs_set_half_quadrants, gs_set_backward_chain (defaults: automatic path choice, segments on, few-tile kernels up to 256 tiles) and the gs_profile_* event log (off).
  *
  * Call sequence for one forward:
  *     gs_preprocess_forward(...)            // per-Gaussian stage + tile counting; writes the counts
@@ -135,6 +135,11 @@ int gs_set_forward_segments(int32_t on);
  * an MI355X.  The forward's wavefronts take half an 8 x 8 quadrant each (half their lanes idle; results unchanged); the backward walks every
  * tile list in two segments, the front one from a per-pixel state the forward recorded at the cut (gradients agree to rounding). */
 int gs_set_half_quadrants(int32_t max_tiles);
+/* Images of more than min_tiles tiles (default 768 = more quadrants than the chip holds backward walkers; negative: the default; values
+ * below 256 act as 256): every quadrant's backward walk is cut into `pieces` consecutive pieces (default 3, the maximum; 1 = one walker per
+ * quadrant) that run as separate workgroups in dispatch order and hand the per-pixel running state on through the image workspace.  The
+ * arithmetic per pixel is the same sequence either way (gradients differ only by the order of the atomic sums). */
+int gs_set_backward_chain(int32_t pieces, int32_t min_tiles);
 /* bytes of the scratch gs_render_backward needs (per-Gaussian 2-D gradient records) */
 uint64_t gs_backward_scratch_bytes(int32_t P);
 

@@ -19,6 +19,8 @@ def run(N=500_000, W=640, H=480, steps=int(os.environ.get("STEPS", 30)), warmup=
     rv = {k: v.to(dev).requires_grad_(True) for k, v in syn.activate(syn.make_params(N, W, H, seed=0, sh_degree=int(sh) if sh else None)).items()}
     dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
     lib = _lib.get()
+    if os.environ.get("CHAIN"):                             # gs_set_backward_chain: pieces of a chained backward walk (1 = one walker per quadrant)
+        lib.gs_set_backward_chain(int(os.environ["CHAIN"]), int(os.environ.get("CHAIN_MIN_TILES", -1)))
     if os.environ.get("HALF"):                              # gs_set_half_quadrants: images of at most this many tiles use half-quadrant wavefronts
         lib.gs_set_half_quadrants(int(os.environ["HALF"]))
 

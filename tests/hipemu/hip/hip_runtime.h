@@ -303,7 +303,12 @@ static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = __atomi
 static inline int atomicMax(int* p, int v) { int o = __atomic_load_n(p, __ATOMIC_RELAXED); while (o < v && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
 static inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 #define __HIP_MEMORY_SCOPE_AGENT 0
-#define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
+template <class T> static inline T hipemu_atomic_load(const T* p, int order) { T v; __atomic_load(p, &v, order); return v; }
+template <class T, class U> static inline void hipemu_atomic_store(T* p, U val, int order) { T v = (T)val; __atomic_store(p, &v, order); }
+#define __hip_atomic_load(p, order, scope) hipemu_atomic_load(p, order)
+#define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store(p, v, order)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define GS_WAIT_VMEM() ((void)0)
 static inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }

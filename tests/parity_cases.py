@@ -137,6 +137,33 @@ def check_whole_quadrants_on_small_images(device, oracle32, oracle64):
         _lib.check(lib.gs_set_half_quadrants(256))
 
 
+def check_chained_backward(device, oracle64, N=5000, W=288, H=272, oracle32=None):
+    """Images of more than 768 tiles walk every quadrant's list in three chained pieces (gs_set_backward_chain): here the threshold is
+    lowered so that a 306-tile image takes that path, with splats large and faint enough for walks of several 64-record chunks; against
+    the one-walker kernel (forward identical, gradients equal up to the order of the atomic sums) and against the fp64 oracle."""
+    from activesplat_amd import _lib
+    lib = _lib.get()
+    rs, rv = util.scene(N, W, H, seed=33, device=device, scale_jitter=0.5)
+    rs = rs._replace(debug=False)
+    rv["opacities"] = (rv["opacities"] * 0.15).clamp(0, 1)
+    rv["scales"] = rv["scales"] * 3.0
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(7))
+    try:
+        _lib.check(lib.gs_set_backward_chain(1, -1))
+        ref = util.run_product(rs, rv, dL)
+        _lib.check(lib.gs_set_backward_chain(3, 256))
+        got = util.run_product(rs, rv, dL)
+        for k in ("color", "depth", "opacity", "radii"):
+            assert np.array_equal(got[k], ref[k]), k
+        for k, g in got["grads"].items():
+            r = ref["grads"][k]
+            assert np.isfinite(g).all(), k
+            assert np.linalg.norm(g.astype(np.float64) - r) <= 2e-5 * max(np.linalg.norm(r), 1e-30), (k, np.linalg.norm(g - r) / np.linalg.norm(r))
+        check_backward(rs._replace(debug=True), rv, oracle64, seed=7, oracle32=oracle32)
+    finally:
+        _lib.check(lib.gs_set_backward_chain(3, -1))
+
+
 #: tally of check_backward's fp32 escape hatch over the session (printed by tests/conftest.py)
 HATCH = {"keys_checked": 0, "fired": 0, "where": []}
 

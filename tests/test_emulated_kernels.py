@@ -150,3 +150,7 @@ def test_emulated_segmented_forward(emu, oracle32):
 
 def test_whole_quadrants_on_small_images(emu, oracle32, oracle64):
     pc.check_whole_quadrants_on_small_images(emu, oracle32, oracle64)
+
+
+def test_emulated_chained_backward(emu, oracle64, oracle32):
+    pc.check_chained_backward(emu, oracle64, oracle32=oracle32)

@@ -256,3 +256,30 @@ def test_two_segment_backward_at_the_reference_resolution(hip):
         r = ref["grads"][k]
         assert np.isfinite(g).all(), k
         assert np.linalg.norm(g.astype(np.float64) - r) <= 2e-5 * max(np.linalg.norm(r), 1e-30), (k, np.linalg.norm(g - r) / np.linalg.norm(r))
+
+
+def test_chained_backward_small(hip, oracle64, oracle32):
+    pc.check_chained_backward(hip, oracle64, oracle32=oracle32)
+
+
+def test_chained_backward_at_full_size_equals_one_walker_per_quadrant(hip):
+    """BASELINE configs[1]'s frame (640 x 480: 1200 tiles, the chained backward is the default there): three pieces per quadrant against
+    one walker per quadrant -- forward identical, gradients equal up to the order of the atomic sums."""
+    from activesplat_amd import _lib
+    lib = _lib.get()
+    rs, rv = util.scene(500_000, 640, 480, seed=0, device=hip)
+    rs = rs._replace(debug=False)
+    dL = torch.randn(3, 480, 640, generator=torch.Generator().manual_seed(5))
+    try:
+        _lib.check(lib.gs_set_backward_chain(1, -1))
+        ref = util.run_product(rs, rv, dL)
+        _lib.check(lib.gs_set_backward_chain(3, -1))
+        got = util.run_product(rs, rv, dL)
+    finally:
+        _lib.check(lib.gs_set_backward_chain(3, -1))
+    for k in ("color", "depth", "opacity", "radii"):
+        assert np.array_equal(got[k], ref[k]), k
+    for k, g in got["grads"].items():
+        r = ref["grads"][k]
+        assert np.isfinite(g).all(), k
+        assert np.linalg.norm(g.astype(np.float64) - r) <= 2e-5 * max(np.linalg.norm(r), 1e-30), (k, np.linalg.norm(g - r) / np.linalg.norm(r))
