@@ -137,13 +137,13 @@ def check_whole_quadrants_on_small_images(device, oracle32, oracle64):
         _lib.check(lib.gs_set_half_quadrants(256))
 
 
-def check_chained_backward(device, oracle64, N=5000, W=288, H=272, oracle32=None):
+def check_chained_backward(device, oracle64, N=5000, W=288, H=272, oracle32=None, seed=33):
     """Images of more than 768 tiles walk every quadrant's list in three chained pieces (gs_set_backward_chain): here the threshold is
     lowered so that a 306-tile image takes that path, with splats large and faint enough for walks of several 64-record chunks; against
     the one-walker kernel (forward identical, gradients equal up to the order of the atomic sums) and against the fp64 oracle."""
     from activesplat_amd import _lib
     lib = _lib.get()
-    rs, rv = util.scene(N, W, H, seed=33, device=device, scale_jitter=0.5)
+    rs, rv = util.scene(N, W, H, seed=seed, device=device, scale_jitter=0.5)
     rs = rs._replace(debug=False)
     rv["opacities"] = (rv["opacities"] * 0.15).clamp(0, 1)
     rv["scales"] = rv["scales"] * 3.0

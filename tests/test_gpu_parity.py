@@ -258,8 +258,9 @@ def test_two_segment_backward_at_the_reference_resolution(hip):
         assert np.linalg.norm(g.astype(np.float64) - r) <= 2e-5 * max(np.linalg.norm(r), 1e-30), (k, np.linalg.norm(g - r) / np.linalg.norm(r))
 
 
-def test_chained_backward_small(hip, oracle64, oracle32):
-    pc.check_chained_backward(hip, oracle64, oracle32=oracle32)
+@pytest.mark.parametrize("seed,N,W,H", [(33, 5000, 288, 272), (34, 9000, 336, 256), (35, 3000, 272, 272), (36, 20000, 400, 304)])
+def test_chained_backward_small(hip, oracle64, oracle32, seed, N, W, H):
+    pc.check_chained_backward(hip, oracle64, N=N, W=W, H=H, oracle32=oracle32, seed=seed)
 
 
 def test_chained_backward_at_full_size_equals_one_walker_per_quadrant(hip):
