@@ -261,6 +261,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
             }
             __builtin_amdgcn_wave_barrier();
             uint32_t jj2_next = *reinterpret_cast<const uint16_t*>(my_list);                // two list entries per read
+            int lj = -1;                             // staged slot of this chunk's last contributor (slots ascend along a stream's list)
             for (int t = 0; t < ntrips; t += 2) {
                 const uint32_t jj2 = jj2_next;
                 jj2_next = *reinterpret_cast<const uint16_t*>(my_list + t + 2);           // next pair: off the critical path
@@ -280,14 +281,15 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
                     const float test_T = T * (1.0f - alpha);
                     const bool vis = !done && p <= 0.0f && alpha >= kAlphaMin;     // sentinel: alpha = 0
                     const bool ok = vis && test_T >= kTmin;
-                    done = done || (vis && !ok);
+                    done = done || (vis != ok);                                    // (ok implies vis: one mask operation, no second compare)
                     const float w = ok ? alpha * T : 0.0f;
                     C0 += a1[u].z * w; C1 += a1[u].w * w; C2 += a2[u].x * w; Dp += a2[u].y * w;
                     if (DEPTH_SQ) Dq += a2[u].y * a2[u].y * w;
                     T = ok ? test_T : T;
-                    last = ok ? base + (uint32_t)jj[u] + 1u : last;
+                    lj = ok ? jj[u] : lj;
                 }
             }
+            last = lj >= 0 ? base + (uint32_t)lj + 1u : last;
             __builtin_amdgcn_wave_barrier();
             if (SEG != 1 && __all(done)) break;
             if (SEG == 1 && __all(!inside || T < kTmin)) break;      // every pixel is below the stop threshold: the rest cannot matter
@@ -516,6 +518,7 @@ __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
                 const float4* plane = s_alpha[pair][ab] + lane;
                 const float4* s2 = s_rec[rb][2];
                 uint32_t jj4_next = ntrips > 0 ? *reinterpret_cast<const uint32_t*>(my_list) : 0x40404040u;
+                int lj = -1;                         // staged slot of this chunk's last contributor (slots ascend along a stream's list)
                 for (int t = 0; t < ntrips; t += 4) {
                     const uint32_t jj4 = jj4_next;
                     jj4_next = *reinterpret_cast<const uint32_t*>(my_list + ((t + 4) & 63));
@@ -532,14 +535,15 @@ __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
                         const float test_T = T * (1.0f - alpha);
                         const bool vis = !done && alpha > 0.0f;
                         const bool ok = vis && test_T >= kTmin;
-                        done = done || (vis && !ok);
+                        done = done || (vis != ok);                              // (ok implies vis)
                         const float w = ok ? alpha * T : 0.0f;
                         C0 += cc.x * w; C1 += cc.y * w; C2 += cc.z * w; Dp += cc.w * w;
                         if (DEPTH_SQ) Dq += cc.w * cc.w * w;
                         T = ok ? test_T : T;
-                        last = ok ? base + (uint32_t)jj[u] + 1u : last;
+                        lj = ok ? jj[u] : lj;
                     }
                 }
+                last = lj >= 0 ? base + (uint32_t)lj + 1u : last;
                 const unsigned long long going = ~__ballot(done);
                 if (lane == 0) s_going[pair] = going;
             }
