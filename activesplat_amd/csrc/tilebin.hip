@@ -170,44 +170,47 @@ __global__ __launch_bounds__(1024) void tile_colscan_kernel(uint32_t* __restrict
     }
 }
 
-// exclusive scan of the per-tile totals: ranges[t] = [start, start+count); counts[0] = D, counts[1] = max
+// exclusive scan of the per-tile totals: ranges[t] = [start, start+count); counts[0] = D, counts[1] = max.  One workgroup, ONE pass: a thread
+// takes ceil(tiles / 1024) consecutive tiles (its own little serial scan), the workgroup scans the thread sums (two barriers in all --
+// the loop over 1024-tile slabs this replaces took three per slab)
+constexpr int kScanPerThreadMax = 8;                 // tiles <= kMaxLdsTiles = 8192 on this path
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ tile_total, int tiles,
                                                          uint2* __restrict__ ranges, uint32_t* __restrict__ counts,
                                                          uint32_t* __restrict__ host_counts)
 {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_m[16];
-    __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_carry = 0;
-    uint32_t vmax = 0;
-    __syncthreads();
-    for (int base = 0; base < tiles; base += 1024) {
-        const int i = base + tid;
-        const uint32_t v = i < tiles ? tile_total[i] : 0u;
-        vmax = max(vmax, v);
-        const uint32_t inc = wave_inclusive_scan(v, lane);
-        if (lane == 63) s_w[wave] = inc;
-        __syncthreads();
-        uint32_t wprefix = 0;
-        for (int w = 0; w < wave; w++) wprefix += s_w[w];
-        const uint32_t carry = s_carry;
-        const uint32_t start = carry + wprefix + inc - v;
-        if (i < tiles) ranges[i] = make_uint2(start, start + v);
-        __syncthreads();
-        if (tid == 1023) s_carry = carry + wprefix + inc;
-        __syncthreads();
+    const int per = (tiles + 1023) >> 10, t0 = tid * per;
+    uint32_t v[kScanPerThreadMax];
+    uint32_t sum = 0, vmax = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThreadMax; k++) {
+        v[k] = (k < per && t0 + k < tiles) ? tile_total[t0 + k] : 0u;
+        sum += v[k];
+        vmax = max(vmax, v[k]);
     }
+    const uint32_t inc = wave_inclusive_scan(sum, lane);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor(vmax, m));
-    if (lane == 0) s_m[wave] = vmax;
+    if (lane == 63) { s_w[wave] = inc; s_m[wave] = vmax; }
     __syncthreads();
+    uint32_t start = inc - sum, total = 0, mx = 0;
+    for (int w = 0; w < 16; w++) {
+        if (w < wave) start += s_w[w];
+        total += s_w[w];
+        mx = max(mx, s_m[w]);
+    }
+#pragma unroll
+    for (int k = 0; k < kScanPerThreadMax; k++) {
+        if (k < per && t0 + k < tiles) ranges[t0 + k] = make_uint2(start, start + v[k]);
+        start += v[k];
+    }
     if (tid == 0) {
-        uint32_t mx = 0;
-        for (int w = 0; w < 16; w++) mx = max(mx, s_m[w]);
-        counts[0] = s_carry; counts[1] = mx;
-        // mapped pinned host memory: the two counters land on the host without a separate D2H copy in the stream
-        if (host_counts) { host_counts[0] = s_carry; host_counts[1] = mx; __threadfence_system(); }
+        counts[0] = total; counts[1] = mx;
+        // mapped pinned host memory: the two counters land on the host without a separate D2H copy in the stream (the kernel's end is the
+        // release the host's event wait pairs with: no fence here -- a system-scope fence costs this one-workgroup kernel a PCIe round trip)
+        if (host_counts) { host_counts[0] = total; host_counts[1] = mx; }
     }
 }
 
