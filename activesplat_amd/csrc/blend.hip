@@ -714,13 +714,32 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     const int tb = lane >> 2, rb = lane & 3;
     const int bxb = (int)c.qx0 + (rb & 1) * 4, byb = (int)c.qy0 + (rb >> 1) * 4;
     float e0[16], e1[16], e2[16], ez[16];
+    if (!DEPTH_GRAD) {
+        // the quadrant's dL/dcolour is already in the wavefront, one pixel per lane in (block, pixel) order: it goes through the still idle
+        // exchange planes instead of 48 more global loads with their address arithmetic per lane (the prologue is paid per chained piece).
+        // (Not for the fused RGB-D backward: with the fourth channel this path costs the kernel its third wavefront's registers.)
+        float* xs = s_m[wave][0];
+        xs[lane] = d0; xs[kWave + lane] = d1; xs[2 * kWave + lane] = d2;
+        __builtin_amdgcn_wave_barrier();
+        const float4* x4 = reinterpret_cast<const float4*>(xs + rb * 16);
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int x = bxb + (i & 3), y = byb + (i >> 2);
-        const bool in = x < cam.W && y < cam.H;
-        const size_t p = (size_t)y * cam.W + x;
-        e0[i] = in ? dL_dcolor[p] : 0.f; e1[i] = in ? dL_dcolor[HW + p] : 0.f; e2[i] = in ? dL_dcolor[2 * HW + p] : 0.f;
-        ez[i] = (DEPTH_GRAD && in) ? dL_ddepth[p] : 0.f;
+        for (int v = 0; v < 4; v++) {
+            const float4 a = x4[v], b = x4[kWave / 4 + v], cc = x4[2 * (kWave / 4) + v];
+            e0[4 * v] = a.x; e0[4 * v + 1] = a.y; e0[4 * v + 2] = a.z; e0[4 * v + 3] = a.w;
+            e1[4 * v] = b.x; e1[4 * v + 1] = b.y; e1[4 * v + 2] = b.z; e1[4 * v + 3] = b.w;
+            e2[4 * v] = cc.x; e2[4 * v + 1] = cc.y; e2[4 * v + 2] = cc.z; e2[4 * v + 3] = cc.w;
+            ez[4 * v] = ez[4 * v + 1] = ez[4 * v + 2] = ez[4 * v + 3] = 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();           // (the planes are written again in the first batch)
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int x = bxb + (i & 3), y = byb + (i >> 2);
+            const bool in = x < cam.W && y < cam.H;
+            const size_t p = (size_t)y * cam.W + x;
+            e0[i] = in ? dL_dcolor[p] : 0.f; e1[i] = in ? dL_dcolor[HW + p] : 0.f; e2[i] = in ? dL_dcolor[2 * HW + p] : 0.f;
+            ez[i] = in ? dL_ddepth[p] : 0.f;
+        }
     }
     const float bxf = (float)bxb, byf = (float)byb;
     const int m_rd = tb * kMT + rb * 16;                         // phase B read offset inside a plane
