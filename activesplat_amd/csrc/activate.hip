@@ -78,6 +78,9 @@ __global__ __launch_bounds__(kBlock) void activate_forward_kernel(int P, int iso
     }
 }
 
+// ACC: the four outputs are ADDED to what d_* already hold (gradient accumulation over the keyframes of a batch in the kernel that produces
+// the gradient: the separate `grad += new` passes of autograd move 3 x 44 bytes per Gaussian and keyframe)
+template <bool ACC>
 __global__ __launch_bounds__(kBlock) void activate_backward_kernel(int P, int iso, Pose pose, const float* __restrict__ rots,
                                                                    const float* __restrict__ o_op, const float* __restrict__ o_scales,
                                                                    const float* __restrict__ g_means, const float* __restrict__ g_rots,
@@ -90,9 +93,11 @@ __global__ __launch_bounds__(kBlock) void activate_backward_kernel(int P, int is
     float R[3][3];
     quat_to_rot(pose.q, R);
     const float gx = g_means ? g_means[3 * i] : 0.f, gy = g_means ? g_means[3 * i + 1] : 0.f, gz = g_means ? g_means[3 * i + 2] : 0.f;
-    d_means[3 * i] = R[0][0] * gx + R[1][0] * gy + R[2][0] * gz;
-    d_means[3 * i + 1] = R[0][1] * gx + R[1][1] * gy + R[2][1] * gz;
-    d_means[3 * i + 2] = R[0][2] * gx + R[1][2] * gy + R[2][2] * gz;
+    const float m0 = R[0][0] * gx + R[1][0] * gy + R[2][0] * gz, m1 = R[0][1] * gx + R[1][1] * gy + R[2][1] * gz,
+                m2 = R[0][2] * gx + R[1][2] * gy + R[2][2] * gz;
+    d_means[3 * i] = ACC ? d_means[3 * i] + m0 : m0;
+    d_means[3 * i + 1] = ACC ? d_means[3 * i + 1] + m1 : m1;
+    d_means[3 * i + 2] = ACC ? d_means[3 * i + 2] + m2 : m2;
     // rotations
     const float4 q4 = reinterpret_cast<const float4*>(rots)[i];
     const float q[4] = {q4.x, q4.y, q4.z, q4.w};
@@ -114,14 +119,19 @@ __global__ __launch_bounds__(kBlock) void activate_backward_kernel(int P, int is
         qmul_bwd_rhs(pose.q, dm, du);
     }
     const float dotu = u[0] * du[0] + u[1] * du[1] + u[2] * du[2] + u[3] * du[3];
-    reinterpret_cast<float4*>(d_rots)[i] = make_float4((du[0] - u[0] * dotu) / nq, (du[1] - u[1] * dotu) / nq,
-                                                       (du[2] - u[2] * dotu) / nq, (du[3] - u[3] * dotu) / nq);
+    float4 dq = make_float4((du[0] - u[0] * dotu) / nq, (du[1] - u[1] * dotu) / nq, (du[2] - u[2] * dotu) / nq, (du[3] - u[3] * dotu) / nq);
+    if (ACC) { const float4 old = reinterpret_cast<const float4*>(d_rots)[i]; dq.x += old.x; dq.y += old.y; dq.z += old.z; dq.w += old.w; }
+    reinterpret_cast<float4*>(d_rots)[i] = dq;
     const float o = o_op[i];
-    d_logit[i] = (g_op ? g_op[i] : 0.f) * o * (1.0f - o);
+    const float dlg = (g_op ? g_op[i] : 0.f) * o * (1.0f - o);
+    d_logit[i] = ACC ? d_logit[i] + dlg : dlg;
     const float s0 = g_scales ? g_scales[3 * i] * o_scales[3 * i] : 0.f, s1 = g_scales ? g_scales[3 * i + 1] * o_scales[3 * i + 1] : 0.f,
                 s2 = g_scales ? g_scales[3 * i + 2] * o_scales[3 * i + 2] : 0.f;
-    if (iso) d_logs[i] = s0 + s1 + s2;
-    else { d_logs[3 * i] = s0; d_logs[3 * i + 1] = s1; d_logs[3 * i + 2] = s2; }
+    if (iso) d_logs[i] = ACC ? d_logs[i] + (s0 + s1 + s2) : s0 + s1 + s2;
+    else {
+        d_logs[3 * i] = ACC ? d_logs[3 * i] + s0 : s0; d_logs[3 * i + 1] = ACC ? d_logs[3 * i + 1] + s1 : s1;
+        d_logs[3 * i + 2] = ACC ? d_logs[3 * i + 2] + s2 : s2;
+    }
 }
 
 hipError_t launch_activate_forward(int P, int iso, const float* pose7, const float* means3D, const float* rots, const float* logit_op,
@@ -136,12 +146,16 @@ hipError_t launch_activate_forward(int P, int iso, const float* pose7, const flo
 
 hipError_t launch_activate_backward(int P, int iso, const float* pose7, const float* rots, const float* o_op, const float* o_scales,
                                     const float* g_means, const float* g_rots, const float* g_op, const float* g_scales, float* d_means,
-                                    float* d_rots, float* d_logit, float* d_logs, hipStream_t st)
+                                    float* d_rots, float* d_logit, float* d_logs, int accumulate, hipStream_t st)
 {
     Pose p; for (int k = 0; k < 4; k++) p.q[k] = pose7[k]; for (int k = 0; k < 3; k++) p.t[k] = pose7[4 + k];
     const int nb = (P + kBlock - 1) / kBlock;
-    if (nb > 0) hipLaunchKernelGGL(activate_backward_kernel, dim3(nb), dim3(kBlock), 0, st, P, iso, p, rots, o_op, o_scales, g_means, g_rots,
-                                   g_op, g_scales, d_means, d_rots, d_logit, d_logs);
+    if (nb > 0 && accumulate)
+        hipLaunchKernelGGL(activate_backward_kernel<true>, dim3(nb), dim3(kBlock), 0, st, P, iso, p, rots, o_op, o_scales, g_means, g_rots,
+                           g_op, g_scales, d_means, d_rots, d_logit, d_logs);
+    else if (nb > 0)
+        hipLaunchKernelGGL(activate_backward_kernel<false>, dim3(nb), dim3(kBlock), 0, st, P, iso, p, rots, o_op, o_scales, g_means, g_rots,
+                           g_op, g_scales, d_means, d_rots, d_logit, d_logs);
     return hipGetLastError();
 }
 

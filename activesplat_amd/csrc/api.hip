@@ -510,9 +510,24 @@ int gs_activate_backward(int32_t P, int32_t isotropic, const float* h_pose7, con
                                         !d_logit_opacities || !d_log_scales)))
         return fail(GS_EINVAL, "gs_activate_backward: bad argument");
     hipError_t e = gs::launch_activate_backward(P, isotropic, h_pose7, unnorm_rotations, out_opacities, out_scales, g_means3D, g_rotations,
-                                                g_opacities, g_scales, d_means3D, d_unnorm_rotations, d_logit_opacities, d_log_scales,
+                                                g_opacities, g_scales, d_means3D, d_unnorm_rotations, d_logit_opacities, d_log_scales, 0,
                                                 (hipStream_t)stream);
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_activate_backward: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_activate_backward_accumulate(int32_t P, int32_t isotropic, const float* h_pose7, const float* unnorm_rotations, const float* out_opacities,
+                                    const float* out_scales, const float* g_means3D, const float* g_rotations, const float* g_opacities,
+                                    const float* g_scales, float* d_means3D, float* d_unnorm_rotations, float* d_logit_opacities,
+                                    float* d_log_scales, gs_stream_t stream)
+{
+    if (P < 0 || !h_pose7 || (P > 0 && (!unnorm_rotations || !out_opacities || !out_scales || !d_means3D || !d_unnorm_rotations ||
+                                        !d_logit_opacities || !d_log_scales)))
+        return fail(GS_EINVAL, "gs_activate_backward_accumulate: bad argument");
+    hipError_t e = gs::launch_activate_backward(P, isotropic, h_pose7, unnorm_rotations, out_opacities, out_scales, g_means3D, g_rotations,
+                                                g_opacities, g_scales, d_means3D, d_unnorm_rotations, d_logit_opacities, d_log_scales, 1,
+                                                (hipStream_t)stream);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_activate_backward_accumulate: %s", hipGetErrorString(e));
     return GS_OK;
 }
 

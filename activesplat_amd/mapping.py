@@ -162,7 +162,7 @@ class _FusedRendervars(torch.autograd.Function):
     transformed_params2rendervar in one launch each way."""
 
     @staticmethod
-    def forward(ctx, means3D, unnorm_rotations, logit_opacities, log_scales, pose7):
+    def forward(ctx, means3D, unnorm_rotations, logit_opacities, log_scales, pose7, accumulate=False):
         import ctypes as C
         from . import _lib
         lib = _lib.get()
@@ -179,6 +179,8 @@ class _FusedRendervars(torch.autograd.Function):
         _lib.check(lib.gs_activate_forward(P, iso, pose, p(m), p(r), p(o), p(s), p(om), p(orr), p(oo), p(os_), st))
         ctx.save_for_backward(r, oo, os_)
         ctx.pose, ctx.iso, ctx.st = pose, iso, st
+        # accumulate: the backward adds its four gradients to the leaves' .grad inside the kernel (and hands autograd nothing)
+        ctx.leaves = (means3D, unnorm_rotations, logit_opacities, log_scales) if accumulate else None
         return om, orr, oo, os_
 
     @staticmethod
@@ -190,16 +192,33 @@ class _FusedRendervars(torch.autograd.Function):
         P, dev = int(r.shape[0]), r.device
         c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
         gm, gr, go, gs_ = c(gm), c(gr), c(go), c(gs_)
-        dm, dr = torch.empty(P, 3, device=dev), torch.empty(P, 4, device=dev)
-        dl, ds = torch.empty(P, 1, device=dev), torch.empty(P, 1 if ctx.iso else 3, device=dev)
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
         st = _lib.stream_ptr(dev)
+        leaves = ctx.leaves
+        if leaves is not None and all(x.is_leaf and x.requires_grad for x in leaves):
+            # a keyframe batch (parallel.sharded_keyframe_step): what autograd would do with the four results is `leaf.grad += result`,
+            # 3 x 44 bytes per Gaussian and keyframe of extra passes -- the kernel adds in place instead
+            have = [x.grad is not None and x.grad.is_contiguous() and x.grad.dtype == torch.float32 and x.grad.shape == x.shape for x in leaves]
+            if all(have):
+                g = [x.grad for x in leaves]
+                _lib.check(lib.gs_activate_backward_accumulate(P, ctx.iso, ctx.pose, p(r), p(oo), p(os_), p(gm), p(gr), p(go), p(gs_),
+                                                               p(g[0]), p(g[1]), p(g[2]), p(g[3]), st))
+                return None, None, None, None, None, None
+            if not any(x.grad is not None for x in leaves):
+                g = [torch.empty_like(x, memory_format=torch.contiguous_format) for x in leaves]
+                _lib.check(lib.gs_activate_backward(P, ctx.iso, ctx.pose, p(r), p(oo), p(os_), p(gm), p(gr), p(go), p(gs_),
+                                                    p(g[0]), p(g[1]), p(g[2]), p(g[3]), st))
+                for x, t in zip(leaves, g):
+                    x.grad = t
+                return None, None, None, None, None, None
+        dm, dr = torch.empty(P, 3, device=dev), torch.empty(P, 4, device=dev)
+        dl, ds = torch.empty(P, 1, device=dev), torch.empty(P, 1 if ctx.iso else 3, device=dev)
         _lib.check(lib.gs_activate_backward(P, ctx.iso, ctx.pose, p(r), p(oo), p(os_), p(gm), p(gr), p(go), p(gs_), p(dm), p(dr),
                                             p(dl), p(ds), st))
-        return dm, dr, dl, ds, None
+        return dm, dr, dl, ds, None, None
 
 
-def fused_rendervar(params, time_idx, pose7=None):
+def fused_rendervar(params, time_idx, pose7=None, accumulate_grads=False):
     """rendervar dict of transform_to_frame(gaussians_grad=True, camera_grad=False) +
     transformed_params2rendervar, built by ONE HIP launch (and one more in the backward).  pose7 = host
     (qw,qx,qy,qz,tx,ty,tz) of the frame's relative w2c; read from params['cam_*'] (one small D2H) if omitted."""
@@ -207,7 +226,7 @@ def fused_rendervar(params, time_idx, pose7=None):
         q = F.normalize(params["cam_unnorm_rots"][..., time_idx].detach()).reshape(4)
         pose7 = torch.cat([q, params["cam_trans"][..., time_idx].detach().reshape(3)]).cpu().tolist()
     m, r, o, s = _FusedRendervars.apply(params["means3D"], params["unnorm_rotations"], params["logit_opacities"],
-                                        params["log_scales"], pose7)
+                                        params["log_scales"], pose7, accumulate_grads)
     # means2D only exists to receive the screen-space gradient: a fresh LEAF (autograd hands it the rasteriser's gradient
     # tensor as .grad without a copy; the reference's `zeros + 0` non-leaf costs an add and a retain_grad clone).  Its VALUES are
     # never read -- the rasteriser takes the tensor as a gradient carrier only -- so it is not filled either (one launch less)
@@ -258,7 +277,7 @@ def fused_mapping_loss(im, depth, depth_sq, gt_im, gt_depth, loss_weights):
 
 def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_for_loss=True, sil_thres=0.99,
              use_l1=True, ignore_outlier_depth_loss=False, do_ba=False, fused=False, fused_loss=False, fused_inputs=False,
-             pose7=None):
+             pose7=None, accumulate_grads=False):
     """Mapping loss: masked depth L1 + 0.8 L1 + 0.2 (1 - SSIM) on colour; updates
     variables['means2D'|'seen'|'max_2D_radius'].
     fused=False: the reference's two raster passes on the same geometry (RGB, then [z,1,z^2]).
@@ -267,10 +286,13 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
                  reference's densifier sees the colour pass only).
     fused_loss : the masked-L1 + L1 + SSIM loss and its gradients come from gs_mapping_loss (csrc/loss.hip) instead
                  of ~40 torch kernels.
-    fused_inputs : transform_to_frame + activations by gs_activate_* (csrc/activate.hip)."""
+    fused_inputs : transform_to_frame + activations by gs_activate_* (csrc/activate.hip).
+    accumulate_grads (with fused_inputs, for `loss.backward()` over a batch of keyframes): the activation backward ADDS its gradients to
+                 the four per-Gaussian parameters' .grad in the kernel instead of handing them to autograd's accumulation passes; gradients
+                 taken with torch.autograd.grad are not delivered in this mode."""
     if fused_inputs and not do_ba:
         tg = None
-        rendervar = fused_rendervar(params, iter_time_idx, pose7)
+        rendervar = fused_rendervar(params, iter_time_idx, pose7, accumulate_grads)
     else:
         tg = transform_to_frame(params, iter_time_idx, gaussians_grad=True, camera_grad=do_ba)
         rendervar = transformed_params2rendervar(params, tg)

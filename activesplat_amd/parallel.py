@@ -126,7 +126,9 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
 
     streams > 1 (GPU only): this rank's keyframes are independent until the optimiser step, so they are rendered on
     `streams` HIP streams in turn -- one frame's kernels fill the tails and the placement imbalance of the other's
-    (two streams: 2404 -> 3062 frames/s on BASELINE configs[1], `two_stream_fps` in the bench line).  Each keyframe's
+    (round 2, one backward walker per quadrant: 2404 -> 3062 frames/s on BASELINE configs[1]; with the chained backward blend of round 3 a 640 x 480
+    keyframe fills the chip by itself and ONE stream is faster -- configs[3] on one GPU: 1371-1442 keyframes/s against 1276-1278 on two; the option is
+    for frames that do not, e.g. the reference's 256 x 256).  Each keyframe's
     gradients are taken with autograd.grad on its own stream and summed after the streams have joined.
     autograd.grad does not populate `means2D.grad`, which the densifier's statistics read (optim.accumulate_mean2d_gradient):
     a caller that densifies from this step's statistics passes densify_statistics=True and gets the serial walk."""
@@ -174,11 +176,15 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
             params[k].grad = g
         total = float(torch.stack(losses).sum())
     else:
-        total = 0.0
+        losses = []
+        one = None
         for i in mine:
             loss, variables = loss_fn(params, keyframes[i], variables)
-            loss.backward()                       # autograd accumulates into .grad across this rank's keyframes
-            total += float(loss.detach())
+            if one is None or one.shape != loss.shape or one.device != loss.device or one.dtype != loss.dtype:
+                one = torch.ones_like(loss)       # dL/dloss = 1, made once per batch instead of once per keyframe (a launch each)
+            loss.backward(one)                    # autograd accumulates into .grad across this rank's keyframes
+            losses.append(loss.detach())          # (read after the loop: a float() here would stall the host once per keyframe)
+        total = float(torch.stack(losses).sum()) if losses else 0.0
     if world <= 1 or not on:
         optimizer.step()                         # one rank (or a caller that overrides rank/world to run the batch alone): no collective
     elif sharded_adam:

@@ -176,7 +176,8 @@ def run_c4(args, dev, rank, world, emit=True):
     weights = dict(im=0.5, depth=1.0)
 
     def loss_fn(p, kf, v):
-        loss, v, _ = M.get_loss(p, kf, v, 0, weights, fused=True, fused_loss=True, fused_inputs=True, pose7=kf["pose7"])
+        loss, v, _ = M.get_loss(p, kf, v, 0, weights, fused=True, fused_loss=True, fused_inputs=True, pose7=kf["pose7"],
+                                accumulate_grads=args.streams <= 1)      # (the multi-stream walk takes its gradients with autograd.grad)
         return loss, v
 
     def barrier():
@@ -269,7 +270,9 @@ def main():
     ap.add_argument("--sh-degree", type=int, default=3, help="-1: precomputed colours (SH degree 0 of the reference's mapper)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--streams", type=int, default=2, help="N > 1 (configs[3]): HIP streams a rank's keyframes are issued on in turn")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="configs[3]: HIP streams a rank's keyframes are issued on in turn (1: with the chained backward blend a 640x480 keyframe fills the chip "
+                         "by itself -- 1371-1442 keyframes/s on one stream against 1276-1278 on two at 2 M Gaussians)")
     ap.add_argument("--no-extras", action="store_true", help="skip every leg but the timed region")
     ap.add_argument("--prep-seconds", type=float, default=0.5, help="untimed preparation in front of the warm-up steps (clock ramp, allocator)")
     ap.add_argument("--cpu-threads", type=int, default=64, help="upper bound on the host threads of the cpu_baseline leg")

@@ -262,6 +262,12 @@ int gs_activate_backward(int32_t P, int32_t isotropic, const float* h_pose7, con
                          const float* out_opacities, const float* out_scales, const float* g_means3D, const float* g_rotations,
                          const float* g_opacities, const float* g_scales, float* d_means3D, float* d_unnorm_rotations,
                          float* d_logit_opacities, float* d_log_scales, gs_stream_t stream);
+/* The same, ADDED to what the four d_* buffers hold: the gradient accumulation over the keyframes of a batch (autograd's `grad += new`
+ * passes) inside the kernel that produces the gradient. */
+int gs_activate_backward_accumulate(int32_t P, int32_t isotropic, const float* h_pose7, const float* unnorm_rotations,
+                                    const float* out_opacities, const float* out_scales, const float* g_means3D, const float* g_rotations,
+                                    const float* g_opacities, const float* g_scales, float* d_means3D, float* d_unnorm_rotations,
+                                    float* d_logit_opacities, float* d_log_scales, gs_stream_t stream);
 
 /* Fused mapping loss, forward AND backward (replaces src/mapper/splatam/splatam.py:213-249 + the SSIM of
  * utils/slam_external.py:54-97 and their autograd):

@@ -457,6 +457,32 @@ def test_fused_rendervar_kernel_matches_reference_transform(backend, tag):
         np.testing.assert_allclose(got[k].cpu().numpy(), p2[k].grad.cpu().numpy(), atol=2e-6 * float(p2[k].grad.abs().max()), rtol=1e-4, err_msg=k)
 
 
+@pytest.mark.parametrize("tag", ["aniso", "iso"])
+def test_fused_rendervar_accumulates_gradients_in_the_kernel(backend, tag):
+    """accumulate_grads=True: three backward passes (three keyframes of a batch, different poses) add their gradients to the parameters'
+    .grad inside gs_activate_backward_accumulate -- equal to autograd's accumulation of the plain mode (same values, one rounding per add)."""
+    from activesplat_amd import mapping as M
+    d = load("transform.npz")
+    keys = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales", "cam_unnorm_rots", "cam_trans")
+    leaves = ("means3D", "unnorm_rotations", "logit_opacities", "log_scales")
+    poses = ([1.0, 0, 0, 0, 0, 0, 0], [0.9238795, 0, 0.3826834, 0, 0.1, -0.2, 0.3], [0.7071068, 0.7071068, 0, 0, -0.5, 0.0, 0.25])
+    g = torch.Generator().manual_seed(1)
+    ws = None
+    got = {}
+    for acc in (False, True):
+        params = {k: T(d[f"{tag}_{k}"]).clone().requires_grad_(True) for k in keys}
+        for n, pose in enumerate(poses):
+            rv = M.fused_rendervar(params, 0, pose, accumulate_grads=acc)
+            if ws is None:
+                ws = [{k: torch.randn(rv[k].shape, generator=g).to(backend) for k in ("means3D", "rotations", "opacities", "scales")} for _ in poses]
+            sum((rv[k] * ws[n][k]).sum() for k in ws[n]).backward()
+        got[acc] = {k: params[k].grad.clone() for k in leaves}
+    for k in leaves:
+        a, b = got[True][k].cpu().numpy(), got[False][k].cpu().numpy()
+        assert np.abs(b).max() > 0, k
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7 * float(np.abs(b).max()), err_msg=k)
+
+
 def test_split_offsets_drawn_in_the_kernel_are_standard_normal_times_scale(backend):
     """gs_densify_children with samples == NULL: counter-based N(0, scale) offsets (slam_external.py:221-224 draws them with
     torch.normal): moments of 300 k draws per axis, per-axis scales, independence of the axes, and repeatability per seed."""
