@@ -533,7 +533,7 @@ int gs_activate_backward_accumulate(int32_t P, int32_t isotropic, const float* h
 
 uint64_t gs_mapping_loss_scratch_bytes(int32_t width, int32_t height)
 {
-    return align_up((uint64_t)(1024 + 9 * (uint64_t)(width > 0 ? width : 1) * (uint64_t)(height > 0 ? height : 1)) * 4);   // 64 accumulator lines + 9 maps
+    return align_up((uint64_t)(gs::kLossAccSlots * 16 + 9 * (uint64_t)(width > 0 ? width : 1) * (uint64_t)(height > 0 ? height : 1)) * 4);   // accumulator lines + 9 maps
 }
 
 int gs_mapping_loss(int32_t width, int32_t height, const float* im, const float* gt_im, const float* depth,

@@ -461,6 +461,7 @@ hipError_t launch_activate_forward(int P, int iso, const float* pose7, const flo
 hipError_t launch_activate_backward(int P, int iso, const float* pose7, const float* rots, const float* o_op, const float* o_scales,
                                     const float* g_means, const float* g_rots, const float* g_op, const float* g_scales, float* d_means,
                                     float* d_rots, float* d_logit, float* d_logs, int accumulate, hipStream_t st);
+constexpr int kLossAccSlots = 256;          // 64-byte accumulator lines at the head of the mapping loss' scratch (loss.hip)
 hipError_t launch_mapping_loss(int W, int H, const float* im, const float* gt, const float* depth, const float* depth_sq,
                                const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
                                float* dL_ddepth, float* scratch, hipStream_t st);

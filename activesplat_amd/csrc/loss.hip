@@ -39,12 +39,19 @@ __device__ __forceinline__ float block_sum(float v, float* s_red, int tid)
 // Accumulators: kAccSlots copies of {sum SSIM, sum |im - gt|, sum masked |gt_depth - depth|, mask count}, one 64-byte line
 // each; a block adds to slot (block index mod kAccSlots).  With a single copy the 4 x 1200 same-line device atomics of a
 // 640x480 frame serialise at the memory side and cost ~70 us -- more than all the arithmetic of the loss.
-constexpr int kAccSlots = 64;
+// (round 3: 256 copies, and a block's four sums leave as ONE request -- four lanes of one atomic instruction on one line -- instead of four:
+// 3600 blocks on 64 lines were 4 x 56 same-line atomics in a row)
+constexpr int kAccSlots = kLossAccSlots;
 constexpr int kAccFloats = kAccSlots * 16;
 __device__ __forceinline__ void acc_totals(const float* __restrict__ acc, float* s_tot, int tid)
 {
     if (tid < kWave) {
-        const float4 v = *reinterpret_cast<const float4*>(acc + tid * 16);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < kAccSlots / kWave; k++) {
+            const float4 u = *reinterpret_cast<const float4*>(acc + (k * kWave + tid) * 16);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
         const float a = wave_sum(v.x), b = wave_sum(v.y), c = wave_sum(v.z), d = wave_sum(v.w);
         if (tid == 0) { s_tot[0] = a; s_tot[1] = b; s_tot[2] = c; s_tot[3] = d; }
     }
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void loss_stats_kernel(int W, int H, const 
     __shared__ float s_x[kLP][kLP + 1];
     __shared__ float s_y[kLP][kLP + 1];
     __shared__ float s_h[5][kLP][kLT + 1];          // horizontal-pass results of x, y, xx, yy, xy
-    __shared__ float s_red[4];
+    __shared__ float s_red[16];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
     const int px = x0 + tx, py = y0 + ty;
@@ -116,13 +123,14 @@ __global__ __launch_bounds__(kBlock) void loss_stats_kernel(int W, int H, const 
         const float unc = depth_sq ? depth_sq[o] - d * d : 0.f;
         if (g > 0.f && d == d && unc == unc) { sum_d = fabsf(g - d); cnt = 1.f; }
     }
-    sum_ssim = block_sum(sum_ssim, s_red, tid);
-    sum_l1 = block_sum(sum_l1, s_red, tid);
-    sum_d = block_sum(sum_d, s_red, tid);
-    cnt = block_sum(cnt, s_red, tid);
-    if (tid == 0) {
+    // the four sums of the workgroup in ONE reduction (two barriers instead of eight): wave sums -> LDS -> four lanes add the four waves' values
+    sum_ssim = wave_sum(sum_ssim); sum_l1 = wave_sum(sum_l1); sum_d = wave_sum(sum_d); cnt = wave_sum(cnt);
+    __syncthreads();
+    if ((tid & 63) == 0) { float* r = s_red + (tid >> 6) * 4; r[0] = sum_ssim; r[1] = sum_l1; r[2] = sum_d; r[3] = cnt; }
+    __syncthreads();
+    if (tid < 4) {
         float* a = acc + (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & (kAccSlots - 1)) * 16;
-        atomicAdd(a, sum_ssim); atomicAdd(a + 1, sum_l1); atomicAdd(a + 2, sum_d); atomicAdd(a + 3, cnt);
+        atomicAdd(a + tid, (s_red[tid] + s_red[4 + tid]) + (s_red[8 + tid] + s_red[12 + tid]));
     }
 }
 

@@ -81,7 +81,7 @@ class SplatMapper:
         self.cam = setup_camera(self.W, self.H, np.asarray(intrinsics), np.eye(4), device=self.device)
         self.densify_cam, self.densify_intrinsics = self.cam, self.intrinsics      # replaced when frames carry a densify copy
         self.first_abs_pose = None
-        self._one = torch.ones((), dtype=torch.float32, device=self.device)
+        self._one = M.unit_gradient(torch.empty((), dtype=torch.float32, device=self.device))   # (the fused loss knows it: no scaling launch)
         self.params = self.variables = self.optimizer = None
         self.keyframe_list, self.selected_keyframes, self.gt_w2c_all_frames = [], [], []
         self.rng = np.random.RandomState(self.cfg["seed"])

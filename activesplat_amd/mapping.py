@@ -234,6 +234,20 @@ def fused_rendervar(params, time_idx, pose7=None, accumulate_grads=False):
             "means2D": torch.empty_like(params["means3D"], requires_grad=True)}
 
 
+#: dL/dloss tensors that are known to hold exactly 1 (the callers' cached root gradients: mapper, parallel.sharded_keyframe_step).  Kept alive
+#: here, so that an address can never come back as another tensor's; _FusedMappingLoss.backward skips its `g * grads` launch for them.
+_UNIT_GRADS = {}
+
+
+def unit_gradient(like: torch.Tensor) -> torch.Tensor:
+    """A cached scalar 1 of `like`'s device and dtype for `loss.backward(unit_gradient(loss))`."""
+    key = (str(like.device), like.dtype)
+    t = _UNIT_GRADS.get(key)
+    if t is None:
+        t = _UNIT_GRADS[key] = torch.ones((), device=like.device, dtype=like.dtype)
+    return t
+
+
 class _FusedMappingLoss(torch.autograd.Function):
     """gs_mapping_loss: value and gradients in two HIP launches (csrc/loss.hip)."""
 
@@ -265,7 +279,11 @@ class _FusedMappingLoss(torch.autograd.Function):
         (grads,) = ctx.saved_tensors
         if g is None:
             return None, None, None, None, None, None, None
-        gd = g * grads                           # one launch for both gradients
+        u = _UNIT_GRADS.get((str(g.device), g.dtype))
+        if u is not None and g.dim() == 0 and g.data_ptr() == u.data_ptr():
+            gd = grads                           # the root gradient is the cached 1: no launch
+        else:
+            gd = g * grads                       # one launch for both gradients
         return gd[:3], gd[3:], None, None, None, None, None
 
 

@@ -176,13 +176,13 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
             params[k].grad = g
         total = float(torch.stack(losses).sum())
     else:
+        from .mapping import unit_gradient
         losses = []
-        one = None
         for i in mine:
             loss, variables = loss_fn(params, keyframes[i], variables)
-            if one is None or one.shape != loss.shape or one.device != loss.device or one.dtype != loss.dtype:
-                one = torch.ones_like(loss)       # dL/dloss = 1, made once per batch instead of once per keyframe (a launch each)
-            loss.backward(one)                    # autograd accumulates into .grad across this rank's keyframes
+            # dL/dloss = 1 from the cache (autograd would fill a fresh one per keyframe: a launch each; the fused loss skips its scaling
+            # launch for this very tensor); autograd accumulates into .grad across this rank's keyframes
+            loss.backward(unit_gradient(loss) if loss.dim() == 0 else None)
             losses.append(loss.detach())          # (read after the loop: a float() here would stall the host once per keyframe)
         total = float(torch.stack(losses).sum()) if losses else 0.0
     if world <= 1 or not on:

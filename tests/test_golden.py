@@ -434,6 +434,29 @@ def test_fused_loss_ragged_image_and_torch_mirror(backend):
     np.testing.assert_allclose(depth.grad.cpu().numpy(), d2.grad.cpu().numpy(), atol=1e-10, rtol=1e-5)
 
 
+def test_fused_loss_backward_with_the_cached_unit_gradient(backend):
+    """loss.backward(mapping.unit_gradient(loss)) -- the root gradient the mapper and the keyframe batch pass -- skips the fused loss' scaling
+    launch: same gradients as the plain loss.backward(); any other upstream gradient still scales."""
+    from activesplat_amd import mapping as M
+    g = torch.Generator().manual_seed(4)
+    H, W = 40, 48
+    base_im, base_d = torch.rand(3, H, W, generator=g).to(backend), (torch.rand(1, H, W, generator=g) * 3).to(backend)
+    gt_im = torch.rand(3, H, W, generator=g).to(backend); gt_d = (torch.rand(1, H, W, generator=g) * 3).to(backend)
+    grads = []
+    for mode in ("plain", "unit", "two"):
+        im, depth = base_im.clone().requires_grad_(True), base_d.clone().requires_grad_(True)
+        loss, _ = M.fused_mapping_loss(im, depth, depth.detach() ** 2 + 0.1, gt_im, gt_d, dict(im=0.5, depth=1.0))
+        if mode == "plain":
+            loss.backward()
+        elif mode == "unit":
+            loss.backward(M.unit_gradient(loss))
+        else:
+            loss.backward(torch.full_like(loss, 2.0))
+        grads.append((im.grad.clone(), depth.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    assert torch.equal(2.0 * grads[0][0], grads[2][0]) and torch.equal(2.0 * grads[0][1], grads[2][1])
+
+
 @pytest.mark.parametrize("tag", ["aniso", "iso"])
 def test_fused_rendervar_kernel_matches_reference_transform(backend, tag):
     """gs_activate_* == transform_to_frame + transformed_params2rendervar of the reference (golden), forward;
