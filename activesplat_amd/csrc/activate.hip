@@ -14,31 +14,6 @@ namespace gs {
 
 struct Pose { float q[4]; float t[3]; };
 
-__device__ __forceinline__ void quat_to_rot(const float* q, float (&R)[3][3])
-{
-    const float r = q[0], x = q[1], y = q[2], z = q[3];
-    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
-    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
-    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
-}
-
-// m = a (x) b  (Hamilton product, w first)
-__device__ __forceinline__ void qmul(const float* a, const float* b, float* m)
-{
-    m[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
-    m[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
-    m[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
-    m[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
-}
-// du = L(a)^T dm  where m = a (x) u is linear in u
-__device__ __forceinline__ void qmul_bwd_rhs(const float* a, const float* dm, float* du)
-{
-    du[0] = a[0] * dm[0] + a[1] * dm[1] + a[2] * dm[2] + a[3] * dm[3];
-    du[1] = -a[1] * dm[0] + a[0] * dm[1] + a[3] * dm[2] - a[2] * dm[3];
-    du[2] = -a[2] * dm[0] - a[3] * dm[1] + a[0] * dm[2] + a[1] * dm[3];
-    du[3] = -a[3] * dm[0] + a[2] * dm[1] - a[1] * dm[2] + a[0] * dm[3];
-}
-
 __global__ __launch_bounds__(kBlock) void activate_forward_kernel(int P, int iso, Pose pose, const float* __restrict__ means3D,
                                                                   const float* __restrict__ rots, const float* __restrict__ logit_op,
                                                                   const float* __restrict__ log_scales, float* __restrict__ o_means,

@@ -80,6 +80,7 @@ bool make_cam(const GsCamera* c, gs::Cam& k)
     k.sh_degree = c->sh_degree; k.sh_coeffs = c->sh_coeffs;
     k.bg = c->bg; k.view = c->viewmatrix; k.proj = c->projmatrix; k.campos = c->campos;
     k.half = 0; k.split = 0;                               // decided by the blend launchers
+    k.act = k.act_iso = k.act_accumulate = 0;
     return true;
 }
 
@@ -253,13 +254,27 @@ int gs_bin_layout(int64_t D, uint32_t max_tile_instances, int32_t width, int32_t
 
 uint64_t gs_backward_scratch_bytes(int32_t P) { return align_up((uint64_t)(P > 0 ? P : 1) * gs::kGradStride * 4); }
 
-int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, const float* shs,
-                          const float* colors_precomp, const float* opacities, const float* scales,
-                          const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_state,
-                          void* image_state, uint32_t* d_counts, uint32_t* h_counts, int32_t want_backward, gs_stream_t stream)
+static bool set_input_activation(gs::Cam& k, const float* h_pose7, int32_t isotropic, int32_t accumulate)
+{
+    k.act = k.act_iso = k.act_accumulate = 0;
+    if (!h_pose7) return true;
+    k.act = 1; k.act_iso = isotropic != 0; k.act_accumulate = accumulate != 0;
+    for (int c = 0; c < 4; c++) k.act_q[c] = h_pose7[c];
+    for (int c = 0; c < 3; c++) k.act_t[c] = h_pose7[4 + c];
+    return k.V == 1;
+}
+
+static int preprocess_forward_impl(const GsCamera* cam, int32_t P, const float* means3D, const float* shs,
+                                   const float* colors_precomp, const float* opacities, const float* scales,
+                                   const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_state,
+                                   void* image_state, uint32_t* d_counts, uint32_t* h_counts, int32_t want_backward, gs_stream_t stream,
+                                   const float* h_pose7, int32_t isotropic)
 {
     gs::Cam k;
     if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_preprocess_forward: invalid camera settings");
+    if (!set_input_activation(k, h_pose7, isotropic, 0)) return fail(GS_EINVAL, "gs_preprocess_forward_raw: one view only");
+    if (k.act && (cov3D_precomp || (shs && k.sh_coeffs != 16)))
+        return fail(GS_EINVAL, "gs_preprocess_forward_raw: scale / rotation parameters with colours or 16-coefficient SH rows only");
     if (P < 0 || !geom_state || !image_state || !d_counts) return fail(GS_EINVAL, "gs_preprocess_forward: null state pointer");
     if (P > 0 && (!means3D || !opacities || !radii)) return fail(GS_EINVAL, "gs_preprocess_forward: null input pointer");
     if ((shs == nullptr) == (colors_precomp == nullptr) && P > 0)
@@ -304,6 +319,26 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, 
     }
     return GS_OK;
 }
+
+int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, const float* shs,
+                          const float* colors_precomp, const float* opacities, const float* scales,
+                          const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_state,
+                          void* image_state, uint32_t* d_counts, uint32_t* h_counts, int32_t want_backward, gs_stream_t stream)
+{
+    return preprocess_forward_impl(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, geom_state,
+                                   image_state, d_counts, h_counts, want_backward, stream, nullptr, 0);
+}
+
+int gs_preprocess_forward_raw(const GsCamera* cam, int32_t P, const float* means3D, const float* shs, const float* colors_precomp,
+                              const float* logit_opacities, const float* log_scales, const float* unnorm_rotations,
+                              const float* h_pose7, int32_t isotropic, int32_t* radii, void* geom_state, void* image_state,
+                              uint32_t* d_counts, uint32_t* h_counts, int32_t want_backward, gs_stream_t stream)
+{
+    if (!h_pose7) return fail(GS_EINVAL, "gs_preprocess_forward_raw: null pose");
+    return preprocess_forward_impl(cam, P, means3D, shs, colors_precomp, logit_opacities, log_scales, unnorm_rotations, nullptr, radii,
+                                   geom_state, image_state, d_counts, h_counts, want_backward, stream, h_pose7, isotropic);
+}
+
 
 int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_tile_instances, void* geom_state,
                       void* bin_state, uint32_t* point_list, void* image_state, float* out_color, float* out_depth,
@@ -370,16 +405,20 @@ int gs_render_forward(const GsCamera* cam, int32_t P, int64_t D, uint32_t max_ti
     return GS_OK;
 }
 
-int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* means3D, const float* shs,
-                       const float* colors_precomp, const float* scales, const float* rotations,
-                       const float* cov3D_precomp, const int32_t* radii, const void* geom_state,
-                       const uint32_t* point_list, const void* image_state, const float* dL_dcolor,
-                       const float* dL_ddepth, float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities, float* dL_dcolors_precomp,
-                       float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* scratch,
-                       int32_t scratch_zeroed, int32_t have_sh_jacobian, gs_stream_t stream)
+static int render_backward_impl(const GsCamera* cam, int32_t P, int64_t D, const float* means3D, const float* shs,
+                                const float* colors_precomp, const float* scales, const float* rotations,
+                                const float* cov3D_precomp, const int32_t* radii, const void* geom_state,
+                                const uint32_t* point_list, const void* image_state, const float* dL_dcolor,
+                                const float* dL_ddepth, float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities, float* dL_dcolors_precomp,
+                                float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* scratch,
+                                int32_t scratch_zeroed, int32_t have_sh_jacobian, gs_stream_t stream, const float* logit,
+                                const float* h_pose7, int32_t isotropic, int32_t accumulate)
 {
     gs::Cam k;
     if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_render_backward: invalid camera settings");
+    if (!set_input_activation(k, h_pose7, isotropic, accumulate)) return fail(GS_EINVAL, "gs_render_backward_raw: one view only");
+    if (k.act && (!logit || cov3D_precomp || (shs && k.sh_coeffs != 16)))
+        return fail(GS_EINVAL, "gs_render_backward_raw: scale / rotation parameters with colours or 16-coefficient SH rows only");
     if (k.V > 1) return fail(GS_EINVAL, "gs_render_backward: multi-view atlas renders are forward-only");
     if (P < 0 || D < 0 || !geom_state || !image_state || !dL_dcolor || !scratch)
         return fail(GS_EINVAL, "gs_render_backward: null pointer");
@@ -408,10 +447,37 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* m
         ScopedStage ps(ST_PREPROCESS_BWD, st);
         e = gs::launch_preprocess_backward(k, P, means3D, shs, scales, rotations, cov3D_precomp, radii, gp.clamped, (shs && have_sh_jacobian) ? gp.sh_jac : nullptr, grad2d,
                                            dL_dmeans2D, dL_dmeans3D, dL_dopacities, dL_dcolors_precomp, dL_dshs, dL_dscales,
-                                           dL_drotations, dL_dcov3D, st);
+                                           dL_drotations, dL_dcov3D, logit, st);
     }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_backward: preprocess %s", hipGetErrorString(e));
     return GS_OK;
+}
+
+int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D, const float* means3D, const float* shs,
+                       const float* colors_precomp, const float* scales, const float* rotations,
+                       const float* cov3D_precomp, const int32_t* radii, const void* geom_state,
+                       const uint32_t* point_list, const void* image_state, const float* dL_dcolor,
+                       const float* dL_ddepth, float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities, float* dL_dcolors_precomp,
+                       float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* scratch,
+                       int32_t scratch_zeroed, int32_t have_sh_jacobian, gs_stream_t stream)
+{
+    return render_backward_impl(cam, P, D, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, radii, geom_state, point_list,
+                                image_state, dL_dcolor, dL_ddepth, dL_dmeans2D, dL_dmeans3D, dL_dopacities, dL_dcolors_precomp, dL_dshs,
+                                dL_dscales, dL_drotations, dL_dcov3D, scratch, scratch_zeroed, have_sh_jacobian, stream, nullptr, nullptr, 0, 0);
+}
+
+int gs_render_backward_raw(const GsCamera* cam, int32_t P, int64_t D, const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* logit_opacities, const float* log_scales, const float* unnorm_rotations, const float* h_pose7,
+                           int32_t isotropic, int32_t accumulate, const int32_t* radii, const void* geom_state, const uint32_t* point_list,
+                           const void* image_state, const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans2D, float* dL_dmeans3D,
+                           float* dL_dlogit_opacities, float* dL_dcolors_precomp, float* dL_dshs, float* dL_dlog_scales,
+                           float* dL_dunnorm_rotations, void* scratch, int32_t scratch_zeroed, int32_t have_sh_jacobian, gs_stream_t stream)
+{
+    if (!h_pose7 || (P > 0 && !logit_opacities)) return fail(GS_EINVAL, "gs_render_backward_raw: null pose / opacity parameters");
+    return render_backward_impl(cam, P, D, means3D, shs, colors_precomp, log_scales, unnorm_rotations, nullptr, radii, geom_state, point_list,
+                                image_state, dL_dcolor, dL_ddepth, dL_dmeans2D, dL_dmeans3D, dL_dlogit_opacities, dL_dcolors_precomp, dL_dshs,
+                                dL_dlog_scales, dL_dunnorm_rotations, nullptr, scratch, scratch_zeroed, have_sh_jacobian, stream,
+                                logit_opacities, h_pose7, isotropic, accumulate);
 }
 
 int gs_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr,

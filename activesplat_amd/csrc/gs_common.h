@@ -41,7 +41,70 @@ struct Cam {
     // launchers; 0 / 1: one walker per quadrant)
     int chain;
     unsigned chain_epoch;
+    // raw-parameter mode of the per-Gaussian kernels (gs_preprocess_forward_raw / gs_render_backward_raw): the inputs are the mapper's
+    // PARAMETERS -- world-frame means, unnormalised quaternions, logit opacities, log scales ([P,1] when act_iso) -- and the frame transform
+    // + activations of slam_helpers.py:252-304,124-139 (activate.hip) happen inside the kernels; act_accumulate: the backward ADDS its
+    // parameter gradients to what the output buffers hold
+    int act, act_iso, act_accumulate;
+    float act_q[4], act_t[3];
 };
+
+// frame transform + activation algebra shared by activate.hip and the raw-parameter mode of the per-Gaussian kernels
+__device__ __forceinline__ void quat_to_rot(const float* q, float (&R)[3][3])
+{
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+// m = a (x) b  (Hamilton product, w first)
+__device__ __forceinline__ void qmul(const float* a, const float* b, float* m)
+{
+    m[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    m[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    m[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    m[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+// du = L(a)^T dm  where m = a (x) u is linear in u
+__device__ __forceinline__ void qmul_bwd_rhs(const float* a, const float* dm, float* du)
+{
+    du[0] = a[0] * dm[0] + a[1] * dm[1] + a[2] * dm[2] + a[3] * dm[3];
+    du[1] = -a[1] * dm[0] + a[0] * dm[1] + a[3] * dm[2] - a[2] * dm[3];
+    du[2] = -a[2] * dm[0] - a[3] * dm[1] + a[0] * dm[2] + a[1] * dm[3];
+    du[3] = -a[3] * dm[0] + a[2] * dm[1] - a[1] * dm[2] + a[0] * dm[3];
+}
+// rotation the rasteriser sees for the parameter quaternion q (w first): normalize(q) (isotropic map), else normalize(q_cam (x) normalize(q))
+__device__ __forceinline__ void activate_rotation(const float* cam_q, int iso, const float* q, float* out)
+{
+    const float inv = 1.0f / fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+    const float u[4] = {q[0] * inv, q[1] * inv, q[2] * inv, q[3] * inv};
+    if (iso) { for (int k = 0; k < 4; k++) out[k] = u[k]; return; }
+    float m[4];
+    qmul(cam_q, u, m);
+    const float invm = 1.0f / fmaxf(sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + m[3] * m[3]), 1e-12f);
+    for (int k = 0; k < 4; k++) out[k] = m[k] * invm;
+}
+// gradient w.r.t. the parameter quaternion q of a gradient g w.r.t. activate_rotation's output
+__device__ __forceinline__ void activate_rotation_bwd(const float* cam_q, int iso, const float* q, const float* g, float* dq)
+{
+    const float nq = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+    const float u[4] = {q[0] / nq, q[1] / nq, q[2] / nq, q[3] / nq};
+    float du[4];
+    if (iso) {
+        for (int k = 0; k < 4; k++) du[k] = g[k];
+    } else {
+        float m[4];
+        qmul(cam_q, u, m);
+        const float nm = fmaxf(sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + m[3] * m[3]), 1e-12f);
+        const float r[4] = {m[0] / nm, m[1] / nm, m[2] / nm, m[3] / nm};
+        const float dot = r[0] * g[0] + r[1] * g[1] + r[2] * g[2] + r[3] * g[3];
+        float dm[4];
+        for (int k = 0; k < 4; k++) dm[k] = (g[k] - r[k] * dot) / nm;
+        qmul_bwd_rhs(cam_q, dm, du);
+    }
+    const float dotu = u[0] * du[0] + u[1] * du[1] + u[2] * du[2] + u[3] * du[3];
+    for (int k = 0; k < 4; k++) dq[k] = (du[k] - u[k] * dotu) / nq;
+}
 
 // Per-Gaussian screen-space record, 3 x float4 = 48 B, one gather per tile instance in the blend.
 //   q0 = (x, y, conic_a, conic_b)   q1 = (conic_c, opacity, r, g)   q2 = (b, depth, ext_x, ext_y)
@@ -420,7 +483,7 @@ hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3
                                       const float* scales, const float* rots, const float* cov3Dp,
                                       const int32_t* radii, const uint32_t* clamped, const float2* sh_jac, const float* grad2d,
                                       float* dmeans2D, float* dmeans3D, float* dopac, float* dcolors, float* dshs,
-                                      float* dscales, float* drots, float* dcov3D, hipStream_t st);
+                                      float* dscales, float* drots, float* dcov3D, const float* logit, hipStream_t st);
 hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,
                              uint2* ranges, uint32_t* d_counts, uint32_t* host_counts, hipStream_t st);
 hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_base, const uint2* ranges,

@@ -173,9 +173,38 @@ __device__ __forceinline__ uint32_t project_gaussian(const Cam& cam, int P, int 
     return ntiles;
 }
 
+// Raw-parameter mode (Cam::act): the staged rows are the mapper's parameters; every thread turns ITS rows into what the rasteriser takes --
+// means into the camera frame, exp of the log scales (one per Gaussian when act_iso: staged [kBlock] wide), the activated rotation -- in place,
+// and returns the opacity sigmoid(logit).  The same formulas as activate.hip (slam_helpers.py:252-304,124-139).
+__device__ __forceinline__ float activate_staged_rows(const Cam& cam, int tid, bool row, float* s_mean, float* s_scale, float* s_rot, float logit)
+{
+    const float ls0 = s_scale[cam.act_iso ? tid : tid * 3];
+    if (cam.act_iso) __syncthreads();                     // (every thread has its [kBlock]-staged value before the 3-wide rows are written)
+    if (row) {
+        float R[3][3];
+        quat_to_rot(cam.act_q, R);
+        const float px = s_mean[tid * 3], py = s_mean[tid * 3 + 1], pz = s_mean[tid * 3 + 2];
+        s_mean[tid * 3] = R[0][0] * px + R[0][1] * py + R[0][2] * pz + cam.act_t[0];
+        s_mean[tid * 3 + 1] = R[1][0] * px + R[1][1] * py + R[1][2] * pz + cam.act_t[1];
+        s_mean[tid * 3 + 2] = R[2][0] * px + R[2][1] * py + R[2][2] * pz + cam.act_t[2];
+        if (cam.act_iso) {
+            const float e = __expf(ls0);
+            s_scale[tid * 3] = e; s_scale[tid * 3 + 1] = e; s_scale[tid * 3 + 2] = e;
+        } else {
+            s_scale[tid * 3] = __expf(ls0); s_scale[tid * 3 + 1] = __expf(s_scale[tid * 3 + 1]); s_scale[tid * 3 + 2] = __expf(s_scale[tid * 3 + 2]);
+        }
+        const float4 q4 = reinterpret_cast<const float4*>(s_rot)[tid];
+        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        float out[4];
+        activate_rotation(cam.act_q, cam.act_iso, q, out);
+        reinterpret_cast<float4*>(s_rot)[tid] = make_float4(out[0], out[1], out[2], out[3]);
+    }
+    return 1.0f / (1.0f + __expf(-logit));
+}
+
 // SH: 0 = colours given, 1 = coefficient rows of any width through per-wave LDS slabs (16-coefficient rows, the layout every caller of
 // the reference uses, take preprocess_forward_sh48_kernel below)
-template <int SH>
+template <int SH, bool ACT = false>        // ACT: raw-parameter mode (colours given or 16-coefficient rows only)
 __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales,
@@ -205,14 +234,18 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     // the per-tile instance counters of the binning stage are zeroed here (saves a memset launch)
     if (vbase + tid < cam.gx * cam.gy) gp.tile_total[vbase + tid] = 0u;
     const int i = base + tid, io = vbase + tid;
-    const float o_in = i < P ? opac[i] : 0.0f;                 // requested up front: not a dependent load inside the visible branch
+    float o_in = i < P ? opac[i] : 0.0f;                       // requested up front: not a dependent load inside the visible branch
     stage_rows<3>(s_mean, means3D, base, nrows, tid);
     if (!SLAB) {
         if (cov3Dp) stage_rows<6>(s_cov, cov3Dp, base, nrows, tid);
-        else { stage_rows<3>(s_scale, scales, base, nrows, tid); stage_rows<4>(s_rot, rots, base, nrows, tid); }
+        else {
+            if (ACT && cam.act_iso) stage_rows<1>(s_scale, scales, base, nrows, tid); else stage_rows<3>(s_scale, scales, base, nrows, tid);
+            stage_rows<4>(s_rot, rots, base, nrows, tid);
+        }
         if (SH == 0) stage_rows<3>(s_col, colors, base, nrows, tid);
     }
     __syncthreads();
+    if (ACT) o_in = activate_staged_rows(cam, tid, tid < nrows, s_mean, s_scale, s_rot, o_in);
 
     // SH -> RGB for every Gaussian: each wavefront streams its own 64 coefficient rows through a private padded LDS slab,
     // 32 rows at a time (coalesced 16 B/lane global reads; lane = row reads at an odd stride are conflict-free)
@@ -272,6 +305,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
 // four workgroups per CU instead of three); slabs with 16-byte aligned rows (gs_common.h: kShPad4), i.e. 128-bit LDS accesses.
 // Measured at 2 M Gaussians against the generic design with compile-time row width (three barriers, both halves' loads held in 48
 // registers: 167 VGPRs, three workgroups per CU, 49-float slab rows): 155 -> 131 us; same arithmetic, same results to the bit.
+template <bool ACT>
 __global__ __launch_bounds__(kBlock, 4) void preprocess_forward_sh48_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ opac,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov3Dp, int32_t* __restrict__ radii, GeomPtrs gp)
@@ -295,11 +329,15 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_forward_sh48_kernel(
     const bool full = row_w + kWave <= P;
     float4 va[6];
     if (full) sh48_half_load(va, shs, row_w, lane);
-    const float o_in = i < P ? opac[i] : 0.0f;
+    float o_in = i < P ? opac[i] : 0.0f;
     stage_rows<3>(s_mean, means3D, base, nrows, tid);
     if (cov3Dp) stage_rows<6>(s_cov, cov3Dp, base, nrows, tid);
-    else { stage_rows<3>(s_scale, scales, base, nrows, tid); stage_rows<4>(s_rot, rots, base, nrows, tid); }
+    else {
+        if (ACT && cam.act_iso) stage_rows<1>(s_scale, scales, base, nrows, tid); else stage_rows<3>(s_scale, scales, base, nrows, tid);
+        stage_rows<4>(s_rot, rots, base, nrows, tid);
+    }
     __syncthreads();
+    if (ACT) o_in = activate_staged_rows(cam, tid, tid < nrows, s_mean, s_scale, s_rot, o_in);
 
     float sh_rgb[3] = {0.f, 0.f, 0.f};
     uint32_t sh_clamp = 0;
@@ -368,10 +406,15 @@ hipError_t launch_preprocess_forward(const Cam& cam, int P, const float* means3D
                                      uint32_t* d_num_rendered, hipStream_t st)
 {
     const int nb = cam.V > 1 ? cam.V * cam.nbv : (P + kBlock - 1) / kBlock;
-    if (nb > 0 && shs && cam.sh_coeffs == 16)
-        hipLaunchKernelGGL(preprocess_forward_sh48_kernel, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, opac, scales, rots, cov3Dp, radii, gp);
-    else if (nb > 0 && shs)
+    if (cam.act && (cov3Dp || (shs && cam.sh_coeffs != 16))) return hipErrorInvalidValue;      // (api.hip refuses these before)
+    if (nb > 0 && shs && cam.sh_coeffs == 16) {
+        if (cam.act) hipLaunchKernelGGL(preprocess_forward_sh48_kernel<true>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, opac, scales, rots, cov3Dp, radii, gp);
+        else hipLaunchKernelGGL(preprocess_forward_sh48_kernel<false>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, opac, scales, rots, cov3Dp, radii, gp);
+    } else if (nb > 0 && shs)
         hipLaunchKernelGGL(preprocess_forward_kernel<1>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
+                           scales, rots, cov3Dp, radii, gp);
+    else if (nb > 0 && cam.act)
+        hipLaunchKernelGGL((preprocess_forward_kernel<0, true>), dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,
                            scales, rots, cov3Dp, radii, gp);
     else if (nb > 0)
         hipLaunchKernelGGL(preprocess_forward_kernel<0>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, colors, opac,

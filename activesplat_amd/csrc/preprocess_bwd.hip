@@ -13,14 +13,17 @@ namespace gs {
 // SH: 0 = colours given, 1 = coefficient rows of any width through per-wave LDS slabs, 3 = the same for 16-coefficient rows
 // (row width 48 known at compile time).  (Slabs with 16-byte aligned rows and 128-bit LDS
 // accesses, as the forward uses them, measured slower here: the wider stores' registers spill next to the hoisted loads.)
-template <int SH>
+// ACT: raw-parameter mode (Cam::act; colours given or 16-coefficient rows): means3D / scales / rots / logit are the mapper's PARAMETERS, the
+// frame transform + activations are recomputed here and the four gradients leave w.r.t. the parameters (activate.hip's backward inline);
+// with Cam::act_accumulate they -- and dcolors -- are ADDED to the output buffers (rows of Gaussians that were not rendered stay untouched).
+template <int SH, bool ACT = false>
 __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov3Dp,
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const float2* __restrict__ sh_jac,
     const float* __restrict__ grad2d, float* __restrict__ dmeans2D, float* __restrict__ dmeans3D, float* __restrict__ dopac,
     float* __restrict__ dcolors, float* __restrict__ dshs, float* __restrict__ dscales,
-    float* __restrict__ drots, float* __restrict__ dcov3D)
+    float* __restrict__ drots, float* __restrict__ dcov3D, const float* __restrict__ logit)
 {
     // per-wave slabs: 32 coefficient rows in, their gradients written back IN PLACE (each element is read before it is overwritten)
     constexpr bool HAS_SH = SH != 0;
@@ -39,7 +42,15 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
     //   ga = (sum Z dx, sum Z dy, sum Z dx dx, sum Z dx dy)  gb = (sum Z dy dy, sum G dL/dalpha, dr, dg)  gc = (db, -, -, -)
     float o_m2d[3] = {0.f, 0.f, 0.f}, o_sc[3] = {0.f, 0.f, 0.f}, o_rot[4] = {0.f, 0.f, 0.f, 0.f};
     float o_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float px = means3D[3 * ic], py = means3D[3 * ic + 1], pz = means3D[3 * ic + 2];
+    float px = means3D[3 * ic], py = means3D[3 * ic + 1], pz = means3D[3 * ic + 2];
+    float actR[3][3];                                          // (ACT) rotation of the frame transform
+    if (ACT) {
+        quat_to_rot(cam.act_q, actR);
+        const float wx = px, wy = py, wz = pz;
+        px = actR[0][0] * wx + actR[0][1] * wy + actR[0][2] * wz + cam.act_t[0];
+        py = actR[1][0] * wx + actR[1][1] * wy + actR[1][2] * wz + cam.act_t[1];
+        pz = actR[2][0] * wx + actR[2][1] * wy + actR[2][2] * wz + cam.act_t[2];
+    }
     const float drgb[3] = {gb.z, gb.w, gc.x};
     // every other per-Gaussian input is requested here as well, whether or not the lane turns out to need it: ONE memory round trip
     // per wavefront instead of three dependent ones (the compiler does not move loads out of the `live` branches below)
@@ -48,10 +59,20 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
     if (HAS_SH && sh_jac) load_sh_jac(sh_jac, (size_t)ic, jac, cl_in);       // (the clamp flags travel in the Jacobian record)
     else if (HAS_SH) cl_in = clamped[ic];
     float sc_in[3] = {0.f, 0.f, 0.f};
-    float4 rq_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rq_in = make_float4(0.f, 0.f, 0.f, 0.f), rq_raw = rq_in;
+    float lg_in = 0.f;
     float cov_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (cov3Dp) {
         for (int c = 0; c < 6; c++) cov_in[c] = cov3Dp[(size_t)ic * 6 + c];
+    } else if (ACT) {
+        if (cam.act_iso) { sc_in[0] = sc_in[1] = sc_in[2] = __expf(scales[ic]); }
+        else { sc_in[0] = __expf(scales[3 * ic]); sc_in[1] = __expf(scales[3 * ic + 1]); sc_in[2] = __expf(scales[3 * ic + 2]); }
+        rq_raw = reinterpret_cast<const float4*>(rots)[ic];
+        const float qr[4] = {rq_raw.x, rq_raw.y, rq_raw.z, rq_raw.w};
+        float qa[4];
+        activate_rotation(cam.act_q, cam.act_iso, qr, qa);
+        rq_in = make_float4(qa[0], qa[1], qa[2], qa[3]);
+        lg_in = logit[ic];
     } else {
         sc_in[0] = scales[3 * ic]; sc_in[1] = scales[3 * ic + 1]; sc_in[2] = scales[3 * ic + 2];
         rq_in = reinterpret_cast<const float4*>(rots)[ic];
@@ -223,6 +244,31 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
             o_rot[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         }
     }
+    if (ACT) {
+        // gradients w.r.t. the parameters (activate.hip's backward): means through the frame rotation, rotation through the normalisations and
+        // the camera quaternion, opacity through the sigmoid, scales through the exponential
+        for (int c = 0; c < 3; c++) dmeans2D[3 * i + c] = o_m2d[c];
+        const bool acc = cam.act_accumulate != 0;
+        if (acc && !live) return;                                   // nothing to add
+        const float dm[3] = {actR[0][0] * dmean[0] + actR[1][0] * dmean[1] + actR[2][0] * dmean[2],
+                             actR[0][1] * dmean[0] + actR[1][1] * dmean[1] + actR[2][1] * dmean[2],
+                             actR[0][2] * dmean[0] + actR[1][2] * dmean[1] + actR[2][2] * dmean[2]};
+        for (int c = 0; c < 3; c++) dmeans3D[3 * i + c] = acc ? dmeans3D[3 * i + c] + dm[c] : dm[c];
+        const float o = 1.0f / (1.0f + __expf(-lg_in));
+        const float dl = (live ? gb.y : 0.f) * o * (1.0f - o);
+        dopac[i] = acc ? dopac[i] + dl : dl;
+        if (dcolors) for (int c = 0; c < 3; c++) { const float v = live ? drgb[c] : 0.f; dcolors[3 * i + c] = acc ? dcolors[3 * i + c] + v : v; }
+        const float ds[3] = {o_sc[0] * sc_in[0], o_sc[1] * sc_in[1], o_sc[2] * sc_in[2]};
+        if (cam.act_iso) { const float v = ds[0] + ds[1] + ds[2]; dscales[i] = acc ? dscales[i] + v : v; }
+        else for (int c = 0; c < 3; c++) dscales[3 * i + c] = acc ? dscales[3 * i + c] + ds[c] : ds[c];
+        const float qr[4] = {rq_raw.x, rq_raw.y, rq_raw.z, rq_raw.w};
+        float dq[4];
+        activate_rotation_bwd(cam.act_q, cam.act_iso, qr, o_rot, dq);
+        float4 out = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        if (acc) { const float4 old = reinterpret_cast<const float4*>(drots)[i]; out.x += old.x; out.y += old.y; out.z += old.z; out.w += old.w; }
+        reinterpret_cast<float4*>(drots)[i] = out;
+        return;
+    }
     for (int c = 0; c < 3; c++) { dmeans2D[3 * i + c] = o_m2d[c]; dmeans3D[3 * i + c] = dmean[c]; }
     dopac[i] = live ? gb.y : 0.f;
     if (dcolors) for (int c = 0; c < 3; c++) dcolors[3 * i + c] = live ? drgb[c] : 0.f;
@@ -235,18 +281,16 @@ hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3
                                       const float* scales, const float* rots, const float* cov3Dp,
                                       const int32_t* radii, const uint32_t* clamped, const float2* sh_jac, const float* grad2d,
                                       float* dmeans2D, float* dmeans3D, float* dopac, float* dcolors, float* dshs,
-                                      float* dscales, float* drots, float* dcov3D, hipStream_t st)
+                                      float* dscales, float* drots, float* dcov3D, const float* logit, hipStream_t st)
 {
     const int nb = (P + kBlock - 1) / kBlock;
-    if (nb > 0 && shs && cam.sh_coeffs == 16)
-        hipLaunchKernelGGL(preprocess_backward_kernel<3>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
-                           cov3Dp, radii, clamped, sh_jac, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
-    else if (nb > 0 && shs)
-        hipLaunchKernelGGL(preprocess_backward_kernel<1>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
-                           cov3Dp, radii, clamped, sh_jac, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
-    else if (nb > 0)
-        hipLaunchKernelGGL(preprocess_backward_kernel<0>, dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots,
-                           cov3Dp, radii, clamped, sh_jac, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D);
+    if (cam.act && (cov3Dp || !logit || !scales || !rots || !dscales || !drots || (shs && cam.sh_coeffs != 16))) return hipErrorInvalidValue;
+#define GS_PBWD(...) hipLaunchKernelGGL((preprocess_backward_kernel<__VA_ARGS__>), dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots, \
+                                        cov3Dp, radii, clamped, sh_jac, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D, logit)
+    if (nb > 0 && shs && cam.sh_coeffs == 16) { if (cam.act) GS_PBWD(3, true); else GS_PBWD(3, false); }
+    else if (nb > 0 && shs) GS_PBWD(1, false);
+    else if (nb > 0) { if (cam.act) GS_PBWD(0, true); else GS_PBWD(0, false); }
+#undef GS_PBWD
     return hipGetLastError();
 }
 

@@ -29,7 +29,7 @@ import torch.nn.functional as F
 from .camera import setup_camera
 from .rasterizer import GaussianRasterizationSettings as Camera
 from .rasterizer import GaussianRasterizer as Renderer
-from .rasterizer import render_rgbd
+from .rasterizer import render_rgbd, render_rgbd_raw
 
 _GAUSSIAN_KEYS = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales")
 
@@ -295,7 +295,7 @@ def fused_mapping_loss(im, depth, depth_sq, gt_im, gt_depth, loss_weights):
 
 def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_for_loss=True, sil_thres=0.99,
              use_l1=True, ignore_outlier_depth_loss=False, do_ba=False, fused=False, fused_loss=False, fused_inputs=False,
-             pose7=None, accumulate_grads=False):
+             pose7=None, accumulate_grads=False, fused_preprocess=False):
     """Mapping loss: masked depth L1 + 0.8 L1 + 0.2 (1 - SSIM) on colour; updates
     variables['means2D'|'seen'|'max_2D_radius'].
     fused=False: the reference's two raster passes on the same geometry (RGB, then [z,1,z^2]).
@@ -307,15 +307,36 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
     fused_inputs : transform_to_frame + activations by gs_activate_* (csrc/activate.hip).
     accumulate_grads (with fused_inputs, for `loss.backward()` over a batch of keyframes): the activation backward ADDS its gradients to
                  the four per-Gaussian parameters' .grad in the kernel instead of handing them to autograd's accumulation passes; gradients
-                 taken with torch.autograd.grad are not delivered in this mode."""
-    if fused_inputs and not do_ba:
+                 taken with torch.autograd.grad are not delivered in this mode.
+    fused_preprocess (with fused; isotropic or anisotropic scale / rotation parameters, `rgb_colors`): no activation launches at all -- the
+                 rasteriser's per-Gaussian kernels take the PARAMETERS and do the frame transform + activations themselves, forward and
+                 backward (rasterizer.render_rgbd_raw); with accumulate_grads the backward also adds into the parameters' .grad."""
+    if fused_preprocess and fused and not do_ba:
+        if pose7 is None:
+            q = F.normalize(params["cam_unnorm_rots"][..., iter_time_idx].detach()).reshape(4)
+            pose7 = torch.cat([q, params["cam_trans"][..., iter_time_idx].detach().reshape(3)]).cpu().tolist()
+        m2d = torch.empty_like(params["means3D"], requires_grad=True)      # gradient carrier only (see fused_rendervar)
+        im, radius, depth, _sil, depth_sq = render_rgbd_raw(curr_data["cam"], params["means3D"], m2d, params["logit_opacities"],
+                                                             params["log_scales"], params["unnorm_rotations"], pose7,
+                                                             colors_precomp=params["rgb_colors"], accumulate_grads=accumulate_grads)
+        variables["means2D"] = m2d
+        if fused_loss and use_l1 and not ignore_outlier_depth_loss:
+            loss, weighted = fused_mapping_loss(im, depth, depth_sq, curr_data["im"], curr_data["depth"], loss_weights)
+            from . import optim as O
+            variables["seen"] = O.visibility_stats(radius, variables["max_2D_radius"])
+            return loss, variables, weighted
+        rendervar = None
+    elif fused_inputs and not do_ba:
         tg = None
         rendervar = fused_rendervar(params, iter_time_idx, pose7, accumulate_grads)
     else:
         tg = transform_to_frame(params, iter_time_idx, gaussians_grad=True, camera_grad=do_ba)
         rendervar = transformed_params2rendervar(params, tg)
-    rendervar["means2D"].retain_grad()
-    if fused:
+    if rendervar is not None:
+        rendervar["means2D"].retain_grad()
+    if rendervar is None:
+        pass                                              # (rendered above, raw-parameter mode; the torch loss below)
+    elif fused:
         im, radius, depth, _sil, depth_sq = render_rgbd(curr_data["cam"], **rendervar)
     else:
         if tg is None:
@@ -325,7 +346,8 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
         depth_sil, _, _, _ = Renderer(raster_settings=curr_data["cam"])(**depth_sil_rendervar)
         depth = depth_sil[0].unsqueeze(0)
         depth_sq = depth_sil[2].unsqueeze(0)
-    variables["means2D"] = rendervar["means2D"]          # densification reads the colour pass' gradient only
+    if rendervar is not None:
+        variables["means2D"] = rendervar["means2D"]      # densification reads the colour pass' gradient only
     if fused_loss and use_l1 and not ignore_outlier_depth_loss:
         loss, weighted = fused_mapping_loss(im, depth, depth_sq, curr_data["im"], curr_data["depth"], loss_weights)
         from . import optim as O

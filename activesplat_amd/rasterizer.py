@@ -128,9 +128,12 @@ class _RasterizeGaussians(torch.autograd.Function):
                  (= opacity) and depth^2 -- see render_rgbd()."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, fused=False):
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, fused=False, raw=None):
+        """raw = (pose7, isotropic, accumulate): means3D / opacities / scales / rotations are the mapper's PARAMETERS (world-frame means, logit
+        opacities, log scales, unnormalised quaternions); frame transform + activations run inside the per-Gaussian kernels (render_rgbd_raw)."""
         lib = _lib.get()
         device = means3D.device
+        leaves = (means3D, opacities, scales, rotations, colors_precomp)     # (raw + accumulate: the backward adds into these tensors' .grad)
         if device.type != "cuda" and not _lib.emulated():
             raise RuntimeError("activesplat_amd rasteriser needs ROCm device tensors (no CPU fallback)")
         P = int(means3D.shape[0])
@@ -152,9 +155,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         d_num = torch.empty(2, dtype=torch.int32, device=device)
         h_num = _host_counters(device, st_handle) if device.type == "cuda" else torch.zeros(2, dtype=torch.int32)
         want_bwd = 1 if any(ctx.needs_input_grad[:8]) else 0
-        _lib.check(lib.gs_preprocess_forward(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
-                                             _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
-                                             _ptr(radii), _ptr(geom), _ptr(image), _ptr(d_num), _ptr(h_num), want_bwd, st))
+        pose = None
+        if raw is not None:
+            pose = (C.c_float * 7)(*[float(v) for v in raw[0]])
+            _lib.check(lib.gs_preprocess_forward_raw(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp), _ptr(opacities),
+                                                     _ptr(scales), _ptr(rotations), pose, 1 if raw[1] else 0, _ptr(radii), _ptr(geom),
+                                                     _ptr(image), _ptr(d_num), _ptr(h_num), want_bwd, st))
+        else:
+            _lib.check(lib.gs_preprocess_forward(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
+                                                 _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+                                                 _ptr(radii), _ptr(geom), _ptr(image), _ptr(d_num), _ptr(h_num), want_bwd, st))
         color = torch.empty(3, H, W, dtype=torch.float32, device=device)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=device)
         opacity = torch.empty(1, H, W, dtype=torch.float32, device=device)
@@ -212,6 +222,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.scratch, ctx.scratch_clean, ctx.sh_jac = scratch, scratch is not None, want_bwd
         ctx.has = (shs is not None, colors_precomp is not None, scales is not None, rotations is not None,
                    cov3D_precomp is not None)
+        ctx.raw = None if raw is None else (pose, 1 if raw[1] else 0, bool(raw[2]), opacities)
+        # in-kernel accumulation only into the very tensors the caller passed (a converted copy has no .grad to add to)
+        same = raw is not None and raw[2] and all(a is b for a, b in zip(leaves, (means3D, opacities, scales, rotations, colors_precomp)))
+        ctx.leaves = leaves if same else None
         if rs.debug:
             last_debug.update(geom=geom, image=image, binning=binning, point_list=point_list, gl=gl, il=il, bl=bl,
                               D=D, P=P, W=W, H=H)
@@ -251,13 +265,43 @@ class _RasterizeGaussians(torch.autograd.Function):
             scratch, clean = torch.empty(int(lib.gs_backward_scratch_bytes(P)), dtype=torch.uint8, device=device), False
         ctx.scratch, ctx.scratch_clean = None, False     # released with this launch (64 B x P); a second backward through the same graph
                                                          # takes a fresh buffer plus a memset
+        if ctx.raw is not None:
+            pose, iso, accumulate, logit = ctx.raw
+            d_sc = z(P, 1 if iso else 3)                  # (gradients w.r.t. the parameters: log scales are [P,1] for an isotropic map)
+            # accumulate: add into the leaves' .grad inside the kernel (what autograd would do with the results in separate passes);
+            # leaves = (means3D, logit opacities, log scales, rotations, colours)
+            leaves, acc, into = ctx.leaves, 0, None
+            if leaves is not None:
+                live = [x for x in leaves if x is not None]
+                ok = all(x.is_leaf and x.requires_grad for x in live)
+                have = [x.grad is not None and x.grad.is_contiguous() and x.grad.dtype == torch.float32 and x.grad.shape == x.shape for x in live]
+                if ok and all(have):
+                    acc, into = 1, [None if x is None else x.grad for x in leaves]
+                elif ok and not any(x.grad is not None for x in live):
+                    into = [None if x is None else torch.empty_like(x, memory_format=torch.contiguous_format) for x in leaves]
+            if into is not None:
+                d_m3d, d_op, d_sc, d_rot = into[0], into[1], into[2], into[3]
+                if has_col:
+                    d_col = into[4]
+            _lib.check(lib.gs_render_backward_raw(
+                C.byref(cam), P, ctx.D, _ptr(means3D), _ptr(shs if has_sh else None), _ptr(colors if has_col else None), _ptr(logit),
+                _ptr(scales), _ptr(rots), pose, iso, acc, _ptr(radii), _ptr(geom), _ptr(point_list), _ptr(image), _ptr(grad_color),
+                _ptr(grad_depth), _ptr(d_m2d), _ptr(d_m3d), _ptr(d_op), _ptr(d_col), _ptr(d_shs), _ptr(d_sc), _ptr(d_rot),
+                _ptr(scratch), 1 if clean else 0, int(ctx.sh_jac), _stream(device)))
+            if into is not None:
+                if not acc:
+                    for x, t in zip(leaves, into):
+                        if x is not None:
+                            x.grad = t
+                return None, d_m2d, d_shs, None, None, None, None, None, None, None, None
+            return d_m3d, d_m2d, d_shs, d_col, d_op, d_sc, d_rot, None, None, None, None
         _lib.check(lib.gs_render_backward(
             C.byref(cam), P, ctx.D, _ptr(means3D), _ptr(shs if has_sh else None), _ptr(colors if has_col else None),
             _ptr(scales if has_sc else None), _ptr(rots if has_rot else None), _ptr(cov3Dp if has_cov else None),
             _ptr(radii), _ptr(geom), _ptr(point_list), _ptr(image), _ptr(grad_color), _ptr(grad_depth),
             _ptr(d_m2d), _ptr(d_m3d), _ptr(d_op), _ptr(d_col), _ptr(d_shs), _ptr(d_sc), _ptr(d_rot), _ptr(d_cov),
             _ptr(scratch), 1 if clean else 0, int(ctx.sh_jac), _stream(device)))
-        return d_m3d, d_m2d, d_shs, d_col, d_op, d_sc, d_rot, d_cov, None, None
+        return d_m3d, d_m2d, d_shs, d_col, d_op, d_sc, d_rot, d_cov, None, None, None
 
 
 def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
@@ -287,6 +331,23 @@ def render_rgbd(raster_settings, means3D, means2D, opacities, shs=None, colors_p
         raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
     return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                      raster_settings, True)
+
+
+def render_rgbd_raw(raster_settings, means3D, means2D, logit_opacities, log_scales, unnorm_rotations, pose7, shs=None, colors_precomp=None,
+                    accumulate_grads=False):
+    """render_rgbd straight from the mapper's PARAMETERS: the frame transform + activations of transform_to_frame /
+    transformed_params2rendervar (slam_helpers.py:252-304,124-139; `mapping.fused_rendervar` does them in two launches of their own) happen
+    inside the per-Gaussian kernels of the rasteriser, forward and backward.  pose7 = host (qw,qx,qy,qz,tx,ty,tz) of the frame's relative
+    w2c (camera quaternion normalised); log_scales [P,1] = isotropic map.  Colours given, or 16-coefficient SH rows.
+    accumulate_grads (for `loss.backward()` over a batch of keyframes): the backward ADDS the gradients of means3D, logit_opacities,
+    log_scales, unnorm_rotations and colors_precomp to those tensors' .grad inside its kernel and hands autograd nothing for them."""
+    if (shs is None) == (colors_precomp is None):
+        raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+    if shs is not None and int(shs.shape[1]) != 16:
+        raise Exception("render_rgbd_raw: SH rows of 16 coefficients only")
+    iso = int(log_scales.shape[1]) == 1
+    return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, logit_opacities, log_scales, unnorm_rotations, None,
+                                     raster_settings, True, (pose7, iso, accumulate_grads))
 
 
 class GaussianRasterizer(nn.Module):

@@ -34,14 +34,15 @@ def configs2_optimise_loop(N, iters, device, fused_densify=True, densify_every=5
 
     def one_iter(it, densify=True):
         params, variables = state["params"], state["variables"]
-        rv = M.fused_rendervar(dict(params, rgb_colors=params["shs"]), 0, [1.0, 0, 0, 0, 0, 0, 0])
-        rv.pop("colors_precomp")
-        rv["means2D"].retain_grad()
-        im, radius, depth, sil, dsq = R.render_rgbd(cam, shs=params["shs"], **rv)
+        # (the per-Gaussian kernels take the parameters themselves: frame transform + activations inside, no activation launches)
+        m2d = torch.empty_like(params["means3D"], requires_grad=True)
+        rv = {"means2D": m2d}
+        im, radius, depth, sil, dsq = R.render_rgbd_raw(cam, params["means3D"], m2d, params["logit_opacities"], params["log_scales"],
+                                                        params["unnorm_rotations"], [1.0, 0, 0, 0, 0, 0, 0], shs=params["shs"])
         loss, _ = M.fused_mapping_loss(im, depth, dsq, gt_im, gt_depth, dict(im=0.5, depth=1.0))
-        loss.backward()
-        variables["means2D"], variables["seen"] = rv["means2D"], radius > 0
-        variables["max_2D_radius"] = torch.maximum(variables["max_2D_radius"], radius.float())
+        loss.backward(M.unit_gradient(loss))             # (cached dL/dloss = 1: no fill launch, and the fused loss skips its scaling launch)
+        variables["means2D"] = rv["means2D"]
+        variables["seen"] = O.visibility_stats(radius, variables["max_2D_radius"])      # one launch: seen + running max radius in place
         with torch.no_grad():
             if it > 0 and densify:
                 n0 = params["means3D"].shape[0]

@@ -9,7 +9,7 @@ single-GPU configuration of BASELINE.json -- configs[2]'s render, the north star
 one 640x480 view, inputs and dL/dcolor resident in HBM.  The K steps run strictly one after the other on one
 stream (the mapper's one-keyframe-per-Adam-step pattern); `value` = frames/s of that sequential loop.
 N > 1: BASELINE.json configs[3] -- 2 M Gaussians replicated on every rank, a batch of 64 keyframes at 640x480 block-partitioned over
-the ranks (64/N each); one "step" = one optimiser step over the batch: every rank renders its keyframes (fused activations ->
+the ranks (64/N each); one "step" = one optimiser step over the batch: every rank renders its keyframes (activations inside the render's per-Gaussian kernels ->
 single-pass RGB-D render -> fused loss -> backward), the flat [N,14] fp32 gradient is reduce-scattered over RCCL, each rank runs the
 fused Adam on its 1/N row block and the updated rows are all-gathered (activesplat_amd/parallel.py).  `value` = keyframes rendered +
 back-propagated per second by the whole job (strong scaling: the batch is fixed); rank 0 also times the same 64-keyframe step alone
@@ -176,8 +176,10 @@ def run_c4(args, dev, rank, world, emit=True):
     weights = dict(im=0.5, depth=1.0)
 
     def loss_fn(p, kf, v):
-        loss, v, _ = M.get_loss(p, kf, v, 0, weights, fused=True, fused_loss=True, fused_inputs=True, pose7=kf["pose7"],
-                                accumulate_grads=args.streams <= 1)      # (the multi-stream walk takes its gradients with autograd.grad)
+        # fused_preprocess: the rasteriser's per-Gaussian kernels take the parameters themselves (no activation launches); accumulate_grads:
+        # they add into .grad in the kernel (the multi-stream walk takes its gradients with autograd.grad instead)
+        loss, v, _ = M.get_loss(p, kf, v, 0, weights, fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=True, pose7=kf["pose7"],
+                                accumulate_grads=args.streams <= 1)
         return loss, v
 
     def barrier():
@@ -250,7 +252,7 @@ def run_c4(args, dev, rank, world, emit=True):
             out["single_gpu_same_workload_fps"] = round(ref, 2)
             out["speedup_vs_single_gpu_same_workload"] = round(out["value"] / ref, 3)
         else:
-            out = {"workload": f"BASELINE configs[3] on ONE GPU: {N} Gaussians, {KF} keyframes per optimiser step (fused activations -> RGB-D render -> "
+            out = {"workload": f"BASELINE configs[3] on ONE GPU: {N} Gaussians, {KF} keyframes per optimiser step (activations inside the per-Gaussian kernels of the RGB-D render -> "
                                "fused loss -> backward per keyframe, fused Adam), no collective", "keyframes_per_s": round(ref, 2),
                    "ms_per_optimiser_step": round(KF / ref * 1e3, 3), "streams": args.streams}
     if world > 1:
@@ -529,7 +531,7 @@ def main():
             dens_ms = [round(x * 1e3, 3) for x in r["densify_seconds"]]
             dens_bytes = 2 * (59 + 118) * 4 * 0.5 * (2_000_000 + n_after)
             out["configs2_loop"] = {
-                "workload": "BASELINE configs[2]: 2M Gaussians, SH degree 3, 640x480, 100-iteration optimise loop (fused activations -> single-pass "
+                "workload": "BASELINE configs[2]: 2M Gaussians, SH degree 3, 640x480, 100-iteration optimise loop (activations inside the per-Gaussian kernels of the single-pass "
                             "RGB-D render -> fused loss -> backward -> fused Adam), densify every 50 iterations (one event in the loop)",
                 "iters": 100, "seconds": round(r["seconds"], 4), "iters_per_s": round(100 / r["seconds"], 2),
                 "gaussians_start": 2_000_000, "gaussians_after_densify": r["counts"], "loss_first_last": r["losses"],

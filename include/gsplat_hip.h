@@ -206,6 +206,24 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D,
                        float* dL_drotations, float* dL_dcov3D, void* scratch, int32_t scratch_zeroed,
                        int32_t have_sh_jacobian, gs_stream_t stream);
 
+/* Raw-parameter mode of the two calls above ("fused pre-activations", one step further than gs_activate_*): the inputs are
+ * the mapper's PARAMETERS -- world-frame means, logit opacities, log scales ([P,3], or [P,1] when isotropic != 0), unnormalised quaternions --
+ * and the frame transform + activations of slam_helpers.py:252-304,124-139 run inside the per-Gaussian kernels (h_pose7: HOST array
+ * {qw,qx,qy,qz,tx,ty,tz} of the frame's relative w2c, as for gs_activate_forward).  Colours given or 16-coefficient SH rows; no precomputed
+ * covariance; one view.  The backward returns the gradients w.r.t. the parameters; accumulate != 0: dL_dmeans3D, dL_dlogit_opacities,
+ * dL_dlog_scales, dL_dunnorm_rotations and dL_dcolors_precomp are ADDED to what the buffers hold (rows of Gaussians that were not rendered stay
+ * untouched) -- the gradient accumulation over the keyframes of a batch without autograd's `grad += new` passes. */
+int gs_preprocess_forward_raw(const GsCamera* cam, int32_t P, const float* means3D, const float* shs, const float* colors_precomp,
+                              const float* logit_opacities, const float* log_scales, const float* unnorm_rotations,
+                              const float* h_pose7, int32_t isotropic, int32_t* radii, void* geom_state, void* image_state,
+                              uint32_t* d_counts, uint32_t* h_counts, int32_t want_backward, gs_stream_t stream);
+int gs_render_backward_raw(const GsCamera* cam, int32_t P, int64_t D, const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* logit_opacities, const float* log_scales, const float* unnorm_rotations, const float* h_pose7,
+                           int32_t isotropic, int32_t accumulate, const int32_t* radii, const void* geom_state, const uint32_t* point_list,
+                           const void* image_state, const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans2D, float* dL_dmeans3D,
+                           float* dL_dlogit_opacities, float* dL_dcolors_precomp, float* dL_dshs, float* dL_dlog_scales,
+                           float* dL_dunnorm_rotations, void* scratch, int32_t scratch_zeroed, int32_t have_sh_jacobian, gs_stream_t stream);
+
 /* Fused dense Adam step over one flat parameter tensor with torch.optim.Adam semantics
  * (non-amsgrad, no weight decay): splatam.py:118-124 uses betas (0.9,0.999), eps 1e-15.
  * `step` is the 1-based step count of this tensor AFTER the increment.  Hyper-parameters are doubles (as the

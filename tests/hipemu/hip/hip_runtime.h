@@ -36,6 +36,7 @@
 typedef int hipError_t;
 typedef void* hipStream_t;
 #define hipSuccess 0
+#define hipErrorInvalidValue 1
 #define hipMemcpyDeviceToHost 2
 #define hipMemcpyHostToDevice 1
 #define hipMemcpyDeviceToDevice 3

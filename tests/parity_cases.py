@@ -137,6 +137,76 @@ def check_whole_quadrants_on_small_images(device, oracle32, oracle64):
         _lib.check(lib.gs_set_half_quadrants(256))
 
 
+def check_raw_parameter_mode(device, n=500):
+    """mapping.get_loss(fused_preprocess=True) -- the rasteriser's per-Gaussian kernels take the mapper's PARAMETERS and do the frame transform
+    + activations themselves (gs_preprocess_forward_raw / gs_render_backward_raw) -- against the activation kernels in front of the rasteriser
+    (fused_inputs) and the reference's torch ops: loss, statistics, gradients; isotropic and anisotropic maps; and, over two keyframes, the
+    in-kernel accumulation into .grad against autograd's."""
+    from activesplat_amd import mapping as M
+    from tests.test_parallel import _scene
+    for iso in (False, True):
+        out = []
+        for mode in ("torch", "kernels", "raw", "raw_acc"):
+            params, kfs = _scene(n=n, device=device)
+            if iso:
+                params["log_scales"] = torch.nn.Parameter(params["log_scales"].detach()[:, :1].clone())
+            nn_ = params["means3D"].shape[0]
+            variables = {k: torch.zeros(nn_, device=device) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+            flags = dict(torch=dict(), kernels=dict(fused=True, fused_loss=True, fused_inputs=True),
+                         raw=dict(fused=True, fused_loss=True, fused_preprocess=True),
+                         raw_acc=dict(fused=True, fused_loss=True, fused_preprocess=True, accumulate_grads=True))[mode]
+            total = 0.0
+            for t in (1, 2):                               # two keyframes: gradients accumulate
+                loss, variables, _ = M.get_loss(params, kfs[t], variables, t, dict(im=0.5, depth=1.0), **flags)
+                loss.backward()
+                total += float(loss.detach())
+            out.append((total, {k: v.grad.clone() for k, v in params.items() if v.grad is not None}, variables["max_2D_radius"].clone(),
+                        variables["seen"].clone()))
+        for o in out[1:]:
+            assert abs(out[0][0] - o[0]) < 4e-6 * abs(out[0][0]), (iso, out[0][0], o[0])
+            assert torch.equal(out[0][2], o[2]) and torch.equal(out[0][3], o[3])
+            for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
+                a, b = out[0][1][k], o[1][k]
+                assert a.shape == b.shape, (k, a.shape, b.shape)
+                if iso and k == "unnorm_rotations":          # equal scales: the rotation does not matter, its gradient is rounding noise
+                    assert float((a - b).norm()) < 1e-5 * float(out[0][1]["means3D"].norm()), (k, float((a - b).norm()))
+                    continue
+                assert float((a - b).norm() / a.norm()) < 3e-4, (iso, k, float((a - b).norm() / a.norm()))
+
+
+def check_raw_parameter_mode_sh(device, n=400, W=64, H=48):
+    """The same with 16-coefficient SH rows (configs[2]'s loop): render_rgbd_raw(shs=...) against fused_rendervar + render_rgbd(shs=...)."""
+    from activesplat_amd import mapping as M, rasterizer as R
+    from activesplat_amd import synthetic as syn
+    from activesplat_amd.camera import setup_camera
+    p = syn.make_params(n, W, H, seed=5, sh_degree=3)
+    cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=device, sh_degree=3)
+    pose = [0.9950042, 0.0, 0.0998334, 0.0, 0.03, -0.02, 0.05]
+    g = torch.Generator().manual_seed(2)
+    dLc, dLd = torch.randn(3, H, W, generator=g).to(device), torch.randn(1, H, W, generator=g).to(device)
+    out = []
+    for raw in (False, True):
+        prm = {k: torch.nn.Parameter(v.clone().to(device)) for k, v in p.items()}
+        if raw:
+            m2d = torch.empty_like(prm["means3D"], requires_grad=True)
+            im, radius, depth, sil, dsq = R.render_rgbd_raw(cam, prm["means3D"], m2d, prm["logit_opacities"], prm["log_scales"], prm["unnorm_rotations"],
+                                                            pose, shs=prm["shs"])
+        else:
+            rv = M.fused_rendervar(dict(prm, rgb_colors=prm["shs"]), 0, pose)
+            rv.pop("colors_precomp")
+            m2d = rv["means2D"]
+            im, radius, depth, sil, dsq = R.render_rgbd(cam, shs=prm["shs"], **rv)
+        ((im * dLc).sum() + (depth * dLd).sum()).backward()
+        out.append((im.detach().clone(), depth.detach().clone(), radius.clone(), {k: v.grad.clone() for k, v in prm.items() if v.grad is not None},
+                    m2d.grad.clone()))
+    a, b = out
+    assert torch.equal(a[2], b[2])
+    assert float((a[0] - b[0]).abs().max()) < 2e-5 and float((a[1] - b[1]).abs().max()) < 2e-4
+    for k in ("means3D", "shs", "unnorm_rotations", "logit_opacities", "log_scales"):
+        assert float((a[3][k] - b[3][k]).norm() / a[3][k].norm()) < 3e-4, (k, float((a[3][k] - b[3][k]).norm() / a[3][k].norm()))
+    assert float((a[4] - b[4]).norm() / a[4].norm()) < 3e-4
+
+
 def check_chained_backward(device, oracle64, N=5000, W=288, H=272, oracle32=None, seed=33):
     """Images of more than 768 tiles walk every quadrant's list in three chained pieces (gs_set_backward_chain): here the threshold is
     lowered so that a 306-tile image takes that path, with splats large and faint enough for walks of several 64-record chunks; against

@@ -114,6 +114,11 @@ def test_emulated_fused_loss_equals_two_pass_loss(emu):
             assert float((a - b).norm() / a.norm()) < 2e-4, k
 
 
+def test_emulated_raw_parameter_rasteriser_equals_the_activation_kernels(emu):
+    pc.check_raw_parameter_mode("cpu")
+    pc.check_raw_parameter_mode_sh("cpu")
+
+
 def test_emulated_optimistic_launch_hit_and_miss_equal_exact_launch(emu):
     pc.check_optimistic_launch(emu)
     pc.check_optimistic_tile_list_growth(emu)
