@@ -561,7 +561,7 @@ def main():
             N1 = 500_000
             params1 = params1 if params1 is not None else syn.make_params(N1, W, H, seed=0)
             cam1 = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=dev)
-            for name, flags in (("reference_call_pattern", {}), ("fused", dict(fused=True, fused_loss=True, fused_inputs=True))):
+            for name, flags in (("reference_call_pattern", {}), ("fused", dict(fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=True))):
                 prm = {k: torch.nn.Parameter(v.to(dev)) for k, v in params1.items()}
                 prm["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([1.0, 0, 0, 0], device=dev).reshape(1, 4, 1))
                 prm["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 1, device=dev))

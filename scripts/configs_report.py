@@ -36,7 +36,7 @@ gt = syn.shell_scene(400_000, seed=2, W=W, H=H)
 gt["logit_opacities"] = gt["logit_opacities"] + 3.0
 seq = list(syn.orbit_sequence(gt, FR, W, H, dev))
 rep = {}
-for name, flags in (("reference_call_pattern", {}), ("fused", dict(fused_render=True, fused_loss=True, fused_inputs=True, fused_growth=True, fused_keyframes=True))):
+for name, flags in (("reference_call_pattern", {}), ("fused", dict(fused_render=True, fused_loss=True, fused_inputs=True, fused_preprocess=True, fused_growth=True, fused_keyframes=True))):
     mp = SplatMapper(syn.intrinsics(W, H), W, H, config=dict(step_num=FR, mapping_iters=10, **flags), device=dev)   # high-res setting: 2 iters/frame
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for fr in seq:

@@ -19,7 +19,7 @@ tim, tdepth = syn.make_targets(W, H)
 data = dict(cam=cam, im=tim.to(dev), depth=tdepth.to(dev), id=0, w2c=torch.eye(4, device=dev))
 opt = O.initialize_optimizer(prm, dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3,
                                        cam_unnorm_rots=0.0, cam_trans=0.0))
-flags = dict(fused=True, fused_loss=True, fused_inputs=True)
+flags = dict(fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=os.environ.get("RAW", "1") == "1")
 
 
 def it():

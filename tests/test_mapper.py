@@ -86,6 +86,21 @@ def test_fused_growth_and_keyframe_scoring_build_the_same_map(emu):
         assert torch.allclose(z, cam[:, 2], rtol=2e-3, atol=2e-3) and bool((z > 0).all())
 
 
+def test_mapper_with_the_raw_parameter_rasteriser_builds_the_same_map(emu):
+    """fused_preprocess (the per-Gaussian kernels take the parameters; no activation launches) against the activation kernels in front of
+    the rasteriser: same schedule and keyframes, map sizes within threshold flips, parameters close after the run."""
+    base = dict(fused_render=True, fused_loss=True, fused_inputs=True)
+    a, _, log_a = run_harness(emu, n_gt=2500, W=48, H=40, frames=6, cfg=base)
+    b, _, log_b = run_harness(emu, n_gt=2500, W=48, H=40, frames=6, cfg=dict(base, fused_preprocess=True))
+    assert [e["keyframes"] for e in log_a] == [e["keyframes"] for e in log_b]
+    na, nb = a.params["means3D"].shape[0], b.params["means3D"].shape[0]
+    assert abs(na - nb) <= max(3, 0.005 * na), (na, nb)
+    if na == nb:
+        for k in ("means3D", "rgb_colors", "logit_opacities", "log_scales"):
+            d = float((a.params[k].detach() - b.params[k].detach()).abs().max())
+            assert d < 5e-3 * max(1.0, float(a.params[k].detach().abs().max())), (k, d)
+
+
 def test_raw_frames_with_densification_resolution(emu):
     """run_raw: uint8 image + metric depth + pose in, resized mapping / densification copies out; the map is seeded and
     grown at the (half) densification resolution while the loss runs at the mapping resolution."""
