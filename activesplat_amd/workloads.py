@@ -9,7 +9,7 @@ from . import synthetic as syn
 from .camera import setup_camera
 
 
-def configs2_optimise_loop(N, iters, device, fused_densify=True, densify_every=50, sh_degree=3, W=640, H=480, seed=0, time_it=False):
+def configs2_optimise_loop(N, iters, device, fused_densify=True, densify_every=50, sh_degree=3, W=640, H=480, seed=0, time_it=False, raw=True):
     """BASELINE configs[2]: N Gaussians with SH coefficients, one 640x480 target, `iters` iterations of
     fused activations -> single-pass RGB-D render -> fused loss -> backward -> densify (every `densify_every`) -> fused Adam.
     Returns dict(losses=[first, last], counts=[N after every densify event], seconds)."""
@@ -34,11 +34,16 @@ def configs2_optimise_loop(N, iters, device, fused_densify=True, densify_every=5
 
     def one_iter(it, densify=True):
         params, variables = state["params"], state["variables"]
-        # (the per-Gaussian kernels take the parameters themselves: frame transform + activations inside, no activation launches)
-        m2d = torch.empty_like(params["means3D"], requires_grad=True)
-        rv = {"means2D": m2d}
-        im, radius, depth, sil, dsq = R.render_rgbd_raw(cam, params["means3D"], m2d, params["logit_opacities"], params["log_scales"],
-                                                        params["unnorm_rotations"], [1.0, 0, 0, 0, 0, 0, 0], shs=params["shs"])
+        if raw:
+            # the per-Gaussian kernels take the parameters themselves: frame transform + activations inside, no activation launches
+            m2d = torch.empty_like(params["means3D"], requires_grad=True)
+            rv = {"means2D": m2d}
+            im, radius, depth, sil, dsq = R.render_rgbd_raw(cam, params["means3D"], m2d, params["logit_opacities"], params["log_scales"],
+                                                            params["unnorm_rotations"], [1.0, 0, 0, 0, 0, 0, 0], shs=params["shs"])
+        else:
+            rv = M.fused_rendervar(dict(params, rgb_colors=params["shs"]), 0, [1.0, 0, 0, 0, 0, 0, 0])
+            rv.pop("colors_precomp")
+            im, radius, depth, sil, dsq = R.render_rgbd(cam, shs=params["shs"], **rv)
         loss, _ = M.fused_mapping_loss(im, depth, dsq, gt_im, gt_depth, dict(im=0.5, depth=1.0))
         loss.backward(M.unit_gradient(loss))             # (cached dL/dloss = 1: no fill launch, and the fused loss skips its scaling launch)
         variables["means2D"] = rv["means2D"]
@@ -63,6 +68,10 @@ def configs2_optimise_loop(N, iters, device, fused_densify=True, densify_every=5
         for _ in range(3):
             one_iter(0)
         if dev.type == "cuda":
+            # the caching allocator's pool at the high-water mark of a densify event (new parameter + moment tensors: ~3 x 59 floats per
+            # Gaussian), as a mapper that has densified before finds it: without it the timed event is a series of hipMalloc calls (1 -> 23 ms)
+            pool = torch.empty(int(N * 1.05) * 3 * 59 * 4, dtype=torch.uint8, device=dev)
+            del pool
             torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(iters):
