@@ -44,7 +44,15 @@ def _loss_fn(params, kf, variables):
     return loss, variables
 
 
-def _worker(rank, world, port, emu_path, q, device="cpu"):
+def _loss_fn_raw(params, kf, variables):
+    """The keyframe loss as bench.py's configs[3] step takes it: raw-parameter rasteriser, fused loss, gradients added into .grad in the kernel."""
+    from activesplat_amd import mapping as M
+    loss, variables, _ = M.get_loss(params, kf, variables, kf["id"], dict(im=0.5, depth=1.0), fused=True, fused_loss=True, fused_preprocess=True,
+                                    accumulate_grads=True)
+    return loss, variables
+
+
+def _worker(rank, world, port, emu_path, q, device="cpu", raw=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -67,7 +75,7 @@ def _worker(rank, world, port, emu_path, q, device="cpu"):
                 seq[k] += params[k].grad
         opt = O.initialize_optimizer(params, lrs)
         assert list(PL.shard_keyframes(len(kfs), rank, world)) == [2 * rank, 2 * rank + 1]
-        _, variables, buf = PL.sharded_keyframe_step(params, variables, kfs, opt, _loss_fn)
+        _, variables, buf = PL.sharded_keyframe_step(params, variables, kfs, opt, _loss_fn_raw if raw else _loss_fn)
         assert buf.flat.shape == (n, 14)
         err = max(float((buf.flat[:, c0:c0 + w] - seq[k]).abs().max() / (seq[k].abs().max() + 1e-12))
                   for k, w, c0 in zip(buf.keys, buf.widths, np.cumsum([0] + buf.widths[:-1])))
@@ -102,6 +110,24 @@ def test_two_rank_gradient_allreduce_equals_sequential_sum(emu_lib_path):
         assert p.exitcode == 0
     for rank, err, same, mx, den in res:
         assert err < 1e-5, (rank, err)          # fp32 sum order differs (local accumulate + ring) but only at rounding level
+        assert same and mx == 2.0 and den == 2.0
+
+
+def test_two_rank_step_with_in_kernel_accumulation_equals_sequential_sum(emu_lib_path):
+    """The same with the keyframe loss of bench.py's configs[3] step (raw-parameter rasteriser, fused loss, the backward adds into .grad in its
+    kernel): the all-reduced gradient equals the sequential sum of the reference-pattern gradients up to the fused paths' rounding."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu_lib_path, q, "cpu", True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, same, mx, den in res:
+        assert err < 1e-3, (rank, err)
         assert same and mx == 2.0 and den == 2.0
 
 
