@@ -164,7 +164,11 @@ def check_raw_parameter_mode(device, n=500):
                         variables["seen"].clone()))
         for o in out[1:]:
             assert abs(out[0][0] - o[0]) < 4e-6 * abs(out[0][0]), (iso, out[0][0], o[0])
-            assert torch.equal(out[0][2], o[2]) and torch.equal(out[0][3], o[3])
+            # (the activations are not bit-identical between torch, activate.hip and the contraction-free per-Gaussian kernels: a radius --
+            # ceil(3 sigma) -- may flip by one for a Gaussian on the boundary, which also moves `seen` for radius 0 <-> 1)
+            dr = (out[0][2] - o[2]).abs()
+            assert float(dr.max()) <= 1.0 and float((dr > 0).float().mean()) < 5e-4, (iso, float(dr.max()), int((dr > 0).sum()))
+            assert float((out[0][3] != o[3]).float().mean()) < 5e-4, int((out[0][3] != o[3]).sum())
             for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
                 a, b = out[0][1][k], o[1][k]
                 assert a.shape == b.shape, (k, a.shape, b.shape)
@@ -200,8 +204,12 @@ def check_raw_parameter_mode_sh(device, n=400, W=64, H=48):
         out.append((im.detach().clone(), depth.detach().clone(), radius.clone(), {k: v.grad.clone() for k, v in prm.items() if v.grad is not None},
                     m2d.grad.clone()))
     a, b = out
-    assert torch.equal(a[2], b[2])
-    assert float((a[0] - b[0]).abs().max()) < 2e-5 and float((a[1] - b[1]).abs().max()) < 2e-4
+    dr = (a[2] - b[2]).abs()
+    assert int(dr.max()) <= 1 and float((dr > 0).float().mean()) < 5e-4, (int(dr.max()), int((dr > 0).sum()))      # (see above: boundary radii)
+    # images: equal up to the activations' rounding, except where it flips an alpha >= 1/255 / T >= 1e-4 test of a pixel (bounded, rare)
+    for x, y, tol in ((a[0], b[0], 5e-5), (a[1], b[1], 5e-4)):
+        d = (x - y).abs()
+        assert float((d > tol).float().mean()) < 1e-3 and float(d.max()) < 0.02 * max(1.0, float(y.abs().max())), (float(d.max()), int((d > tol).sum()))
     for k in ("means3D", "shs", "unnorm_rotations", "logit_opacities", "log_scales"):
         assert float((a[3][k] - b[3][k]).norm() / a[3][k].norm()) < 3e-4, (k, float((a[3][k] - b[3][k]).norm() / a[3][k].norm()))
     assert float((a[4] - b[4]).norm() / a[4].norm()) < 3e-4
