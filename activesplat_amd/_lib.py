@@ -84,8 +84,8 @@ def _bind(lib):
     lib.gs_preprocess_forward.argtypes = [C.POINTER(GsCamera), i32] + [vp] * 7 + [vp, vp, vp, vp, vp, i32, vp]
     lib.gs_render_forward.argtypes = [C.POINTER(GsCamera), i32, i64, C.c_uint32] + [vp] * 8 + [vp, vp]
     lib.gs_render_backward.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 6 + [vp] * 6 + [vp] * 8 + [vp, i32, i32, vp]
-    # (cam, P, means3D, shs, colors, logit, log_scales, unnorm_rot, h_pose7, isotropic, radii, geom, image, d_counts, h_counts, want_backward, stream)
-    lib.gs_preprocess_forward_raw.argtypes = [C.POINTER(GsCamera), i32] + [vp] * 6 + [vp, i32] + [vp] * 5 + [i32, vp]
+    # (cam, P, means3D, shs, colors, logit, log_scales, unnorm_rot, h_pose7, isotropic, max_2D_radius, seen, radii, geom, image, d_counts, h_counts, want_backward, stream)
+    lib.gs_preprocess_forward_raw.argtypes = [C.POINTER(GsCamera), i32] + [vp] * 6 + [vp, i32] + [vp, vp] + [vp] * 5 + [i32, vp]
     # (cam, P, D, means3D, shs, colors, logit, log_scales, unnorm_rot, h_pose7, isotropic, accumulate, radii, geom, point_list, image,
     #  dL_dcolor, dL_ddepth, 7 gradient outputs, scratch, scratch_zeroed, have_sh_jacobian, stream)
     lib.gs_render_backward_raw.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 6 + [vp, i32, i32] + [vp] * 4 + [vp] * 2 + [vp] * 7 + [vp, i32, i32, vp]

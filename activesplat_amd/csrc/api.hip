@@ -103,6 +103,7 @@ gs::GeomPtrs carve_geom(void* base, int32_t P, const gs::Cam& k)
     g.tile_total = (uint32_t*)(b + L.tile_total); g.tile_base = (uint32_t*)(b + L.tile_base);
     g.sh_jac = (float2*)(b + L.sh_jac);
     g.depth_bits = (uint32_t*)(b + L.depth_bits);
+    g.vis_max = nullptr; g.vis_seen = nullptr;
     return g;
 }
 
@@ -268,7 +269,7 @@ static int preprocess_forward_impl(const GsCamera* cam, int32_t P, const float* 
                                    const float* colors_precomp, const float* opacities, const float* scales,
                                    const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_state,
                                    void* image_state, uint32_t* d_counts, uint32_t* h_counts, int32_t want_backward, gs_stream_t stream,
-                                   const float* h_pose7, int32_t isotropic)
+                                   const float* h_pose7, int32_t isotropic, float* max_2D_radius, uint8_t* seen)
 {
     gs::Cam k;
     if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_preprocess_forward: invalid camera settings");
@@ -288,6 +289,7 @@ static int preprocess_forward_impl(const GsCamera* cam, int32_t P, const float* 
     const int32_t Pv = virtual_count(k, P);
     gs::GeomPtrs gp = carve_geom(geom_state, Pv, k);
     if (!(want_backward && shs)) gp.sh_jac = nullptr;        // written only for SH inputs whose backward will follow
+    gp.vis_max = k.act ? max_2D_radius : nullptr; gp.vis_seen = k.act ? seen : nullptr;
     GsImageLayout IL; gs_image_layout(k.W, k.H, &IL);
     uint2* ranges = (uint2*)((char*)image_state + IL.ranges);
     const int tiles = k.gx * k.gy;
@@ -326,17 +328,17 @@ int gs_preprocess_forward(const GsCamera* cam, int32_t P, const float* means3D, 
                           void* image_state, uint32_t* d_counts, uint32_t* h_counts, int32_t want_backward, gs_stream_t stream)
 {
     return preprocess_forward_impl(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, geom_state,
-                                   image_state, d_counts, h_counts, want_backward, stream, nullptr, 0);
+                                   image_state, d_counts, h_counts, want_backward, stream, nullptr, 0, nullptr, nullptr);
 }
 
 int gs_preprocess_forward_raw(const GsCamera* cam, int32_t P, const float* means3D, const float* shs, const float* colors_precomp,
                               const float* logit_opacities, const float* log_scales, const float* unnorm_rotations,
-                              const float* h_pose7, int32_t isotropic, int32_t* radii, void* geom_state, void* image_state,
-                              uint32_t* d_counts, uint32_t* h_counts, int32_t want_backward, gs_stream_t stream)
+                              const float* h_pose7, int32_t isotropic, float* max_2D_radius, uint8_t* seen, int32_t* radii, void* geom_state,
+                              void* image_state, uint32_t* d_counts, uint32_t* h_counts, int32_t want_backward, gs_stream_t stream)
 {
     if (!h_pose7) return fail(GS_EINVAL, "gs_preprocess_forward_raw: null pose");
     return preprocess_forward_impl(cam, P, means3D, shs, colors_precomp, logit_opacities, log_scales, unnorm_rotations, nullptr, radii,
-                                   geom_state, image_state, d_counts, h_counts, want_backward, stream, h_pose7, isotropic);
+                                   geom_state, image_state, d_counts, h_counts, want_backward, stream, h_pose7, isotropic, max_2D_radius, seen);
 }
 
 

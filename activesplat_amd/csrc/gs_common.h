@@ -122,6 +122,10 @@ struct GeomPtrs {
     uint32_t* depth_bits;  // [P]: bit pattern of the view-space depth (the binning key), compact copy of geom[.][9] for coalesced reads
     float2* sh_jac;        // [P][5]: d(rgb before the clamp)/d(unit view direction), 3x3 row-major, and the colour clamp flags in the tenth word
                            // (SH inputs with a backward to follow): 40 B per Gaussian
+    // raw-parameter mode only (caller's tensors, not part of the workspace): the mapper's visibility statistics of this render --
+    // vis_max[i] = max(vis_max[i], radius), vis_seen[i] = radius > 0 (splatam.py:296-298) -- written where the radius is computed
+    float* vis_max;
+    uint8_t* vis_seen;
 };
 
 // ---- wave-64 helpers ---------------------------------------------------------------------------

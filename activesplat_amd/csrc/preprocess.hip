@@ -54,9 +54,10 @@ template <bool HAS_SH>
 __device__ __forceinline__ uint32_t project_gaussian(const Cam& cam, int P, int view, int i, int io, int tid, const float* s_mean,
                                                      const float* s_scale, const float* s_rot, const float* s_cov, const float* s_col,
                                                      bool has_cov, float o, const float (&sh_rgb)[3], uint32_t sh_clamp,
-                                                     int32_t* __restrict__ radii, const GeomPtrs& gp)
+                                                     int32_t* __restrict__ radii, const GeomPtrs& gp, int* radius_out = nullptr)
 {
     uint32_t ntiles = 0;
+    if (radius_out) *radius_out = 0;
     if (i < P) {
         const float* m = cam.view + 16 * view;
         const float* q = cam.proj + 16 * view;
@@ -157,6 +158,7 @@ __device__ __forceinline__ uint32_t project_gaussian(const Cam& cam, int P, int 
             }
         }
         radii[io] = radius;
+        if (radius_out) *radius_out = radius;
         gp.geom[(size_t)io * 3] = g0; gp.geom[(size_t)io * 3 + 1] = g1; gp.geom[(size_t)io * 3 + 2] = g2;
         gp.rect[io] = rc;
         gp.tiles[io] = ntiles;
@@ -290,8 +292,13 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
         else { stage_rows<3>(s_scale, scales, base, nrows, tid); stage_rows<4>(s_rot, rots, base, nrows, tid); }
         __syncthreads();
     }
+    int radius = 0;
     const uint32_t ntiles = project_gaussian<HAS_SH>(cam, P, view, i, io, tid, s_mean, s_scale, s_rot, s_cov, s_col, cov3Dp != nullptr, o_in,
-                                                     sh_rgb, sh_clamp, radii, gp);
+                                                     sh_rgb, sh_clamp, radii, gp, ACT ? &radius : nullptr);
+    if (ACT && i < P) {                                   // the mapper's visibility statistics of this render (raw-parameter mode)
+        if (gp.vis_max) gp.vis_max[i] = fmaxf(gp.vis_max[i], (float)radius);
+        if (gp.vis_seen) gp.vis_seen[i] = radius > 0 ? 1 : 0;
+    }
     // per-block tile count -> block_sums (scanned by scan_block_sums_kernel)
     const uint32_t ws = wave_sum_u32(ntiles);
     if ((tid & 63) == 0) s_wsum[tid >> 6] = ws;
@@ -367,8 +374,13 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_forward_sh48_kernel(
             sh_rgb[0] = fmaxf(acc[0], 0.f); sh_rgb[1] = fmaxf(acc[1], 0.f); sh_rgb[2] = fmaxf(acc[2], 0.f);
         }
     }
+    int radius = 0;
     const uint32_t ntiles = project_gaussian<true>(cam, P, view, i, io, tid, s_mean, s_scale, s_rot, s_cov, nullptr, cov3Dp != nullptr, o_in,
-                                                   sh_rgb, sh_clamp, radii, gp);
+                                                   sh_rgb, sh_clamp, radii, gp, ACT ? &radius : nullptr);
+    if (ACT && i < P) {
+        if (gp.vis_max) gp.vis_max[i] = fmaxf(gp.vis_max[i], (float)radius);
+        if (gp.vis_seen) gp.vis_seen[i] = radius > 0 ? 1 : 0;
+    }
     const uint32_t ws = wave_sum_u32(ntiles);
     if (lane == 0) s_wsum[wave] = ws;
     __syncthreads();

@@ -316,14 +316,23 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
             q = F.normalize(params["cam_unnorm_rots"][..., iter_time_idx].detach()).reshape(4)
             pose7 = torch.cat([q, params["cam_trans"][..., iter_time_idx].detach().reshape(3)]).cpu().tolist()
         m2d = torch.empty_like(params["means3D"], requires_grad=True)      # gradient carrier only (see fused_rendervar)
+        # seen + the running max radius are written by the render's per-Gaussian kernel where the tensors allow it
+        mx = variables["max_2D_radius"]
+        stats_in_render = fused_loss and use_l1 and not ignore_outlier_depth_loss and mx.dtype == torch.float32 and mx.is_contiguous() \
+            and mx.device == params["means3D"].device and mx.numel() == params["means3D"].shape[0]
+        seen = torch.empty(mx.numel(), dtype=torch.bool, device=mx.device) if stats_in_render else None
         im, radius, depth, _sil, depth_sq = render_rgbd_raw(curr_data["cam"], params["means3D"], m2d, params["logit_opacities"],
                                                              params["log_scales"], params["unnorm_rotations"], pose7,
-                                                             colors_precomp=params["rgb_colors"], accumulate_grads=accumulate_grads)
+                                                             colors_precomp=params["rgb_colors"], accumulate_grads=accumulate_grads,
+                                                             visibility=(mx, seen) if stats_in_render else None)
         variables["means2D"] = m2d
         if fused_loss and use_l1 and not ignore_outlier_depth_loss:
             loss, weighted = fused_mapping_loss(im, depth, depth_sq, curr_data["im"], curr_data["depth"], loss_weights)
-            from . import optim as O
-            variables["seen"] = O.visibility_stats(radius, variables["max_2D_radius"])
+            if stats_in_render:
+                variables["seen"] = seen
+            else:
+                from . import optim as O
+                variables["seen"] = O.visibility_stats(radius, variables["max_2D_radius"])
             return loss, variables, weighted
         rendervar = None
     elif fused_inputs and not do_ba:

@@ -158,9 +158,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         pose = None
         if raw is not None:
             pose = (C.c_float * 7)(*[float(v) for v in raw[0]])
+            vis_max, vis_seen = raw[3] if len(raw) > 3 and raw[3] is not None else (None, None)
             _lib.check(lib.gs_preprocess_forward_raw(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp), _ptr(opacities),
-                                                     _ptr(scales), _ptr(rotations), pose, 1 if raw[1] else 0, _ptr(radii), _ptr(geom),
-                                                     _ptr(image), _ptr(d_num), _ptr(h_num), want_bwd, st))
+                                                     _ptr(scales), _ptr(rotations), pose, 1 if raw[1] else 0, _ptr(vis_max), _ptr(vis_seen),
+                                                     _ptr(radii), _ptr(geom), _ptr(image), _ptr(d_num), _ptr(h_num), want_bwd, st))
         else:
             _lib.check(lib.gs_preprocess_forward(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
                                                  _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
@@ -334,20 +335,28 @@ def render_rgbd(raster_settings, means3D, means2D, opacities, shs=None, colors_p
 
 
 def render_rgbd_raw(raster_settings, means3D, means2D, logit_opacities, log_scales, unnorm_rotations, pose7, shs=None, colors_precomp=None,
-                    accumulate_grads=False):
+                    accumulate_grads=False, visibility=None):
     """render_rgbd straight from the mapper's PARAMETERS: the frame transform + activations of transform_to_frame /
     transformed_params2rendervar (slam_helpers.py:252-304,124-139; `mapping.fused_rendervar` does them in two launches of their own) happen
     inside the per-Gaussian kernels of the rasteriser, forward and backward.  pose7 = host (qw,qx,qy,qz,tx,ty,tz) of the frame's relative
     w2c (camera quaternion normalised); log_scales [P,1] = isotropic map.  Colours given, or 16-coefficient SH rows.
     accumulate_grads (for `loss.backward()` over a batch of keyframes): the backward ADDS the gradients of means3D, logit_opacities,
-    log_scales, unnorm_rotations and colors_precomp to those tensors' .grad inside its kernel and hands autograd nothing for them."""
+    log_scales, unnorm_rotations and colors_precomp to those tensors' .grad inside its kernel and hands autograd nothing for them.
+    visibility = (max_2D_radius [P] float32, seen [P] bool), both contiguous on the device: the mapper's statistics of this render
+    (splatam.py:296-298: max_2D_radius = max(max_2D_radius, radius) in place, seen = radius > 0) written by the forward kernel itself."""
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
     if shs is not None and int(shs.shape[1]) != 16:
         raise Exception("render_rgbd_raw: SH rows of 16 coefficients only")
     iso = int(log_scales.shape[1]) == 1
+    if visibility is not None:
+        mx, seen = visibility
+        P = int(means3D.shape[0])
+        if not (mx.dtype == torch.float32 and mx.is_contiguous() and mx.numel() == P and seen.dtype == torch.bool and seen.is_contiguous()
+                and seen.numel() == P and mx.device == means3D.device and seen.device == means3D.device):
+            raise Exception("render_rgbd_raw: visibility = (float32 [P], bool [P]) contiguous tensors on the parameters' device")
     return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, logit_opacities, log_scales, unnorm_rotations, None,
-                                     raster_settings, True, (pose7, iso, accumulate_grads))
+                                     raster_settings, True, (pose7, iso, accumulate_grads, visibility))
 
 
 class GaussianRasterizer(nn.Module):

@@ -212,11 +212,13 @@ int gs_render_backward(const GsCamera* cam, int32_t P, int64_t D,
  * {qw,qx,qy,qz,tx,ty,tz} of the frame's relative w2c, as for gs_activate_forward).  Colours given or 16-coefficient SH rows; no precomputed
  * covariance; one view.  The backward returns the gradients w.r.t. the parameters; accumulate != 0: dL_dmeans3D, dL_dlogit_opacities,
  * dL_dlog_scales, dL_dunnorm_rotations and dL_dcolors_precomp are ADDED to what the buffers hold (rows of Gaussians that were not rendered stay
- * untouched) -- the gradient accumulation over the keyframes of a batch without autograd's `grad += new` passes. */
+ * untouched) -- the gradient accumulation over the keyframes of a batch without autograd's `grad += new` passes.
+ * max_2D_radius / seen (both nullable): the mapper's visibility statistics of this render, as gs_visibility_stats would leave them --
+ * max_2D_radius[i] = max(max_2D_radius[i], radii[i]) in place, seen[i] = radii[i] > 0 -- written by the forward kernel itself. */
 int gs_preprocess_forward_raw(const GsCamera* cam, int32_t P, const float* means3D, const float* shs, const float* colors_precomp,
                               const float* logit_opacities, const float* log_scales, const float* unnorm_rotations,
-                              const float* h_pose7, int32_t isotropic, int32_t* radii, void* geom_state, void* image_state,
-                              uint32_t* d_counts, uint32_t* h_counts, int32_t want_backward, gs_stream_t stream);
+                              const float* h_pose7, int32_t isotropic, float* max_2D_radius, uint8_t* seen, int32_t* radii, void* geom_state,
+                              void* image_state, uint32_t* d_counts, uint32_t* h_counts, int32_t want_backward, gs_stream_t stream);
 int gs_render_backward_raw(const GsCamera* cam, int32_t P, int64_t D, const float* means3D, const float* shs, const float* colors_precomp,
                            const float* logit_opacities, const float* log_scales, const float* unnorm_rotations, const float* h_pose7,
                            int32_t isotropic, int32_t accumulate, const int32_t* radii, const void* geom_state, const uint32_t* point_list,
