@@ -53,6 +53,30 @@ def test_no_cpu_fallback_and_argument_errors():
           scales=rv["scales"], rotations=rv["rotations"], cov3D_precomp=torch.zeros(10, 6))
 
 
+def test_raw_parameter_entry_points_refuse_what_they_do_not_take():
+    """render_rgbd_raw: exactly one of colours / SH rows, SH rows of 16 coefficients only, visibility tensors of the stated types; the
+    knob gs_set_backward_chain refuses piece counts outside 1..3 (all checked before anything touches the device)."""
+    import __graft_entry__ as ge
+    from activesplat_amd import _lib, rasterizer as R
+    from tests import util
+    ge.build()
+    _lib.unload_for_tests()
+    lib = _lib.get()
+    rs, rv = util.scene(10, 32, 32)
+    m2d = torch.zeros(10, 3)
+    raw = dict(means3D=rv["means3D"], means2D=m2d, logit_opacities=torch.zeros(10, 1), log_scales=torch.zeros(10, 3),
+               unnorm_rotations=rv["rotations"], pose7=[1.0, 0, 0, 0, 0, 0, 0])
+    with pytest.raises(Exception, match="either SHs or precomputed colors"):
+        R.render_rgbd_raw(rs, **raw)
+    with pytest.raises(Exception, match="16 coefficients"):
+        R.render_rgbd_raw(rs, shs=torch.zeros(10, 9, 3), **raw)
+    with pytest.raises(Exception, match="visibility"):
+        R.render_rgbd_raw(rs, colors_precomp=rv["colors_precomp"], visibility=(torch.zeros(10, dtype=torch.float64), torch.zeros(10, dtype=torch.bool)), **raw)
+    assert lib.gs_set_backward_chain(0, -1) != 0 and b"pieces out of range" in lib.gs_last_error()
+    assert lib.gs_set_backward_chain(4, -1) != 0
+    assert lib.gs_set_backward_chain(3, -1) == 0
+
+
 def test_dropin_module_name_and_settings_tuple():
     import diff_gaussian_rasterization as d
     from diff_gaussian_rasterization import GaussianRasterizationSettings as Camera
