@@ -308,7 +308,7 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
     accumulate_grads (with fused_inputs, for `loss.backward()` over a batch of keyframes): the activation backward ADDS its gradients to
                  the four per-Gaussian parameters' .grad in the kernel instead of handing them to autograd's accumulation passes; gradients
                  taken with torch.autograd.grad are not delivered in this mode.
-    fused_preprocess (with fused; isotropic or anisotropic scale / rotation parameters, `rgb_colors`): no activation launches at all -- the
+    fused_preprocess (with fused; isotropic or anisotropic scale / rotation parameters, `rgb_colors` or 16-coefficient `shs` rows): no activation launches at all -- the
                  rasteriser's per-Gaussian kernels take the PARAMETERS and do the frame transform + activations themselves, forward and
                  backward (rasterizer.render_rgbd_raw); with accumulate_grads the backward also adds into the parameters' .grad."""
     if fused_preprocess and fused and not do_ba:
@@ -323,7 +323,8 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
         seen = torch.empty(mx.numel(), dtype=torch.bool, device=mx.device) if stats_in_render else None
         im, radius, depth, _sil, depth_sq = render_rgbd_raw(curr_data["cam"], params["means3D"], m2d, params["logit_opacities"],
                                                              params["log_scales"], params["unnorm_rotations"], pose7,
-                                                             colors_precomp=params["rgb_colors"], accumulate_grads=accumulate_grads,
+                                                             colors_precomp=None if "shs" in params else params["rgb_colors"],
+                                                             shs=params.get("shs"), accumulate_grads=accumulate_grads,
                                                              visibility=(mx, seen) if stats_in_render else None)
         variables["means2D"] = m2d
         if fused_loss and use_l1 and not ignore_outlier_depth_loss:

@@ -15,6 +15,22 @@ import torch
 import torch.distributed as dist
 
 GRAD_KEYS = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales")
+#: maps whose colour is a row of SH coefficients (BASELINE configs[2]: `shs` [N,16,3]) exchange those rows in place of `rgb_colors`:
+#: G = 3 + 48 + 4 + 1 + 3 = 59 floats per Gaussian, 472 MB at N = 2 M
+SH_KEY = "shs"
+
+
+def grad_keys(params):
+    """The per-Gaussian tensors of `params` whose gradients one optimiser step exchanges, in flat-buffer column order."""
+    return [k for k in ("means3D", "rgb_colors", SH_KEY, "unnorm_rotations", "logit_opacities", "log_scales") if k in params]
+
+
+def _row_width(p) -> int:
+    """floats per Gaussian of a per-Gaussian tensor ([N,3] -> 3, [N,16,3] -> 48)"""
+    w = 1
+    for d in p.shape[1:]:
+        w *= int(d)
+    return w
 
 
 def shard_keyframes(num_keyframes: int, rank: int, world: int) -> range:
@@ -31,6 +47,18 @@ last_exchange = {}
 
 def _backend(group=None) -> str:
     return str(dist.get_backend(group)).lower()
+
+
+def _rccl_collectives(t, group=None) -> bool:
+    """Does this group run the tensor collectives (reduce_scatter_tensor / all_gather_into_tensor) for `t`?  "nccl" (= RCCL on ROCm) in the
+    backend's name decides; a group made without an explicit backend ("cpu:gloo,cuda:nccl", which some torch versions report as
+    "undefined") is decided by where the tensor lives."""
+    b = _backend(group)
+    if "nccl" in b:
+        return True
+    if b == "gloo":
+        return False
+    return bool(t.is_cuda)
 
 
 def _stream(t):
@@ -55,7 +83,7 @@ def _row_tensors(params, keys, optimizer=None, target="param"):
             g = g.contiguous().float()
         keep.append(g)
         t = arr[i]
-        t.width = int(p.shape[1])
+        t.width = _row_width(p)
         t.grad = g.data_ptr() if g is not None else None
         t.param = (g.data_ptr() if g is not None else None) if target == "grad" else p.data_ptr()
         t.step = 1
@@ -71,9 +99,11 @@ class FlatGradBuffer:
     """One contiguous [N_padded, G] fp32 buffer that the per-key gradients are packed into for a single collective
     (gs_pack_columns: ONE launch writes gradients, zero columns of keys without a gradient and the zero padding rows)."""
 
-    def __init__(self, params, keys=GRAD_KEYS, pad_to=1):
-        self.keys = [k for k in keys if k in params]
-        self.widths = [params[k].shape[1] for k in self.keys]
+    def __init__(self, params, keys=None, pad_to=1):
+        self.keys = grad_keys(params) if keys is None else [k for k in keys if k in params]
+        self.widths = [_row_width(params[k]) for k in self.keys]
+        if sum(self.widths) > 64:
+            raise RuntimeError(f"keyframe-sharded step: {sum(self.widths)} floats per Gaussian, gs_pack_columns takes at most 64")
         self.n = int(params[self.keys[0]].shape[0])
         self.n_padded = (self.n + pad_to - 1) // pad_to * pad_to
         dev = params[self.keys[0]].device
@@ -137,9 +167,13 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
     world = (dist.get_world_size() if on else 1) if world is None else world
     optimizer.zero_grad(set_to_none=True)
     mine = list(shard_keyframes(len(keyframes), rank, world))
-    dev = params[GRAD_KEYS[0]].device
+    keys = grad_keys(params)
+    dev = params[keys[0]].device
+    rev = None
+    if timing and dev.type == "cuda":                   # this rank's keyframes (render + loss + backward), event-timed: bench.py's per-rank figure
+        rev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        rev[0].record()
     if streams > 1 and dev.type == "cuda" and len(mine) > 1 and not densify_statistics:
-        keys = [k for k in GRAD_KEYS if k in params]
         main = torch.cuda.current_stream(dev)
         pool = [torch.cuda.Stream(device=dev) for _ in range(streams)]
         for s in pool:
@@ -153,6 +187,12 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
             with torch.cuda.stream(pool[n % streams]):
                 loss, vs[n % streams] = loss_fn(params, keyframes[i], vs[n % streams])
                 g = torch.autograd.grad(loss, [params[k] for k in keys], allow_unused=True)
+                if all(x is None for x in g):
+                    # a loss_fn with accumulate_grads=True (mapping.get_loss / rasterizer.render_rgbd_raw) adds its gradients into .grad inside
+                    # the backward kernel and hands autograd nothing: on this multi-stream walk they would be replaced by zeros -- and the
+                    # kernels of several side streams would be adding into one .grad without ordering
+                    raise RuntimeError("sharded_keyframe_step(streams > 1): loss_fn returned no gradient for any per-Gaussian tensor -- in-kernel "
+                                       "gradient accumulation (accumulate_grads=True) only works on the serial walk (streams=1)")
                 g = [torch.zeros_like(params[k]) if x is None else x for k, x in zip(keys, g)]
                 if partial[n % streams] is None:
                     partial[n % streams] = list(g)
@@ -185,6 +225,9 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
             loss.backward(unit_gradient(loss) if loss.dim() == 0 else None)
             losses.append(loss.detach())          # (read after the loop: a float() here would stall the host once per keyframe)
         total = float(torch.stack(losses).sum()) if losses else 0.0
+    if rev is not None:
+        rev[1].record()
+        last_exchange["render_events"] = rev
     if world <= 1 or not on:
         optimizer.step()                         # one rank (or a caller that overrides rank/world to run the batch alone): no collective
     elif sharded_adam:
@@ -211,7 +254,7 @@ def _reduce_scatter_rows(flat_padded, out, rank, group):
     development knob of bench.py) has no reduce-scatter: all-reduce, then the row block.  The branch is decided by the BACKEND --
     a collective that fails raises."""
     rows = out.shape[0]
-    if _backend(group) == "nccl":
+    if _rccl_collectives(out, group):
         dist.reduce_scatter_tensor(out, flat_padded, op=dist.ReduceOp.SUM, group=group)
         return "reduce_scatter_tensor"
     dist.all_reduce(flat_padded, op=dist.ReduceOp.SUM, group=group)
@@ -220,7 +263,7 @@ def _reduce_scatter_rows(flat_padded, out, rank, group):
 
 
 def _all_gather_rows(full_padded, mine, group):
-    if _backend(group) == "nccl":
+    if _rccl_collectives(mine, group):
         dist.all_gather_into_tensor(full_padded, mine, group=group)
         return "all_gather_into_tensor"
     parts = list(full_padded.chunk(dist.get_world_size(group), dim=0))
@@ -234,14 +277,15 @@ def reduce_scatter_adam_step(params, optimizer, group=None, timing=False):
     buffer) -> all-gather -> unpack (1 launch).  The buffers live on the optimizer and are reused from step to step."""
     from . import _lib
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    keys = [k for k in GRAD_KEYS if k in params]
+    keys = grad_keys(params)
     n = int(params[keys[0]].shape[0])
     plan = getattr(optimizer, "_shard_plan", None)
-    if plan is None or plan["n"] != n or plan["world"] != world or plan["buf"].padded.device != params[keys[0]].device:
+    ident = (n, world, rank, id(group), tuple(keys), params[keys[0]].device)
+    if plan is None or plan["ident"] != ident:
         rows, lo, hi = _row_block(n, rank, world)
         buf = FlatGradBuffer(params, pad_to=rows * world)          # whole row blocks: rows * world >= n
         G = buf.padded.shape[1]
-        plan = optimizer._shard_plan = dict(n=n, world=world, rows=rows, lo=lo, hi=hi, buf=buf,
+        plan = optimizer._shard_plan = dict(ident=ident, n=n, world=world, rows=rows, lo=lo, hi=hi, buf=buf,
                                             gshard=torch.empty(rows, G, dtype=torch.float32, device=buf.padded.device),
                                             pshard=torch.empty(rows, G, dtype=torch.float32, device=buf.padded.device))
     buf, rows, lo, hi = plan["buf"], plan["rows"], plan["lo"], plan["hi"]
@@ -268,6 +312,15 @@ def reduce_scatter_adam_step(params, optimizer, group=None, timing=False):
     last_exchange.update(backend=_backend(group), reduce=how_r, gather=how_g, bytes=buf.padded.numel() * 4, events=ev)
 
 
+def render_ms():
+    """Milliseconds this rank's keyframes of the most recent timed step took (render + loss + backward, before the exchange); None if not timed."""
+    ev = last_exchange.get("render_events")
+    if not ev:
+        return None
+    ev[1].synchronize()
+    return float(ev[0].elapsed_time(ev[1]))
+
+
 def exchange_ms():
     """Milliseconds of the most recent timed exchange + sharded Adam (reduce_scatter_adam_step(timing=True)); None if not timed."""
     ev = last_exchange.get("events")
@@ -280,7 +333,7 @@ def exchange_ms():
 def gather_moments(params, optimizer, group=None):
     """Make exp_avg / exp_avg_sq complete on every rank (each rank only advanced its own row block)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    for k in GRAD_KEYS:
+    for k in grad_keys(params):
         st = optimizer.state.get(params.get(k))
         if not st:
             continue

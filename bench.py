@@ -141,12 +141,33 @@ class RenderWorkload:
         return st, sb, D
 
 
+def self_launch(n, same_dev):
+    """Re-execute this command line as n ranks of one node through torch.distributed.run (127.0.0.1 rendezvous on a free port), pass the
+    ranks' output through and return their exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and not same_dev:
+        print(f"bench.py: --gpus {n} but {have} device(s) visible; nothing measured", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if same_dev:
+        env.setdefault("BENCH_BACKEND", "gloo")               # RCCL refuses two ranks on one device
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    note(f"--gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd[1:9])} ...")
+    return subprocess.call(cmd, env=env)
+
+
 def pmc_file(pattern):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     return files[-1] if files else None
 
 
-def run_c4(args, dev, rank, world, emit=True):
+def run_c4(args, dev, rank, world, emit=True, ranks_info=None):
     """BASELINE configs[3]: 64 keyframes sharded over the ranks, RCCL gradient exchange, sharded fused Adam."""
     import torch.distributed as dist
     from activesplat_amd import mapping as M, optim as O, parallel as PL, setup_camera
@@ -156,6 +177,14 @@ def run_c4(args, dev, rank, world, emit=True):
     K = syn.intrinsics(W, H)
     raw = syn.shell_scene(N, seed=0, W=W, H=H)
     lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
+    sh = args.c4_sh_degree >= 0
+    if sh:
+        # the map's colour as 16-coefficient SH rows (configs[2]'s map): the exchange carries G = 59 floats per Gaussian instead of 14
+        g = torch.Generator().manual_seed(7)
+        shs = 0.2 * torch.randn(N, 16, 3, generator=g)
+        shs[:, 0, :] = (raw.pop("rgb_colors") - 0.5) / 0.28209479177387814
+        raw["shs"] = shs
+        lrs = {("shs" if k == "rgb_colors" else k): v for k, v in lrs.items()}
 
     def fresh():
         prm = {k: torch.nn.Parameter(v.to(dev)) for k, v in raw.items()}
@@ -163,7 +192,7 @@ def run_c4(args, dev, rank, world, emit=True):
         prm["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 1, device=dev))
         return prm, O.initialize_optimizer(prm, lrs), {k: torch.zeros(N, device=dev) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
     params, opt, variables = fresh()
-    cam = setup_camera(W, H, K, np.eye(4), device=dev)
+    cam = setup_camera(W, H, K, np.eye(4), device=dev, sh_degree=max(args.c4_sh_degree, 0))
     mine = set(PL.shard_keyframes(KF, rank, world)) if world > 1 else set(range(KF))
     keyframes = []
     for i in range(KF):
@@ -189,7 +218,7 @@ def run_c4(args, dev, rank, world, emit=True):
         torch.cuda.synchronize()
 
     state = dict(v=variables, it=0)
-    ex_ms = []
+    ex_ms, rd_ms = [], []
 
     def step():
         _, state["v"], _ = PL.sharded_keyframe_step(params, state["v"], keyframes, opt, loss_fn, rank=rank, world=world,
@@ -199,11 +228,12 @@ def run_c4(args, dev, rank, world, emit=True):
             if state["it"] % args.stats_every == 0:            # the densifier's statistics are combined (sum, sum, max) every k-th step
                 PL.all_reduce_statistics(state["v"])
             ex_ms.append(PL.last_exchange.get("events"))
+            rd_ms.append(PL.last_exchange.get("render_events"))
     if world > 1:
         for _ in range(args.warmup):
             step()
         barrier()
-        ex_ms.clear()
+        ex_ms.clear(); rd_ms.clear()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -215,21 +245,34 @@ def run_c4(args, dev, rank, world, emit=True):
         D = int(R.last_stats["num_rendered"])
         exch = dict(PL.last_exchange); exch.pop("events", None)
         ex = [float(a.elapsed_time(b)) for a, b in (e for e in ex_ms if e)]
+        # every rank's own keyframes (render + loss + backward, before the exchange), event-timed per step: the load balance of the shards
+        rd = [float(a.elapsed_time(b)) for a, b in (e for e in rd_ms if e)]
+        mine_ms = torch.tensor([float(np.mean(rd)) if rd else 0.0, float(np.mean(ex)) if ex else 0.0], device=dev, dtype=torch.float64)
+        all_ms = [torch.zeros_like(mine_ms) for _ in range(world)]
+        dist.all_gather(all_ms, mine_ms)
+        per_rank = [round(float(t[0]), 3) for t in all_ms]
+        per_rank_ex = [round(float(t[1]), 3) for t in all_ms]
         out = {
             "metric": METRIC + " (configs[3]: keyframes/s of the 64-keyframe optimiser step incl. loss, gradient exchange and Adam)",
             "value": round(KF * args.steps / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[3]: {N} Gaussians, {KF} keyframes at {W}x{H} block-partitioned over {world} ranks "
-                                   f"({KF // max(world, 1)} per rank), one optimiser step per batch, reduce-scatter of the [N,14] fp32 gradient "
+                                   f"({KF // max(world, 1)} per rank), one optimiser step per batch, reduce-scatter of the [N,{'59' if sh else '14'}] fp32 gradient "
                                    "-> sharded fused Adam -> all-gather of the updated rows",
                        "gaussians": N, "width": W, "height": H, "keyframes_per_step": KF, "keyframes_per_rank_per_step": KF // max(world, 1),
-                       "tile_instances_D_last_keyframe": D, "streams": args.streams,
+                       "tile_instances_D_last_keyframe": D, "streams": args.streams, "exchange_floats_per_gaussian": 59 if sh else 14,
                        "grad_exchange": dict(exch, note="the collectives that actually ran (activesplat_amd.parallel.last_exchange)"),
                        "statistics_all_reduce_every": args.stats_every,
                        "loss": "fused mapping loss (L1 + SSIM + masked depth) through the single-pass RGB-D render",
                        "parallelism": f"keyframe-sharded x{world}"},
             "exchange_plus_adam_ms": round(float(np.mean(ex)), 4) if ex else None,
+            "rccl_ranks": world if "nccl" in str(exch.get("backend")) else 0,
+            "ranks": ranks_info,
+            "per_rank_keyframes_ms": {"values": per_rank, "min": min(per_rank), "mean": round(float(np.mean(per_rank)), 3), "max": max(per_rank),
+                                      "max_over_mean": round(max(per_rank) / max(float(np.mean(per_rank)), 1e-9), 4),
+                                      "note": "a rank's own keyframes of one step (render + loss + backward, before the exchange), hipEvents, mean over the timed steps"},
+            "per_rank_exchange_plus_adam_ms": per_rank_ex,
         }
     else:
         out = {}
@@ -255,6 +298,50 @@ def run_c4(args, dev, rank, world, emit=True):
             out = {"workload": f"BASELINE configs[3] on ONE GPU: {N} Gaussians, {KF} keyframes per optimiser step (activations inside the per-Gaussian kernels of the RGB-D render -> "
                                "fused loss -> backward per keyframe, fused Adam), no collective", "keyframes_per_s": round(ref, 2),
                    "ms_per_optimiser_step": round(KF / ref * 1e3, 3), "streams": args.streams}
+            # ---- what ONE device can say about the 8-GPU run: every rank's shard of the batch timed alone (load balance: D differs per
+            # view), and the exchange as a ONE-rank RCCL group runs it (pack -> reduce_scatter_tensor -> Adam -> all_gather_into_tensor ->
+            # unpack; there the Adam still covers ALL rows and nothing crosses xGMI) ----
+            try:
+                R8 = args.predict_ranks
+                per = []
+                for r in range(R8):
+                    ms = []
+                    for rep in range(3):
+                        PL.sharded_keyframe_step(p1, s1["v"], keyframes, o1, loss_fn, rank=r, world=R8, sharded_adam=True, streams=1, timing=True)
+                        if rep:
+                            ms.append(PL.render_ms())
+                    per.append(round(float(np.mean(ms)), 3))
+                pred = {"ranks": R8, "per_rank_ms": per, "max_over_mean": round(max(per) / float(np.mean(per)), 4),
+                        "note": f"rank r's {KF // R8} keyframes of the batch (render + loss + backward) on this one device, hipEvents, mean of 2 steps"}
+                try:
+                    import socket
+                    import torch.distributed as dist
+                    with socket.socket() as sk:
+                        sk.bind(("127.0.0.1", 0))
+                        port = sk.getsockname()[1]
+                    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+                    try:
+                        xs = []
+                        for rep in range(6):
+                            PL.reduce_scatter_adam_step(p1, o1, timing=True)
+                            if rep:
+                                xs.append(PL.exchange_ms())
+                        ex1 = float(np.mean(xs))
+                        S = float(PL.last_exchange["bytes"])
+                        wire = 2.0 * (S / R8) / 153e9 * 1e3           # direct reduce-scatter + all-gather: S/ranks per peer and direction, one xGMI link each
+                        pred.update(exchange_1rank_rccl_ms=round(ex1, 4), exchange_collectives=[PL.last_exchange.get("reduce"), PL.last_exchange.get("gather")],
+                                    exchange_bytes=int(S), wire_model_ms=round(wire, 4),
+                                    predicted_keyframes_per_s=round(KF / ((max(per) + ex1 + wire) * 1e-3), 1),
+                                    predicted_speedup_vs_this_gpu=round(KF / ((max(per) + ex1 + wire) * 1e-3) / ref, 3),
+                                    prediction="keyframes / (slowest rank's shard + the measured 1-rank RCCL exchange incl. Adam on ALL rows + the modelled xGMI "
+                                               "time of the 8-rank collectives): a model from one device, not a measurement of 8")
+                    finally:
+                        dist.destroy_process_group()
+                except Exception as e:
+                    pred["exchange_error"] = str(e)
+                out["eight_gpu_prediction"] = pred
+            except Exception as e:
+                out["eight_gpu_prediction"] = {"error": str(e)}
     if world > 1:
         barrier()
         if rank == 0 and emit:
@@ -280,33 +367,55 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=64, help="upper bound on the host threads of the cpu_baseline leg")
     ap.add_argument("--c4-gaussians", type=int, default=2_000_000, help="configs[3]: Gaussians of the replicated map")
     ap.add_argument("--keyframes", type=int, default=64, help="configs[3]: keyframes per optimiser step, sharded over the ranks")
+    ap.add_argument("--c4-sh-degree", type=int, default=-1, help="configs[3]: -1 = `rgb_colors` (the reference mapper's map, G = 14 floats per Gaussian "
+                                                                 "in the exchange); 0..3 = 16-coefficient SH rows (`shs`, G = 59)")
+    ap.add_argument("--predict-ranks", type=int, default=8, help="configs[3] on one GPU: ranks of the load-balance / exchange prediction leg")
     ap.add_argument("--stats-every", type=int, default=10, help="configs[3]: all-reduce the densifier's statistics every k-th step")
     ap.add_argument("--workload", choices=("auto", "c4"), default="auto", help="auto: configs[2]'s render on one GPU, configs[3] on several")
     args = ap.parse_args()
 
+    # development knobs for exercising the N > 1 code path on a 1-GPU box: all ranks on device 0, gloo instead of RCCL
+    same_dev = bool(os.environ.get("BENCH_SAME_DEVICE"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher's environment: start the N ranks ourselves (one process per GPU, RCCL) -- a bare run must
+        # never measure one GPU and print it under --gpus N
+        raise SystemExit(self_launch(args.gpus, same_dev))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
     dist_on = world > 1
-    # development knobs for exercising the N > 1 code path on a 1-GPU box: all ranks on device 0, gloo instead of RCCL
-    same_dev = bool(os.environ.get("BENCH_SAME_DEVICE"))
+    if dist_on and not same_dev and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but {torch.cuda.device_count()} device(s) visible (BENCH_SAME_DEVICE=1 puts every rank on device 0: development only)")
     torch.cuda.set_device(0 if same_dev else local_rank)
     dev = torch.device("cuda", 0 if same_dev else local_rank)
+    ranks_info = None
     if dist_on:
         import torch.distributed as dist
-        if os.environ.get("BENCH_BACKEND") == "gloo":
+        want = "gloo" if os.environ.get("BENCH_BACKEND") == "gloo" else "nccl"
+        if want == "gloo":
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        # what is really running: N ranks, the backend asked for, N distinct devices
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        assert str(dist.get_backend()).lower() == want, dist.get_backend()
+        prop = torch.cuda.get_device_properties(dev)
+        me = dict(rank=rank, pid=os.getpid(), device=int(dev.index), name=prop.name,
+                  uuid=str(getattr(prop, "uuid", "")), pci_bus_id=int(getattr(prop, "pci_bus_id", -1)))
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+        ids = {(r["device"], r["uuid"], r["pci_bus_id"]) for r in ranks_info}
+        if not same_dev and len(ids) != world:
+            raise SystemExit(f"bench.py: {world} ranks on {len(ids)} distinct device(s): {ranks_info}")
 
     from activesplat_amd import GaussianRasterizer, _lib, setup_camera
     from activesplat_amd import rasterizer as R
     from activesplat_amd import synthetic as syn
     lib = _lib.get()                                        # fail loudly if the HIP library is missing
     if dist_on or args.workload == "c4":
-        out = run_c4(args, dev, rank, world)
+        out = run_c4(args, dev, rank, world, ranks_info=ranks_info)
         if not dist_on:
             print(json.dumps(out))
         return

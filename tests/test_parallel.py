@@ -131,7 +131,7 @@ def test_two_rank_step_with_in_kernel_accumulation_equals_sequential_sum(emu_lib
         assert same and mx == 2.0 and den == 2.0
 
 
-def _worker_sharded_adam(rank, world, port, emu_path, q):
+def _worker_sharded_adam(rank, world, port, emu_path, q, sh=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -139,10 +139,13 @@ def _worker_sharded_adam(rank, world, port, emu_path, q):
         from activesplat_amd import _lib, optim as O, parallel as PL
         _lib.load_for_tests(emu_path)
         n = 601                                                    # not a multiple of the world size
-        widths = dict(means3D=3, rgb_colors=3, unnorm_rotations=4, logit_opacities=1, log_scales=3)
+        widths = dict(means3D=(3,), rgb_colors=(3,), unnorm_rotations=(4,), logit_opacities=(1,), log_scales=(3,))
         lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3)
+        if sh:                                                     # configs[2]'s map: 16-coefficient SH rows instead of rgb_colors, G = 59
+            widths = {("shs" if k == "rgb_colors" else k): ((16, 3) if k == "rgb_colors" else w) for k, w in widths.items()}
+            lrs = {("shs" if k == "rgb_colors" else k): v for k, v in lrs.items()}
         g0 = torch.Generator().manual_seed(5)
-        init = {k: torch.randn(n, w, generator=g0) for k, w in widths.items()}
+        init = {k: torch.randn(n, *w, generator=g0) for k, w in widths.items()}
         runs = []
         for mode in ("allreduce", "reduce_scatter"):
             params = {k: torch.nn.Parameter(v.clone()) for k, v in init.items()}
@@ -150,7 +153,7 @@ def _worker_sharded_adam(rank, world, port, emu_path, q):
             gr = torch.Generator().manual_seed(100 + rank)         # every rank holds different local gradients
             for _ in range(3):
                 for k, w in widths.items():
-                    params[k].grad = torch.randn(n, w, generator=gr)
+                    params[k].grad = torch.randn(n, *w, generator=gr)
                 if mode == "allreduce":
                     PL.all_reduce_gradients(params)
                     opt.step()
@@ -162,16 +165,18 @@ def _worker_sharded_adam(rank, world, port, emu_path, q):
                              opt.state[params[k]]["exp_avg_sq"].clone(), float(opt.state[params[k]]["step"])) for k in widths})
         same = all(torch.equal(a, b) for k in widths for a, b in zip(runs[0][k][:3], runs[1][k][:3]))
         steps = all(runs[0][k][3] == runs[1][k][3] == 3.0 for k in widths)
-        q.put((rank, same, steps))
+        G = int(PL.last_exchange["bytes"]) // 4 // (2 * ((n + 1) // 2))
+        q.put((rank, same, steps and G == (59 if sh else 14)))
     finally:
         dist.destroy_process_group()
 
 
-def test_reduce_scatter_sharded_adam_equals_allreduce_adam(emu_lib_path):
+@pytest.mark.parametrize("sh", [False, True], ids=["rgb-G14", "shs-G59"])
+def test_reduce_scatter_sharded_adam_equals_allreduce_adam(emu_lib_path, sh):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_sharded_adam, args=(r, 2, port, emu_lib_path, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_sharded_adam, args=(r, 2, port, emu_lib_path, q, sh)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in procs)
@@ -222,6 +227,21 @@ def test_two_stream_keyframe_batch_equals_serial_batch(hip):
 
 
 @pytest.mark.gpu
+def test_multi_stream_batch_refuses_in_kernel_accumulation(hip):
+    """streams > 1 takes every keyframe's gradients with autograd.grad; a loss_fn that adds them into .grad inside the backward kernel
+    (accumulate_grads=True) hands autograd nothing -- the step must say so instead of stepping on zeros."""
+    from activesplat_amd import optim as O, parallel as PL
+    params, kfs = _scene(n=5000, W=64, H=48, K=4, device=hip)
+    n = params["means3D"].shape[0]
+    variables = {k: torch.zeros(n, device=hip) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+    opt = O.initialize_optimizer(params, dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3,
+                                              cam_unnorm_rots=0.0, cam_trans=0.0))
+    with pytest.raises(RuntimeError, match="accumulate_grads"):
+        PL.sharded_keyframe_step(params, variables, kfs, opt, _loss_fn_raw, rank=0, world=1, streams=2)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_gauss,kf", [(200_000, 8), (2_000_000, 64)], ids=["200k-8kf", "configs3-2M-64kf"])
 def test_bench_configs3_workload_two_ranks_on_one_device(hip, n_gauss, kf):
     """`bench.py --gpus 2` = BASELINE configs[3] (keyframe batch sharded over the ranks, reduce-scatter -> sharded Adam -> all-gather),
@@ -250,6 +270,59 @@ def test_bench_configs3_workload_two_ranks_on_one_device(hip, n_gauss, kf):
     assert d["config"]["grad_exchange"]["reduce"] == "all_reduce+slice"             # what actually ran (gloo has no reduce-scatter)
     assert d["exchange_plus_adam_ms"] > 0
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]          # only rank 0 prints
+
+
+def test_bench_gpus_n_without_enough_devices_refuses():
+    """`python bench.py --gpus 2` with no launcher environment starts its own ranks -- and where fewer than 2 devices are visible (this
+    container has none) it must exit non-zero without printing a result line, never measure one GPU under the name of two."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two devices visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_SAME_DEVICE", "BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "--gpus 2" in r.stderr and "device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_launches_its_own_ranks(hip):
+    """`python bench.py --gpus 2 ...` with NO distributed environment (the form the driver uses for N = 1): bench.py re-executes itself
+    through torch.distributed.run, and the line says two ranks ran (same-device development knob: this box has one GPU, so gloo)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_SAME_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--c4-gaussians", "200000",
+                        "--keyframes", "8", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["keyframes_per_rank_per_step"] == 4
+    assert [x["rank"] for x in d["ranks"]] == [0, 1] and len({x["pid"] for x in d["ranks"]}) == 2
+    assert d["rccl_ranks"] == 0 and d["config"]["grad_exchange"]["backend"] == "gloo"      # (RCCL refuses two ranks on one device)
+    pr = d["per_rank_keyframes_ms"]
+    assert len(pr["values"]) == 2 and pr["min"] > 0 and pr["max"] >= pr["mean"] >= pr["min"] and pr["max_over_mean"] >= 1.0
+
+
+@pytest.mark.gpu
+def test_bench_configs3_with_sh_rows_exchanges_59_floats(hip):
+    """configs[3] with configs[2]'s map (16-coefficient SH rows): the exchange carries G = 59 floats per Gaussian."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_SAME_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--c4-gaussians", "100000",
+                        "--keyframes", "4", "--c4-sh-degree", "3", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["exchange_floats_per_gaussian"] == 59
+    assert d["config"]["grad_exchange"]["bytes"] == 100000 * 59 * 4 and d["value"] > 0
 
 
 def _worker_nccl_one_rank(port, q):
