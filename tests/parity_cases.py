@@ -31,6 +31,13 @@ def build_case(name, device):
         kw = dict(w2c=util.pose(0.25, (0.1, -0.05, 0.3)), bg=(1.0, 1.0, 1.0))
     elif name == "scale_modifier":
         kw = dict(scale_modifier=0.37, bg=(0.2, 0.1, 0.4))
+    elif name == "scale_modifier_001":      # the planner's scale_modifier (visualizer.py:935-936) on an ordinary view: every splat shrinks to the low-pass footprint
+        N, kw = 4000, dict(scale_modifier=0.01, bg=(0.1, 0.0, 0.2))
+    elif name in ("topdown_1000m", "topdown_1000m_white"):
+        # the planner's top-down map camera (src/visualizer/visualizer.py:923-937,1577-1601 through splatam.py:413-434): 1000 m above the scene,
+        # focal length 2e4 px, far = 100 (no far cull: everything is ~1000 deep), scale_modifier 0.01; black background (the depth / silhouette
+        # pass and the "free map") and white (the colour pass)
+        return topdown_scene(20000, device, bg=(1.0, 1.0, 1.0) if name.endswith("white") else (0.0, 0.0, 0.0))
     elif name == "behind_camera":           # about half the Gaussians are near-culled
         kw = dict(w2c=util.pose(0.0, (0.0, 0.0, -2.0)))
     elif name == "all_culled":              # D == 0
@@ -104,9 +111,36 @@ def build_case(name, device):
     return rs, rv
 
 
+def topdown_camera(W=360, H=300, scene_w=18.0, scene_h=15.0, centre=(0.3, -0.2), height=1000.0, bg=(0.0, 0.0, 0.0), device="cpu", scale_modifier=0.01):
+    """The settings get_topdown_cam + render_o3d_image hand the rasteriser (visualizer.py:1577-1601): camera `height` metres up the -y axis
+    looking along +y, fov from the scene's extent, principal point at the integer image centre, near 0.01 / far 100."""
+    from activesplat_amd.camera import setup_camera
+    c2w = np.eye(4)
+    c2w[:3, :3] = np.array([[1, 0, 0], [0, 0, 1], [0, -1, 0]], dtype=np.float64)
+    c2w[:3, 3] = [centre[0], -height, centre[1]]
+    fx, fy = W / (scene_w / height), H / (scene_h / height)          # fov2focal(2 atan(extent / 2h), pixels)
+    K = np.array([[fx, 0.0, W // 2], [0.0, fy, H // 2], [0.0, 0.0, 1.0]])
+    return setup_camera(W, H, K, np.linalg.inv(c2w), near=0.01, far=100, scale_modifier=scale_modifier, bg=bg, device=device)
+
+
+def topdown_scene(N, device, seed=12, bg=(0.0, 0.0, 0.0), W=360, H=300):
+    """A room-scale map (18 m x 15 m footprint, heights -1.6 .. 0.2 m in the mapper's y-down world frame, splats of 1-8 cm) under the
+    top-down camera; a tenth of it lies outside the footprint."""
+    g = torch.Generator().manual_seed(seed)
+    xz = (torch.rand(N, 2, generator=g) - 0.5) * torch.tensor([20.0, 16.5])
+    y = -1.6 + 1.8 * torch.rand(N, 1, generator=g)
+    means = torch.cat([xz[:, :1], y, xz[:, 1:]], 1)
+    scales = torch.exp(torch.log(torch.tensor(0.03)) + 0.5 * torch.randn(N, 3, generator=g))
+    rv = dict(means3D=means.float(), rotations=torch.nn.functional.normalize(torch.randn(N, 4, generator=g)),
+              opacities=torch.sigmoid(torch.randn(N, 1, generator=g) + 1.0), scales=scales.float(), colors_precomp=torch.rand(N, 3, generator=g))
+    rs = topdown_camera(W, H, bg=bg, device=device)._replace(debug=True)
+    return rs, {k: v.to(device).contiguous() for k, v in rv.items()}
+
+
 BIG_TILE_CASES = ["merge_tiles", "merge_tiles_large", "merge_passes", "merge_passes_even", "bucket_lists", "bucket_lists_long", "crowded_depth",
                   "crowded_depth_long", "equal_depth"]
-CASES = ["basic", "ragged_image", "tiny_lookaround", "lookaround_intrinsics", "posed_white_bg", "scale_modifier", "behind_camera", "all_culled",
+CASES = ["basic", "ragged_image", "tiny_lookaround", "lookaround_intrinsics", "posed_white_bg", "scale_modifier", "scale_modifier_001", "topdown_1000m",
+         "topdown_1000m_white", "behind_camera", "all_culled",
          "huge_gaussians", "dense_overdraw", "low_opacity", "one_gaussian", "not_multiple_of_block", "sh0", "sh1", "sh2",
          "sh3", "sh2_ragged", "sh3_half_culled", "cov3d_precomp"]
 

@@ -40,7 +40,8 @@ def test_emulated_forward_radix_path_matches_oracle(emu, oracle32, case):
 
 
 @pytest.mark.parametrize("case", ["basic", "ragged_image", "posed_white_bg", "scale_modifier", "dense_overdraw",
-                                  "huge_gaussians", "all_culled", "sh3", "sh2_ragged", "sh3_half_culled", "cov3d_precomp", "lookaround_intrinsics"])
+                                  "huge_gaussians", "all_culled", "sh3", "sh2_ragged", "sh3_half_culled", "cov3d_precomp", "lookaround_intrinsics",
+                                  "scale_modifier_001", "topdown_1000m", "topdown_1000m_white"])
 def test_emulated_backward_matches_fp64_oracle(emu, oracle64, case):
     rs, rv = pc.build_case(case, emu)
     pc.check_backward(rs, rv, oracle64)

@@ -26,9 +26,11 @@ def test_forward_matches_oracle(hip, oracle32, case, path):
 
 
 @pytest.mark.parametrize("case", pc.CASES)
-def test_backward_matches_fp64_oracle(hip, oracle64, case):
+def test_backward_matches_fp64_oracle(hip, oracle64, oracle32, case):
     rs, rv = pc.build_case(case, hip)
-    pc.check_backward(rs, rv, oracle64)
+    # (the top-down camera -- focal length 2e4 px, depths ~1000 -- leaves the fp32 ORACLE at 0.9953-0.997 of the elements inside the
+    # tolerance: there, and only there, a miss is judged against the fp32 oracle's own error and tallied)
+    pc.check_backward(rs, rv, oracle64, oracle32=oracle32 if case.startswith("topdown") else None)
 
 
 def test_midsize_scene_forward_backward(hip, oracle32, oracle64):
@@ -175,8 +177,9 @@ def test_more_tiles_than_the_lds_histogram_holds(hip, oracle32, oracle64):
     rs, rv = pc.build_case("many_tiles", hip)
     pc.check_forward(rs, rv, oracle32)
     assert util.artefacts()["path"] == 2
-    # sub-pixel Gaussians at this focal length: the fp32 ORACLE itself sits at 0.988-0.995 of the fp64 one here
-    pc.check_backward(rs, rv, oracle64, min_frac=0.985)
+    # sub-pixel Gaussians at this focal length: the fp32 ORACLE itself sits at 0.988-0.995 of the fp64 one here -- the stated 0.995 bar with
+    # the (tallied) fp32 escape hatch instead of a looser bar
+    pc.check_backward(rs, rv, oracle64, oracle32=oracle32)
 
 
 def test_zero_gaussians(hip):
@@ -221,7 +224,7 @@ def test_random_scene_matches_oracle_on_gpu(hip, oracle32, oracle64, seed):
     from tests.test_randomized import _draw
     rs, rv = _draw(5000 + seed, hip)
     pc.check_forward(rs, rv, oracle32)
-    pc.check_backward(rs, rv, oracle64, min_frac=0.99, oracle32=oracle32)
+    pc.check_backward(rs, rv, oracle64, oracle32=oracle32)          # the stated 0.995 / 1e-3 bar; the fp32 escape hatch is tallied (conftest)
 
 
 def test_segmented_forward(hip, oracle32):
