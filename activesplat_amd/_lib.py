@@ -53,7 +53,10 @@ SORT_AUTO, SORT_TILE_LDS, SORT_RADIX = 0, 1, 2
 
 
 # every symbol include/gsplat_hip.h declares (tests check the library exports all of them)
-SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
+#: the GS_ABI_VERSION of include/gsplat_hip.h this binding was written against (checked when a library is bound)
+ABI_VERSION = 4
+
+SYMBOLS = ("gs_abi_version", "gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
            "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_set_half_quadrants", "gs_set_backward_chain", "gs_preprocess_forward", "gs_preprocess_forward_raw", "gs_render_forward", "gs_render_backward", "gs_render_backward_raw", "gs_adam_step", "gs_adam_step_multi",
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
            "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward", "gs_activate_backward_accumulate",
@@ -64,6 +67,15 @@ SYMBOLS = ("gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_sc
 
 def _bind(lib):
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    # a stale prebuilt library (another round's .so, an old emulated build) must fail HERE, not misread pointers later
+    try:
+        lib.gs_abi_version.restype = i32
+        have = int(lib.gs_abi_version())
+    except AttributeError:
+        have = None
+    if have != ABI_VERSION:
+        raise RuntimeError(f"{getattr(lib, '_name', 'library')}: C ABI version {have}, this binding needs {ABI_VERSION} (include/gsplat_hip.h "
+                           "GS_ABI_VERSION) -- rebuild it: python -c 'import __graft_entry__ as g; g.build()'")
     lib.gs_geom_layout.argtypes = [i32, i32, i32, C.POINTER(GsGeomLayout)]
     lib.gs_atlas_layout.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.gs_atlas_layout.restype = C.c_int

@@ -112,7 +112,8 @@ gs::GeomPtrs carve_geom(void* base, int32_t P, const gs::Cam& k)
 extern "C" {
 
 const char* gs_last_error(void) { return g_err; }
-const char* gs_version(void) { return "activesplat_amd gsplat_hip 0.1 (gfx950)"; }
+const char* gs_version(void) { return "activesplat_amd gsplat_hip 0.4 (gfx950)"; }
+int32_t gs_abi_version(void) { return GS_ABI_VERSION; }
 
 int gs_profile_enable(int32_t on)
 {

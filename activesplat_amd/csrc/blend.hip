@@ -754,11 +754,21 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
         // (as late as possible: this walker's own loads are in flight while the piece in front of it finishes)
         // (state and flag travel as device-scope atomics, which bypass the non-coherent cache levels: no acquire on the poll -- a cache
         // invalidate per poll of thousands of waiting wavefronts costs everybody's record gathers their hits)
-        while (__hip_atomic_load(chain_fl + piece - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cam.chain_epoch) __builtin_amdgcn_s_sleep(16);
+        // HARDWARE ASSUMPTION: workgroups of one launch start in index order, so the piece in front (a lower index on
+        // this XCD) is resident or done when this one polls.  The poll is BOUNDED all the same (~0.3 s of polling): if the assumption ever
+        // failed, the walk goes on with NaN state -- NaN gradients for this quadrant's Gaussians, loud in every consumer -- instead of hanging
+        // the device.
+        int polls = 0;
+        bool handed = true;
+        while (__hip_atomic_load(chain_fl + piece - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cam.chain_epoch) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++polls > (1 << 21)) { handed = false; break; }
+        }
         GS_WAIT_VMEM();
         const float* in = chain_st + (piece - 1) * 2 * kWave;
         T = __hip_atomic_load(in + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         S = __hip_atomic_load(in + kWave + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!handed) T = __builtin_nanf("");
     }
     for (int ch = cmax; ch >= cmin; ch--) {
         const float4 q0 = r0, q1 = r1, q2 = r2;
@@ -954,7 +964,10 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
     Cam cam = cam_in;
     cam.half = (segments <= 1 || !seg_T) && cam.gx * cam.gy <= g_half_quadrant_tiles;          // few tiles: the producer / consumer forward
     cam.split = cam.V == 1 && split_state && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles);      // (the backward refuses atlases)
-    cam.chain = (cam.V == 1 && split_state && cam.gx * cam.gy > max(g_chain_min_tiles, kFewTiles) && g_chain_pieces > 1) ? g_chain_pieces : 0;
+    // (the forward's only use of `chain` is to zero the hand-over flags of the chained backward walks.  It does so for EVERY image whose
+    // workspace holds them -- more than kFewTiles tiles -- whatever gs_set_backward_chain says at this moment: the backward takes its own
+    // decision from the knob when IT is launched, and must find zeroed flags even if the knob changed in between)
+    cam.chain = (cam.V == 1 && split_state && cam.gx * cam.gy > kFewTiles) ? kChainPieces : 0;
     const int nb = ((cam.gx * cam.gy + 7) >> 3) << 3;
 #define GS_FWD(DSQ, SEG, GRID)                                                                                                     \
     hipLaunchKernelGGL((blend_forward_streams_kernel<DSQ, kFwdStreams, SEG, 4>), GRID, dim3(kBlock), 0, st, cam, ranges, point_list, geom, \

@@ -94,7 +94,9 @@ class GaussianAdam:
         # The descriptor array of the launch is kept from step to step: while the same parameter and moment tensors take part, only the
         # gradient pointers, step counters and hyper-parameters are refreshed (building seven ctypes structures per step was a good part
         # of this function's host time; a mapping iteration at the reference's 256 x 256 is bound by host time, not by the GPU).
-        ident = tuple((id(p), p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for _, p, st, _ in live)
+        # (keyed on addresses AND sizes: after a prune + densify in one iteration the caching allocator can hand a freed address to a tensor
+        # with another row count)
+        ident = tuple((p.numel(), p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for _, p, st, _ in live)
         cache = getattr(self, "_launch_cache", None)
         if cache is None or cache[0] != ident:
             arr = (_lib.GsAdamTensor * len(live))()
@@ -107,7 +109,7 @@ class GaussianAdam:
         for i, (g, p, st, grad) in enumerate(live):
             t = arr[i]
             b1, b2 = g["betas"]
-            t.grad = grad.data_ptr(); t.step = st["step"]; t.lr = float(g["lr"])
+            t.n = p.numel(); t.grad = grad.data_ptr(); t.step = st["step"]; t.lr = float(g["lr"])
             t.beta1 = float(b1); t.beta2 = float(b2); t.eps = float(g["eps"])
         _lib.check(lib.gs_adam_step_multi(len(live), arr, _stream(live[0][1])))
 

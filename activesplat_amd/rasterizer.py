@@ -21,6 +21,7 @@ All compute is in libgsplat_hip.so through the C ABI of include/gsplat_hip.h; th
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import threading
 from typing import NamedTuple
@@ -46,11 +47,9 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
-#: statistics of the most recent forward on this process (read by bench.py / tests)
+#: statistics of the most recent forward on this process (read by bench.py / tests).  Process-global and unsynchronised: with forwards
+#: in flight on several threads it holds the numbers of whichever finished last -- informational, nothing in the product path reads it
 last_stats = {"num_rendered": 0, "P": 0}
-#: with raster_settings.debug=True the state buffers of the most recent forward are kept here so
-#: that tests can check the integer artefacts (layouts: include/gsplat_hip.h)
-last_debug = {}
 #: per (P, W, H, device): (pair capacity, tile-list capacity) guessed for the next frame's optimistic launch
 _capacity = {}
 #: set False to always size the binning workspace from the exact counts (one mid-pipeline host sync per forward)
@@ -61,6 +60,29 @@ optimistic = True
 #: threaded layout (SURVEY section 8b "Threading") -- must never share one
 _tls = threading.local()
 _capacity_lock = threading.Lock()
+
+
+@contextlib.contextmanager
+def capture():
+    """`with capture() as state:` -- the state buffers of the forwards run inside the block by THIS thread (the last one wins) are put
+    into `state` (geom / image / binning workspaces, point_list, their layouts, D, P, W, H; layouts in include/gsplat_hip.h) so that
+    tests and bench.py can decode the integer artefacts.  Nothing is retained outside a capture block: the reference's `debug=True`
+    settings flag alone does not pin any buffer."""
+    stack = getattr(_tls, "captures", None)
+    if stack is None:
+        stack = _tls.captures = []
+    state = {}
+    stack.append(state)
+    try:
+        yield state
+    finally:
+        stack.remove(state)
+
+
+def _require_rocm(device):
+    """The product path takes ROCm device tensors only (no CPU fallback)."""
+    if device.type != "cuda":
+        raise RuntimeError("activesplat_amd rasteriser needs ROCm device tensors (no CPU fallback)")
 
 
 def _host_counters(device, stream_handle):
@@ -134,8 +156,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         lib = _lib.get()
         device = means3D.device
         leaves = (means3D, opacities, scales, rotations, colors_precomp)     # (raw + accumulate: the backward adds into these tensors' .grad)
-        if device.type != "cuda" and not _lib.emulated():
-            raise RuntimeError("activesplat_amd rasteriser needs ROCm device tensors (no CPU fallback)")
+        _require_rocm(device)
         P = int(means3D.shape[0])
         means3D = _f32(means3D, device)
         shs, colors_precomp = _f32(shs, device), _f32(colors_precomp, device)
@@ -227,9 +248,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         # in-kernel accumulation only into the very tensors the caller passed (a converted copy has no .grad to add to)
         same = raw is not None and raw[2] and all(a is b for a, b in zip(leaves, (means3D, opacities, scales, rotations, colors_precomp)))
         ctx.leaves = leaves if same else None
-        if rs.debug:
-            last_debug.update(geom=geom, image=image, binning=binning, point_list=point_list, gl=gl, il=il, bl=bl,
-                              D=D, P=P, W=W, H=H)
+        caps = getattr(_tls, "captures", None)
+        if caps:
+            caps[-1].update(geom=geom, image=image, binning=binning, point_list=point_list, gl=gl, il=il, bl=bl, D=D, P=P, W=W, H=H)
         e = torch.empty(0, device=device)
         ctx.save_for_backward(means3D, shs if shs is not None else e, colors_precomp if colors_precomp is not None else e,
                               scales if scales is not None else e, rotations if rotations is not None else e,
@@ -403,8 +424,7 @@ def render_views(settings_list, means3D, opacities, shs=None, colors_precomp=Non
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
     device = means3D.device
-    if device.type != "cuda" and not _lib.emulated():
-        raise RuntimeError("activesplat_amd rasteriser needs ROCm device tensors (no CPU fallback)")
+    _require_rocm(device)
     P, W, H = int(means3D.shape[0]), int(rs0.image_width), int(rs0.image_height)
     means3D, shs, colors_precomp = _f32(means3D, device), _f32(shs, device), _f32(colors_precomp, device)
     opacities, scales, rotations, cov3D_precomp = _f32(opacities, device), _f32(scales, device), _f32(rotations, device), _f32(cov3D_precomp, device)

@@ -509,11 +509,12 @@ def main():
                     GaussianRasterizer(raster_settings=wl.cam)(means2D=m2d0, **rv_ng)
                 torch.cuda.synchronize()
                 out["forward_only_fps"] = round(args.steps / (time.perf_counter() - t1), 1)
-                GaussianRasterizer(raster_settings=wl.cam._replace(debug=True))(means2D=m2d0, **rv_ng)
-            il = R.last_debug["il"]
-            ncontrib = R.last_debug["image"][il.n_contrib:il.n_contrib + 4 * W * H].view(torch.int32)
+                with R.capture() as state:
+                    GaussianRasterizer(raster_settings=wl.cam)(means2D=m2d0, **rv_ng)
+            il = state["il"]
+            ncontrib = state["image"][il.n_contrib:il.n_contrib + 4 * W * H].view(torch.int32)
             E = int(ncontrib.to(torch.int64).sum().item())          # list entries walked, summed over pixels
-            R.last_debug.clear()
+            del state
             tf, tb = stages["blend_forward"]["avg_us"] * 1e-6, stages["blend_backward"]["avg_us"] * 1e-6
             out["blend_flops"] = {"evaluations_E": E, "forward_frac_fp32_peak": round(E * 12 / tf / FP32_PEAK, 4),
                                   "backward_frac_fp32_peak": round(E * 40 / tb / FP32_PEAK, 4), "peak_tflops": FP32_PEAK / 1e12,

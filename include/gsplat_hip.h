@@ -145,6 +145,11 @@ uint64_t gs_backward_scratch_bytes(int32_t P);
 
 const char* gs_last_error(void);
 const char* gs_version(void);
+/* Integer version of THIS binary interface: bumped whenever an entry point's argument list or a published record layout changes (e.g.
+ * the seed argument of gs_densify_children, the 40-byte SH Jacobian record).  A host binding compares it with the GS_ABI_VERSION it was
+ * written against before the first call, so that a stale prebuilt library fails at load time instead of misreading its arguments. */
+#define GS_ABI_VERSION 4
+int32_t gs_abi_version(void);
 
 /* Optional per-stage timing (hipEvents recorded on the caller's stream around each stage's launches).
  * Off by default; bench.py switches it on for its roofline leg.  gs_profile_collect synchronises the
@@ -163,7 +168,10 @@ int gs_profile_collect(float* ms_sum, int32_t* calls, int32_t n_stages);
  * async copy otherwise (read them after synchronising `stream` or an event recorded behind this call). Exactly one of shs/colors_precomp and
  * exactly one of (scales,rotations)/cov3D_precomp must be given.
  * want_backward != 0 with shs: the stage also stores, per Gaussian, the 3x3 block sum_k coef[k] (x) grad b_k(direction) in the geom
- * state, so that gs_render_backward (have_sh_jacobian = 1) does not read the coefficient rows a second time. */
+ * state, so that gs_render_backward (have_sh_jacobian = 1) does not read the coefficient rows a second time.
+ * PAIRING RULE: want_backward and have_sh_jacobian go together.  With want_backward != 0 the colour clamp flags travel in the Jacobian
+ * record and the separate `clamped` array is NOT written: a backward over that geom state must pass have_sh_jacobian = 1 (with 0 it
+ * would read an unwritten `clamped` array); with want_backward = 0 the backward must pass have_sh_jacobian = 0. */
 int gs_preprocess_forward(const GsCamera* cam, int32_t P,
                           const float* means3D, const float* shs, const float* colors_precomp,
                           const float* opacities, const float* scales, const float* rotations,

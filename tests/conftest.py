@@ -36,10 +36,10 @@ def emu_lib_path():
 @pytest.fixture()
 def emu(emu_lib_path):
     """Bind activesplat_amd to the emulated kernels for the duration of one test."""
-    from activesplat_amd import _lib
-    _lib.load_for_tests(emu_lib_path)
+    from tests import util
+    undo = util.use_emulated_kernels(emu_lib_path)   # (the product path refuses host tensors; the emulated build is the one thing that takes them)
     yield "cpu"
-    _lib.unload_for_tests()
+    undo()
 
 
 @pytest.fixture()

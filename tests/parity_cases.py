@@ -499,12 +499,12 @@ def check_segmented_forward(device, oracle32):
     lib = _lib.get()
     rs, rv = build_case("merge_tiles_large", device)                 # 48 x 48: 9 tiles of ~12 k records
     got, ref = check_forward(rs, rv, oracle32)
-    assert int(R.last_debug["bl"].segments) > 1
+    assert int(util.LAST["bl"].segments) > 1
     seg = util.artefacts()
     _lib.check(lib.gs_set_forward_segments(0))
     try:
         one = util.run_product(rs, rv)
-        assert int(R.last_debug["bl"].segments) == 1
+        assert int(util.LAST["bl"].segments) == 1
         art = util.artefacts()
     finally:
         _lib.check(lib.gs_set_forward_segments(1))

@@ -117,6 +117,27 @@ def test_full_size_properties(hip):
         assert np.linalg.norm(gb - 2 * ga) / np.linalg.norm(2 * ga) < 1e-4, k                      # atomics reorder sums only
 
 
+def test_topdown_camera_full_size_properties(hip):
+    """The planner's top-down view at size (1 M Gaussians, 360 x 300, 1000 m, scale_modifier 0.01, far = 100): every visible splat collapses
+    to the low-pass footprint (radius 3), nothing is far-culled, the opacity map is not empty, keys are sorted and the ranges partition
+    [0, D), and the image is affine in the background (white-background colour = black-background colour + 1 - opacity)."""
+    N = 1_000_000
+    rs, rv = pc.topdown_scene(N, hip)
+    a = util.run_product(rs, rv)
+    art = util.artefacts()
+    assert set(np.unique(a["radii"]).tolist()) <= {0, 3}
+    inside = ((rv["means3D"][:, 0] - 0.3).abs() < 8.9) & ((rv["means3D"][:, 2] + 0.2).abs() < 7.4)
+    assert (a["radii"][inside.cpu().numpy()] == 3).all()                # no far cull, no near cull: everything over the footprint renders
+    assert float((a["opacity"] > 0.5).mean()) > 0.9
+    keys = art["keys_sorted"]
+    assert (keys[1:] >= keys[:-1]).all() and int(art["tiles_touched"].sum()) == a["D"]
+    rg = art["ranges"]; ne = rg[rg[:, 1] > rg[:, 0]]
+    assert ne[0, 0] == 0 and ne[-1, 1] == a["D"] and (ne[1:, 0] == ne[:-1, 1]).all()
+    b = util.run_product(rs._replace(bg=torch.ones(3, device=hip)), rv)
+    assert np.array_equal(a["opacity"], b["opacity"]) and np.array_equal(a["depth"], b["depth"])
+    np.testing.assert_allclose(b["color"], a["color"] + (1.0 - a["opacity"]), atol=2e-6)
+
+
 def test_adam_matches_torch_on_gpu(hip):
     from activesplat_amd import _lib
     lib = _lib.get()

@@ -59,7 +59,8 @@ def _worker(rank, world, port, emu_path, q, device="cpu", raw=False):
     try:
         from activesplat_amd import _lib, optim as O, parallel as PL
         if device == "cpu":
-            _lib.load_for_tests(emu_path)
+            from tests import util
+            util.use_emulated_kernels(emu_path)
         params, kfs = _scene(device=device) if device == "cpu" else _scene(n=20000, W=128, H=96, device=device)
         n = params["means3D"].shape[0]
         variables = {k: torch.zeros(n, device=device) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
@@ -136,8 +137,9 @@ def _worker_sharded_adam(rank, world, port, emu_path, q, sh=False):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from activesplat_amd import _lib, optim as O, parallel as PL
-        _lib.load_for_tests(emu_path)
+        from activesplat_amd import optim as O, parallel as PL
+        from tests import util
+        util.use_emulated_kernels(emu_path)
         n = 601                                                    # not a multiple of the world size
         widths = dict(means3D=(3,), rgb_colors=(3,), unnorm_rotations=(4,), logit_opacities=(1,), log_scales=(3,))
         lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3)

@@ -35,12 +35,32 @@ def scene(N, W, H, seed=0, device="cpu", w2c=None, bg=(0.0, 0.0, 0.0), scale_mod
     return rs, rv
 
 
+def use_emulated_kernels(path):
+    """TEST-ONLY: bind activesplat_amd to the host-emulated build of the kernel sources (tests/hipemu) and let the rasteriser take host
+    tensors for it (the product path refuses them); returns the undo function."""
+    from activesplat_amd import _lib
+    _lib.load_for_tests(path)
+    require = R._require_rocm
+    R._require_rocm = lambda device: None
+
+    def undo():
+        R._require_rocm = require
+        _lib.unload_for_tests()
+    return undo
+
+
+#: state buffers of the most recent run_product() forward (rasterizer.capture()): what artefacts() decodes
+LAST = {}
+
+
 def run_product(rs, rv, dL=None):
     """-> dict(color, radii, depth, opacity[, grads])"""
     inp = {k: v.detach().clone().requires_grad_(dL is not None) for k, v in rv.items()}
     P = inp["means3D"].shape[0]
     m2d = torch.zeros(P, 3, device=inp["means3D"].device, requires_grad=dL is not None)
-    color, radii, depth, opacity = R.GaussianRasterizer(raster_settings=rs)(means2D=m2d, **inp)
+    with R.capture() as state:
+        color, radii, depth, opacity = R.GaussianRasterizer(raster_settings=rs)(means2D=m2d, **inp)
+    LAST.clear(); LAST.update(state)
     out = dict(color=color.detach().cpu().numpy(), radii=radii.cpu().numpy(), depth=depth.cpu().numpy(),
                opacity=opacity.cpu().numpy(), D=R.last_stats["num_rendered"])
     if dL is not None:
@@ -61,7 +81,7 @@ def run_oracle(oracle, rs, rv, dL=None):
 
 def artefacts():
     """Integer artefacts of the most recent debug forward, decoded via the published layouts."""
-    d = R.last_debug
+    d = LAST
     P, D, W, H = d["P"], d["D"], d["W"], d["H"]
     gl, il, bl = d["gl"], d["il"], d["bl"]
     geom = d["geom"].cpu().numpy(); image = d["image"].cpu().numpy(); binning = d["binning"].cpu().numpy()
