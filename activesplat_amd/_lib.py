@@ -54,10 +54,10 @@ SORT_AUTO, SORT_TILE_LDS, SORT_RADIX = 0, 1, 2
 
 # every symbol include/gsplat_hip.h declares (tests check the library exports all of them)
 #: the GS_ABI_VERSION of include/gsplat_hip.h this binding was written against (checked when a library is bound)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 SYMBOLS = ("gs_abi_version", "gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
-           "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_set_half_quadrants", "gs_set_backward_chain", "gs_preprocess_forward", "gs_preprocess_forward_raw", "gs_render_forward", "gs_render_backward", "gs_render_backward_raw", "gs_adam_step", "gs_adam_step_multi",
+           "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_set_half_quadrants", "gs_set_backward_chain", "gs_preprocess_forward", "gs_preprocess_forward_raw", "gs_render_forward", "gs_render_backward", "gs_render_backward_raw", "gs_render_backward_raw_adam", "gs_adam_step", "gs_adam_step_multi",
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
            "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward", "gs_activate_backward_accumulate",
            "gs_grow_scratch_bytes", "gs_grow_gaussians", "gs_keyframe_overlap", "gs_visibility_stats", "gs_accumulate_grad2d",
@@ -101,6 +101,11 @@ def _bind(lib):
     # (cam, P, D, means3D, shs, colors, logit, log_scales, unnorm_rot, h_pose7, isotropic, accumulate, radii, geom, point_list, image,
     #  dL_dcolor, dL_ddepth, 7 gradient outputs, scratch, scratch_zeroed, have_sh_jacobian, stream)
     lib.gs_render_backward_raw.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 6 + [vp, i32, i32] + [vp] * 4 + [vp] * 2 + [vp] * 7 + [vp, i32, i32, vp]
+    # (cam, P, D, means3D, shs, colors, logit, log_scales, unnorm_rot, h_pose7, isotropic, radii, geom, point_list, image, dL_dcolor, dL_ddepth,
+    #  dL_dmeans2D, scratch, scratch_zeroed, have_sh_jacobian, adam5, stream)
+    lib.gs_render_backward_raw_adam.argtypes = [C.POINTER(GsCamera), i32, i64] + [vp] * 6 + [vp, i32] + [vp] * 4 + [vp] * 2 + [vp] + [vp, i32, i32] + \
+        [C.POINTER(GsAdamTensor), vp]
+    lib.gs_render_backward_raw_adam.restype = C.c_int
     lib.gs_preprocess_forward_raw.restype = C.c_int
     lib.gs_render_backward_raw.restype = C.c_int
     lib.gs_adam_step.argtypes = [i64, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, i32, vp]

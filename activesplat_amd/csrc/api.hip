@@ -415,7 +415,7 @@ static int render_backward_impl(const GsCamera* cam, int32_t P, int64_t D, const
                                 const float* dL_ddepth, float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities, float* dL_dcolors_precomp,
                                 float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* scratch,
                                 int32_t scratch_zeroed, int32_t have_sh_jacobian, gs_stream_t stream, const float* logit,
-                                const float* h_pose7, int32_t isotropic, int32_t accumulate)
+                                const float* h_pose7, int32_t isotropic, int32_t accumulate, const GsAdamTensor* adam5 = nullptr)
 {
     gs::Cam k;
     if (!make_cam(cam, k)) return fail(GS_EINVAL, "gs_render_backward: invalid camera settings");
@@ -426,11 +426,30 @@ static int render_backward_impl(const GsCamera* cam, int32_t P, int64_t D, const
     if (P < 0 || D < 0 || !geom_state || !image_state || !dL_dcolor || !scratch)
         return fail(GS_EINVAL, "gs_render_backward: null pointer");
     if (P == 0) return GS_OK;
-    if (!means3D || !radii || !dL_dmeans2D || !dL_dmeans3D || !dL_dopacities)
-        return fail(GS_EINVAL, "gs_render_backward: null input/output pointer");
-    if (shs ? !dL_dshs : !dL_dcolors_precomp) return fail(GS_EINVAL, "gs_render_backward: missing colour gradient output");
-    if (cov3D_precomp ? !dL_dcov3D : (!scales || !rotations || !dL_dscales || !dL_drotations))
-        return fail(GS_EINVAL, "gs_render_backward: missing covariance inputs/outputs");
+    gs::FusedAdam fa{};
+    if (adam5) {
+        // the optimiser step inside the per-Gaussian kernel: the five descriptors must describe the very tensors this call reads
+        if (!k.act || accumulate) return fail(GS_EINVAL, "gs_render_backward_raw_adam: raw-parameter mode without accumulation only");
+        if (!means3D || !radii || !dL_dmeans2D || !scales || !rotations || (shs == nullptr) == (colors_precomp == nullptr))
+            return fail(GS_EINVAL, "gs_render_backward_raw_adam: null input/output pointer");
+        if (shs && !have_sh_jacobian) return fail(GS_EINVAL, "gs_render_backward_raw_adam: SH rows need the forward's saved Jacobian (have_sh_jacobian = 1)");
+        const float* par[5] = {means3D, logit, scales, rotations, shs ? shs : colors_precomp};
+        const int64_t width[5] = {3, 1, isotropic ? 1 : 3, 4, shs ? 48 : 3};
+        for (int t = 0; t < 5; ++t) {
+            const GsAdamTensor& a = adam5[t];
+            if (a.param != par[t] || !a.exp_avg || !a.exp_avg_sq || a.step < 1 || a.n != width[t] * (int64_t)P)
+                return fail(GS_EINVAL, "gs_render_backward_raw_adam: descriptor of %s does not describe the input tensor (param / moments / n / step)",
+                            t == 0 ? "means3D" : t == 1 ? "logit_opacities" : t == 2 ? "log_scales" : t == 3 ? "unnorm_rotations" : "the colours");
+            fa.p[t] = a.param; fa.m[t] = a.exp_avg; fa.v[t] = a.exp_avg_sq;
+            fa.c[t] = gs::adam_coef(a.lr, a.beta1, a.beta2, a.eps, a.step);
+        }
+    } else {
+        if (!means3D || !radii || !dL_dmeans2D || !dL_dmeans3D || !dL_dopacities)
+            return fail(GS_EINVAL, "gs_render_backward: null input/output pointer");
+        if (shs ? !dL_dshs : !dL_dcolors_precomp) return fail(GS_EINVAL, "gs_render_backward: missing colour gradient output");
+        if (cov3D_precomp ? !dL_dcov3D : (!scales || !rotations || !dL_dscales || !dL_drotations))
+            return fail(GS_EINVAL, "gs_render_backward: missing covariance inputs/outputs");
+    }
     hipStream_t st = (hipStream_t)stream;
     gs::GeomPtrs gp = carve_geom(const_cast<void*>(geom_state), P, k);
     GsImageLayout IL; gs_image_layout(k.W, k.H, &IL);
@@ -450,7 +469,7 @@ static int render_backward_impl(const GsCamera* cam, int32_t P, int64_t D, const
         ScopedStage ps(ST_PREPROCESS_BWD, st);
         e = gs::launch_preprocess_backward(k, P, means3D, shs, scales, rotations, cov3D_precomp, radii, gp.clamped, (shs && have_sh_jacobian) ? gp.sh_jac : nullptr, grad2d,
                                            dL_dmeans2D, dL_dmeans3D, dL_dopacities, dL_dcolors_precomp, dL_dshs, dL_dscales,
-                                           dL_drotations, dL_dcov3D, logit, st);
+                                           dL_drotations, dL_dcov3D, logit, adam5 ? &fa : nullptr, st);
     }
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_render_backward: preprocess %s", hipGetErrorString(e));
     return GS_OK;
@@ -481,6 +500,18 @@ int gs_render_backward_raw(const GsCamera* cam, int32_t P, int64_t D, const floa
                                 image_state, dL_dcolor, dL_ddepth, dL_dmeans2D, dL_dmeans3D, dL_dlogit_opacities, dL_dcolors_precomp, dL_dshs,
                                 dL_dlog_scales, dL_dunnorm_rotations, nullptr, scratch, scratch_zeroed, have_sh_jacobian, stream,
                                 logit_opacities, h_pose7, isotropic, accumulate);
+}
+
+int gs_render_backward_raw_adam(const GsCamera* cam, int32_t P, int64_t D, const float* means3D, const float* shs, const float* colors_precomp,
+                                const float* logit_opacities, const float* log_scales, const float* unnorm_rotations, const float* h_pose7,
+                                int32_t isotropic, const int32_t* radii, const void* geom_state, const uint32_t* point_list,
+                                const void* image_state, const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans2D, void* scratch,
+                                int32_t scratch_zeroed, int32_t have_sh_jacobian, const GsAdamTensor* adam5, gs_stream_t stream)
+{
+    if (!h_pose7 || !adam5 || (P > 0 && !logit_opacities)) return fail(GS_EINVAL, "gs_render_backward_raw_adam: null pose / opacity parameters / descriptors");
+    return render_backward_impl(cam, P, D, means3D, shs, colors_precomp, log_scales, unnorm_rotations, nullptr, radii, geom_state, point_list,
+                                image_state, dL_dcolor, dL_ddepth, dL_dmeans2D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                scratch, scratch_zeroed, have_sh_jacobian, stream, logit_opacities, h_pose7, isotropic, 0, adam5);
 }
 
 int gs_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr,

@@ -376,8 +376,11 @@ __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
         zf = (size_t)blockIdx.x * pw + tid; zf_end = min(total, (size_t)blockIdx.x * pw + pw);
     }
     const size_t HWs = (size_t)cam.W * cam.H;
-    const bool record = cam.split != 0 && zero_fill != nullptr && split_state != nullptr;
-    if (split_state && blockIdx.x == 0 && tid == 0) reinterpret_cast<uint32_t*>(split_state + (kCutLevels * 5 + 4) * HWs)[0] = record ? 1u : 0u;
+    // (the recorded planes and their "recorded" word exist only in the workspace of an image of at most kFewTiles tiles; gs_set_half_quadrants
+    // may send a larger image here, whose workspace holds the chained backward's hand-over state at that offset instead)
+    const bool few = ntiles <= kFewTiles;
+    const bool record = few && cam.split != 0 && zero_fill != nullptr && split_state != nullptr;
+    if (few && split_state && blockIdx.x == 0 && tid == 0) reinterpret_cast<uint32_t*>(split_state + (kCutLevels * 5 + 4) * HWs)[0] = record ? 1u : 0u;
     if ((int)(blockIdx.x >> 3) >= per || tile >= ntiles) {                             // (uniform for the workgroup)
         for (; zf < zf_end; zf += kPcWaves * kWave) zero_fill[zf] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
@@ -992,6 +995,10 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
         else { GS_FWD(false, 1, grid); GS_FWD(false, 2, grid); }
     } else if (cam.half || cam.split) {
         // images of few tiles: one producer / consumer workgroup per tile
+        if (cam.chain > 1) {      // (an image of more than kFewTiles tiles sent here by gs_set_half_quadrants: this kernel does not clear the hand-over flags)
+            hipError_t e = hipMemsetAsync(split_state + (size_t)cam.gx * cam.gy * 4 * kChainStateFloats, 0, (size_t)cam.gx * cam.gy * 4 * (kChainPieces - 1) * sizeof(uint32_t), st);
+            if (e != hipSuccess) return e;
+        }
         const dim3 grid(((cam.gx * cam.gy + 7) >> 3) << 3), block(kPcWaves * kWave);
         if (out_depth_sq)
             hipLaunchKernelGGL((blend_forward_pc_kernel<true>), grid, block, 0, st, cam, ranges, point_list, geom, out_color, out_depth, out_opacity,

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 
 #include "../../include/gsplat_hip.h"
 
@@ -105,6 +106,18 @@ __device__ __forceinline__ void activate_rotation_bwd(const float* cam_q, int is
     const float dotu = u[0] * du[0] + u[1] * du[1] + u[2] * du[2] + u[3] * du[3];
     for (int k = 0; k < 4; k++) dq[k] = (du[k] - u[k] * dotu) / nq;
 }
+
+// The optimiser step INSIDE the raw-parameter backward (gs_render_backward_raw_adam; single-keyframe steps -- the reference's loop,
+// src/mapper/splatam/__init__.py:470-480, and BASELINE configs[2]'s): the thread that forms a Gaussian's parameter gradient applies
+// Adam to the parameter and its two moments in place -- no gradient tensor is written and read back.  Tensor order: 0 means3D,
+// 1 logit opacities, 2 log scales, 3 unnormalised rotations, 4 colours or 16-coefficient SH rows.
+struct AdamCoef { float one_m_b1, b2, one_m_b2, step_size, inv_bc2s, eps; };
+struct FusedAdam {
+    float* p[5];
+    float* m[5];
+    float* v[5];
+    AdamCoef c[5];
+};
 
 // Per-Gaussian screen-space record, 3 x float4 = 48 B, one gather per tile instance in the blend.
 //   q0 = (x, y, conic_a, conic_b)   q1 = (conic_c, opacity, r, g)   q2 = (b, depth, ext_x, ext_y)
@@ -383,6 +396,20 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
     p = p - step_size * (m / denom);
 }
 
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamCoef& c)
+{
+    adam_elem(p, g, m, v, c.one_m_b1, c.b2, c.one_m_b2, c.step_size, c.inv_bc2s, c.eps);
+}
+// host side: torch's bias corrections, in double, as launch_adam_multi forms them
+inline AdamCoef adam_coef(double lr, double beta1, double beta2, double eps, int step)
+{
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    AdamCoef c;
+    c.one_m_b1 = (float)(1.0 - beta1); c.b2 = (float)beta2; c.one_m_b2 = (float)(1.0 - beta2);
+    c.step_size = (float)(lr / bc1); c.inv_bc2s = (float)(1.0 / sqrt(bc2)); c.eps = (float)eps;
+    return c;
+}
+
 // Colour sums and (optionally) the direction Jacobian of ONE 16-coefficient row that sits 16-byte aligned in LDS: the row is read four
 // coefficients (three ds_read_b128) at a time and consumed at once, in the order of the scalar formulation above (colour: k ascending, one
 // FMA per channel; Jacobian: sh_direction_jacobian's sequence) -- same results to the bit, a dozen live registers instead of 48.
@@ -487,7 +514,7 @@ hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3
                                       const float* scales, const float* rots, const float* cov3Dp,
                                       const int32_t* radii, const uint32_t* clamped, const float2* sh_jac, const float* grad2d,
                                       float* dmeans2D, float* dmeans3D, float* dopac, float* dcolors, float* dshs,
-                                      float* dscales, float* drots, float* dcov3D, const float* logit, hipStream_t st);
+                                      float* dscales, float* drots, float* dcov3D, const float* logit, const FusedAdam* adam, hipStream_t st);
 hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_total, uint32_t* tile_base,
                              uint2* ranges, uint32_t* d_counts, uint32_t* host_counts, hipStream_t st);
 hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_base, const uint2* ranges,

@@ -16,14 +16,24 @@ namespace gs {
 // ACT: raw-parameter mode (Cam::act; colours given or 16-coefficient rows): means3D / scales / rots / logit are the mapper's PARAMETERS, the
 // frame transform + activations are recomputed here and the four gradients leave w.r.t. the parameters (activate.hip's backward inline);
 // with Cam::act_accumulate they -- and dcolors -- are ADDED to the output buffers (rows of Gaussians that were not rendered stay untouched).
-template <int SH, bool ACT = false>
-__global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
+// ADAM (with ACT, never with accumulation): the optimiser step rides along -- every Gaussian's thread applies Adam (adam_elem: the arithmetic of
+// adam.hip, contraction-free, so the result is the separate step's to the bit) to its parameters and moments in place with the gradient it has
+// just formed (zero for a Gaussian that was not rendered: its moments still decay and its parameter still moves); the SH gradient rows go
+// from the slab straight into a coalesced p / m / v update instead of out to HBM and back (2 x 192 B per Gaussian and step less).  The
+// parameter gradients are NOT written; dmeans2D is.
+// workgroups per CU the register budget is sized for: 4 (128 VGPRs); the raw-parameter SH variants -- which carry the activation algebra and,
+// with ADAM, the update's operands on top of the slab traffic -- are the tightest: 32 bytes of scratch per lane at 4, none at 3 (A/B knob)
+#ifndef GS_PBWD_RAW_SH_WGS
+#define GS_PBWD_RAW_SH_WGS 4
+#endif
+template <int SH, bool ACT = false, bool ADAM = false>
+__global__ __launch_bounds__(kBlock, (ACT && SH == 3) ? GS_PBWD_RAW_SH_WGS : 4) void preprocess_backward_kernel(
     Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov3Dp,
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const float2* __restrict__ sh_jac,
     const float* __restrict__ grad2d, float* __restrict__ dmeans2D, float* __restrict__ dmeans3D, float* __restrict__ dopac,
     float* __restrict__ dcolors, float* __restrict__ dshs, float* __restrict__ dscales,
-    float* __restrict__ drots, float* __restrict__ dcov3D, const float* __restrict__ logit)
+    float* __restrict__ drots, float* __restrict__ dcov3D, const float* __restrict__ logit, FusedAdam ad)
 {
     // per-wave slabs: 32 coefficient rows in, their gradients written back IN PLACE (each element is read before it is overwritten)
     constexpr bool HAS_SH = SH != 0;
@@ -105,23 +115,30 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
                     sh_basis_and_grad(deg, ux, uy, uz, b, bx, by, bz);
                     const uint32_t cl = cl_in;
                     float du[3] = {0.f, 0.f, 0.f};
-                    if (sh_jac) {
+                    // (k loops over the full 16 coefficients with predicates: constant indices keep b[] / bx[] ... in registers -- a loop bound
+                    // of nb made them indexed locals in scratch memory in the ADAM instantiation)
+                    if (ADAM || sh_jac) {                              // (ADAM: the API guarantees the saved Jacobian)
                         const float jr[3][3] = {{jac[0], jac[1], jac[2]}, {jac[3], jac[4], jac[5]}, {jac[6], jac[7], jac[8]}};
                         for (int ch = 0; ch < 3; ch++) {
                             const float g = ((cl >> (8 * ch)) & 1u) ? 0.f : drgb[ch];
                             du[0] += g * jr[ch][0]; du[1] += g * jr[ch][1]; du[2] += g * jr[ch][2];
-                            for (int k = 0; k < nb; k++) dsh[3 * k + ch] = g * b[k];
-                            for (int k = nb; k < M; k++) dsh[3 * k + ch] = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 16; k++)
+                                if (k < M) dsh[3 * k + ch] = k < nb ? g * b[k] : 0.f;
                         }
                     } else {
                         for (int ch = 0; ch < 3; ch++) {
                             const float g = ((cl >> (8 * ch)) & 1u) ? 0.f : drgb[ch];
-                            for (int k = 0; k < nb; k++) {
-                                const float coef = dsh[3 * k + ch];
-                                dsh[3 * k + ch] = g * b[k];
-                                du[0] += g * coef * bx[k]; du[1] += g * coef * by[k]; du[2] += g * coef * bz[k];
+#pragma unroll
+                            for (int k = 0; k < 16; k++) {
+                                if (k < nb) {
+                                    const float coef = dsh[3 * k + ch];
+                                    dsh[3 * k + ch] = g * b[k];
+                                    du[0] += g * coef * bx[k]; du[1] += g * coef * by[k]; du[2] += g * coef * bz[k];
+                                } else if (k < M) {
+                                    dsh[3 * k + ch] = 0.f;
+                                }
                             }
-                            for (int k = nb; k < M; k++) dsh[3 * k + ch] = 0.f;
                         }
                     }
                     const float dot = ux * du[0] + uy * du[1] + uz * du[2];
@@ -131,7 +148,24 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            sh_wave_rows_from_lds<KC>(slab, dshs, row0, nrows, K, lane);
+            if (ADAM) {
+                // the wavefront's (up to) 32 gradient rows against the same rows of the coefficients and their two moments: 16 B per lane,
+                // coalesced, non-temporal (each is touched once per step); K = 48 is a multiple of 4, so a piece never straddles two rows
+                float4* p4 = reinterpret_cast<float4*>(ad.p[4] + (size_t)row0 * K);
+                float4* m4 = reinterpret_cast<float4*>(ad.m[4] + (size_t)row0 * K);
+                float4* v4 = reinterpret_cast<float4*>(ad.v[4] + (size_t)row0 * K);
+                const int total4 = (nrows * K) >> 2;
+                for (int q4 = lane; q4 < total4; q4 += kWave) {
+                    float4 pp = load_stream(&p4[q4]), mm = load_stream(&m4[q4]), vv = load_stream(&v4[q4]);
+                    const int e = q4 << 2, rr = e / K, cc = e - rr * K;
+                    const float* gs_ = slab + rr * stride + cc;
+                    adam_elem(pp.x, gs_[0], mm.x, vv.x, ad.c[4]); adam_elem(pp.y, gs_[1], mm.y, vv.y, ad.c[4]);
+                    adam_elem(pp.z, gs_[2], mm.z, vv.z, ad.c[4]); adam_elem(pp.w, gs_[3], mm.w, vv.w, ad.c[4]);
+                    store_stream(&p4[q4], pp); store_stream(&m4[q4], mm); store_stream(&v4[q4], vv);
+                }
+            } else {
+                sh_wave_rows_from_lds<KC>(slab, dshs, row0, nrows, K, lane);
+            }
         }
         if (!in_range) return;
     }
@@ -248,11 +282,56 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_backward_kernel(
         // gradients w.r.t. the parameters (activate.hip's backward): means through the frame rotation, rotation through the normalisations and
         // the camera quaternion, opacity through the sigmoid, scales through the exponential
         for (int c = 0; c < 3; c++) dmeans2D[3 * i + c] = o_m2d[c];
-        const bool acc = cam.act_accumulate != 0;
+        const bool acc = !ADAM && cam.act_accumulate != 0;
         if (acc && !live) return;                                   // nothing to add
         const float dm[3] = {actR[0][0] * dmean[0] + actR[1][0] * dmean[1] + actR[2][0] * dmean[2],
                              actR[0][1] * dmean[0] + actR[1][1] * dmean[1] + actR[2][1] * dmean[2],
                              actR[0][2] * dmean[0] + actR[1][2] * dmean[1] + actR[2][2] * dmean[2]};
+        if (ADAM) {
+            // the step of this Gaussian's 11 (isotropic: 9) scalar parameters (+ 3 colours), in place; gradients exactly as the plain path
+            // would have stored them
+            const float o = 1.0f / (1.0f + __expf(-lg_in));
+            const float dl = (live ? gb.y : 0.f) * o * (1.0f - o);
+            const float ds[3] = {o_sc[0] * sc_in[0], o_sc[1] * sc_in[1], o_sc[2] * sc_in[2]};
+            const float qr[4] = {rq_raw.x, rq_raw.y, rq_raw.z, rq_raw.w};
+            float dq[4];
+            activate_rotation_bwd(cam.act_q, cam.act_iso, qr, o_rot, dq);
+            // every operand this thread needs is requested before the first update (one round trip; named scalars: no indexed locals)
+            const int ns = cam.act_iso ? 1 : 3;
+            const size_t i3 = (size_t)3 * i, is = (size_t)ns * i;
+#define GS_LD3(T, j) float p##T##j = ad.p[T][(T == 2 ? is : i3) + j], m##T##j = ad.m[T][(T == 2 ? is : i3) + j], v##T##j = ad.v[T][(T == 2 ? is : i3) + j]
+#define GS_ST3(T, j, g) do { adam_elem(p##T##j, (g), m##T##j, v##T##j, ad.c[T]);                                                  \
+                             ad.p[T][(T == 2 ? is : i3) + j] = p##T##j; ad.m[T][(T == 2 ? is : i3) + j] = m##T##j; ad.v[T][(T == 2 ? is : i3) + j] = v##T##j; } while (0)
+            GS_LD3(0, 0); GS_LD3(0, 1); GS_LD3(0, 2);
+            float lp = ad.p[1][i], lm = ad.m[1][i], lv = ad.v[1][i];
+            GS_LD3(2, 0);
+            float p21 = 0.f, m21 = 0.f, v21 = 0.f, p22 = 0.f, m22 = 0.f, v22 = 0.f;
+            if (!cam.act_iso) { p21 = ad.p[2][is + 1]; m21 = ad.m[2][is + 1]; v21 = ad.v[2][is + 1]; p22 = ad.p[2][is + 2]; m22 = ad.m[2][is + 2]; v22 = ad.v[2][is + 2]; }
+            float4 rp = reinterpret_cast<const float4*>(ad.p[3])[i], rm = reinterpret_cast<const float4*>(ad.m[3])[i],
+                   rv = reinterpret_cast<const float4*>(ad.v[3])[i];
+            float p40 = 0.f, m40 = 0.f, v40 = 0.f, p41 = 0.f, m41 = 0.f, v41 = 0.f, p42 = 0.f, m42 = 0.f, v42 = 0.f;
+            if (!HAS_SH) {
+                p40 = ad.p[4][i3]; m40 = ad.m[4][i3]; v40 = ad.v[4][i3]; p41 = ad.p[4][i3 + 1]; m41 = ad.m[4][i3 + 1]; v41 = ad.v[4][i3 + 1];
+                p42 = ad.p[4][i3 + 2]; m42 = ad.m[4][i3 + 2]; v42 = ad.v[4][i3 + 2];
+            }
+            GS_ST3(0, 0, dm[0]); GS_ST3(0, 1, dm[1]); GS_ST3(0, 2, dm[2]);
+            adam_elem(lp, dl, lm, lv, ad.c[1]);
+            ad.p[1][i] = lp; ad.m[1][i] = lm; ad.v[1][i] = lv;
+            if (cam.act_iso) {
+                GS_ST3(2, 0, ds[0] + ds[1] + ds[2]);
+            } else {
+                GS_ST3(2, 0, ds[0]); GS_ST3(2, 1, ds[1]); GS_ST3(2, 2, ds[2]);
+            }
+            adam_elem(rp.x, dq[0], rm.x, rv.x, ad.c[3]); adam_elem(rp.y, dq[1], rm.y, rv.y, ad.c[3]);
+            adam_elem(rp.z, dq[2], rm.z, rv.z, ad.c[3]); adam_elem(rp.w, dq[3], rm.w, rv.w, ad.c[3]);
+            reinterpret_cast<float4*>(ad.p[3])[i] = rp; reinterpret_cast<float4*>(ad.m[3])[i] = rm; reinterpret_cast<float4*>(ad.v[3])[i] = rv;
+            if (!HAS_SH) {
+                GS_ST3(4, 0, live ? drgb[0] : 0.f); GS_ST3(4, 1, live ? drgb[1] : 0.f); GS_ST3(4, 2, live ? drgb[2] : 0.f);
+            }
+#undef GS_LD3
+#undef GS_ST3
+            return;
+        }
         for (int c = 0; c < 3; c++) dmeans3D[3 * i + c] = acc ? dmeans3D[3 * i + c] + dm[c] : dm[c];
         const float o = 1.0f / (1.0f + __expf(-lg_in));
         const float dl = (live ? gb.y : 0.f) * o * (1.0f - o);
@@ -281,15 +360,17 @@ hipError_t launch_preprocess_backward(const Cam& cam, int P, const float* means3
                                       const float* scales, const float* rots, const float* cov3Dp,
                                       const int32_t* radii, const uint32_t* clamped, const float2* sh_jac, const float* grad2d,
                                       float* dmeans2D, float* dmeans3D, float* dopac, float* dcolors, float* dshs,
-                                      float* dscales, float* drots, float* dcov3D, const float* logit, hipStream_t st)
+                                      float* dscales, float* drots, float* dcov3D, const float* logit, const FusedAdam* adam, hipStream_t st)
 {
     const int nb = (P + kBlock - 1) / kBlock;
-    if (cam.act && (cov3Dp || !logit || !scales || !rots || !dscales || !drots || (shs && cam.sh_coeffs != 16))) return hipErrorInvalidValue;
+    if (cam.act && (cov3Dp || !logit || !scales || !rots || (!adam && (!dscales || !drots)) || (shs && cam.sh_coeffs != 16))) return hipErrorInvalidValue;
+    if (adam && (!cam.act || cam.act_accumulate)) return hipErrorInvalidValue;
+    const FusedAdam ad = adam ? *adam : FusedAdam{};
 #define GS_PBWD(...) hipLaunchKernelGGL((preprocess_backward_kernel<__VA_ARGS__>), dim3(nb), dim3(kBlock), 0, st, cam, P, means3D, shs, scales, rots, \
-                                        cov3Dp, radii, clamped, sh_jac, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D, logit)
-    if (nb > 0 && shs && cam.sh_coeffs == 16) { if (cam.act) GS_PBWD(3, true); else GS_PBWD(3, false); }
+                                        cov3Dp, radii, clamped, sh_jac, grad2d, dmeans2D, dmeans3D, dopac, dcolors, dshs, dscales, drots, dcov3D, logit, ad)
+    if (nb > 0 && shs && cam.sh_coeffs == 16) { if (adam) GS_PBWD(3, true, true); else if (cam.act) GS_PBWD(3, true); else GS_PBWD(3, false); }
     else if (nb > 0 && shs) GS_PBWD(1, false);
-    else if (nb > 0) { if (cam.act) GS_PBWD(0, true); else GS_PBWD(0, false); }
+    else if (nb > 0) { if (adam) GS_PBWD(0, true, true); else if (cam.act) GS_PBWD(0, true); else GS_PBWD(0, false); }
 #undef GS_PBWD
     return hipGetLastError();
 }

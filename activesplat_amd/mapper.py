@@ -48,6 +48,8 @@ DEFAULT_CONFIG = dict(
     fused_loss=False,        # masked-L1 + L1 + SSIM value and gradients by gs_mapping_loss
     fused_inputs=False,      # transform_to_frame + activations by gs_activate_*
     fused_preprocess=False,  # ... or inside the rasteriser's per-Gaussian kernels (rasterizer.render_rgbd_raw; needs fused_render): no activation launches
+    fused_adam=False,        # ... and the Adam step of an iteration inside that render's backward kernel (needs fused_preprocess; iterations whose
+                             # prune / densify event replaces the parameter tensors take the separate step, as the reference's loop effectively does)
     fused_growth=False,      # add_new_gaussians: one forward + gs_grow_gaussians
     fused_keyframes=False,   # keyframe overlap scores by gs_keyframe_overlap (one launch for all keyframes)
     high_loss_samples=True,  # the per-frame no-grad render of get_high_loss_samples (__init__.py:184-258) before mapping a frame
@@ -171,10 +173,14 @@ class SplatMapper:
             else:
                 kf = self.keyframe_list[pick]
                 it_id, it_color, it_depth = kf["id"], kf["color"], kf["depth"]
+            in_backward = cfg.get("fused_adam", False) and cfg.get("fused_preprocess", False) and cfg["fused_render"] \
+                and not (mc["prune_gaussians"] and O.prune_event(it, mc["pruning_dict"])) \
+                and not (mc["use_gaussian_splatting_densification"] and O.densify_event(it, mc["densify_dict"]))
             loss, self.variables, losses = M.get_loss(self.params, self._data(it_color, it_depth, it_id), self.variables, it_id,
                                                       mc["loss_weights"], mc["use_sil_for_loss"], mc["sil_thres"], mc["use_l1"],
                                                       mc["ignore_outlier_depth_loss"], fused=cfg["fused_render"], fused_loss=cfg["fused_loss"],
-                                                      fused_inputs=cfg["fused_inputs"], fused_preprocess=cfg.get("fused_preprocess", False))
+                                                      fused_inputs=cfg["fused_inputs"], fused_preprocess=cfg.get("fused_preprocess", False),
+                                                      fused_adam=self.optimizer if in_backward else None)
             loss.backward(gradient=self._one)           # cached dL/dloss = 1: saves autograd's ones_like launch per iteration
             with torch.no_grad():
                 if mc["prune_gaussians"]:

@@ -295,7 +295,7 @@ def fused_mapping_loss(im, depth, depth_sq, gt_im, gt_depth, loss_weights):
 
 def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_for_loss=True, sil_thres=0.99,
              use_l1=True, ignore_outlier_depth_loss=False, do_ba=False, fused=False, fused_loss=False, fused_inputs=False,
-             pose7=None, accumulate_grads=False, fused_preprocess=False):
+             pose7=None, accumulate_grads=False, fused_preprocess=False, fused_adam=None):
     """Mapping loss: masked depth L1 + 0.8 L1 + 0.2 (1 - SSIM) on colour; updates
     variables['means2D'|'seen'|'max_2D_radius'].
     fused=False: the reference's two raster passes on the same geometry (RGB, then [z,1,z^2]).
@@ -310,7 +310,9 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
                  taken with torch.autograd.grad are not delivered in this mode.
     fused_preprocess (with fused; isotropic or anisotropic scale / rotation parameters, `rgb_colors` or 16-coefficient `shs` rows): no activation launches at all -- the
                  rasteriser's per-Gaussian kernels take the PARAMETERS and do the frame transform + activations themselves, forward and
-                 backward (rasterizer.render_rgbd_raw); with accumulate_grads the backward also adds into the parameters' .grad."""
+                 backward (rasterizer.render_rgbd_raw); with accumulate_grads the backward also adds into the parameters' .grad.
+    fused_adam (with fused_preprocess; the GaussianAdam that owns the parameters): the backward kernel also applies this iteration's Adam
+                 step to the five per-Gaussian tensors in place (no gradient tensors; a following optimizer.step() skips them)."""
     if fused_preprocess and fused and not do_ba:
         if pose7 is None:
             q = F.normalize(params["cam_unnorm_rots"][..., iter_time_idx].detach()).reshape(4)
@@ -324,7 +326,7 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
         im, radius, depth, _sil, depth_sq = render_rgbd_raw(curr_data["cam"], params["means3D"], m2d, params["logit_opacities"],
                                                              params["log_scales"], params["unnorm_rotations"], pose7,
                                                              colors_precomp=None if "shs" in params else params["rgb_colors"],
-                                                             shs=params.get("shs"), accumulate_grads=accumulate_grads,
+                                                             shs=params.get("shs"), accumulate_grads=accumulate_grads, adam=fused_adam,
                                                              visibility=(mx, seen) if stats_in_render else None)
         variables["means2D"] = m2d
         if fused_loss and use_l1 and not ignore_outlier_depth_loss:

@@ -114,6 +114,52 @@ class GaussianAdam:
         _lib.check(lib.gs_adam_step_multi(len(live), arr, _stream(live[0][1])))
 
 
+    @torch.no_grad()
+    def backward_step_descriptors(self, tensors):
+        """For the optimiser step INSIDE the rasteriser's backward (rasterizer.render_rgbd_raw(adam=...), gs_render_backward_raw_adam): the
+        GsAdamTensor descriptors of `tensors` (parameters of this optimiser, in the kernel's order), with this step's bookkeeping done --
+        state created on first use, step counters advanced -- exactly as step() would.  The kernel then updates parameter and moments in
+        place; the tensors keep .grad = None, so a later step() skips them."""
+        by_id = {id(p): g for g in self.param_groups for p in g["params"]}
+        arr = (_lib.GsAdamTensor * len(tensors))()
+        for i, p in enumerate(tensors):
+            g = by_id.get(id(p))
+            if g is None:
+                raise RuntimeError("fused Adam: a rendered tensor is not a parameter of this optimiser")
+            if p.grad is not None:
+                raise RuntimeError("fused Adam: a parameter already holds a gradient (accumulated keyframes?) -- step() it or zero_grad() first")
+            if not p.is_contiguous() or p.dtype != torch.float32:
+                raise RuntimeError("GaussianAdam needs contiguous fp32 parameters")
+            st = self.state.get(p)
+            if st is None or len(st) == 0:
+                st = self.state[p] = {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+            st["step"] = int(st["step"]) + 1
+            b1, b2 = g["betas"]
+            arr[i] = _lib.GsAdamTensor(p.numel(), p.data_ptr(), None, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                       float(g["lr"]), float(b1), float(b2), float(g["eps"]), int(st["step"]), 0)
+        return arr
+
+
+def densify_event(iter, densify_dict) -> bool:
+    """Does densify(..., iter, densify_dict) restructure the map or reset parameters at this iteration (as opposed to only accumulating
+    statistics)?  A loop that steps the optimiser inside the backward kernel takes the separate step on such iterations: row surgery
+    replaces the parameter tensors between backward and step, and the reference's step then skips them (slam_external.py:110-193)."""
+    if iter > densify_dict["stop_after"]:
+        return False
+    if iter >= densify_dict["start_after"] and iter % densify_dict["densify_every"] == 0:
+        return True
+    return bool(iter > 0 and iter % densify_dict["reset_opacities_every"] == 0 and densify_dict.get("reset_opacities", False))
+
+
+def prune_event(iter, prune_dict) -> bool:
+    """Does prune_gaussians(..., iter, prune_dict) remove rows or reset opacities at this iteration?  (see densify_event)"""
+    if iter > prune_dict["stop_after"]:
+        return False
+    if iter >= prune_dict["start_after"] and iter % prune_dict["prune_every"] == 0:
+        return True
+    return bool(iter > 0 and iter % prune_dict["reset_opacities_every"] == 0 and prune_dict["reset_opacities"])
+
+
 def initialize_optimizer(params, lrs_dict, tracking=False):
     groups = [{"params": [v], "name": k, "lr": lrs_dict[k]} for k, v in params.items()]
     return GaussianAdam(groups) if tracking else GaussianAdam(groups, lr=0.0, eps=1e-15)

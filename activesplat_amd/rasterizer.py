@@ -156,6 +156,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         lib = _lib.get()
         device = means3D.device
         leaves = (means3D, opacities, scales, rotations, colors_precomp)     # (raw + accumulate: the backward adds into these tensors' .grad)
+        shs_in = shs
         _require_rocm(device)
         P = int(means3D.shape[0])
         means3D = _f32(means3D, device)
@@ -246,8 +247,17 @@ class _RasterizeGaussians(torch.autograd.Function):
                    cov3D_precomp is not None)
         ctx.raw = None if raw is None else (pose, 1 if raw[1] else 0, bool(raw[2]), opacities)
         # in-kernel accumulation only into the very tensors the caller passed (a converted copy has no .grad to add to)
-        same = raw is not None and raw[2] and all(a is b for a, b in zip(leaves, (means3D, opacities, scales, rotations, colors_precomp)))
+        adam = raw[4] if raw is not None and len(raw) > 4 else None
+        same = raw is not None and (raw[2] or adam is not None) and all(a is b for a, b in zip(leaves, (means3D, opacities, scales, rotations, colors_precomp)))
         ctx.leaves = leaves if same else None
+        ctx.adam = None
+        if adam is not None:
+            # the optimiser step inside the backward kernel: it updates the caller's parameter tensors in place
+            if raw[2]:
+                raise Exception("render_rgbd_raw: adam= and accumulate_grads= exclude each other")
+            if not same or (shs is not None and shs is not shs_in):
+                raise Exception("render_rgbd_raw(adam=...): the parameters must be contiguous, 16-byte aligned fp32 tensors on the device (they are updated in place)")
+            ctx.adam = (adam, leaves[:4] + (shs_in if shs_in is not None else leaves[4],))
         caps = getattr(_tls, "captures", None)
         if caps:
             caps[-1].update(geom=geom, image=image, binning=binning, point_list=point_list, gl=gl, il=il, bl=bl, D=D, P=P, W=W, H=H)
@@ -287,6 +297,16 @@ class _RasterizeGaussians(torch.autograd.Function):
             scratch, clean = torch.empty(int(lib.gs_backward_scratch_bytes(P)), dtype=torch.uint8, device=device), False
         ctx.scratch, ctx.scratch_clean = None, False     # released with this launch (64 B x P); a second backward through the same graph
                                                          # takes a fresh buffer plus a memset
+        if ctx.raw is not None and ctx.adam is not None:
+            # single-keyframe step: Adam on the five per-Gaussian tensors rides in the per-Gaussian backward kernel (no gradient tensors)
+            pose, iso, _acc, logit = ctx.raw
+            opt, tensors = ctx.adam
+            desc = opt.backward_step_descriptors(tensors)
+            _lib.check(lib.gs_render_backward_raw_adam(
+                C.byref(cam), P, ctx.D, _ptr(means3D), _ptr(shs if has_sh else None), _ptr(colors if has_col else None), _ptr(logit),
+                _ptr(scales), _ptr(rots), pose, iso, _ptr(radii), _ptr(geom), _ptr(point_list), _ptr(image), _ptr(grad_color),
+                _ptr(grad_depth), _ptr(d_m2d), _ptr(scratch), 1 if clean else 0, int(ctx.sh_jac), desc, _stream(device)))
+            return None, d_m2d, None, None, None, None, None, None, None, None, None
         if ctx.raw is not None:
             pose, iso, accumulate, logit = ctx.raw
             d_sc = z(P, 1 if iso else 3)                  # (gradients w.r.t. the parameters: log scales are [P,1] for an isotropic map)
@@ -356,7 +376,7 @@ def render_rgbd(raster_settings, means3D, means2D, opacities, shs=None, colors_p
 
 
 def render_rgbd_raw(raster_settings, means3D, means2D, logit_opacities, log_scales, unnorm_rotations, pose7, shs=None, colors_precomp=None,
-                    accumulate_grads=False, visibility=None):
+                    accumulate_grads=False, visibility=None, adam=None):
     """render_rgbd straight from the mapper's PARAMETERS: the frame transform + activations of transform_to_frame /
     transformed_params2rendervar (slam_helpers.py:252-304,124-139; `mapping.fused_rendervar` does them in two launches of their own) happen
     inside the per-Gaussian kernels of the rasteriser, forward and backward.  pose7 = host (qw,qx,qy,qz,tx,ty,tz) of the frame's relative
@@ -364,7 +384,13 @@ def render_rgbd_raw(raster_settings, means3D, means2D, logit_opacities, log_scal
     accumulate_grads (for `loss.backward()` over a batch of keyframes): the backward ADDS the gradients of means3D, logit_opacities,
     log_scales, unnorm_rotations and colors_precomp to those tensors' .grad inside its kernel and hands autograd nothing for them.
     visibility = (max_2D_radius [P] float32, seen [P] bool), both contiguous on the device: the mapper's statistics of this render
-    (splatam.py:296-298: max_2D_radius = max(max_2D_radius, radius) in place, seen = radius > 0) written by the forward kernel itself."""
+    (splatam.py:296-298: max_2D_radius = max(max_2D_radius, radius) in place, seen = radius > 0) written by the forward kernel itself.
+    adam = the optim.GaussianAdam that owns the five tensors (single-keyframe steps -- the reference's loss.backward(); optimizer.step() on one
+    frame, src/mapper/splatam/__init__.py:470-480): the backward kernel that forms a Gaussian's parameter gradients applies the Adam update
+    to parameters and moments IN PLACE (gs_render_backward_raw_adam; same arithmetic as optimizer.step(), bit for bit) and writes no
+    gradient tensors -- the five tensors keep .grad = None, a following optimizer.step() skips them; means2D.grad is delivered as usual.
+    Not for gradient accumulation over several keyframes, and not on iterations whose densify / prune event replaces the tensors between
+    backward and step (optim.densify_event)."""
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
     if shs is not None and int(shs.shape[1]) != 16:
@@ -377,7 +403,7 @@ def render_rgbd_raw(raster_settings, means3D, means2D, logit_opacities, log_scal
                 and seen.numel() == P and mx.device == means3D.device and seen.device == means3D.device):
             raise Exception("render_rgbd_raw: visibility = (float32 [P], bool [P]) contiguous tensors on the parameters' device")
     return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, logit_opacities, log_scales, unnorm_rotations, None,
-                                     raster_settings, True, (pose7, iso, accumulate_grads, visibility))
+                                     raster_settings, True, (pose7, iso, accumulate_grads, visibility, adam))
 
 
 class GaussianRasterizer(nn.Module):

@@ -9,9 +9,12 @@ from . import synthetic as syn
 from .camera import setup_camera
 
 
-def configs2_optimise_loop(N, iters, device, fused_densify=True, densify_every=50, sh_degree=3, W=640, H=480, seed=0, time_it=False, raw=True):
+def configs2_optimise_loop(N, iters, device, fused_densify=True, densify_every=50, sh_degree=3, W=640, H=480, seed=0, time_it=False, raw=True,
+                           fused_adam=True):
     """BASELINE configs[2]: N Gaussians with SH coefficients, one 640x480 target, `iters` iterations of
     fused activations -> single-pass RGB-D render -> fused loss -> backward -> densify (every `densify_every`) -> fused Adam.
+    fused_adam (with raw): on iterations without a densify event the Adam step rides in the backward's per-Gaussian kernel
+    (render_rgbd_raw(adam=...)); same parameters afterwards, bit for bit.
     Returns dict(losses=[first, last], counts=[N after every densify event], seconds)."""
     import time
     from activesplat_amd import mapping as M, optim as O
@@ -38,8 +41,10 @@ def configs2_optimise_loop(N, iters, device, fused_densify=True, densify_every=5
             # the per-Gaussian kernels take the parameters themselves: frame transform + activations inside, no activation launches
             m2d = torch.empty_like(params["means3D"], requires_grad=True)
             rv = {"means2D": m2d}
+            in_backward = fused_adam and not (it > 0 and densify and O.densify_event(it, ddict))
             im, radius, depth, sil, dsq = R.render_rgbd_raw(cam, params["means3D"], m2d, params["logit_opacities"], params["log_scales"],
-                                                            params["unnorm_rotations"], [1.0, 0, 0, 0, 0, 0, 0], shs=params["shs"])
+                                                            params["unnorm_rotations"], [1.0, 0, 0, 0, 0, 0, 0], shs=params["shs"],
+                                                            adam=opt if in_backward else None)
         else:
             rv = M.fused_rendervar(dict(params, rgb_colors=params["shs"]), 0, [1.0, 0, 0, 0, 0, 0, 0])
             rv.pop("colors_precomp")

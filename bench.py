@@ -671,7 +671,8 @@ def main():
             N1 = 500_000
             params1 = params1 if params1 is not None else syn.make_params(N1, W, H, seed=0)
             cam1 = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=dev)
-            for name, flags in (("reference_call_pattern", {}), ("fused", dict(fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=True))):
+            for name, flags in (("reference_call_pattern", {}), ("fused", dict(fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=True)),
+                                ("fused_adam_in_backward", dict(fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=True, adam=True))):
                 prm = {k: torch.nn.Parameter(v.to(dev)) for k, v in params1.items()}
                 prm["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([1.0, 0, 0, 0], device=dev).reshape(1, 4, 1))
                 prm["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 1, device=dev))
@@ -681,8 +682,12 @@ def main():
                 opt = O.initialize_optimizer(prm, dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05,
                                                        log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0))
 
+                flags = dict(flags)
+                in_bwd = flags.pop("adam", False)
+
                 def it():
-                    loss, _, _ = M.get_loss(prm, data, var, 0, dict(im=0.5, depth=1.0), pose7=[1.0, 0, 0, 0, 0, 0, 0] if flags else None, **flags)
+                    loss, _, _ = M.get_loss(prm, data, var, 0, dict(im=0.5, depth=1.0), pose7=[1.0, 0, 0, 0, 0, 0, 0] if flags else None,
+                                            fused_adam=opt if in_bwd else None, **flags)
                     loss.backward()
                     with torch.no_grad():
                         opt.step(); opt.zero_grad(set_to_none=True)

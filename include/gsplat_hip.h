@@ -148,7 +148,7 @@ const char* gs_version(void);
 /* Integer version of THIS binary interface: bumped whenever an entry point's argument list or a published record layout changes (e.g.
  * the seed argument of gs_densify_children, the 40-byte SH Jacobian record).  A host binding compares it with the GS_ABI_VERSION it was
  * written against before the first call, so that a stale prebuilt library fails at load time instead of misreading its arguments. */
-#define GS_ABI_VERSION 4
+#define GS_ABI_VERSION 5
 int32_t gs_abi_version(void);
 
 /* Optional per-stage timing (hipEvents recorded on the caller's stream around each stage's launches).
@@ -255,6 +255,22 @@ typedef struct GsAdamTensor {
     int32_t reserved;       /* padding; set to 0 */
 } GsAdamTensor;
 int gs_adam_step_multi(int32_t count, const GsAdamTensor* tensors, gs_stream_t stream);
+
+/* gs_render_backward_raw with the optimiser step INSIDE (single-keyframe steps: the reference's mapping loop -- loss.backward() followed by
+ * optimizer.step() on the same keyframe's gradients, src/mapper/splatam/__init__.py:470-480 -- and BASELINE configs[2]'s loop): the
+ * per-Gaussian backward kernel applies Adam to the five per-Gaussian parameter tensors and their moments in place with the gradient it
+ * forms, instead of writing gradient tensors that gs_adam_step_multi reads back one launch later.  Same arithmetic as gs_adam_step*, so the
+ * parameters and moments afterwards are those of gs_render_backward_raw + gs_adam_step_multi, bit for bit.
+ * adam5: HOST array of exactly five descriptors in the order {means3D, logit_opacities, log_scales, unnorm_rotations, colours | SH rows};
+ * .param must be the very tensors passed as inputs (they are updated in place), .grad is ignored, .n = elements of the tensor
+ * (3P, P, 3P | P, 4P, 3P | 48P), .step >= 1 is the step number this call performs.  Gaussians that were not rendered are stepped with a zero
+ * gradient (their moments decay), as a dense optimiser does.  dL_dmeans2D is written as usual; no parameter gradient is written, no
+ * accumulation.  SH rows need have_sh_jacobian = 1 (the kernel overwrites the rows it would otherwise read). */
+int gs_render_backward_raw_adam(const GsCamera* cam, int32_t P, int64_t D, const float* means3D, const float* shs, const float* colors_precomp,
+                                const float* logit_opacities, const float* log_scales, const float* unnorm_rotations, const float* h_pose7,
+                                int32_t isotropic, const int32_t* radii, const void* geom_state, const uint32_t* point_list,
+                                const void* image_state, const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans2D, void* scratch,
+                                int32_t scratch_zeroed, int32_t have_sh_jacobian, const GsAdamTensor* adam5, gs_stream_t stream);
 
 /* Keyframe-sharded optimiser step (activesplat_amd/parallel.py; SURVEY.md section 8e -- new capability, the reference steps one
  * keyframe on one GPU, src/mapper/splatam/__init__.py:450-480): glue between the K per-key tensors ([N, width] fp32, K <= 8,

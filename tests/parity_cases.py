@@ -249,6 +249,68 @@ def check_raw_parameter_mode_sh(device, n=400, W=64, H=48):
     assert float((a[4] - b[4]).norm() / a[4].norm()) < 3e-4
 
 
+def check_adam_inside_the_backward(device, n=600, W=64, H=48, steps=3, exact=True):
+    """render_rgbd_raw(adam=optimizer) -- the Adam step of the five per-Gaussian tensors inside the per-Gaussian backward kernel
+    (gs_render_backward_raw_adam) -- against backward + GaussianAdam.step() (whose arithmetic the golden adam.npz fixture pins): parameters,
+    both moments, step counters and means2D.grad after every one of `steps` iterations; colours / 16-coefficient SH rows, anisotropic /
+    isotropic maps; about a third of the Gaussians behind the camera (zero gradient: moments decay, parameters still move).
+    exact=True (the emulated build on ONE host thread, where the blend backward's atomic sums have a fixed order): BIT for bit.
+    exact=False (the device: two runs of the atomics sum in different orders, and Adam turns a gradient at rounding-noise level into a
+    step of +-lr): the first moments within 1e-5 relative L2, the second within 2e-5, and the parameters equal within 1e-6 of their
+    scale on all but 0.1 % of the elements."""
+    from activesplat_amd import optim as O, rasterizer as R
+    from activesplat_amd import synthetic as syn
+    from activesplat_amd.camera import setup_camera
+    pose = [0.9950042, 0.0, 0.0998334, 0.0, 0.03, -0.02, -1.2]
+    g = torch.Generator().manual_seed(4)
+    dLc, dLd = torch.randn(3, H, W, generator=g).to(device), torch.randn(1, H, W, generator=g).to(device)
+    for sh, iso in ((False, False), (False, True), (True, False)):
+        p0 = syn.make_params(n, W, H, seed=6, sh_degree=3 if sh else None)
+        if sh:
+            p0.pop("rgb_colors")
+        if iso:
+            p0["log_scales"] = p0["log_scales"][:, :1].contiguous()
+        cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=device, sh_degree=3 if sh else 0)
+        lrs = dict(means3D=1e-3, rgb_colors=2.5e-3, shs=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3)
+        runs = []
+        for fused in (False, True):
+            prm = {k: torch.nn.Parameter(v.clone().to(device)) for k, v in p0.items()}
+            opt = O.initialize_optimizer(prm, {k: lrs[k] for k in prm})
+            hist = []
+            for it in range(steps):
+                m2d = torch.empty_like(prm["means3D"], requires_grad=True)
+                col = dict(shs=prm["shs"]) if sh else dict(colors_precomp=prm["rgb_colors"])
+                im, radius, depth, sil, dsq = R.render_rgbd_raw(cam, prm["means3D"], m2d, prm["logit_opacities"], prm["log_scales"],
+                                                                prm["unnorm_rotations"], pose, adam=opt if fused else None, **col)
+                ((im * dLc).sum() + (depth * dLd).sum()).backward()
+                if fused:
+                    assert all(v.grad is None for v in prm.values())
+                opt.step()                                  # (fused: nothing holds a gradient -- a no-op)
+                opt.zero_grad(set_to_none=True)
+                hist.append(({k: v.detach().clone() for k, v in prm.items()},
+                             {k: (opt.state[v]["exp_avg"].clone(), opt.state[v]["exp_avg_sq"].clone(), int(opt.state[v]["step"])) for k, v in prm.items()},
+                             m2d.grad.clone(), int((radius > 0).sum())))
+            runs.append(hist)
+        for it, (a, b) in enumerate(zip(*runs)):
+            assert 0.3 * n < a[3] < 0.95 * n, a[3]
+            rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm().clamp_min(1e-30))  # noqa: E731
+            if exact:
+                assert torch.equal(a[2], b[2]), ("means2D.grad", sh, iso, it)
+            else:
+                assert rel(a[2], b[2]) < 1e-5, ("means2D.grad", sh, iso, it, rel(a[2], b[2]))
+            for k in a[0]:
+                assert a[1][k][2] == b[1][k][2] == it + 1, (k, sh, iso, it)
+                if exact:
+                    assert torch.equal(a[0][k], b[0][k]), (k, sh, iso, it, float((a[0][k] - b[0][k]).abs().max()))
+                    assert torch.equal(a[1][k][0], b[1][k][0]) and torch.equal(a[1][k][1], b[1][k][1]), (k, sh, iso, it)
+                    continue
+                if iso and k == "unnorm_rotations":          # equal scales: the rotation's gradient is rounding noise, which Adam amplifies to +-lr
+                    continue
+                assert rel(a[1][k][0], b[1][k][0]) < 1e-5 and rel(a[1][k][1], b[1][k][1]) < 2e-5, (k, sh, iso, it, rel(a[1][k][0], b[1][k][0]))
+                d = (a[0][k] - b[0][k]).abs()
+                assert float((d > 1e-6 * float(b[0][k].abs().max())).float().mean()) < 1e-3, (k, sh, iso, it, float(d.max()))
+
+
 def check_chained_backward(device, oracle64, N=5000, W=288, H=272, oracle32=None, seed=33):
     """Images of more than 768 tiles walk every quadrant's list in three chained pieces (gs_set_backward_chain): here the threshold is
     lowered so that a 306-tile image takes that path, with splats large and faint enough for walks of several 64-record chunks; against

@@ -120,6 +120,19 @@ def test_emulated_raw_parameter_rasteriser_equals_the_activation_kernels(emu):
     pc.check_raw_parameter_mode_sh("cpu")
 
 
+def test_emulated_adam_inside_the_backward_equals_backward_plus_step(emu):
+    """(one OpenMP thread for the emulator's block loop: the blend backward's float atomics then sum in a fixed order and the two loops can be
+    compared bit for bit)"""
+    import ctypes
+    omp = ctypes.CDLL("libgomp.so.1")
+    before = omp.omp_get_max_threads()
+    omp.omp_set_num_threads(1)
+    try:
+        pc.check_adam_inside_the_backward(emu)
+    finally:
+        omp.omp_set_num_threads(before)
+
+
 def test_emulated_optimistic_launch_hit_and_miss_equal_exact_launch(emu):
     pc.check_optimistic_launch(emu)
     pc.check_optimistic_tile_list_growth(emu)

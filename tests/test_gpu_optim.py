@@ -107,7 +107,9 @@ def test_mapper_harness_gpu(hip):
     for fr in (seq[0], seq[9]):
         im, depth, opacity = mp.render_rgbd(fr["w2c"])
         seen = (fr["depth"] > 0)[0]
-        assert util.psnr(im[:, seen].cpu().numpy(), fr["color"][:, seen].cpu().numpy()) > 24.0       # (measured: 26.1 dB)
+        ps = util.psnr(im[:, seen].cpu().numpy(), fr["color"][:, seen].cpu().numpy())
+        print(f"mapper harness re-render PSNR frame {fr['id']}: {ps:.2f} dB")
+        assert ps > 24.0, ps
         err = ((depth / opacity.clamp_min(1e-6))[0][seen] - fr["depth"][0][seen]).abs().median()
         assert float(err) < 0.1
 

@@ -310,6 +310,10 @@ def test_chained_backward_at_full_size_equals_one_walker_per_quadrant(hip):
         assert np.linalg.norm(g.astype(np.float64) - r) <= 2e-5 * max(np.linalg.norm(r), 1e-30), (k, np.linalg.norm(g - r) / np.linalg.norm(r))
 
 
+def test_adam_inside_the_backward_equals_backward_plus_step(hip):
+    pc.check_adam_inside_the_backward(hip, n=30000, W=160, H=128, exact=False)
+
+
 def test_raw_parameter_rasteriser_equals_the_activation_kernels(hip):
     pc.check_raw_parameter_mode(hip, n=20000)
     pc.check_raw_parameter_mode_sh(hip, n=20000, W=160, H=128)

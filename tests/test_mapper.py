@@ -101,6 +101,26 @@ def test_mapper_with_the_raw_parameter_rasteriser_builds_the_same_map(emu):
             assert d < 5e-3 * max(1.0, float(a.params[k].detach().abs().max())), (k, d)
 
 
+def test_mapper_with_adam_inside_the_backward_builds_the_same_map(emu):
+    """fused_adam: every mapping iteration's Adam step inside the raw-parameter backward kernel against the separate optimizer.step()
+    (on ONE emulator thread the two loops are the same arithmetic in the same order: identical maps, bit for bit)."""
+    import ctypes
+    omp = ctypes.CDLL("libgomp.so.1")
+    before = omp.omp_get_max_threads()
+    omp.omp_set_num_threads(1)
+    try:
+        base = dict(fused_render=True, fused_loss=True, fused_inputs=True, fused_preprocess=True)
+        a, _, log_a = run_harness(emu, n_gt=2000, W=48, H=40, frames=6, cfg=base)
+        b, _, log_b = run_harness(emu, n_gt=2000, W=48, H=40, frames=6, cfg=dict(base, fused_adam=True))
+    finally:
+        omp.omp_set_num_threads(before)
+    assert log_a == log_b and a.stats["iters"] == b.stats["iters"] > 0
+    for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
+        assert torch.equal(a.params[k].detach(), b.params[k].detach()), k
+        sa, sb = a.optimizer.state[a.params[k]], b.optimizer.state[b.params[k]]
+        assert int(sa["step"]) == int(sb["step"]) and torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), k
+
+
 def test_raw_frames_with_densification_resolution(emu):
     """run_raw: uint8 image + metric depth + pose in, resized mapping / densification copies out; the map is seeded and
     grown at the (half) densification resolution while the loss runs at the mapping resolution."""
