@@ -967,6 +967,9 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
 #ifndef GS_BWD_PC_WAVES
 #define GS_BWD_PC_WAVES 5
 #endif
+#ifndef GS_PC_ABLATE
+#define GS_PC_ABLATE 0          // measurement builds only (scripts/exp): 1 = consumer without phase B / gather, 2 = producer without phase A
+#endif
 template <bool DEPTH_GRAD>
 __global__ __launch_bounds__(2 * kWave, GS_BWD_PC_WAVES) void blend_backward_pc_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -1083,6 +1086,7 @@ __global__ __launch_bounds__(2 * kWave, GS_BWD_PC_WAVES) void blend_backward_pc_
             for (int t0 = 0; t0 < ntrips; t0 += kBT) {
                 const int tend = min(kBT, ntrips - t0);
                 uint32_t jj2_next = *reinterpret_cast<const uint16_t*>(my_list + t0);
+#if GS_PC_ABLATE != 2           // (ablation 2, results wrong on purpose: no phase A)
                 for (int t = 0; t < tend; t += 2) {
                     const uint32_t jj2 = jj2_next;
                     jj2_next = *reinterpret_cast<const uint16_t*>(my_list + t0 + t + 2);
@@ -1116,6 +1120,9 @@ __global__ __launch_bounds__(2 * kWave, GS_BWD_PC_WAVES) void blend_backward_pc_
                         w2[u * kMT] = a_eff * T;
                     }
                 }
+#else
+                (void)tend; (void)jj2_next; (void)rel_last;
+#endif
                 __syncthreads();                                 // (X) planes full
                 __syncthreads();                                 // (Y) planes read
             }
@@ -1165,6 +1172,10 @@ __global__ __launch_bounds__(2 * kWave, GS_BWD_PC_WAVES) void blend_backward_pc_
             const float4 g0 = gp4[0], g1 = gp4[1], g2 = gp4[2], g3 = gp4[3];
             const float4 v0 = wp4[0], v1 = wp4[1], v2 = wp4[2], v3 = wp4[3];
             __syncthreads();                                     // (Y) the producer may overwrite the planes
+#if GS_PC_ABLATE == 1           // (ablation 1, results wrong on purpose: no phase B, no gather)
+            racc[0] += g0.x + v0.x + rc.x + opb; (void)g1; (void)g2; (void)g3; (void)v1; (void)v2; (void)v3; (void)p0; (void)p1; (void)p2; (void)p3;
+            continue;
+#endif
             const float gg[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
             const float ww[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
             const float ddx[4] = {rc.x - bxf, rc.x - (bxf + 1.0f), rc.x - (bxf + 2.0f), rc.x - (bxf + 3.0f)};

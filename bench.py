@@ -243,7 +243,7 @@ def run_c4(args, dev, rank, world, emit=True, ranks_info=None):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         D = int(R.last_stats["num_rendered"])
-        exch = dict(PL.last_exchange); exch.pop("events", None)
+        exch = {k: v for k, v in PL.last_exchange.items() if k not in ("events", "render_events")}
         ex = [float(a.elapsed_time(b)) for a, b in (e for e in ex_ms if e)]
         # every rank's own keyframes (render + loss + backward, before the exchange), event-timed per step: the load balance of the shards
         rd = [float(a.elapsed_time(b)) for a, b in (e for e in rd_ms if e)]

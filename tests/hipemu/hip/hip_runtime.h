@@ -14,6 +14,7 @@
 // timing.
 #pragma once
 #include <ucontext.h>
+#include <time.h>
 
 #include <algorithm>
 #include <cmath>
@@ -308,7 +309,10 @@ template <class T> static inline T hipemu_atomic_load(const T* p, int order) { T
 template <class T, class U> static inline void hipemu_atomic_store(T* p, U val, int order) { T v = (T)val; __atomic_store(p, &v, order); }
 #define __hip_atomic_load(p, order, scope) hipemu_atomic_load(p, order)
 #define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store(p, v, order)
-#define __builtin_amdgcn_s_sleep(x) ((void)0)
+// a waiting wavefront on the device sleeps ~64 x clocks per s_sleep; here the poller gives its host thread away for a moment, so that a bounded
+// poll loop of the kernels (2^21..2^22 polls) stays a bound of seconds, as on the device, instead of milliseconds
+static inline void hipemu_sleep() { struct timespec ts = {0, 2000}; nanosleep(&ts, nullptr); }
+#define __builtin_amdgcn_s_sleep(x) hipemu_sleep()
 #define GS_WAIT_VMEM() ((void)0)
 static inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
