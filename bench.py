@@ -162,6 +162,39 @@ def self_launch(n, same_dev):
     return subprocess.call(cmd, env=env)
 
 
+def mapping_iteration_ms(dev, params_cpu, W, H, flags, iters=20, warm=5):
+    """One ActiveSplat mapping iteration (get_loss + backward + Adam + zero_grad) on the given map: (wall ms, hipEvent ms) per iteration."""
+    from activesplat_amd import mapping as M, optim as O, setup_camera
+    from activesplat_amd import synthetic as syn
+    n = params_cpu["means3D"].shape[0]
+    cam1 = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=dev)
+    prm = {k: torch.nn.Parameter(v.to(dev)) for k, v in params_cpu.items()}
+    prm["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([1.0, 0, 0, 0], device=dev).reshape(1, 4, 1))
+    prm["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 1, device=dev))
+    var = {k: torch.zeros(n, device=dev) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+    tim, tdepth = syn.make_targets(W, H)
+    data = dict(cam=cam1, im=tim.to(dev), depth=tdepth.to(dev), id=0, w2c=torch.eye(4, device=dev))
+    opt = O.initialize_optimizer(prm, dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05,
+                                           log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0))
+    flags = dict(flags)
+    in_bwd = flags.pop("adam", False)
+
+    def it():
+        loss, _, _ = M.get_loss(prm, data, var, 0, dict(im=0.5, depth=1.0), pose7=[1.0, 0, 0, 0, 0, 0, 0] if flags else None,
+                                fused_adam=opt if in_bwd else None, **flags)
+        loss.backward(M.unit_gradient(loss) if flags else None)
+        with torch.no_grad():
+            opt.step(); opt.zero_grad(set_to_none=True)
+    for _ in range(warm):
+        it()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); t1 = time.perf_counter(); a.record()
+    for _ in range(iters):
+        it()
+    b.record(); torch.cuda.synchronize()
+    return (time.perf_counter() - t1) / iters * 1e3, a.elapsed_time(b) / iters
+
+
 def pmc_file(pattern):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     return files[-1] if files else None
@@ -477,6 +510,22 @@ def main():
                             "peak_ginst_s": VALU_ISSUE_PEAK / 1e9, "frac": round(vi / (stages[dom]["avg_us"] * 1e-6) / VALU_ISSUE_PEAK, 4),
                             "source": os.path.basename(f2)}
                 all_traffic = {k: int(v["traffic_bytes"]) for k, v in pm.items() if "traffic_bytes" in v}
+            # counter bytes next to the model's bytes, per stage (the binning stages share one kernel name in the counter tables: one figure for all)
+            if all_traffic:
+                first = lambda *names: next((all_traffic[n] for n in names if n in all_traffic), None)  # noqa: E731
+                per_stage = {"preprocess_forward+scan": first("preprocess_forward_sh48_kernel", "preprocess_forward_kernel"),
+                             "blend_forward": first("blend_forward_streams_kernel"), "blend_backward": first("blend_backward_kernel", "blend_backward_pc_kernel"),
+                             "preprocess_backward": first("preprocess_backward_kernel")}
+                for k, v in per_stage.items():
+                    if v is not None and k in stages:
+                        stages[k]["pmc_bytes"] = int(v)
+                        stages[k]["frac_hbm_pmc"] = round(v / (stages[k]["avg_us"] * 1e-6) / HBM_PEAK, 4)
+                binning = 2 * all_traffic.get("tile_bin_kernel", 0) + all_traffic.get("tile_colscan_kernel", 0) + all_traffic.get("tile_scan_kernel", 0) + \
+                    all_traffic.get("tile_bucket_sort_kernel", 0)
+                if binning and "tile_scatter+sort" in stages and "tile_count+scan" in stages:
+                    us = stages["tile_scatter+sort"]["avg_us"] + stages["tile_count+scan"]["avg_us"]
+                    stages["tile_scatter+sort"]["pmc_bytes_with_count_and_scans"] = int(binning)
+                    stages["tile_scatter+sort"]["frac_hbm_pmc_with_count_and_scans"] = round(binning / (us * 1e-6) / HBM_PEAK, 4)
         except Exception:
             pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9,
@@ -623,6 +672,33 @@ def main():
             out["side_legs"] = side
         except Exception as e:
             out["side_legs"] = {"error": str(e)}
+        # ---- the reference's own operating points (config/datasets/gibson.json: 256 x 256; config/datasets/gibson_high_resolution.json +
+        # config/env/activesplat_high_resolution_pointnav.yaml: 512 x 512, 10 iterations per mapped frame), SH degree 0 ----
+        try:
+            note("operating points 256x256 / 512x512")
+            ops = {}
+            for w_, n_ in ((256, 200_000), (256, 1_000_000), (512, 200_000), (512, 1_000_000)):
+                w1 = RenderWorkload(n_, w_, w_, dev, sh_degree=None)
+                for _ in range(4):
+                    w1.step()
+                t = w1.sequential(60, 10)
+                st1, _, D1 = w1.stages(lib, 20)
+                p1 = w1.params
+                del w1
+                torch.cuda.empty_cache()
+                flags = dict(fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=True)
+                wall, ev = mapping_iteration_ms(dev, p1, w_, w_, dict(flags, adam=True), iters=40, warm=10)
+                wall0, ev0 = mapping_iteration_ms(dev, p1, w_, w_, flags, iters=40, warm=10)
+                ops[f"{w_}x{w_}_{n_ // 1000}k"] = {"render_fwd_bwd_us": round(t * 1e6, 1), "tile_instances_D": D1,
+                                                   "stages_us": {k: v["avg_us"] for k, v in st1.items()},
+                                                   "mapping_iteration_ms": {"fused_adam_in_backward": round(wall, 4), "fused_adam_in_backward_gpu": round(ev, 4),
+                                                                            "fused_separate_adam": round(wall0, 4), "fused_separate_adam_gpu": round(ev0, 4)}}
+                torch.cuda.empty_cache()
+            out["operating_points"] = dict(ops, note="the reference's frame sizes, precomputed colours; render = GaussianRasterizer forward + backward, frames one after "
+                                                     "the other; mapping iteration = get_loss (single-pass RGB-D render from the parameters, one-launch loss) + backward "
+                                                     "+ Adam + zero_grad: wall clock and hipEvent span per iteration")
+        except Exception as e:
+            out["operating_points"] = {"error": str(e)}
         # ---- configs[2]'s optimise loop: 2 M / SH-3, 100 iterations, fused Adam (5 tensors incl. the coefficients) + one densify event ----
         try:
             note("configs[2] optimise loop")
@@ -666,38 +742,14 @@ def main():
         # ---- informational leg: one full ActiveSplat mapping iteration (get_loss + backward + Adam) on configs[1]'s scene,
         # with the reference's call pattern (two raster passes, torch loss, torch activations) vs this build's fused paths
         try:
-            from activesplat_amd import mapping as M, optim as O
             its = {}
             N1 = 500_000
             params1 = params1 if params1 is not None else syn.make_params(N1, W, H, seed=0)
-            cam1 = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=dev)
             for name, flags in (("reference_call_pattern", {}), ("fused", dict(fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=True)),
                                 ("fused_adam_in_backward", dict(fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=True, adam=True))):
-                prm = {k: torch.nn.Parameter(v.to(dev)) for k, v in params1.items()}
-                prm["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([1.0, 0, 0, 0], device=dev).reshape(1, 4, 1))
-                prm["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 1, device=dev))
-                var = {k: torch.zeros(N1, device=dev) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
-                tim, tdepth = syn.make_targets(W, H)
-                data = dict(cam=cam1, im=tim.to(dev), depth=tdepth.to(dev), id=0, w2c=torch.eye(4, device=dev))
-                opt = O.initialize_optimizer(prm, dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05,
-                                                       log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0))
-
-                flags = dict(flags)
-                in_bwd = flags.pop("adam", False)
-
-                def it():
-                    loss, _, _ = M.get_loss(prm, data, var, 0, dict(im=0.5, depth=1.0), pose7=[1.0, 0, 0, 0, 0, 0, 0] if flags else None,
-                                            fused_adam=opt if in_bwd else None, **flags)
-                    loss.backward()
-                    with torch.no_grad():
-                        opt.step(); opt.zero_grad(set_to_none=True)
-                for _ in range(5):
-                    it()
-                torch.cuda.synchronize(); t1 = time.perf_counter()
-                for _ in range(20):
-                    it()
-                torch.cuda.synchronize()
-                its[name + "_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
+                wall, ev = mapping_iteration_ms(dev, params1, W, H, flags)
+                its[name + "_ms"] = round(wall, 4)
+                its[name + "_gpu_ms"] = round(ev, 4)
             out["mapping_iteration"] = dict(its, note="get_loss (RGB + depth/silhouette render, L1+SSIM+depth loss) + backward + Adam on configs[1]'s "
                                             "scene; reference_call_pattern = splatam.py:172-301 op for op on this rasteriser")
         except Exception as e:

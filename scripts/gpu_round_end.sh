@@ -1,11 +1,11 @@
 # End-of-round evidence run: parity tests, bench line, rocprof kernel summaries, PMC passes.  Run via gpurun from the repo root:
-#   gpurun --timeout 1800 -- 'bash scripts/gpu_round_end.sh r03'
+#   gpurun --timeout 1800 -- 'bash scripts/gpu_round_end.sh r04'
 # Every step is bounded by its own timeout; outputs land in gpurun_out/final (copy what is to be judged into profiles/).
 # The headline workload (bench.py, N = 1) is BASELINE configs[2]'s render: 2 M Gaussians, SH degree 3, 640x480, forward + backward.
-R=$PWD; TAG=${1:-r03}
+R=$PWD; TAG=${1:-r04}
 mkdir -p gpurun_out/final
 timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/final/build_smoke.log 2>&1; echo build+smoke rc=$?
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 | tee gpurun_out/final/pytest_gpu.log
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -40 > gpurun_out/final/${TAG}_pytest_gpu.log; tail -4 gpurun_out/final/${TAG}_pytest_gpu.log
 timeout 400 python bench.py > gpurun_out/final/${TAG}_bench.json 2> gpurun_out/final/bench.err; echo bench rc=$?; head -c 400 gpurun_out/final/${TAG}_bench.json; echo
 timeout 100 python bench.py --gpus 1 --steps 20 --warmup 5 --no-extras > gpurun_out/final/${TAG}_bench_driver_flags.json 2>/dev/null; head -c 300 gpurun_out/final/${TAG}_bench_driver_flags.json; echo
 export TMPDIR=/tmp; cd /tmp
@@ -24,6 +24,11 @@ python scripts/pmc_summarise.py gpurun_out/final ${TAG}_2m > gpurun_out/final/${
 cp profiles/${TAG}_2m_pmc_summary.json gpurun_out/final/ 2>/dev/null
 # the bench line once more, now that this round's PMC summary exists (roofline.traffic reads it)
 timeout 400 python bench.py > gpurun_out/final/${TAG}_bench.json 2> gpurun_out/final/bench.err; echo bench rc=$?
+# BASELINE configs[2]'s loop and the configs[4] substitute (256 x 256 and 512 x 512, PSNR + SSIM, HIP loop vs oracle-backed loop); the planner's top-down camera
+timeout 600 python scripts/configs_report.py > gpurun_out/final/${TAG}_configs.json 2> gpurun_out/final/configs.err; echo configs rc=$?
+timeout 200 python scripts/topdown_time.py > gpurun_out/final/${TAG}_topdown.json 2> gpurun_out/final/topdown.err; echo topdown rc=$?
+# `bench.py --gpus 2` with no launcher environment (both ranks on this one device: gloo): the self-launch path's line
+BENCH_SAME_DEVICE=1 timeout 300 python bench.py --gpus 2 --steps 3 --warmup 1 --no-extras > gpurun_out/final/${TAG}_bench_gpus2_same_device.json 2> gpurun_out/final/bench2.err; echo bench2 rc=$?
 # planner panorama, densify event
 timeout 200 python scripts/lookaround_times.py > gpurun_out/final/${TAG}_lookaround.txt 2>&1
 N=3000000 timeout 200 python scripts/densify_time.py > gpurun_out/final/${TAG}_densify.txt 2>&1
