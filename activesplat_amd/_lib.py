@@ -59,7 +59,7 @@ ABI_VERSION = 6
 SYMBOLS = ("gs_abi_version", "gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
            "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_set_half_quadrants", "gs_set_backward_chain", "gs_set_backward_pc", "gs_preprocess_forward", "gs_preprocess_forward_raw", "gs_render_forward", "gs_render_backward", "gs_render_backward_raw", "gs_render_backward_raw_adam", "gs_adam_step", "gs_adam_step_multi",
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
-           "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_mapping_loss_fused_scratch_bytes", "gs_mapping_loss_fused", "gs_activate_forward", "gs_activate_backward", "gs_activate_backward_accumulate",
+           "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward", "gs_activate_backward_accumulate",
            "gs_grow_scratch_bytes", "gs_grow_gaussians", "gs_keyframe_overlap", "gs_visibility_stats", "gs_accumulate_grad2d",
            "gs_gather_rows_zero_tail", "gs_densify_classify", "gs_densify_children", "gs_atlas_layout",
            "gs_pack_columns", "gs_adam_rows", "gs_unpack_columns", "gs_compact3_scratch_bytes", "gs_compact_index3")
@@ -128,9 +128,6 @@ def _bind(lib):
     lib.gs_mapping_loss_scratch_bytes.restype = C.c_uint64
     lib.gs_mapping_loss.argtypes = [i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]
     lib.gs_mapping_loss.restype = C.c_int
-    lib.gs_mapping_loss_fused_scratch_bytes.restype = C.c_uint64
-    lib.gs_mapping_loss_fused.argtypes = [i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]
-    lib.gs_mapping_loss_fused.restype = C.c_int
     lib.gs_compact_scratch_bytes.argtypes = [i64]
     lib.gs_compact_scratch_bytes.restype = C.c_uint64
     lib.gs_compact_index.argtypes = [i64, vp, vp, vp, vp, vp]

@@ -654,20 +654,6 @@ int gs_mapping_loss(int32_t width, int32_t height, const float* im, const float*
     return GS_OK;
 }
 
-uint64_t gs_mapping_loss_fused_scratch_bytes(void) { return align_up(gs::mapping_loss_fused_scratch_bytes()); }
-
-int gs_mapping_loss_fused(int32_t width, int32_t height, const float* im, const float* gt_im, const float* depth,
-                          const float* depth_sq, const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
-                          float* dL_ddepth, void* scratch, gs_stream_t stream)
-{
-    if (width <= 0 || height <= 0 || !im || !gt_im || !depth || !gt_depth || !losses || !dL_dim || !dL_ddepth || !scratch)
-        return fail(GS_EINVAL, "gs_mapping_loss_fused: bad argument");
-    hipError_t e = gs::launch_mapping_loss_fused(width, height, im, gt_im, depth, depth_sq, gt_depth, w_im, w_depth, losses, dL_dim,
-                                                 dL_ddepth, (float*)scratch, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_mapping_loss_fused: %s", hipGetErrorString(e));
-    return GS_OK;
-}
-
 uint64_t gs_compact_scratch_bytes(int64_t n) { return align_up(gs::compact_scratch_bytes(n > 0 ? n : 1)); }
 
 int gs_compact_index(int64_t n, const uint8_t* keep, uint32_t* src_index, uint32_t* d_count, void* scratch, gs_stream_t stream)

@@ -604,9 +604,6 @@ __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
 // LDS 11.8 KB per wave; the wavefronts share nothing, so a workgroup is ONE wavefront (NW = 1): LDS and CU slots are handed out at
 // that granularity and 4800 small workgroups drain more evenly than 1200 whole-tile ones.
 // ---------------------------------------------------------------------------------------------------
-#ifndef GS_WAIT_VMEM
-#define GS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")      // (the host emulator of the tests defines it empty)
-#endif
 constexpr int kBT = 16;                // list positions per batch: 16 x 4 rows = one (row, position) pair per lane in phase B
 constexpr int kMT = kWave + 4;         // floats per position in an exchange plane: +4 makes phase B's b128 reads conflict-free
 constexpr int kPairStride = 12;        // floats per pair / record slot in the sum exchanges: components 0-4 at [0,5), 5-9 at [6,11)

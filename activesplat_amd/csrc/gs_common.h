@@ -141,6 +141,15 @@ struct GeomPtrs {
     uint8_t* vis_seen;
 };
 
+// wait for every outstanding vector-memory operation of this wavefront (returning atomics included): the cheap way to order a
+// device-scope atomic behind earlier ones without a release fence (which writes the L2 back).  The host emulator defines both empty.
+#ifndef GS_WAIT_VMEM
+#define GS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+#ifndef GS_KEEP
+#define GS_KEEP(x) asm volatile("" ::"v"(x))          // keeps a returning atomic's result (and with it the "returning" form) alive
+#endif
+
 // ---- wave-64 helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -560,10 +569,6 @@ constexpr int kLossAccSlots = 256;          // 64-byte accumulator lines at the 
 hipError_t launch_mapping_loss(int W, int H, const float* im, const float* gt, const float* depth, const float* depth_sq,
                                const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
                                float* dL_ddepth, float* scratch, hipStream_t st);
-uint64_t mapping_loss_fused_scratch_bytes();
-hipError_t launch_mapping_loss_fused(int W, int H, const float* im, const float* gt, const float* depth, const float* depth_sq,
-                                     const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
-                                     float* dL_ddepth, float* scratch, hipStream_t st);
 hipError_t launch_visibility_stats(int P, const int32_t* radii, uint8_t* seen, float* max_radius, hipStream_t st);
 hipError_t launch_accumulate_grad2d(int P, const float* grad, const uint8_t* seen, float* accum, float* denom, hipStream_t st);
 uint64_t grow_scratch_bytes(int64_t npix);

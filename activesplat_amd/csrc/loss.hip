@@ -208,216 +208,6 @@ __global__ __launch_bounds__(kBlock) void loss_grad_kernel(int W, int H, const f
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// ONE launch (gs_mapping_loss_fused): statistics and gradients in the same workgroup.  dL/dim at a pixel needs the SSIM partials of the
-// 11 x 11 pixels around it, which the two-launch form fetches from the partial maps the first launch wrote.  Here a workgroup (16 x 16
-// output pixels of one colour channel) computes the partials of its tile AND of the 5-pixel halo around it itself -- from a 36 x 36 input
-// window, 2.6x the statistics work of the tile alone, all of it in LDS -- and convolves them right away: no partial maps (72 B per pixel
-// written and read back), no second pass over the inputs, no second launch.  The partials of a halo pixel are formed by the same operations
-// in the same order as in the workgroup that owns it, so every workgroup sees identical values.
-// The one global dependency is the depth term's normalisation (the count of valid depth pixels).  The grid therefore ends with a few
-// extra workgroups that write dL/ddepth: workgroups start in index order, so when these are dispatched every tile workgroup has been, and
-// they only wait (ticket counter, bounded poll) for the tiles' sums to arrive; the first of them also writes the loss scalars, the last
-// one to finish zeroes the accumulators and counters again -- the scratch (16 KB, zeroed ONCE by its owner) is ready for the next launch
-// without a memset.
-// LDS: inputs 2 x 36 x 37 floats + horizontal sums 5 x 36 x 27 floats = 30 KB (the partial maps and the second horizontal pass reuse them).
-// ---------------------------------------------------------------------------------------------------
-constexpr int kLQ = kLP + 2 * kLH;   // 36: tile + halo + the halo's own window
-constexpr int kLossDepthPix = 4;     // depth pixels per thread of an extra workgroup
-
-__global__ __launch_bounds__(kBlock) void loss_fused_kernel(int W, int H, int gx, int gy, const float* __restrict__ im,
-                                                            const float* __restrict__ gt, const float* __restrict__ depth,
-                                                            const float* __restrict__ depth_sq, const float* __restrict__ gt_depth,
-                                                            float* __restrict__ acc, unsigned* __restrict__ ctl, float w_im, float w_depth,
-                                                            float* __restrict__ dL_dim, float* __restrict__ dL_ddepth, float* __restrict__ losses)
-{
-    __shared__ float s_in[2][kLQ][kLQ + 1];            // x, y; later: the three partial maps [3][26][27]
-    __shared__ float s_h[5][kLQ][kLP + 1];             // horizontal sums of x, y, xx, yy, xy over 36 rows x 26 columns; later [3][26][17]
-    __shared__ float s_red[16];
-    __shared__ float s_tot[4];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const unsigned n_tile = (unsigned)(gx * gy * 3);
-    const size_t HW = (size_t)W * H;
-    const float n3 = 3.0f * (float)HW;
-    if (blockIdx.x >= n_tile) {
-        // ---- extra workgroups: dL/ddepth (needs the mask count), the loss scalars, the reset of the scratch ----
-        const unsigned eb = blockIdx.x - n_tile, n_extra = gridDim.x - n_tile;
-        const size_t p0 = ((size_t)eb * kBlock + tid) * kLossDepthPix;
-        float dv[kLossDepthPix], gv[kLossDepthPix], uv[kLossDepthPix];
-#pragma unroll
-        for (int k = 0; k < kLossDepthPix; k++) {           // (requested before the wait)
-            const size_t o = p0 + k;
-            const bool in = o < HW;
-            dv[k] = in ? depth[o] : 0.f; gv[k] = in ? gt_depth[o] : 0.f;
-            uv[k] = (in && depth_sq) ? depth_sq[o] - dv[k] * dv[k] : 0.f;
-        }
-        // every tile workgroup has a lower index, i.e. has been dispatched: the wait ends when the last of them has added its sums.  Bounded
-        // all the same (see blend_backward_kernel's hand-over): on a timeout the gradients are poisoned with NaN instead of hanging the device
-        bool ok = true;
-        if (tid == 0) {
-            int polls = 0;
-            while (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_tile) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++polls > (1 << 22)) { ok = false; break; }
-            }
-            s_red[8] = ok ? 1.f : 0.f;
-        }
-        __syncthreads();
-        __threadfence();
-        ok = s_red[8] != 0.f;
-        if (tid < kWave) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < kAccSlots / kWave; k++) {
-                const float* a = acc + (k * kWave + tid) * 16;
-                v.x += __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.y += __hip_atomic_load(a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v.z += __hip_atomic_load(a + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.w += __hip_atomic_load(a + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            const float a = wave_sum(v.x), b = wave_sum(v.y), c = wave_sum(v.z), d = wave_sum(v.w);
-            if (tid == 0) { s_tot[0] = a; s_tot[1] = b; s_tot[2] = c; s_tot[3] = d; }
-        }
-        __syncthreads();
-        const float cnt = ok ? s_tot[3] : __builtin_nanf("");
-#pragma unroll
-        for (int k = 0; k < kLossDepthPix; k++) {
-            const size_t o = p0 + k;
-            if (o >= HW) break;
-            const bool m = gv[k] > 0.f && dv[k] == dv[k] && uv[k] == uv[k];
-            const float diff = dv[k] - gv[k];
-            const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-            dL_ddepth[o] = m ? w_depth * sgn / cnt : 0.f;
-        }
-        if (eb == 0 && tid == 0) {
-            const float l_im = w_im * (0.8f * s_tot[1] / n3 + 0.2f * (1.0f - s_tot[0] / n3));
-            const float l_depth = w_depth * s_tot[2] / cnt;
-            losses[0] = l_im + l_depth; losses[1] = l_im; losses[2] = l_depth; losses[3] = l_im + l_depth;
-        }
-        // the last extra workgroup to get here (all of them have read the totals) hands the scratch back zeroed
-        __syncthreads();
-        if (tid == 0) {
-            __threadfence();
-            s_red[9] = atomicAdd(ctl + 1, 1u) == n_extra - 1 ? 1.f : 0.f;
-        }
-        __syncthreads();
-        if (s_red[9] != 0.f) {
-            for (int e = tid; e < kAccFloats; e += kBlock) __hip_atomic_store(acc + e, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid == 0) { __hip_atomic_store(ctl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        }
-        return;
-    }
-    // ---- tile workgroups ----
-    const int per = gx * gy;
-    const int ch = (int)(blockIdx.x / (unsigned)per), tl = (int)(blockIdx.x - (unsigned)(ch * per));
-    const int x0 = (tl % gx) * kLT, y0 = (tl / gx) * kLT;
-    const int px = x0 + tx, py = y0 + ty;
-    const bool inside = px < W && py < H;
-    for (int e = tid; e < kLQ * kLQ; e += kBlock) {
-        const int r = e / kLQ, c = e - r * kLQ;
-        const int ix = x0 + c - 2 * kLH, iy = y0 + r - 2 * kLH;
-        const bool in = ix >= 0 && ix < W && iy >= 0 && iy < H;
-        const size_t o = ch * HW + (size_t)iy * W + ix;
-        s_in[0][r][c] = in ? im[o] : 0.f;
-        s_in[1][r][c] = in ? gt[o] : 0.f;
-    }
-    __syncthreads();
-    const float xc = s_in[0][ty + 2 * kLH][tx + 2 * kLH], yc = s_in[1][ty + 2 * kLH][tx + 2 * kLH];       // this thread's own pixel
-    for (int e = tid; e < kLQ * kLP; e += kBlock) {           // horizontal pass: 36 rows x 26 columns
-        const int r = e / kLP, c = e - r * kLP;
-        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = kWin[k], xv = s_in[0][r][c + k], yv = s_in[1][r][c + k];
-            a += w * xv; b += w * yv; aa += w * xv * xv; bb += w * yv * yv; ab += w * xv * yv;
-        }
-        s_h[0][r][c] = a; s_h[1][r][c] = b; s_h[2][r][c] = aa; s_h[3][r][c] = bb; s_h[4][r][c] = ab;
-    }
-    __syncthreads();
-    // vertical pass + SSIM partials over the 26 x 26 region (tile + halo); the partial maps take the inputs' place
-    float (*s_p)[kLP][kLP + 1] = reinterpret_cast<float (*)[kLP][kLP + 1]>(&s_in[0][0][0]);
-    float sum_ssim = 0.f;
-    for (int e = tid; e < kLP * kLP; e += kBlock) {
-        const int r = e / kLP, c = e - r * kLP;
-        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = kWin[k];
-            m1 += w * s_h[0][r + k][c]; m2 += w * s_h[1][r + k][c]; e11 += w * s_h[2][r + k][c];
-            e22 += w * s_h[3][r + k][c]; e12 += w * s_h[4][r + k][c];
-        }
-        const int gxp = x0 + c - kLH, gyp = y0 + r - kLH;
-        const bool in = gxp >= 0 && gxp < W && gyp >= 0 && gyp < H;
-        const float c1 = 0.0001f, c2 = 0.0009f;
-        const float A1 = 2.f * m1 * m2 + c1, A2 = 2.f * (e12 - m1 * m2) + c2;
-        const float B1 = m1 * m1 + m2 * m2 + c1, B2 = (e11 - m1 * m1) + (e22 - m2 * m2) + c2;
-        const float inv = 1.0f / (B1 * B2);
-        const float S = A1 * A2 * inv;
-        // (the reads of s_in ended at the barrier above; s_p[.][r][c] is written by this thread only)
-        s_p[0][r][c] = in ? 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * (1.0f / B1 - 1.0f / B2) : 0.f;   // dS/dmu1
-        s_p[1][r][c] = in ? -S / B2 : 0.f;                                                                // dS/dE[x^2]
-        s_p[2][r][c] = in ? 2.f * A1 * inv : 0.f;                                                         // dS/dE[xy]
-        const bool own = r >= kLH && r < kLH + kLT && c >= kLH && c < kLH + kLT;
-        if (in && own) sum_ssim += S;
-    }
-    __syncthreads();
-    float (*s_g)[kLP][kLT + 1] = reinterpret_cast<float (*)[kLP][kLT + 1]>(&s_h[0][0][0]);
-    for (int e = tid; e < kLP * kLT; e += kBlock) {           // second horizontal pass: 26 rows x 16 columns
-        const int r = e / kLT, c = e - r * kLT;
-        float a = 0.f, b = 0.f, d = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = kWin[k];
-            a += w * s_p[0][r][c + k]; b += w * s_p[1][r][c + k]; d += w * s_p[2][r][c + k];
-        }
-        s_g[0][r][c] = a; s_g[1][r][c] = b; s_g[2][r][c] = d;
-    }
-    __syncthreads();
-    float g1 = 0.f, g2 = 0.f, g3 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = kWin[k];
-        g1 += w * s_g[0][ty + k][tx]; g2 += w * s_g[1][ty + k][tx]; g3 += w * s_g[2][ty + k][tx];
-    }
-    float sum_l1 = 0.f;
-    if (inside) {
-        const float k_ssim = -0.2f * w_im / n3, k_l1 = 0.8f * w_im / n3;
-        const float diff = xc - yc;
-        const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-        dL_dim[ch * HW + (size_t)py * W + px] = k_ssim * (g1 + 2.f * xc * g2 + yc * g3) + k_l1 * sgn;
-        sum_l1 = fabsf(diff);
-    }
-    float sum_d = 0.f, cnt = 0.f;
-    if (inside && ch == 0) {
-        const size_t o = (size_t)py * W + px;
-        const float d = depth[o], g = gt_depth[o];
-        const float unc = depth_sq ? depth_sq[o] - d * d : 0.f;
-        if (g > 0.f && d == d && unc == unc) { sum_d = fabsf(g - d); cnt = 1.f; }
-    }
-    sum_ssim = wave_sum(sum_ssim); sum_l1 = wave_sum(sum_l1); sum_d = wave_sum(sum_d); cnt = wave_sum(cnt);
-    __syncthreads();
-    if ((tid & 63) == 0) { float* r = s_red + (tid >> 6) * 4; r[0] = sum_ssim; r[1] = sum_l1; r[2] = sum_d; r[3] = cnt; }
-    __syncthreads();
-    if (tid < 4) atomicAdd(acc + (blockIdx.x & (kAccSlots - 1)) * 16 + tid, (s_red[tid] + s_red[4 + tid]) + (s_red[8 + tid] + s_red[12 + tid]));
-    __syncthreads();
-    if (tid == 0) { __threadfence(); atomicAdd(ctl, 1u); }    // this workgroup's sums have arrived
-}
-
-// scratch of the one-launch form: the accumulator lines, then two control words (tile ticket, extra-workgroup ticket)
-uint64_t mapping_loss_fused_scratch_bytes() { return (uint64_t)(kAccFloats + 16) * sizeof(float); }
-
-hipError_t launch_mapping_loss_fused(int W, int H, const float* im, const float* gt, const float* depth, const float* depth_sq,
-                                     const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
-                                     float* dL_ddepth, float* scratch, hipStream_t st)
-{
-    const int gx = (W + kLT - 1) / kLT, gy = (H + kLT - 1) / kLT;
-    const size_t HW = (size_t)W * H;
-    const unsigned n_extra = (unsigned)((HW + (size_t)kBlock * kLossDepthPix - 1) / ((size_t)kBlock * kLossDepthPix));
-    float* acc = scratch;
-    unsigned* ctl = reinterpret_cast<unsigned*>(scratch + kAccFloats);
-    hipLaunchKernelGGL(loss_fused_kernel, dim3((unsigned)(gx * gy * 3) + n_extra), dim3(kBlock), 0, st, W, H, gx, gy, im, gt, depth, depth_sq,
-                       gt_depth, acc, ctl, w_im, w_depth, dL_dim, dL_ddepth, losses);
-    return hipGetLastError();
-}
-
 hipError_t launch_mapping_loss(int W, int H, const float* im, const float* gt, const float* depth, const float* depth_sq,
                                const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
                                float* dL_ddepth, float* scratch, hipStream_t st)

@@ -248,25 +248,8 @@ def unit_gradient(like: torch.Tensor) -> torch.Tensor:
     return t
 
 
-#: True: gs_mapping_loss_fused (statistics + gradients in ONE launch, no partial maps, no memset); False: gs_mapping_loss (two launches)
-LOSS_ONE_LAUNCH = True
-#: the one-launch loss' scratch (accumulator lines + tickets): zeroed ONCE here, handed back zeroed by every launch; one per (device, stream)
-_LOSS_SCRATCH = {}
-
-
-def _loss_scratch(lib, dev):
-    from . import _lib
-    key = (dev.index, _lib.stream_handle(dev))
-    buf = _LOSS_SCRATCH.get(key)
-    if buf is None:
-        if len(_LOSS_SCRATCH) >= 64:
-            _LOSS_SCRATCH.pop(next(iter(_LOSS_SCRATCH)))
-        buf = _LOSS_SCRATCH[key] = torch.zeros(int(lib.gs_mapping_loss_fused_scratch_bytes()), dtype=torch.uint8, device=dev)
-    return buf
-
-
 class _FusedMappingLoss(torch.autograd.Function):
-    """gs_mapping_loss_fused / gs_mapping_loss: value and gradients in one (two) HIP launches (csrc/loss.hip)."""
+    """gs_mapping_loss: value and gradients in two HIP launches (csrc/loss.hip)."""
 
     @staticmethod
     def forward(ctx, im, depth, depth_sq, gt_im, gt_depth, w_im, w_depth):
@@ -282,13 +265,9 @@ class _FusedMappingLoss(torch.autograd.Function):
         d_im, d_depth = grads[:3], grads[3:]
         st = _lib.stream_ptr(dev)
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-        if LOSS_ONE_LAUNCH:
-            _lib.check(lib.gs_mapping_loss_fused(W, H, p(im_), p(gt_), p(depth_), p(dsq_), p(gtd_), float(w_im), float(w_depth), p(buf),
-                                                 p(d_im), p(d_depth), p(_loss_scratch(lib, dev)), st))
-        else:
-            scratch = torch.empty(int(lib.gs_mapping_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
-            _lib.check(lib.gs_mapping_loss(W, H, p(im_), p(gt_), p(depth_), p(dsq_), p(gtd_), float(w_im), float(w_depth), p(buf),
-                                           p(d_im), p(d_depth), p(scratch), st))
+        scratch = torch.empty(int(lib.gs_mapping_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gs_mapping_loss(W, H, p(im_), p(gt_), p(depth_), p(dsq_), p(gtd_), float(w_im), float(w_depth), p(buf),
+                                       p(d_im), p(d_depth), p(scratch), st))
         ctx.save_for_backward(grads)
         ctx.set_materialize_grads(False)
         losses, loss = buf[:3], buf[3]          # two views of one small buffer: no clone kernel for the scalar

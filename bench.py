@@ -695,7 +695,7 @@ def main():
                                                                             "fused_separate_adam": round(wall0, 4), "fused_separate_adam_gpu": round(ev0, 4)}}
                 torch.cuda.empty_cache()
             out["operating_points"] = dict(ops, note="the reference's frame sizes, precomputed colours; render = GaussianRasterizer forward + backward, frames one after "
-                                                     "the other; mapping iteration = get_loss (single-pass RGB-D render from the parameters, one-launch loss) + backward "
+                                                     "the other; mapping iteration = get_loss (single-pass RGB-D render from the parameters, fused loss) + backward "
                                                      "+ Adam + zero_grad: wall clock and hipEvent span per iteration")
         except Exception as e:
             out["operating_points"] = {"error": str(e)}

@@ -327,16 +327,7 @@ uint64_t gs_mapping_loss_scratch_bytes(int32_t width, int32_t height);
 int gs_mapping_loss(int32_t width, int32_t height, const float* im, const float* gt_im, const float* depth,
                     const float* depth_sq, const float* gt_depth, float w_im, float w_depth, float* losses,
                     float* dL_dim, float* dL_ddepth, void* scratch, gs_stream_t stream);
-/* The same loss in ONE launch: every workgroup computes the SSIM partials of its tile and of the 5-pixel halo around it and convolves them
- * itself (no partial maps, no second pass), and the grid ends with a few workgroups that write dL_ddepth once the tiles' sums -- among them
- * the count of valid depth pixels it is normalised by -- have arrived.  Same values as gs_mapping_loss up to the order of the block sums.
- * scratch: gs_mapping_loss_fused_scratch_bytes() bytes that the CALLER ZEROES ONCE (hipMemset) before the first call; every call leaves
- * them zeroed again for the next one on the same stream (no memset per call).  Calls that can overlap (different streams) need scratch
- * buffers of their own. */
-uint64_t gs_mapping_loss_fused_scratch_bytes(void);
-int gs_mapping_loss_fused(int32_t width, int32_t height, const float* im, const float* gt_im, const float* depth,
-                          const float* depth_sq, const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
-                          float* dL_ddepth, void* scratch, gs_stream_t stream);
+
 
 /* Stream compaction for prune / densify surgery (replaces the boolean-mask gathers of
  * src/mapper/splatam/utils/slam_external.py:143-164 remove_points and the torch.cat appends of

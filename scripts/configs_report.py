@@ -27,7 +27,7 @@ out["configs2_optimise_loop"] = dict(gaussians_start=N, gaussians_after_densify=
                                      densify_event_ms=[round(x * 1e3, 3) for x in r["densify_seconds"]],
                                      densify="every 50 iterations (grad_thresh 2e-4, split into 2, opacity cull 0.005), fused: one classification kernel, "
                                              "one index, one gather per tensor",
-                                     note="raw-parameter single-pass RGB-D render (SH-3) + one-launch loss + backward with the Adam step inside (5 tensors incl. shs)")
+                                     note="raw-parameter single-pass RGB-D render (SH-3) + fused loss + backward with the Adam step inside (5 tensors incl. shs)")
 torch.cuda.empty_cache()
 
 # ---- configs[4] substitute: mapper harness on a synthetic RGB-D spin (no Habitat / Gibson / ROS here), at the reference's two shipped operating points:

@@ -434,32 +434,6 @@ def test_fused_loss_ragged_image_and_torch_mirror(backend):
     np.testing.assert_allclose(depth.grad.cpu().numpy(), d2.grad.cpu().numpy(), atol=1e-10, rtol=1e-5)
 
 
-def test_fused_loss_one_launch_equals_two_launches(backend, monkeypatch):
-    """gs_mapping_loss_fused (tile + halo statistics and gradients in one workgroup, dL/ddepth by the grid's last workgroups, scratch
-    handed back zeroed) against gs_mapping_loss (two launches through the partial maps): the same gradients BIT for bit -- a halo pixel's
-    partials are formed by the same operations as in the workgroup that owns it --, the loss values equal up to the order of the block
-    sums; a ragged image with invalid depth pixels and a 4 x 3-tile one, the one-launch form three times in a row on one scratch."""
-    from activesplat_amd import mapping as M
-    g = torch.Generator().manual_seed(8)
-    for H, W in ((37, 50), (48, 64), (16, 16)):
-        im = torch.rand(3, H, W, generator=g).to(backend)
-        depth = (torch.rand(1, H, W, generator=g) * 3).to(backend)
-        gt_im = torch.rand(3, H, W, generator=g).to(backend); gt_d = (torch.rand(1, H, W, generator=g) * 3).to(backend)
-        gt_d[0, :3, :9] = 0.0
-        depth[0, 5, 5] = float("nan")
-        runs = []
-        for one in (False, True, True, True):
-            monkeypatch.setattr(M, "LOSS_ONE_LAUNCH", one)
-            a, b = im.clone().requires_grad_(True), depth.clone().requires_grad_(True)
-            loss, parts = M.fused_mapping_loss(a, b, depth ** 2 + 0.1, gt_im, gt_d, dict(im=0.5, depth=1.0))
-            loss.backward()
-            runs.append((float(loss.detach()), float(parts["im"]), float(parts["depth"]), a.grad.clone(), b.grad.clone()))
-        for r in runs[1:]:
-            for k in range(3):
-                np.testing.assert_allclose(r[k], runs[0][k], rtol=2e-6)
-            assert torch.equal(r[3], runs[0][3]) and torch.equal(r[4], runs[0][4]), (H, W)
-
-
 def test_fused_loss_backward_with_the_cached_unit_gradient(backend):
     """loss.backward(mapping.unit_gradient(loss)) -- the root gradient the mapper and the keyframe batch pass -- skips the fused loss' scaling
     launch: same gradients as the plain loss.backward(); any other upstream gradient still scales."""
