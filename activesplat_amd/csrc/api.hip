@@ -161,12 +161,6 @@ int gs_set_backward_chain(int32_t pieces, int32_t min_tiles)
     return GS_OK;
 }
 
-int gs_set_backward_pc(int32_t on)
-{
-    gs::g_backward_pc = on != 0;
-    return GS_OK;
-}
-
 int gs_set_forward_segments(int32_t on)
 {
     g_segments_enabled = on != 0;

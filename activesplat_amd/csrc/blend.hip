@@ -944,318 +944,6 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Backward, producer / consumer form (gs_set_backward_pc; images of more than kFewTiles tiles).
-//
-// A quadrant's walk above is a serial LATENCY chain: a wavefront needs ~5.5 us per 64-record chunk whether one or three wavefronts share its
-// SIMD (wave timeline, profiles/README.md), and per chunk it runs staging + list build, phase A and phase B + gather + flush back to back.
-// Here the two halves run on TWO wavefronts of one workgroup, one batch apart:
-//   PRODUCER (wave 0): record prefetch, staging, per-block lists, phase A (lane = pixel: alpha, the T / S replay) -> the two exchange planes;
-//                      owns the chained pieces' hand-over state (T, S);
-//   CONSUMER (wave 1): phase B (lane = (position, row): the ten moments of its block), the gather into per-record register sums, the flush.
-// A batch's chain is max(A, B) instead of A + B.  Both wavefronts of a kernel get the same register allocation, so the consumer does NOT
-// keep its block's dL/dcolour in 48 registers: the quadrant's dL/dcolour (and dL/ddepth) sits in LDS (1 KB) and is read four pixels at a
-// time -- ~80 registers per wavefront, five wavefronts per SIMD; LDS: 16 KB per workgroup, ten workgroups (2560 quadrants) per CU.
-// Synchronisation: workgroup barriers, the same sequence on both wavefronts -- per chunk Z (consumer done with the previous chunk's staged
-// records) and W (records, lists and masks of this chunk staged), per batch X (planes full) and Y (planes read into the consumer's
-// registers).  Same arithmetic per (pixel, record) and per (block, record) as blend_backward_kernel; the sums reach the gradient records
-// through the same atomics.
-// ---------------------------------------------------------------------------------------------------
-#ifndef GS_BWD_PC_WAVES
-#define GS_BWD_PC_WAVES 5
-#endif
-#ifndef GS_PC_ABLATE
-#define GS_PC_ABLATE 0          // measurement builds only (scripts/exp): 1 = consumer without phase B / gather, 2 = producer without phase A
-#endif
-template <bool DEPTH_GRAD>
-__global__ __launch_bounds__(2 * kWave, GS_BWD_PC_WAVES) void blend_backward_pc_kernel(
-    Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ geom, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, float* __restrict__ grad2d,
-    const float* __restrict__ split_state)
-{
-    __shared__ float4 s_rec[3][kWave + 1];
-    __shared__ __attribute__((aligned(16))) uint8_t s_list[4 * kWave + 16];
-    __shared__ __attribute__((aligned(16))) float s_m[2][kMPlane];
-    __shared__ __attribute__((aligned(16))) float s_pair[kWave * kPairStride];       // consumer-private: pair sums, then the flush's record sums
-    __shared__ __attribute__((aligned(16))) float s_dl[DEPTH_GRAD ? 4 : 3][kWave];   // the quadrant's dL/dcolour (dL/ddepth), (block, pixel) order
-    __shared__ unsigned long long s_mask[4];
-    __shared__ __attribute__((aligned(16))) uint8_t s_ulist[kWave + 16];
-    __shared__ int s_ntrips;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const bool producer = tid < kWave;
-    TileCtx c;
-    const int pieces = cam.chain > 1 ? cam.chain : 1;
-    const unsigned group = gridDim.x / (unsigned)pieces;
-    const int piece = pieces > 1 ? (int)(blockIdx.x / group) : 0;
-    if (!tile_ctx_at<1>(cam, pieces > 1 ? blockIdx.x - (unsigned)piece * group : blockIdx.x, 0, lane, c)) return;
-    const int row = lane >> 4, l16 = lane & 15;
-    const int px = (int)c.qx0 + (row & 1) * 4 + (l16 & 3), py = (int)c.qy0 + (row >> 1) * 4 + (l16 >> 2);
-    const bool inside = px < cam.W && py < cam.H;
-    const float pxf = (float)px, pyf = (float)py;
-    float4* s0 = s_rec[0]; float4* s1 = s_rec[1]; float4* s2 = s_rec[2];
-    float* m1p = s_m[0]; float* m2p = s_m[1];
-    const uint2 range = ranges[c.tile];
-    const uint32_t* list = point_list + range.x;
-    const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
-    const uint32_t last = inside ? n_contrib[pix] : 0u;
-    uint32_t wmax = last;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor(wmax, m));
-    if (wmax == 0) return;                                       // (the same value on both wavefronts)
-    int cmin = 0, ctop = (int)((wmax - 1) / kWave);
-    if (pieces > 1) {
-        const int n = ctop + 1;
-        ctop = n - (n * piece) / pieces - 1; cmin = n - (n * (piece + 1)) / pieces;
-    }
-
-    if (producer) {
-        // ================================ PRODUCER ================================
-        write_sentinel(s0, s1, s2, lane);
-        const uint8_t* my_list = s_list + row * kWave;
-        const float Tf = inside ? final_T[pix] : 0.f;
-        const float d0 = inside ? dL_dcolor[pix] : 0.f, d1 = inside ? dL_dcolor[HW + pix] : 0.f, d2 = inside ? dL_dcolor[2 * HW + pix] : 0.f;
-        const float dz_ = (DEPTH_GRAD && inside) ? dL_ddepth[pix] : 0.f;
-        const float tfbg = Tf * (cam.bg[0] * d0 + cam.bg[1] * d1 + cam.bg[2] * d2);
-        s_dl[0][lane] = d0; s_dl[1][lane] = d1; s_dl[2][lane] = d2;
-        if (DEPTH_GRAD) s_dl[DEPTH_GRAD ? 3 : 0][lane] = dz_;
-        float T = Tf, S = 0.f;
-        const int chain_q = __builtin_amdgcn_readfirstlane(c.tile * 4 + c.quad);
-        float* const chain_st = const_cast<float*>(split_state) + (size_t)chain_q * kChainStateFloats;
-        uint32_t* const chain_fl = reinterpret_cast<uint32_t*>(const_cast<float*>(split_state) + (size_t)cam.gx * cam.gy * 4 * kChainStateFloats) +
-                                   (size_t)chain_q * (kChainPieces - 1);
-        uint32_t rmax = last;
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) rmax = max(rmax, (uint32_t)__shfl_xor(rmax, m));
-        const uint32_t rm0 = (uint32_t)__builtin_amdgcn_readlane((int)rmax, 0), rm1 = (uint32_t)__builtin_amdgcn_readlane((int)rmax, 16);
-        const uint32_t rm2 = (uint32_t)__builtin_amdgcn_readlane((int)rmax, 32), rm3 = (uint32_t)__builtin_amdgcn_readlane((int)rmax, 48);
-        const int cmax = ctop;
-        uint32_t id_next = (cmax >= cmin && (uint32_t)cmax * kWave + lane < wmax) ? list[cmax * kWave + lane] : kNoId;
-        uint32_t id_next2 = cmax >= cmin + 1 ? list[(cmax - 1) * kWave + lane] : kNoId;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
-        if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
-        __syncthreads();                                         // (0) dL planes written
-        if (pieces > 1 && piece > 0) {
-            // (see blend_backward_kernel: in-order dispatch assumption, bounded poll, NaN poison)
-            int polls = 0;
-            bool handed = true;
-            while (__hip_atomic_load(chain_fl + piece - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cam.chain_epoch) {
-                __builtin_amdgcn_s_sleep(16);
-                if (++polls > (1 << 21)) { handed = false; break; }
-            }
-            GS_WAIT_VMEM();
-            const float* in = chain_st + (piece - 1) * 2 * kWave;
-            T = __hip_atomic_load(in + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            S = __hip_atomic_load(in + kWave + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!handed) T = __builtin_nanf("");
-        }
-        for (int ch = cmax; ch >= cmin; ch--) {
-            const float4 q0 = r0, q1 = r1, q2 = r2;
-            const uint32_t id_cur = id_next;
-            id_next = id_next2;
-            id_next2 = ch >= cmin + 2 ? list[(ch - 2) * kWave + lane] : kNoId;
-            r2 = make_float4(0.f, 0.f, -1.f, -1.f);
-            if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
-            const bool live = id_cur != kNoId;
-            const uint32_t cpos = (uint32_t)ch * kWave;
-            const bool h0 = live && cpos < rm0 && subblock_hit(q0, q2, c.qx0, c.qy0), h1 = live && cpos < rm1 && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0);
-            const bool h2 = live && cpos < rm2 && subblock_hit(q0, q2, c.qx0, c.qy0 + 4.0f), h3 = live && cpos < rm3 && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0 + 4.0f);
-            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
-            const bool any = (m0 | m1 | m2 | m3) != 0ull;
-            const int n0 = (int)__popcll(m0), n1 = (int)__popcll(m1), n2 = (int)__popcll(m2), n3 = (int)__popcll(m3);
-            const int ntrips = any ? max(max(n0, n1), max(n2, n3)) : 0;
-            __syncthreads();                                     // (Z) the consumer is done with the previous chunk's records, lists and masks
-            if (any) {
-                stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
-                reinterpret_cast<uint32_t*>(s_list)[lane] = 0x40404040u;
-                __builtin_amdgcn_wave_barrier();
-#define GS_RANK(m) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u)))
-                if (h0) s_list[0 * kWave + n0 - 1 - GS_RANK(m0)] = (uint8_t)lane;
-                if (h1) s_list[1 * kWave + n1 - 1 - GS_RANK(m1)] = (uint8_t)lane;
-                if (h2) s_list[2 * kWave + n2 - 1 - GS_RANK(m2)] = (uint8_t)lane;
-                if (h3) s_list[3 * kWave + n3 - 1 - GS_RANK(m3)] = (uint8_t)lane;
-#undef GS_RANK
-            }
-            if (lane == 0) { s_mask[0] = m0; s_mask[1] = m1; s_mask[2] = m2; s_mask[3] = m3; s_ntrips = ntrips; }
-            __syncthreads();                                     // (W) staged
-            if (!any) continue;
-            const int rel_last = (int)min(last, (uint32_t)(ch + 1) * kWave) - ch * kWave;
-            for (int t0 = 0; t0 < ntrips; t0 += kBT) {
-                const int tend = min(kBT, ntrips - t0);
-                uint32_t jj2_next = *reinterpret_cast<const uint16_t*>(my_list + t0);
-#if GS_PC_ABLATE != 2           // (ablation 2, results wrong on purpose: no phase A)
-                for (int t = 0; t < tend; t += 2) {
-                    const uint32_t jj2 = jj2_next;
-                    jj2_next = *reinterpret_cast<const uint16_t*>(my_list + t0 + t + 2);
-                    const int jj[2] = {(int)(jj2 & 0xffu), (int)(jj2 >> 8)};
-                    float4 a0[2], a1[2], a2[2];
-                    float dx[2], dy[2], G[2], alpha[2];
-                    bool ok[2];
-#pragma unroll
-                    for (int u = 0; u < 2; u++) { a0[u] = s0[jj[u]]; a1[u] = s1[jj[u]]; a2[u] = s2[jj[u]]; }
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        dx[u] = a0[u].x - pxf; dy[u] = a0[u].y - pyf;
-                        const float p = (a0[u].z * dx[u] + a0[u].w * dy[u]) * dx[u] + (a1[u].x * dy[u]) * dy[u];
-                        G[u] = __builtin_amdgcn_exp2f(p);
-                        alpha[u] = fminf(0.99f, a1[u].y * G[u]);
-                        ok[u] = jj[u] < rel_last && p <= 0.0f && alpha[u] >= kAlphaMin;
-                    }
-                    float* w1 = m1p + (t * kMT + lane); float* w2 = m2p + (t * kMT + lane);
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const float a_eff = ok[u] ? alpha[u] : 0.0f;
-                        const float G_eff = ok[u] ? G[u] : 0.0f;
-                        const float rcp = __builtin_amdgcn_rcpf(1.0f - a_eff);
-                        T = T * rcp;
-                        float cd = a1[u].z * d0 + a1[u].w * d1 + a2[u].x * d2;
-                        if (DEPTH_GRAD) cd += a2[u].y * dz_;
-                        const float dot = cd - S;
-                        const float dL_dalpha = dot * T - tfbg * rcp;
-                        S += a_eff * dot;
-                        w1[u * kMT] = G_eff * dL_dalpha;
-                        w2[u * kMT] = a_eff * T;
-                    }
-                }
-#else
-                (void)tend; (void)jj2_next; (void)rel_last;
-#endif
-                __syncthreads();                                 // (X) planes full
-                __syncthreads();                                 // (Y) planes read
-            }
-        }
-        if (pieces > 1 && piece < pieces - 1) {
-            float* out = chain_st + piece * 2 * kWave;
-            __hip_atomic_store(out + lane, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(out + kWave + lane, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            GS_WAIT_VMEM();
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) __hip_atomic_store(chain_fl + piece, cam.chain_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
-    // ================================ CONSUMER ================================
-    // phase B role: the block of row rb at list position tb of the batch
-    const int tb = lane >> 2, rb = lane & 3;
-    const float bxf = (float)((int)c.qx0 + (rb & 1) * 4), byf = (float)((int)c.qy0 + (rb >> 1) * 4);
-    const int m_rd = tb * kMT + rb * 16;
-    const uint8_t* list_b = s_list + rb * kWave + tb;
-    const float4* dl0 = reinterpret_cast<const float4*>(&s_dl[0][rb * 16]);
-    const float4* dl1 = reinterpret_cast<const float4*>(&s_dl[1][rb * 16]);
-    const float4* dl2 = reinterpret_cast<const float4*>(&s_dl[2][rb * 16]);
-    const float4* dl3 = reinterpret_cast<const float4*>(&s_dl[DEPTH_GRAD ? 3 : 0][rb * 16]);
-    const int fl_rec = lane / 10, fl_comp = lane - fl_rec * 10;
-    const int fl_off = fl_comp < 5 ? fl_comp : fl_comp + 1;
-    __syncthreads();                                             // (0)
-    for (int ch = ctop; ch >= cmin; ch--) {
-        __syncthreads();                                         // (Z)
-        __syncthreads();                                         // (W)
-        const int ntrips = s_ntrips;
-        if (ntrips == 0) continue;
-        const unsigned long long m0 = s_mask[0], m1 = s_mask[1], m2 = s_mask[2], m3 = s_mask[3];
-#define GS_RANK(m) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u)))
-        // where this lane's record sits in every row's list (0xff: not in it) -- the producer's list build, from the same masks
-        const int p0 = ((m0 >> lane) & 1ull) ? (int)__popcll(m0) - 1 - GS_RANK(m0) : 0xff, p1 = ((m1 >> lane) & 1ull) ? (int)__popcll(m1) - 1 - GS_RANK(m1) : 0xff;
-        const int p2 = ((m2 >> lane) & 1ull) ? (int)__popcll(m2) - 1 - GS_RANK(m2) : 0xff, p3 = ((m3 >> lane) & 1ull) ? (int)__popcll(m3) - 1 - GS_RANK(m3) : 0xff;
-#undef GS_RANK
-        float racc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int t0 = 0; t0 < ntrips; t0 += kBT) {
-            __syncthreads();                                     // (X)
-            const int jjb = (int)list_b[t0];
-            const float4 rc = s0[jjb];
-            const float opb = s1[jjb].y;
-            const float4* gp4 = reinterpret_cast<const float4*>(m1p + m_rd);
-            const float4* wp4 = reinterpret_cast<const float4*>(m2p + m_rd);
-            const float4 g0 = gp4[0], g1 = gp4[1], g2 = gp4[2], g3 = gp4[3];
-            const float4 v0 = wp4[0], v1 = wp4[1], v2 = wp4[2], v3 = wp4[3];
-            __syncthreads();                                     // (Y) the producer may overwrite the planes
-#if GS_PC_ABLATE == 1           // (ablation 1, results wrong on purpose: no phase B, no gather)
-            racc[0] += g0.x + v0.x + rc.x + opb; (void)g1; (void)g2; (void)g3; (void)v1; (void)v2; (void)v3; (void)p0; (void)p1; (void)p2; (void)p3;
-            continue;
-#endif
-            const float gg[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
-            const float ww[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-            const float ddx[4] = {rc.x - bxf, rc.x - (bxf + 1.0f), rc.x - (bxf + 2.0f), rc.x - (bxf + 3.0f)};
-            const float ddy[4] = {rc.y - byf, rc.y - (byf + 1.0f), rc.y - (byf + 2.0f), rc.y - (byf + 3.0f)};
-            float gc[4], gr[4], rx[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                gc[q] = (gg[q] + gg[4 + q]) + (gg[8 + q] + gg[12 + q]);
-                gr[q] = (gg[4 * q] + gg[4 * q + 1]) + (gg[4 * q + 2] + gg[4 * q + 3]);
-                rx[q] = fmaf(gg[4 * q + 3], ddx[3], fmaf(gg[4 * q + 2], ddx[2], fmaf(gg[4 * q + 1], ddx[1], gg[4 * q] * ddx[0])));
-            }
-            const float t0x = gc[0] * ddx[0], t1x = gc[1] * ddx[1], t2x = gc[2] * ddx[2], t3x = gc[3] * ddx[3];
-            const float u0 = gr[0] * ddy[0], u1 = gr[1] * ddy[1], u2 = gr[2] * ddy[2], u3 = gr[3] * ddy[3];
-            float sm[10];
-            sm[0] = opb * ((rx[0] + rx[1]) + (rx[2] + rx[3]));
-            sm[1] = opb * ((u0 + u1) + (u2 + u3));
-            sm[2] = opb * fmaf(t3x, ddx[3], fmaf(t2x, ddx[2], fmaf(t1x, ddx[1], t0x * ddx[0])));
-            sm[3] = opb * fmaf(rx[3], ddy[3], fmaf(rx[2], ddy[2], fmaf(rx[1], ddy[1], rx[0] * ddy[0])));
-            sm[4] = opb * fmaf(u3, ddy[3], fmaf(u2, ddy[2], fmaf(u1, ddy[1], u0 * ddy[0])));
-            sm[5] = (gr[0] + gr[1]) + (gr[2] + gr[3]);
-            // colour (depth) moments against the block's dL/dcolour, four pixels per LDS read, pixels in ascending order (the register form's order)
-            sm[6] = sm[7] = sm[8] = sm[9] = 0.0f;
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const float4 ea = dl0[v], eb = dl1[v], ec = dl2[v];
-                const float e0_[4] = {ea.x, ea.y, ea.z, ea.w}, e1_[4] = {eb.x, eb.y, eb.z, eb.w}, e2_[4] = {ec.x, ec.y, ec.z, ec.w};
-                float ez_[4] = {0.f, 0.f, 0.f, 0.f};
-                if (DEPTH_GRAD) { const float4 ed = dl3[v]; ez_[0] = ed.x; ez_[1] = ed.y; ez_[2] = ed.z; ez_[3] = ed.w; }
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if (v == 0 && i == 0) {
-                        sm[6] = ww[0] * e0_[0]; sm[7] = ww[0] * e1_[0]; sm[8] = ww[0] * e2_[0]; sm[9] = DEPTH_GRAD ? ww[0] * ez_[0] : 0.0f;
-                    } else {
-                        sm[6] = fmaf(ww[4 * v + i], e0_[i], sm[6]); sm[7] = fmaf(ww[4 * v + i], e1_[i], sm[7]); sm[8] = fmaf(ww[4 * v + i], e2_[i], sm[8]);
-                        if (DEPTH_GRAD) sm[9] = fmaf(ww[4 * v + i], ez_[i], sm[9]);
-                    }
-                }
-            }
-            float4* ps = reinterpret_cast<float4*>(s_pair + lane * kPairStride);
-            ps[0] = make_float4(sm[0], sm[1], sm[2], sm[3]);
-            ps[1] = make_float4(sm[4], 0.f, sm[5], sm[6]);
-            ps[2] = make_float4(sm[7], sm[8], sm[9], 0.f);
-            __builtin_amdgcn_wave_barrier();
-            {
-                const int pr[4] = {p0 - t0, p1 - t0, p2 - t0, p3 - t0};
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if ((unsigned)pr[r] < (unsigned)kBT) {
-                        const float4* q = reinterpret_cast<const float4*>(s_pair + (pr[r] * 4 + r) * kPairStride);
-                        const float4 qa = q[0], qb = q[1], qc = q[2];
-                        racc[0] += qa.x; racc[1] += qa.y; racc[2] += qa.z; racc[3] += qa.w; racc[4] += qb.x;
-                        racc[5] += qb.z; racc[6] += qb.w; racc[7] += qc.x; racc[8] += qc.y; racc[9] += qc.z;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        // flush: as in blend_backward_kernel, from the consumer's own slots
-        {
-            const unsigned long long many = m0 | m1 | m2 | m3;
-            const int n_any = (int)__popcll(many);
-            float* fls = s_pair;
-            if ((many >> lane) & 1ull) {
-                s_ulist[(int)__builtin_amdgcn_mbcnt_hi((uint32_t)(many >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)many, 0u))] = (uint8_t)lane;
-                float4* f4 = reinterpret_cast<float4*>(fls + lane * kPairStride);
-                f4[0] = make_float4(racc[0], racc[1], racc[2], racc[3]);
-                f4[1] = make_float4(racc[4], 0.f, racc[5], racc[6]);
-                f4[2] = make_float4(racc[7], racc[8], racc[9], 0.f);
-            }
-            __builtin_amdgcn_wave_barrier();
-            const int krec = min(fl_rec, 5);
-            for (int g = 0; g < n_any; g += 6) {
-                const bool valid = lane < 60 && g + krec < n_any;
-                const int slot = (int)s_ulist[min(g + krec, kWave + 15)];
-                const float val = valid ? fls[slot * kPairStride + fl_off] : 0.0f;
-                const uint32_t id = valid ? __float_as_uint(s2[slot].z) : 0u;
-                if (val != 0.0f) atomicAdd(grad2d + (size_t)id * kGradStride + fl_comp, val);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // images of at most this many tiles (gs_set_half_quadrants; the name dates from the first few-tile variant) take the few-tile kernels:
 // 256 tiles x 4 quadrants are one walker per SIMD of this chip and every walker's chunk-by-chunk chain is exposed.  Forward: producer /
 // consumer workgroups (blend_forward_pc_kernel: 256 x 256, 200 k Gaussians 80 -> 65 us, 1 M 87 -> 74 us; 120 x 150 76 -> 68 us); backward:
@@ -1265,8 +953,6 @@ int g_half_quadrant_tiles = 256;
 // pieces of a chained backward walk (images of more than kChainMinTiles tiles); 1 switches the chaining off (tests, A/B measurements)
 int g_chain_pieces = kChainPieces;
 int g_chain_min_tiles = kChainMinTiles;
-// the producer / consumer form of the backward (gs_set_backward_pc) for images of more than kFewTiles tiles
-int g_backward_pc = 0;
 
 hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
@@ -1344,14 +1030,9 @@ hipError_t launch_blend_backward(const Cam& cam_in, const uint2* ranges, const u
 #define GS_BWD(DG, FEW)                                                                                                          \
     hipLaunchKernelGGL((blend_backward_kernel<DG, 1, FEW>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom, final_T, \
                        n_contrib, dL_dcolor, dL_ddepth, grad2d, split_state)
-#define GS_BWD_PC(DG)                                                                                                            \
-    hipLaunchKernelGGL((blend_backward_pc_kernel<DG>), dim3(per * 8 * 4), dim3(2 * kWave), 0, st, cam, ranges, point_list, geom, final_T, \
-                       n_contrib, dL_dcolor, dL_ddepth, grad2d, split_state)
     if (cam.split) { if (dL_ddepth) GS_BWD(true, true); else GS_BWD(false, true); }
-    else if (g_backward_pc && cam.gx * cam.gy > kFewTiles && split_state) { if (dL_ddepth) GS_BWD_PC(true); else GS_BWD_PC(false); }
     else { if (dL_ddepth) GS_BWD(true, false); else GS_BWD(false, false); }
 #undef GS_BWD
-#undef GS_BWD_PC
     return hipGetLastError();
 }
 

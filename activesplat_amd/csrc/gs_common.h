@@ -532,7 +532,6 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
 extern int g_half_quadrant_tiles;
 extern int g_chain_pieces;
 extern int g_chain_min_tiles;
-extern int g_backward_pc;
 // images of few tiles (at most kFewTiles; the knob above can only lower the limit): the forward records every pixel's running state
 // at the list positions 128 * 2^k, k < kCutLevels, for the two-segment backward.  Planes of H*W floats: [k][T, C0, C1, C2, D], then the
 // four totals, then one word "recorded"

@@ -514,7 +514,7 @@ def main():
             if all_traffic:
                 first = lambda *names: next((all_traffic[n] for n in names if n in all_traffic), None)  # noqa: E731
                 per_stage = {"preprocess_forward+scan": first("preprocess_forward_sh48_kernel", "preprocess_forward_kernel"),
-                             "blend_forward": first("blend_forward_streams_kernel"), "blend_backward": first("blend_backward_kernel", "blend_backward_pc_kernel"),
+                             "blend_forward": first("blend_forward_streams_kernel"), "blend_backward": first("blend_backward_kernel"),
                              "preprocess_backward": first("preprocess_backward_kernel")}
                 for k, v in per_stage.items():
                     if v is not None and k in stages:

@@ -140,10 +140,6 @@ int gs_set_half_quadrants(int32_t max_tiles);
  * quadrant) that run as separate workgroups in dispatch order and hand the per-pixel running state on through the image workspace.  The
  * arithmetic per pixel is the same sequence either way (gradients differ only by the order of the atomic sums). */
 int gs_set_backward_chain(int32_t pieces, int32_t min_tiles);
-/* Development knob: on != 0 selects the producer / consumer form of the backward blend (two wavefronts per quadrant: the per-pixel replay
- * on one, the per-block moments, gather and flush on the other, one batch apart) for images of more than 256 tiles.  Same results up to
- * the order of the atomic sums. */
-int gs_set_backward_pc(int32_t on);
 /* bytes of the scratch gs_render_backward needs (per-Gaussian 2-D gradient records) */
 uint64_t gs_backward_scratch_bytes(int32_t P);
 

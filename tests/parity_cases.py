@@ -338,36 +338,6 @@ def check_chained_backward(device, oracle64, N=5000, W=288, H=272, oracle32=None
         _lib.check(lib.gs_set_backward_chain(3, -1))
 
 
-def check_backward_producer_consumer(device, oracle64, N=5000, W=288, H=272, oracle32=None, seed=33, chain=3):
-    """gs_set_backward_pc: the producer / consumer form of the backward blend (two wavefronts per quadrant) on an image of more than 256
-    tiles, with and without chained pieces: forward identical, gradients equal to the one-wavefront kernel's up to the order of the atomic
-    sums, and against the fp64 oracle; also through the fused RGB-D backward (depth gradient)."""
-    from activesplat_amd import _lib
-    lib = _lib.get()
-    rs, rv = util.scene(N, W, H, seed=seed, device=device, scale_jitter=0.5)
-    rs = rs._replace(debug=False)
-    rv["opacities"] = (rv["opacities"] * 0.15).clamp(0, 1)
-    rv["scales"] = rv["scales"] * 3.0
-    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(7))
-    try:
-        _lib.check(lib.gs_set_backward_chain(chain, 256))
-        _lib.check(lib.gs_set_backward_pc(0))
-        ref = util.run_product(rs, rv, dL)
-        _lib.check(lib.gs_set_backward_pc(1))
-        got = util.run_product(rs, rv, dL)
-        for k in ("color", "depth", "opacity", "radii"):
-            assert np.array_equal(got[k], ref[k]), k
-        for k, g in got["grads"].items():
-            r = ref["grads"][k]
-            assert np.isfinite(g).all(), k
-            assert np.linalg.norm(g.astype(np.float64) - r) <= 2e-5 * max(np.linalg.norm(r), 1e-30), (k, np.linalg.norm(g - r) / np.linalg.norm(r))
-        check_backward(rs._replace(debug=True), rv, oracle64, seed=7, oracle32=oracle32)
-        check_fused_rgbd(rs, rv, oracle64)
-    finally:
-        _lib.check(lib.gs_set_backward_pc(0))
-        _lib.check(lib.gs_set_backward_chain(3, -1))
-
-
 #: tally of check_backward's fp32 escape hatch over the session (printed by tests/conftest.py)
 HATCH = {"keys_checked": 0, "fired": 0, "where": []}
 

@@ -173,8 +173,3 @@ def test_whole_quadrants_on_small_images(emu, oracle32, oracle64):
 
 def test_emulated_chained_backward(emu, oracle64, oracle32):
     pc.check_chained_backward(emu, oracle64, oracle32=oracle32)
-
-
-@pytest.mark.parametrize("chain", [1, 3])
-def test_emulated_backward_producer_consumer(emu, oracle64, oracle32, chain):
-    pc.check_backward_producer_consumer(emu, oracle64, N=3000, W=272, H=272, oracle32=oracle32, chain=chain)

@@ -287,33 +287,6 @@ def test_chained_backward_small(hip, oracle64, oracle32, seed, N, W, H):
     pc.check_chained_backward(hip, oracle64, N=N, W=W, H=H, oracle32=oracle32, seed=seed)
 
 
-@pytest.mark.parametrize("chain,seed,N,W,H", [(1, 33, 5000, 288, 272), (3, 34, 9000, 336, 256), (3, 36, 20000, 400, 304)])
-def test_backward_producer_consumer_small(hip, oracle64, oracle32, chain, seed, N, W, H):
-    pc.check_backward_producer_consumer(hip, oracle64, N=N, W=W, H=H, oracle32=oracle32, seed=seed, chain=chain)
-
-
-def test_backward_producer_consumer_at_full_size_equals_one_wavefront_per_quadrant(hip):
-    """BASELINE configs[1]'s frame with the producer / consumer backward against the one-wavefront kernel (both chained in three pieces)."""
-    from activesplat_amd import _lib
-    lib = _lib.get()
-    rs, rv = util.scene(500_000, 640, 480, seed=0, device=hip)
-    rs = rs._replace(debug=False)
-    dL = torch.randn(3, 480, 640, generator=torch.Generator().manual_seed(5))
-    try:
-        _lib.check(lib.gs_set_backward_pc(0))
-        ref = util.run_product(rs, rv, dL)
-        _lib.check(lib.gs_set_backward_pc(1))
-        got = util.run_product(rs, rv, dL)
-    finally:
-        _lib.check(lib.gs_set_backward_pc(0))
-    for k in ("color", "depth", "opacity", "radii"):
-        assert np.array_equal(got[k], ref[k]), k
-    for k, g in got["grads"].items():
-        r = ref["grads"][k]
-        assert np.isfinite(g).all(), k
-        assert np.linalg.norm(g.astype(np.float64) - r) <= 2e-5 * max(np.linalg.norm(r), 1e-30), (k, np.linalg.norm(g - r) / np.linalg.norm(r))
-
-
 def test_chained_backward_at_full_size_equals_one_walker_per_quadrant(hip):
     """BASELINE configs[1]'s frame (640 x 480: 1200 tiles, the chained backward is the default there): three pieces per quadrant against
     one walker per quadrant -- forward identical, gradients equal up to the order of the atomic sums."""
