@@ -50,6 +50,8 @@ DEFAULT_CONFIG = dict(
     fused_preprocess=False,  # ... or inside the rasteriser's per-Gaussian kernels (rasterizer.render_rgbd_raw; needs fused_render): no activation launches
     fused_adam=False,        # ... and the Adam step of an iteration inside that render's backward kernel (needs fused_preprocess; iterations whose
                              # prune / densify event replaces the parameter tensors take the separate step, as the reference's loop effectively does)
+    fused_iteration=False,   # ... and the whole iteration (get_loss + backward + step + zero_grad) as four library calls without autograd
+                             # (mapping.mapping_iteration; needs fused_render, fused_loss, fused_preprocess; event iterations take the usual path)
     fused_growth=False,      # add_new_gaussians: one forward + gs_grow_gaussians
     fused_keyframes=False,   # keyframe overlap scores by gs_keyframe_overlap (one launch for all keyframes)
     high_loss_samples=True,  # the per-frame no-grad render of get_high_loss_samples (__init__.py:184-258) before mapping a frame
@@ -176,6 +178,20 @@ class SplatMapper:
             in_backward = cfg.get("fused_adam", False) and cfg.get("fused_preprocess", False) and cfg["fused_render"] \
                 and not (mc["prune_gaussians"] and O.prune_event(it, mc["pruning_dict"])) \
                 and not (mc["use_gaussian_splatting_densification"] and O.densify_event(it, mc["densify_dict"]))
+            direct = cfg.get("fused_iteration", False) and cfg.get("fused_preprocess", False) and cfg["fused_render"] and cfg["fused_loss"] \
+                and mc["use_l1"] and not mc["ignore_outlier_depth_loss"] \
+                and not (mc["prune_gaussians"] and O.prune_event(it, mc["pruning_dict"])) \
+                and not (mc["use_gaussian_splatting_densification"] and O.densify_event(it, mc["densify_dict"]))
+            if direct:
+                # the whole iteration without autograd; a densify iteration that only accumulates statistics still does so below
+                loss, self.variables, losses = M.mapping_iteration(self.params, self._data(it_color, it_depth, it_id), self.variables, it_id,
+                                                                   mc["loss_weights"], self.optimizer)
+                if mc["use_gaussian_splatting_densification"]:
+                    self.params, self.variables = O.densify(self.params, self.variables, self.optimizer, it, mc["densify_dict"])
+                self._last_losses = {k: v.detach() for k, v in losses.items()}
+                self.stats["iters"] += 1
+                self.stats["iter_time"] += time.perf_counter() - t0
+                continue
             loss, self.variables, losses = M.get_loss(self.params, self._data(it_color, it_depth, it_id), self.variables, it_id,
                                                       mc["loss_weights"], mc["use_sil_for_loss"], mc["sil_thres"], mc["use_l1"],
                                                       mc["ignore_outlier_depth_loss"], fused=cfg["fused_render"], fused_loss=cfg["fused_loss"],

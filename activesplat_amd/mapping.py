@@ -385,6 +385,61 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
     return loss, variables, weighted
 
 
+class _DirectCtx:
+    """Stands in for an autograd context when the Functions' forward / backward are called directly (mapping_iteration)."""
+    needs_input_grad = (True,) * 8 + (False,) * 3
+    saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
+@torch.no_grad()
+def mapping_iteration(params, curr_data, variables, iter_time_idx, loss_weights, optimizer, pose7=None):
+    """One whole mapping iteration of the reference's loop (src/mapper/splatam/__init__.py:470-480: get_loss, loss.backward(), optimizer.step(),
+    optimizer.zero_grad) WITHOUT autograd: the four library calls of the fused path -- per-Gaussian forward on the parameters, render,
+    fused loss, backward with the Adam step inside -- are issued one after the other by the very code get_loss(fused=True, fused_loss=True,
+    fused_preprocess=True, fused_adam=optimizer) + loss.backward() runs, minus the graph, the engine's thread hand-over and the Function
+    boundaries.  At the reference's 256 x 256 frames the iteration is bound by exactly that host time (GPU busy ~230 us, wall ~320 us through
+    autograd).  Same parameters, moments and statistics afterwards.  For iterations without a prune / densify event (optim.densify_event /
+    prune_event) and the default loss options (use_l1, no outlier rejection, no bundle adjustment).
+    -> (loss, variables, {'im', 'depth', 'loss'}); variables['means2D'].grad, ['seen'] and ['max_2D_radius'] are updated as get_loss +
+    backward leave them."""
+    from . import rasterizer as R
+    if pose7 is None:
+        q = F.normalize(params["cam_unnorm_rots"][..., iter_time_idx].detach()).reshape(4)
+        pose7 = torch.cat([q, params["cam_trans"][..., iter_time_idx].detach().reshape(3)]).cpu().tolist()
+    mx = variables["max_2D_radius"]
+    means = params["means3D"]
+    if not (mx.dtype == torch.float32 and mx.is_contiguous() and mx.device == means.device and mx.numel() == means.shape[0]):
+        raise RuntimeError("mapping_iteration: variables['max_2D_radius'] must be a contiguous float32 [N] tensor on the parameters' device")
+    seen = torch.empty(mx.numel(), dtype=torch.bool, device=mx.device)
+    m2d = torch.empty_like(means, requires_grad=True)          # gradient carrier only: its .grad is what the densifier reads
+    shs = params.get("shs")
+    colors = None if shs is not None else params["rgb_colors"]
+    if shs is not None and int(shs.shape[1]) != 16:
+        raise Exception("mapping_iteration: SH rows of 16 coefficients only")
+    iso = int(params["log_scales"].shape[1]) == 1
+    rctx = _DirectCtx()
+    im, radius, depth, _sil, depth_sq = R._RasterizeGaussians.forward(
+        rctx, means, m2d, shs, colors, params["logit_opacities"], params["log_scales"], params["unnorm_rotations"], None, curr_data["cam"], True,
+        (pose7, iso, False, (mx, seen), optimizer))
+    lctx = _DirectCtx()
+    loss, parts = _FusedMappingLoss.forward(lctx, im, depth, depth_sq, curr_data["im"], curr_data["depth"], loss_weights["im"], loss_weights["depth"])
+    grads = lctx.saved_tensors[0]                               # dL/dim [3,H,W] and dL/ddepth [1,H,W] for dL/dloss = 1
+    out = R._RasterizeGaussians.backward(rctx, grads[:3], None, grads[3:], None, None)
+    m2d.grad = out[1]
+    variables["means2D"] = m2d
+    variables["seen"] = seen
+    return loss, variables, {"im": parts[1], "depth": parts[2], "loss": loss}
+
+
 # ---------------------------------------------------------------------------------------------------
 # map initialisation / growth (splatam.py:25-115,304-379)
 # ---------------------------------------------------------------------------------------------------

@@ -120,23 +120,36 @@ class GaussianAdam:
         GsAdamTensor descriptors of `tensors` (parameters of this optimiser, in the kernel's order), with this step's bookkeeping done --
         state created on first use, step counters advanced -- exactly as step() would.  The kernel then updates parameter and moments in
         place; the tensors keep .grad = None, so a later step() skips them."""
-        by_id = {id(p): g for g in self.param_groups for p in g["params"]}
-        arr = (_lib.GsAdamTensor * len(tensors))()
-        for i, p in enumerate(tensors):
-            g = by_id.get(id(p))
-            if g is None:
-                raise RuntimeError("fused Adam: a rendered tensor is not a parameter of this optimiser")
+        # (the descriptor array is kept from call to call while the same tensors take part: only step counters and hyper-parameters are refreshed)
+        cache = getattr(self, "_backward_cache", None)
+        ident = tuple((id(p), p.data_ptr(), p.numel()) for p in tensors)
+        if cache is None or cache[0] != ident:
+            by_id = {id(p): g for g in self.param_groups for p in g["params"]}
+            arr = (_lib.GsAdamTensor * len(tensors))()
+            entries = []
+            for i, p in enumerate(tensors):
+                g = by_id.get(id(p))
+                if g is None:
+                    raise RuntimeError("fused Adam: a rendered tensor is not a parameter of this optimiser")
+                if not p.is_contiguous() or p.dtype != torch.float32:
+                    raise RuntimeError("GaussianAdam needs contiguous fp32 parameters")
+                st = self.state.get(p)
+                if st is None or len(st) == 0:
+                    st = self.state[p] = {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+                arr[i] = _lib.GsAdamTensor(p.numel(), p.data_ptr(), None, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), 0.0, 0.0, 0.0, 0.0, 1, 0)
+                entries.append((g, st, p))
+            cache = self._backward_cache = (ident, arr, entries, tuple((st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for _, st, _ in entries))
+        _, arr, entries, moments = cache
+        for i, (g, st, p) in enumerate(entries):
             if p.grad is not None:
                 raise RuntimeError("fused Adam: a parameter already holds a gradient (accumulated keyframes?) -- step() it or zero_grad() first")
-            if not p.is_contiguous() or p.dtype != torch.float32:
-                raise RuntimeError("GaussianAdam needs contiguous fp32 parameters")
-            st = self.state.get(p)
-            if st is None or len(st) == 0:
-                st = self.state[p] = {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+            if (st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) != moments[i]:      # (row surgery replaced the moments: rebuild)
+                self._backward_cache = None
+                return self.backward_step_descriptors(tensors)
             st["step"] = int(st["step"]) + 1
             b1, b2 = g["betas"]
-            arr[i] = _lib.GsAdamTensor(p.numel(), p.data_ptr(), None, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                       float(g["lr"]), float(b1), float(b2), float(g["eps"]), int(st["step"]), 0)
+            t = arr[i]
+            t.lr = float(g["lr"]); t.beta1 = float(b1); t.beta2 = float(b2); t.eps = float(g["eps"]); t.step = int(st["step"])
         return arr
 
 

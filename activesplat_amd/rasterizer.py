@@ -285,13 +285,6 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_color = torch.zeros(3, int(ctx.rs.image_height), int(ctx.rs.image_width), device=device)
         grad_color = _f32(grad_color, device)
         grad_depth = _f32(grad_depth, device) if (ctx.fused and grad_depth is not None) else None
-        z = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731  (kernel writes every row)
-        d_m2d, d_m3d, d_op = z(P, 3), z(P, 3), z(P, 1)
-        d_col = z(P, 3) if has_col else None
-        d_shs = z(P, M, 3) if has_sh else None
-        d_sc = z(P, 3) if has_sc else None
-        d_rot = z(P, 4) if has_rot else None
-        d_cov = z(P, 6) if has_cov else None
         scratch, clean = ctx.scratch, ctx.scratch_clean
         if scratch is None:
             scratch, clean = torch.empty(int(lib.gs_backward_scratch_bytes(P)), dtype=torch.uint8, device=device), False
@@ -300,6 +293,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if ctx.raw is not None and ctx.adam is not None:
             # single-keyframe step: Adam on the five per-Gaussian tensors rides in the per-Gaussian backward kernel (no gradient tensors)
             pose, iso, _acc, logit = ctx.raw
+            d_m2d = torch.empty(P, 3, dtype=torch.float32, device=device)
             opt, tensors = ctx.adam
             desc = opt.backward_step_descriptors(tensors)
             _lib.check(lib.gs_render_backward_raw_adam(
@@ -307,6 +301,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _ptr(scales), _ptr(rots), pose, iso, _ptr(radii), _ptr(geom), _ptr(point_list), _ptr(image), _ptr(grad_color),
                 _ptr(grad_depth), _ptr(d_m2d), _ptr(scratch), 1 if clean else 0, int(ctx.sh_jac), desc, _stream(device)))
             return None, d_m2d, None, None, None, None, None, None, None, None, None
+        z = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731  (kernel writes every row)
+        d_m2d, d_m3d, d_op = z(P, 3), z(P, 3), z(P, 1)
+        d_col = z(P, 3) if has_col else None
+        d_shs = z(P, M, 3) if has_sh else None
+        d_sc = z(P, 3) if has_sc else None
+        d_rot = z(P, 4) if has_rot else None
+        d_cov = z(P, 6) if has_cov else None
         if ctx.raw is not None:
             pose, iso, accumulate, logit = ctx.raw
             d_sc = z(P, 1 if iso else 3)                  # (gradients w.r.t. the parameters: log scales are [P,1] for an isotropic map)

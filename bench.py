@@ -178,8 +178,12 @@ def mapping_iteration_ms(dev, params_cpu, W, H, flags, iters=20, warm=5):
                                            log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0))
     flags = dict(flags)
     in_bwd = flags.pop("adam", False)
+    direct = flags.pop("direct", False)
 
     def it():
+        if direct:                                             # the iteration's four library calls, no autograd
+            M.mapping_iteration(prm, data, var, 0, dict(im=0.5, depth=1.0), opt, pose7=[1.0, 0, 0, 0, 0, 0, 0])
+            return
         loss, _, _ = M.get_loss(prm, data, var, 0, dict(im=0.5, depth=1.0), pose7=[1.0, 0, 0, 0, 0, 0, 0] if flags else None,
                                 fused_adam=opt if in_bwd else None, **flags)
         loss.backward(M.unit_gradient(loss) if flags else None)
@@ -689,9 +693,11 @@ def main():
                 flags = dict(fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=True)
                 wall, ev = mapping_iteration_ms(dev, p1, w_, w_, dict(flags, adam=True), iters=40, warm=10)
                 wall0, ev0 = mapping_iteration_ms(dev, p1, w_, w_, flags, iters=40, warm=10)
+                walld, evd = mapping_iteration_ms(dev, p1, w_, w_, dict(flags, direct=True), iters=40, warm=10)
                 ops[f"{w_}x{w_}_{n_ // 1000}k"] = {"render_fwd_bwd_us": round(t * 1e6, 1), "tile_instances_D": D1,
                                                    "stages_us": {k: v["avg_us"] for k, v in st1.items()},
-                                                   "mapping_iteration_ms": {"fused_adam_in_backward": round(wall, 4), "fused_adam_in_backward_gpu": round(ev, 4),
+                                                   "mapping_iteration_ms": {"without_autograd": round(walld, 4), "without_autograd_gpu": round(evd, 4),
+                                                                            "fused_adam_in_backward": round(wall, 4), "fused_adam_in_backward_gpu": round(ev, 4),
                                                                             "fused_separate_adam": round(wall0, 4), "fused_separate_adam_gpu": round(ev0, 4)}}
                 torch.cuda.empty_cache()
             out["operating_points"] = dict(ops, note="the reference's frame sizes, precomputed colours; render = GaussianRasterizer forward + backward, frames one after "
@@ -750,7 +756,8 @@ def main():
             N1 = 500_000
             params1 = params1 if params1 is not None else syn.make_params(N1, W, H, seed=0)
             for name, flags in (("reference_call_pattern", {}), ("fused", dict(fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=True)),
-                                ("fused_adam_in_backward", dict(fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=True, adam=True))):
+                                ("fused_adam_in_backward", dict(fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=True, adam=True)),
+                                ("fused_without_autograd", dict(fused=True, direct=True))):
                 wall, ev = mapping_iteration_ms(dev, params1, W, H, flags)
                 its[name + "_ms"] = round(wall, 4)
                 its[name + "_gpu_ms"] = round(ev, 4)

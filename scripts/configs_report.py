@@ -34,7 +34,7 @@ torch.cuda.empty_cache()
 # 256 x 256 (config/datasets/gibson.json) and 512 x 512 with 10 mapping iterations per mapped frame (config/datasets/gibson_high_resolution.json,
 # config/env/activesplat_high_resolution_pointnav.yaml:41-47) ----
 FR = 31
-FUSED = dict(fused_render=True, fused_loss=True, fused_inputs=True, fused_preprocess=True, fused_adam=True, fused_growth=True, fused_keyframes=True)
+FUSED = dict(fused_render=True, fused_loss=True, fused_inputs=True, fused_preprocess=True, fused_adam=True, fused_iteration=True, fused_growth=True, fused_keyframes=True)
 
 
 def quality(mp, seq):

@@ -23,6 +23,9 @@ flags = dict(fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=os
 
 
 def it():
+    if os.environ.get("DIRECT") == "1":                       # the iteration's four library calls without autograd
+        M.mapping_iteration(prm, data, var, 0, dict(im=0.5, depth=1.0), opt, pose7=[1.0, 0, 0, 0, 0, 0, 0])
+        return
     loss, _, _ = M.get_loss(prm, data, var, 0, dict(im=0.5, depth=1.0), pose7=[1.0, 0, 0, 0, 0, 0, 0],
                             fused_adam=opt if os.environ.get("ADAM") == "1" else None, **flags)      # ADAM=1: the step inside the backward kernel
     loss.backward(M.unit_gradient(loss))

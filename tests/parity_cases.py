@@ -311,6 +311,53 @@ def check_adam_inside_the_backward(device, n=600, W=64, H=48, steps=3, exact=Tru
                 assert float((d > 1e-6 * float(b[0][k].abs().max())).float().mean()) < 1e-3, (k, sh, iso, it, float(d.max()))
 
 
+def check_mapping_iteration_without_autograd(device, n=500, exact=True):
+    """mapping.mapping_iteration (the iteration's four library calls issued directly) against get_loss(fused..., fused_adam=) + backward + step +
+    zero_grad through autograd: parameters, moments, loss, means2D.grad, seen, max_2D_radius after three iterations on three keyframes;
+    anisotropic and isotropic maps.  exact: bit for bit (emulated kernels on one host thread); else to the order of the atomic sums."""
+    from activesplat_amd import mapping as M, optim as O
+    from tests.test_parallel import _scene
+    lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
+    for iso in (False, True):
+        outs = []
+        for direct in (False, True):
+            params, kfs = _scene(n=n, device=device)
+            if iso:
+                params["log_scales"] = torch.nn.Parameter(params["log_scales"].detach()[:, :1].clone())
+            nn_ = params["means3D"].shape[0]
+            var = {k: torch.zeros(nn_, device=device) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+            opt = O.initialize_optimizer(params, lrs)
+            for it in range(3):
+                kf = kfs[it]
+                if direct:
+                    loss, var, parts = M.mapping_iteration(params, kf, var, kf["id"], dict(im=0.5, depth=1.0), opt)
+                    assert all(p.grad is None for p in params.values())
+                else:
+                    loss, var, parts = M.get_loss(params, kf, var, kf["id"], dict(im=0.5, depth=1.0), fused=True, fused_loss=True, fused_preprocess=True,
+                                                  fused_adam=opt)
+                    loss.backward(M.unit_gradient(loss))
+                    with torch.no_grad():
+                        opt.step(); opt.zero_grad(set_to_none=True)
+            outs.append(({k: v.detach().clone() for k, v in params.items()},
+                         {k: (opt.state[v]["exp_avg"].clone(), int(opt.state[v]["step"])) for k, v in params.items() if v in opt.state and len(opt.state[v])},
+                         var["means2D"].grad.clone(), var["seen"].clone(), var["max_2D_radius"].clone(), float(loss.detach()), float(parts["im"])))
+        a, b = outs
+        assert abs(a[5] - b[5]) <= (0.0 if exact else 1e-6 * abs(a[5])) and abs(a[6] - b[6]) <= (0.0 if exact else 1e-6 * abs(a[6]))
+        assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+        for k in a[1]:
+            assert a[1][k][1] == b[1][k][1] == 3, k
+        if exact:
+            assert torch.equal(a[2], b[2])
+            assert all(torch.equal(a[0][k], b[0][k]) for k in a[0]) and all(torch.equal(a[1][k][0], b[1][k][0]) for k in a[1])
+        else:
+            rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm().clamp_min(1e-30))  # noqa: E731
+            assert rel(a[2], b[2]) < 5e-5
+            for k in a[1]:
+                if iso and k == "unnorm_rotations":
+                    continue
+                assert rel(a[1][k][0], b[1][k][0]) < 5e-5, (k, rel(a[1][k][0], b[1][k][0]))
+
+
 def check_chained_backward(device, oracle64, N=5000, W=288, H=272, oracle32=None, seed=33):
     """Images of more than 768 tiles walk every quadrant's list in three chained pieces (gs_set_backward_chain): here the threshold is
     lowered so that a 306-tile image takes that path, with splats large and faint enough for walks of several 64-record chunks; against

@@ -133,6 +133,17 @@ def test_emulated_adam_inside_the_backward_equals_backward_plus_step(emu):
         omp.omp_set_num_threads(before)
 
 
+def test_emulated_mapping_iteration_without_autograd_equals_the_autograd_path(emu):
+    import ctypes
+    omp = ctypes.CDLL("libgomp.so.1")
+    before = omp.omp_get_max_threads()
+    omp.omp_set_num_threads(1)
+    try:
+        pc.check_mapping_iteration_without_autograd(emu)
+    finally:
+        omp.omp_set_num_threads(before)
+
+
 def test_emulated_optimistic_launch_hit_and_miss_equal_exact_launch(emu):
     pc.check_optimistic_launch(emu)
     pc.check_optimistic_tile_list_growth(emu)

@@ -121,7 +121,7 @@ def test_mapper_harness_report_configuration_psnr(hip):
     from activesplat_amd import mapping as M
     from tests import util
     from tests.test_mapper import run_harness
-    flags = dict(fused_render=True, fused_loss=True, fused_inputs=True, fused_preprocess=True, fused_adam=True, fused_growth=True, fused_keyframes=True)
+    flags = dict(fused_render=True, fused_loss=True, fused_inputs=True, fused_preprocess=True, fused_adam=True, fused_iteration=True, fused_growth=True, fused_keyframes=True)
     mp, seq, log = run_harness(hip, n_gt=400_000, W=256, H=256, frames=31, cfg=dict(mapping_iters=10, **flags))
     assert all(e["iters"] == 2 for e in log)
     ps, ss = [], []

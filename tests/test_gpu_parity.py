@@ -314,6 +314,10 @@ def test_adam_inside_the_backward_equals_backward_plus_step(hip):
     pc.check_adam_inside_the_backward(hip, n=30000, W=160, H=128, exact=False)
 
 
+def test_mapping_iteration_without_autograd_equals_the_autograd_path(hip):
+    pc.check_mapping_iteration_without_autograd(hip, n=20000, exact=False)
+
+
 def test_raw_parameter_rasteriser_equals_the_activation_kernels(hip):
     pc.check_raw_parameter_mode(hip, n=20000)
     pc.check_raw_parameter_mode_sh(hip, n=20000, W=160, H=128)

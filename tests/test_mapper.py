@@ -112,13 +112,15 @@ def test_mapper_with_adam_inside_the_backward_builds_the_same_map(emu):
         base = dict(fused_render=True, fused_loss=True, fused_inputs=True, fused_preprocess=True)
         a, _, log_a = run_harness(emu, n_gt=2000, W=48, H=40, frames=6, cfg=base)
         b, _, log_b = run_harness(emu, n_gt=2000, W=48, H=40, frames=6, cfg=dict(base, fused_adam=True))
+        c, _, log_c = run_harness(emu, n_gt=2000, W=48, H=40, frames=6, cfg=dict(base, fused_adam=True, fused_iteration=True))   # ... and without autograd
     finally:
         omp.omp_set_num_threads(before)
-    assert log_a == log_b and a.stats["iters"] == b.stats["iters"] > 0
-    for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
-        assert torch.equal(a.params[k].detach(), b.params[k].detach()), k
-        sa, sb = a.optimizer.state[a.params[k]], b.optimizer.state[b.params[k]]
-        assert int(sa["step"]) == int(sb["step"]) and torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), k
+    assert log_a == log_b == log_c and a.stats["iters"] == b.stats["iters"] == c.stats["iters"] > 0
+    for other in (b, c):
+        for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
+            assert torch.equal(a.params[k].detach(), other.params[k].detach()), k
+            sa, sb = a.optimizer.state[a.params[k]], other.optimizer.state[other.params[k]]
+            assert int(sa["step"]) == int(sb["step"]) and torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), k
 
 
 def test_raw_frames_with_densification_resolution(emu):
