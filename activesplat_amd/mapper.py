@@ -82,6 +82,10 @@ class SplatMapper:
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
         self.W, self.H = int(width), int(height)
         self.intrinsics = torch.as_tensor(np.asarray(intrinsics), dtype=torch.float32, device=self.device)
+        self._k_host = np.asarray(intrinsics, dtype=np.float64)
+        self._pose_host = {}               # frame id -> (quaternion, translation) as this mapper wrote them into the camera parameters (host tensors)
+        lrs = self.cfg["mapping"]["lrs"]
+        self._poses_fixed = float(lrs.get("cam_unnorm_rots", 0.0)) == 0.0 and float(lrs.get("cam_trans", 0.0)) == 0.0
         self.first_frame_w2c = torch.eye(4, device=self.device)
         self.cam = setup_camera(self.W, self.H, np.asarray(intrinsics), np.eye(4), device=self.device)
         self.densify_cam, self.densify_intrinsics = self.cam, self.intrinsics      # replaced when frames carry a densify copy
@@ -102,7 +106,21 @@ class SplatMapper:
         return {k: float(v.detach()) for k, v in self._last_losses.items()}
 
     # -- helpers ---------------------------------------------------------------------------------
+    @staticmethod
+    def _w2c_host(quat, pos):
+        """4x4 w2c of a (w,x,y,z) quaternion + translation, on the HOST (the same torch ops as on the device, ~15 of them: issued as
+        device launches they were 0.3 ms of host time per call, several times per frame)."""
+        w2c = torch.eye(4)
+        w2c[:3, :3] = M.build_rotation(F.normalize(quat.view(1, 4)))
+        w2c[:3, 3] = pos
+        return w2c
+
     def _w2c(self, frame_id):
+        # the poses this mapper wrote into the camera parameters are still on the host (tracking is skipped and their learning rates are
+        # zero in the shipped configuration); a pose that is optimised is read from the parameters
+        host = self._pose_host.get(int(frame_id)) if self._poses_fixed else None
+        if host is not None:
+            return self._w2c_host(*host).to(self.device)
         rot = F.normalize(self.params["cam_unnorm_rots"][..., frame_id].detach())
         w2c = torch.eye(4, device=self.device)
         w2c[:3, :3] = M.build_rotation(rot)
@@ -119,13 +137,12 @@ class SplatMapper:
         fid = int(frame["id"])
         color = frame["color"].to(self.device).float()
         depth = frame["depth"].to(self.device).float()
-        quat = torch.as_tensor(frame["quat"], dtype=torch.float32, device=self.device)
-        pos = torch.as_tensor(frame["position"], dtype=torch.float32, device=self.device)
+        quat_h = torch.as_tensor(np.asarray(frame["quat"], dtype=np.float32)).reshape(4).clone()
+        pos_h = torch.as_tensor(np.asarray(frame["position"], dtype=np.float32)).reshape(3).clone()
+        self._pose_host[fid] = (quat_h, pos_h)
+        quat, pos = quat_h.to(self.device), pos_h.to(self.device)
         if self.params is not None and cfg.get("high_loss_samples", True):
-            init = torch.eye(4, device=self.device)
-            init[:3, :3] = M.build_rotation(F.normalize(quat.view(1, 4)))
-            init[:3, 3] = pos
-            self.high_loss_mask = self.high_loss_samples_mask(init, depth)
+            self.high_loss_mask = self.high_loss_samples_mask(self._w2c_host(quat_h, pos_h), depth)       # (host pose: the camera block is built on the host)
         # densification-resolution copy of the frame (reference :362-376); defaults to the mapping resolution
         d_color = frame["densify_color"].to(self.device).float() if "densify_color" in frame else color
         d_depth = frame["densify_depth"].to(self.device).float() if "densify_depth" in frame else depth
@@ -135,9 +152,10 @@ class SplatMapper:
             self.densify_cam = setup_camera(d_color.shape[2], d_color.shape[1], self.densify_intrinsics.cpu().numpy(), np.eye(4),
                                             device=self.device)
         if fid == 0:
-            init_w2c = torch.eye(4, device=self.device)
-            init_w2c[:3, :3] = M.build_rotation(quat.view(1, 4))
-            init_w2c[:3, 3] = pos
+            init_w2c = torch.eye(4)
+            init_w2c[:3, :3] = M.build_rotation(quat_h.view(1, 4))
+            init_w2c[:3, 3] = pos_h
+            init_w2c = init_w2c.to(self.device)
             mask = (d_depth > 0).reshape(-1)
             cld, msd = M.get_pointcloud(d_color, d_depth, self.densify_intrinsics, init_w2c, mask=mask, compute_mean_sq_dist=True)
             self.params, self.variables = M.initialize_params(cld, cfg["step_num"], msd, cfg["gaussian_distribution"])
@@ -156,8 +174,8 @@ class SplatMapper:
                 self.params, self.variables = M.add_new_gaussians(self.params, self.variables, d_data,
                                                                   mc["sil_thres"], fid, cfg["gaussian_distribution"],
                                                                   fused=cfg.get("fused_growth", False),
-                                                                  pose7=[float(v) for v in F.normalize(quat.view(1, 4)).view(4).tolist()]
-                                                                  + [float(v) for v in pos.tolist()] if cfg.get("fused_growth", False) else None)
+                                                                  pose7=[float(v) for v in F.normalize(quat_h.view(1, 4)).view(4).tolist()]
+                                                                  + [float(v) for v in pos_h.tolist()] if cfg.get("fused_growth", False) else None)
             with torch.no_grad():
                 sel = keyframe_selection_overlap(depth, self._w2c(fid), self.intrinsics, self.keyframe_list[:-1],
                                                  cfg["mapping_window_size"] - 2, fused=cfg.get("fused_keyframes", False))
@@ -267,8 +285,19 @@ class SplatMapper:
     # -- no-grad consumers (reference: render_rgbd / get_*_invisibility, __init__.py:604-838) ----------------
     @torch.no_grad()
     def render_rgbd(self, w2c, scale_modifier=1.0, width=None, height=None, intrinsics=None):
-        k = self.intrinsics.cpu().numpy() if intrinsics is None else np.asarray(intrinsics)
+        k = self._k_host if intrinsics is None else np.asarray(intrinsics)
         cfgv = dict(self.cfg["viz"], viz_w=width or self.W, viz_h=height or self.H)
+        if self.cfg.get("fused_preprocess", False) and "rgb_colors" in self.params:
+            # the map's PARAMETERS straight into the rasteriser (activations inside its per-Gaussian kernel, identity frame transform: the
+            # view is the camera's): no activation launches, and none of the depth / silhouette "colours" every caller discards
+            from . import rasterizer as R
+            cam = setup_camera(cfgv["viz_w"], cfgv["viz_h"], k, w2c.cpu() if torch.is_tensor(w2c) else w2c, cfgv["viz_near"], cfgv["viz_far"],
+                               scale_modifier=scale_modifier, device=self.device, bg=(1.0, 1.0, 1.0))
+            p = self.params
+            im, _radii, depth, opacity, _dsq = R.render_rgbd_raw(cam, p["means3D"].detach(), torch.empty(0, device=self.device), p["logit_opacities"].detach(),
+                                                                 p["log_scales"].detach(), p["unnorm_rotations"].detach(), [1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0],
+                                                                 colors_precomp=p["rgb_colors"].detach())
+            return im, depth, opacity
         rv, dv = M.get_rendervars(self.params, w2c)
         im, depth, opacity, _ = M.render(w2c, k, rv, dv, cfgv, scale_modifier=scale_modifier, device=self.device,
                                          with_silhouette=False)

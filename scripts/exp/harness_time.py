@@ -10,7 +10,9 @@ gt = syn.shell_scene(400_000, seed=2, W=W, H=H)
 gt["logit_opacities"] = gt["logit_opacities"] + 3.0
 seq = list(syn.orbit_sequence(gt, FR, W, H, dev))
 for name, flags in (("fused render/loss/inputs", dict(fused_render=True, fused_loss=True, fused_inputs=True)),
-                    ("+ fused growth + keyframes", dict(fused_render=True, fused_loss=True, fused_inputs=True, fused_growth=True, fused_keyframes=True))):
+                    ("+ fused growth + keyframes", dict(fused_render=True, fused_loss=True, fused_inputs=True, fused_growth=True, fused_keyframes=True)),
+                    ("+ raw parameters, Adam in the backward, no autograd", dict(fused_render=True, fused_loss=True, fused_inputs=True, fused_growth=True, fused_keyframes=True,
+                                                                                 fused_preprocess=True, fused_adam=True, fused_iteration=True))):
     for rep in range(2):
         mp = SplatMapper(syn.intrinsics(W, H), W, H, config=dict(step_num=FR, mapping_iters=10, **flags), device=dev)
         torch.cuda.synchronize(); t0 = time.perf_counter()
