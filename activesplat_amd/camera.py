@@ -32,10 +32,18 @@ def setup_camera(w, h, k, w2c, near=0.01, far=100, scale_modifier=1.0, bg=(0.0, 
                                 [0.0, 0.0, 1.0, 0.0]], dtype=torch.float32, device=work).unsqueeze(0).transpose(1, 2)
     full_proj = view.bmm(opengl_proj)
     # values as the reference builds them; stored contiguous and 16-byte aligned so that the rasteriser passes the
-    # pointers through instead of re-packing a transposed view / an offset slice on every call
-    view, full_proj, cam_center = view.contiguous().to(device), full_proj.contiguous().to(device), cam_center.clone().to(device)
+    # pointers through instead of re-packing a transposed view / an offset slice on every call.  Host-built blocks travel in ONE
+    # buffer (one host-to-device copy instead of four): view at float 0, projection at 16, camera centre at 32, background at 36
+    bg_t = torch.tensor(list(bg), dtype=torch.float32)
+    if work.type == "cpu":
+        pack = torch.empty(40, dtype=torch.float32)
+        pack[0:16] = view.reshape(16); pack[16:32] = full_proj.reshape(16); pack[32:35] = cam_center; pack[36:39] = bg_t
+        pack = pack.to(device)
+        view, full_proj, cam_center, bg_t = pack[0:16].view(1, 4, 4), pack[16:32].view(1, 4, 4), pack[32:35], pack[36:39]
+    else:
+        view, full_proj, cam_center, bg_t = view.contiguous().to(device), full_proj.contiguous().to(device), cam_center.clone().to(device), bg_t.to(device)
     return GaussianRasterizationSettings(
         image_height=int(h), image_width=int(w), tanfovx=w / (2 * fx), tanfovy=h / (2 * fy),
-        bg=torch.tensor(list(bg), dtype=torch.float32, device=device), scale_modifier=scale_modifier,
+        bg=bg_t, scale_modifier=scale_modifier,
         viewmatrix=view, projmatrix=full_proj, sh_degree=sh_degree, campos=cam_center,
         prefiltered=False, debug=False)
