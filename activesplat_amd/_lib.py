@@ -54,10 +54,10 @@ SORT_AUTO, SORT_TILE_LDS, SORT_RADIX = 0, 1, 2
 
 # every symbol include/gsplat_hip.h declares (tests check the library exports all of them)
 #: the GS_ABI_VERSION of include/gsplat_hip.h this binding was written against (checked when a library is bound)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SYMBOLS = ("gs_abi_version", "gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
-           "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_set_half_quadrants", "gs_set_backward_chain", "gs_preprocess_forward", "gs_preprocess_forward_raw", "gs_render_forward", "gs_render_backward", "gs_render_backward_raw", "gs_render_backward_raw_adam", "gs_adam_step", "gs_adam_step_multi",
+           "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_set_half_quadrants", "gs_set_backward_chain", "gs_set_backward_segments", "gs_preprocess_forward", "gs_preprocess_forward_raw", "gs_render_forward", "gs_render_backward", "gs_render_backward_raw", "gs_render_backward_raw_adam", "gs_adam_step", "gs_adam_step_multi",
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
            "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward", "gs_activate_backward_accumulate",
            "gs_grow_scratch_bytes", "gs_grow_gaussians", "gs_keyframe_overlap", "gs_visibility_stats", "gs_accumulate_grad2d",
@@ -86,6 +86,8 @@ def _bind(lib):
     lib.gs_set_half_quadrants.restype = C.c_int
     lib.gs_set_backward_chain.argtypes = [i32, i32]
     lib.gs_set_backward_chain.restype = C.c_int
+    lib.gs_set_backward_segments.argtypes = [i32]
+    lib.gs_set_backward_segments.restype = C.c_int
     lib.gs_set_forward_segments.restype = C.c_int
     lib.gs_image_layout.argtypes = [i32, i32, C.POINTER(GsImageLayout)]
     lib.gs_bin_layout.argtypes = [i64, C.c_uint32, i32, i32, C.POINTER(GsBinLayout)]

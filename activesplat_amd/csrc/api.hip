@@ -161,6 +161,13 @@ int gs_set_backward_chain(int32_t pieces, int32_t min_tiles)
     return GS_OK;
 }
 
+int gs_set_backward_segments(int32_t segments)
+{
+    if (segments < 1 || segments > gs::kFewSegmentsMax) return fail(GS_EINVAL, "gs_set_backward_segments: 1, 2 or 3");
+    gs::g_few_segments = segments;
+    return GS_OK;
+}
+
 int gs_set_forward_segments(int32_t on)
 {
     g_segments_enabled = on != 0;

@@ -39,18 +39,18 @@ struct TileCtx {
 
 // Workgroup b runs on XCD b & 7 (round-robin dispatch) and takes entry (b >> 3) of that XCD's contiguous band of tiles (neighbouring
 // tiles share Gaussians: their records are reused in one 4 MiB L2); a tile is NW-wavefront workgroups of quadrant walkers -- four
-// 8 x 8 quadrants, or four quadrants x two list segments (the few-tile backward).
+// 8 x 8 quadrants, or four quadrants x `segments` list segments (the few-tile backward: 2 or 3).
 template <int NW>
-__device__ __forceinline__ bool tile_ctx_at(const Cam& cam, unsigned block, int wave, int lane, TileCtx& c, bool segments = false)
+__device__ __forceinline__ bool tile_ctx_at(const Cam& cam, unsigned block, int wave, int lane, TileCtx& c, int segments = 0)
 {
-    const int G = (segments ? 8 : 4) / NW;                   // workgroups per tile
+    const int G = (segments > 1 ? 4 * segments : 4) / NW;    // workgroups per tile
     const int ntiles = cam.gx * cam.gy, per = (ntiles + 7) >> 3;
     const int idx = (int)(block >> 3);
     c.tile = (int)(block & 7) * per + idx / G;
     if (idx / G >= per || c.tile >= ntiles) return false;
     int quad = (idx % G) * NW + wave;
-    c.seg = segments ? quad >> 2 : 0;                        // (list segments: walkers 0-3 = front segment of the four quadrants, 4-7 = back)
-    if (segments) quad &= 3;
+    c.seg = segments > 1 ? quad >> 2 : 0;                    // (list segments: walkers 0-3 = front segment of the four quadrants, 4-7 = the next, ...)
+    if (segments > 1) quad &= 3;
     c.tx = c.tile % cam.gx; c.ty = c.tile / cam.gx; c.quad = quad;
     const int qx = c.tx * kTile + (quad & 1) * kQuad, qy = c.ty * kTile + (quad >> 1) * kQuad;
     c.px = qx + (lane & 7); c.py = qy + (lane >> 3);
@@ -60,7 +60,7 @@ __device__ __forceinline__ bool tile_ctx_at(const Cam& cam, unsigned block, int 
 }
 
 template <int NW>
-__device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, TileCtx& c, bool segments = false)
+__device__ __forceinline__ bool tile_ctx_nw(const Cam& cam, int wave, int lane, TileCtx& c, int segments = 0)
 {
     return tile_ctx_at<NW>(cam, blockIdx.x, wave, lane, c, segments);
 }
@@ -511,8 +511,8 @@ __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
             if (it >= 1 && !__all(done)) {
                 const int ab = (it - 1) & 1, lb = (it - 1) % 3, rb = (it - 1) & 3;
                 const uint32_t base = (uint32_t)(it - 1) * kWave;
-                if (record && base >= (uint32_t)kCutFirst && base < ((uint32_t)kCutFirst << kCutLevels) && (base & (base - 1u)) == 0u && inside) {
-                    const int k = 31 - __clz((int)base) - 7;                                   // 128 -> 0, 256 -> 1, ...
+                const int k = record ? cut_level(base) : -1;                                   // (base is wave-uniform)
+                if (k >= 0 && inside) {
                     float* stt = split_state + (size_t)k * 5 * HWs + (size_t)py * cam.W + px;
                     stt[0] = T; stt[HWs] = C0; stt[2 * HWs] = C1; stt[3 * HWs] = C2; stt[4 * HWs] = Dp;
                 }
@@ -609,7 +609,7 @@ constexpr int kMT = kWave + 4;         // floats per position in an exchange pla
 constexpr int kPairStride = 12;        // floats per pair / record slot in the sum exchanges: components 0-4 at [0,5), 5-9 at [6,11)
 constexpr int kMPlane = (kBT - 1) * kMT + kWave;   // floats of one exchange plane
 
-template <bool DEPTH_GRAD, int NW, bool FEW = false>        // FEW: two list segments per quadrant (images of few tiles)
+template <bool DEPTH_GRAD, int NW, bool FEW = false>        // FEW: two or three list segments per quadrant (images of few tiles)
 __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -621,8 +621,8 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     __shared__ __attribute__((aligned(16))) float s_m[NW][2][kMPlane];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
-    const bool split = FEW && cam.split != 0;
-    // Chained walks (images of more quadrants than resident walkers; never together with `split`): the grid is cam.chain groups of
+    const int nseg = FEW ? cam.split : 0;                    // 0: one walker per quadrant; 2 / 3: list segments (walkers) per quadrant
+    // Chained walks (images of more quadrants than resident walkers; never together with list segments): the grid is cam.chain groups of
     // workgroups, group p walks piece p of every quadrant (piece 0 = the deepest third of the chunks).  A quadrant's pieces form a serial
     // chain -- piece p starts from the (T, S) piece p - 1 ends with -- but 3 x 4800 short items pack the chip's 3072 walker slots far
     // better than 4800 long ones: a wavefront's pace does not depend on how many share its SIMD (the walk is a latency chain), so with one
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     const int pieces = (!FEW && cam.chain > 1) ? cam.chain : 1;
     const unsigned group = gridDim.x / (unsigned)pieces;
     const int piece = pieces > 1 ? (int)(blockIdx.x / group) : 0;
-    if (!tile_ctx_at<NW>(cam, pieces > 1 ? blockIdx.x - (unsigned)piece * group : blockIdx.x, wave, lane, c, split)) return;
+    if (!tile_ctx_at<NW>(cam, pieces > 1 ? blockIdx.x - (unsigned)piece * group : blockIdx.x, wave, lane, c, nseg)) return;
     // phase A role: row (lane>>4) = 4x4 sub-block, (lane&15) = pixel inside it
     const int row = lane >> 4, l16 = lane & 15;
     const int px = (int)c.qx0 + (row & 1) * 4 + (l16 & 3), py = (int)c.qy0 + (row >> 1) * 4 + (l16 >> 2);
@@ -650,29 +650,32 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
 
     const float Tf = inside ? final_T[pix] : 0.f;
     uint32_t last = inside ? n_contrib[pix] : 0u;
-    // Two list segments per quadrant (cam.split and the forward recorded): the quadrant's walk, wmax positions deep, is cut at the recorded
-    // position 128 * 2^k nearest (in ratio) to half of it.  The BACK walker (c.seg = 1) replays positions >= m_cut exactly as the
-    // one-walker kernel would; the FRONT walker (c.seg = 0) takes the pixels that contributed past the cut from the recorded state -- T in
-    // front of record m_cut, behind-colour = (totals - sums up to the cut) / T -- and everything else as usual.
+    // List segments (cam.split = 2 or 3, and the forward recorded): the quadrant's walk, wmax positions deep, is cut at the recorded
+    // positions nearest to wmax / nseg, 2 wmax / nseg.  Walker s takes the positions [cut s, cut s+1): the LAST one replays from the
+    // final state exactly as the one-walker kernel would; the others take the pixels that contributed past their upper cut from the state
+    // recorded there -- T in front of that record, behind-colour = (totals - sums up to the cut) / T -- and everything else as usual.
     uint32_t wmax = last;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor(wmax, m));
     if (wmax == 0) return;
-    uint32_t m_cut = 0;
-    int k_cut = 0;
-    if (split) {
+    uint32_t seg_lo = 0u, seg_hi = wmax;
+    int k_hi = -1;                                           // level of the recorded state this walker resumes from (-1: the final state)
+    if (nseg > 1) {
         const bool recorded = split_state && reinterpret_cast<const uint32_t*>(split_state + (kCutLevels * 5 + 4) * HW)[0] == 1u;
-        if (recorded && wmax >= 2u * kCutFirst) {
-            // the recorded position nearest to half the depth (in ratio): wmax / 2 in [2^j / sqrt2, 2^j sqrt2)  ->  2^j
-            const uint32_t target = (uint32_t)((unsigned long long)wmax * 46341ull >> 16);      // wmax / 2 * sqrt2
-            k_cut = max(0, min(kCutLevels - 1, 31 - __clz((int)target) - 7));
-            m_cut = (uint32_t)kCutFirst << k_cut;
-            if (m_cut >= wmax) m_cut = 0u;
-        }
-        if (m_cut == 0u && c.seg == 1) return;                  // nothing to share: the front walker does the whole list
+        // (named scalars, no indexed local: kFewSegmentsMax = 3)
+        uint32_t cut1 = recorded ? cut_nearest((uint32_t)((unsigned long long)wmax / (unsigned)nseg)) : 0u;
+        if (cut1 >= wmax) cut1 = 0u;
+        uint32_t cut2 = (recorded && nseg > 2) ? cut_nearest((uint32_t)((unsigned long long)wmax * 2u / (unsigned)nseg)) : cut1;
+        if (cut2 >= wmax || cut2 <= cut1) cut2 = cut1;       // (no usable position there: an empty segment)
+        // walker 0: [0, cut1), walker 1: [cut1, cut2) (two segments: [cut1, wmax)), walker 2: [cut2, wmax)
+        const int s_ = c.seg;
+        seg_lo = s_ == 0 ? 0u : (s_ == 1 ? cut1 : cut2);
+        seg_hi = s_ >= nseg - 1 ? wmax : (s_ == 0 ? cut1 : cut2);
+        if (s_ >= nseg || seg_hi <= seg_lo) return;          // nothing in this segment: a neighbour covers it
+        if (seg_hi < wmax) k_hi = cut_level(seg_hi);
     }
-    const bool resumed = m_cut != 0u && c.seg == 0 && last > m_cut;
-    if (m_cut != 0u && c.seg == 0) { last = min(last, m_cut); wmax = min(wmax, m_cut); }
+    const bool resumed = k_hi >= 0 && last > seg_hi;
+    if (k_hi >= 0) { last = min(last, seg_hi); wmax = min(wmax, seg_hi); }
     const float d0 = inside ? dL_dcolor[pix] : 0.f, d1 = inside ? dL_dcolor[HW + pix] : 0.f,
                 d2 = inside ? dL_dcolor[2 * HW + pix] : 0.f;
     const float dz_ = (DEPTH_GRAD && inside) ? dL_ddepth[pix] : 0.f;
@@ -682,15 +685,14 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     // (four vector operations per record less than the component-wise form)
     float T = Tf, S = 0.f;
     if (resumed) {
-        const float* st = split_state + (size_t)k_cut * 5 * HW + pix;
+        const float* st = split_state + (size_t)k_hi * 5 * HW + pix;
         const float* tot = split_state + (size_t)kCutLevels * 5 * HW + pix;
         T = st[0];
         const float it = 1.0f / T;                               // (T in front of a record that contributed later is >= 1e-4)
         S = ((tot[0] - st[HW]) * it) * d0 + ((tot[HW] - st[2 * HW]) * it) * d1 + ((tot[2 * HW] - st[3 * HW]) * it) * d2;
         if (DEPTH_GRAD) S += ((tot[3 * HW] - st[4 * HW]) * it) * dz_;
     }
-    if (c.seg == 1 && wmax <= m_cut) return;
-    int cmin = c.seg == 1 ? (int)(m_cut / kWave) : 0;            // the back walker stops at the cut
+    int cmin = (int)(seg_lo / kWave);                            // a walker stops at its lower cut
     int ctop = (int)((wmax - 1) / kWave);                        // first (deepest) chunk of this walker
     // (wave-uniform values, kept in scalar registers: the kernel sits at its register budget)
     const int chain_q = __builtin_amdgcn_readfirstlane(c.tile * 4 + c.quad);
@@ -953,6 +955,8 @@ int g_half_quadrant_tiles = 256;
 // pieces of a chained backward walk (images of more than kChainMinTiles tiles); 1 switches the chaining off (tests, A/B measurements)
 int g_chain_pieces = kChainPieces;
 int g_chain_min_tiles = kChainMinTiles;
+// list segments (walkers) per quadrant in the few-tile backward: 3 x 256 tiles x 4 quadrants = the chip's 3072 walker slots (gs_set_backward_segments)
+int g_few_segments = kFewSegmentsMax;
 
 hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
@@ -963,7 +967,7 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
     // four walkers of a tile gather the same records, and on one CU three of them hit its L1
     Cam cam = cam_in;
     cam.half = (segments <= 1 || !seg_T) && cam.gx * cam.gy <= g_half_quadrant_tiles;          // few tiles: the producer / consumer forward
-    cam.split = cam.V == 1 && split_state && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles);      // (the backward refuses atlases)
+    cam.split = (cam.V == 1 && split_state && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles)) && g_few_segments > 1 ? g_few_segments : 0;      // (the backward refuses atlases; > 0 makes the forward record)
     // (the forward's only use of `chain` is to zero the hand-over flags of the chained backward walks.  It does so for EVERY image whose
     // workspace holds them -- more than kFewTiles tiles -- whatever gs_set_backward_chain says at this moment: the backward takes its own
     // decision from the knob when IT is launched, and must find zeroed flags even if the knob changed in between)
@@ -1022,11 +1026,11 @@ hipError_t launch_blend_backward(const Cam& cam_in, const uint2* ranges, const u
     // segments (the forward of such an image has recorded the state at the cut; if it has not, the back walkers exit at once)
     Cam cam = cam_in;
     cam.half = 0;
-    cam.split = split_state != nullptr && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles);
+    cam.split = (split_state != nullptr && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles) && g_few_segments > 1) ? g_few_segments : 0;
     cam.chain = (cam.V == 1 && split_state && cam.gx * cam.gy > max(g_chain_min_tiles, kFewTiles) && g_chain_pieces > 1) ? g_chain_pieces : 0;
     static std::atomic<unsigned> epoch{0};
     do { cam.chain_epoch = ++epoch; } while (cam.chain_epoch == 0u);          // (the forward leaves zero in the hand-over flags)
-    const int per = ((cam.gx * cam.gy + 7) >> 3) * (cam.split ? 2 : cam.chain > 1 ? cam.chain : 1);
+    const int per = ((cam.gx * cam.gy + 7) >> 3) * (cam.split ? cam.split : cam.chain > 1 ? cam.chain : 1);
 #define GS_BWD(DG, FEW)                                                                                                          \
     hipLaunchKernelGGL((blend_backward_kernel<DG, 1, FEW>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom, final_T, \
                        n_contrib, dL_dcolor, dL_ddepth, grad2d, split_state)

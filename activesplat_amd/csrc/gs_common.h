@@ -532,6 +532,7 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
 extern int g_half_quadrant_tiles;
 extern int g_chain_pieces;
 extern int g_chain_min_tiles;
+extern int g_few_segments;
 // images of few tiles (at most kFewTiles; the knob above can only lower the limit): the forward records every pixel's running state
 // at the list positions 128 * 2^k, k < kCutLevels, for the two-segment backward.  Planes of H*W floats: [k][T, C0, C1, C2, D], then the
 // four totals, then one word "recorded"
@@ -542,8 +543,40 @@ constexpr int kChainPieces = 3;
 constexpr int kChainMinTiles = 768;                       // default threshold: 3072 resident walkers / 4 quadrants (gs_set_backward_chain lowers it for tests)
 constexpr int kChainStateFloats = (kChainPieces - 1) * 2 * kWave;
 inline size_t chain_state_words(size_t tiles) { return tiles * 4 * (kChainStateFloats + (kChainPieces - 1)); }
-constexpr int kCutLevels = 12;
-constexpr int kCutFirst = 128;
+// Recorded list positions (all multiples of the 64-record chunk): every kCutStep-th position up to kCutLinear (levels 0 .. kCutLinear /
+// kCutStep - 1), then the powers of two up to kCutLast.  (Round 3 recorded 128 * 2^k only: a list of 1900 could be cut at 1024 and nowhere
+// near a third or two thirds of it.)
+constexpr int kCutStep = 256;
+constexpr int kCutLinear = 4096;
+constexpr int kCutLast = 131072;
+constexpr int kCutLevels = kCutLinear / kCutStep + 5;          // 16 + {8192, 16384, 32768, 65536, 131072}
+constexpr int kFewSegmentsMax = 3;                             // list segments (walkers) per quadrant in the few-tile backward
+// level of a recorded position, or -1
+__host__ __device__ inline int cut_level(uint32_t pos)
+{
+    if (pos >= (uint32_t)kCutStep && pos <= (uint32_t)kCutLinear) return pos % kCutStep == 0 ? (int)(pos / kCutStep) - 1 : -1;
+    if (pos > (uint32_t)kCutLinear && pos <= (uint32_t)kCutLast && (pos & (pos - 1u)) == 0u) {
+        int l = kCutLinear / kCutStep - 1;
+        for (uint32_t q = kCutLinear; q < pos; q <<= 1) ++l;
+        return l;
+    }
+    return -1;
+}
+// the recorded position nearest to `target` (absolute distance below kCutLinear, ratio above); 0 if the target is below half the first one
+__host__ __device__ inline uint32_t cut_nearest(uint32_t target)
+{
+    if (target < (uint32_t)kCutStep / 2) return 0u;
+    if (target <= (uint32_t)kCutLinear + kCutStep / 2) {
+        uint32_t k = (target + kCutStep / 2) / kCutStep;
+        if (k < 1u) k = 1u;
+        if (k > (uint32_t)(kCutLinear / kCutStep)) k = kCutLinear / kCutStep;
+        return k * kCutStep;
+    }
+    uint32_t pos = kCutLinear;
+    // the next power of two is nearer (in ratio) once target >= pos * sqrt(2)
+    while (pos < (uint32_t)kCutLast && (unsigned long long)target * 46341ull >= ((unsigned long long)pos << 17)) pos <<= 1;       // target >= 2 pos / sqrt 2
+    return pos;
+}
 hipError_t launch_emit(const Cam& cam, int P, GeomPtrs gp, uint64_t* keys, uint32_t* vals, hipStream_t st);
 hipError_t launch_ranges(int64_t D, const uint64_t* keys_sorted, uint2* ranges, hipStream_t st);
 hipError_t launch_blend_forward(const Cam& cam, const uint2* ranges, const uint32_t* point_list, const float4* geom,

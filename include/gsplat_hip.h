@@ -140,6 +140,11 @@ int gs_set_half_quadrants(int32_t max_tiles);
  * quadrant) that run as separate workgroups in dispatch order and hand the per-pixel running state on through the image workspace.  The
  * arithmetic per pixel is the same sequence either way (gradients differ only by the order of the atomic sums). */
 int gs_set_backward_chain(int32_t pieces, int32_t min_tiles);
+/* Test / tuning knob: list segments (walkers) per quadrant in the backward blend of images of few tiles (at most 256): 3 (default: 3 x 256
+ * tiles x 4 quadrants = the chip's 3072 walker slots), 2, or 1 (one walker per quadrant; the forward then records nothing).  The walkers
+ * of a quadrant resume from the per-pixel state the forward recorded at every 256th list position up to 4096 and at the powers of two
+ * beyond. */
+int gs_set_backward_segments(int32_t segments);
 /* bytes of the scratch gs_render_backward needs (per-Gaussian 2-D gradient records) */
 uint64_t gs_backward_scratch_bytes(int32_t P);
 
@@ -148,7 +153,7 @@ const char* gs_version(void);
 /* Integer version of THIS binary interface: bumped whenever an entry point's argument list or a published record layout changes (e.g.
  * the seed argument of gs_densify_children, the 40-byte SH Jacobian record).  A host binding compares it with the GS_ABI_VERSION it was
  * written against before the first call, so that a stale prebuilt library fails at load time instead of misreading its arguments. */
-#define GS_ABI_VERSION 6
+#define GS_ABI_VERSION 7
 int32_t gs_abi_version(void);
 
 /* Optional per-stage timing (hipEvents recorded on the caller's stream around each stage's launches).

@@ -358,6 +358,55 @@ def check_mapping_iteration_without_autograd(device, n=500, exact=True):
                 assert rel(a[1][k][0], b[1][k][0]) < 5e-5, (k, rel(a[1][k][0], b[1][k][0]))
 
 
+def check_few_tile_backward_segments(device, oracle64, oracle32=None, N=20000, W=64, H=48, seed=41):
+    """Images of at most 256 tiles: the backward walks every quadrant's list in 3 (default), 2 or 1 segments on as many wavefronts, the
+    front ones resuming from the per-pixel state the forward recorded (every 256th list position up to 4096, powers of two beyond).  A scene
+    of faint splats whose quadrants reach ~1-4 k list positions deep, so that cuts at thirds exist: forward outputs identical for every
+    setting, gradients equal to the one-walker kernel's up to the order of the sums, the fp64 oracle, and the fused RGB-D variant."""
+    from activesplat_amd import _lib
+    lib = _lib.get()
+    rs, rv = util.scene(N, W, H, seed=seed, device=device, scale_jitter=0.4)
+    rs = rs._replace(debug=False)
+    rv["opacities"] = (rv["opacities"] * 0.03).clamp(0, 1)
+    rv["scales"] = rv["scales"] * 2.0
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(3))
+    try:
+        _lib.check(lib.gs_set_backward_segments(1))
+        ref = util.run_product(rs, rv, dL)
+        art = util.artefacts()
+        deep = int(art["n_contrib"].max())
+        assert deep >= 3 * 256, deep                              # deep enough for two cuts
+        assert int(util.LAST["bl"].segments) == 1                 # (not the segmented forward of very long lists: it records nothing)
+        for segs in (2, 3):
+            _lib.check(lib.gs_set_backward_segments(segs))
+            got = util.run_product(rs, rv, dL)
+            for k in ("color", "depth", "opacity", "radii"):
+                assert np.array_equal(got[k], ref[k]), (segs, k)
+            for k, g in got["grads"].items():
+                r = ref["grads"][k]
+                assert np.isfinite(g).all(), (segs, k)
+                assert np.linalg.norm(g.astype(np.float64) - r) <= 3e-5 * max(np.linalg.norm(r), 1e-30), (segs, k, np.linalg.norm(g - r) / np.linalg.norm(r))
+        check_backward(rs._replace(debug=True), rv, oracle64, seed=3, oracle32=oracle32)
+        # the fused RGB-D backward (depth gradient through the same segments): three segments against one walker
+        from activesplat_amd import rasterizer as R
+        g = torch.Generator().manual_seed(5)
+        dLc, dLd = torch.randn(3, H, W, generator=g).to(device), torch.randn(1, H, W, generator=g).to(device)
+        both = []
+        for segs in (1, 3):
+            _lib.check(lib.gs_set_backward_segments(segs))
+            inp = {k: v.detach().clone().requires_grad_(True) for k, v in rv.items()}
+            m2d = torch.zeros(N, 3, device=device, requires_grad=True)
+            color, radii, depth, sil, dsq = R.render_rgbd(rs, means2D=m2d, **inp)
+            ((color * dLc).sum() + (depth * dLd).sum()).backward()
+            both.append({**{k: v.grad.detach().double() for k, v in inp.items()}, "means2D": m2d.grad.detach().double()})
+        for k in both[0]:
+            assert float((both[1][k] - both[0][k]).norm() / both[0][k].norm().clamp_min(1e-30)) <= 3e-5, k
+        if N <= 30000:
+            check_fused_rgbd(rs, rv, oracle64)
+    finally:
+        _lib.check(lib.gs_set_backward_segments(3))
+
+
 def check_chained_backward(device, oracle64, N=5000, W=288, H=272, oracle32=None, seed=33):
     """Images of more than 768 tiles walk every quadrant's list in three chained pieces (gs_set_backward_chain): here the threshold is
     lowered so that a 306-tile image takes that path, with splats large and faint enough for walks of several 64-record chunks; against

@@ -75,6 +75,7 @@ def test_raw_parameter_entry_points_refuse_what_they_do_not_take():
     assert lib.gs_set_backward_chain(0, -1) != 0 and b"pieces out of range" in lib.gs_last_error()
     assert lib.gs_set_backward_chain(4, -1) != 0
     assert lib.gs_set_backward_chain(3, -1) == 0
+    assert lib.gs_set_backward_segments(0) != 0 and lib.gs_set_backward_segments(4) != 0 and lib.gs_set_backward_segments(3) == 0
 
 
 def test_dropin_module_name_and_settings_tuple():

@@ -184,3 +184,7 @@ def test_whole_quadrants_on_small_images(emu, oracle32, oracle64):
 
 def test_emulated_chained_backward(emu, oracle64, oracle32):
     pc.check_chained_backward(emu, oracle64, oracle32=oracle32)
+
+
+def test_emulated_few_tile_backward_segments(emu, oracle64, oracle32):
+    pc.check_few_tile_backward_segments(emu, oracle64, oracle32, N=9000, W=48, H=48)

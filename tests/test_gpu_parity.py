@@ -257,6 +257,11 @@ def test_whole_quadrants_on_small_images(hip, oracle32, oracle64):
     pc.check_whole_quadrants_on_small_images(hip, oracle32, oracle64)
 
 
+def test_few_tile_backward_segments(hip, oracle64, oracle32):
+    pc.check_few_tile_backward_segments(hip, oracle64, oracle32, N=30000, W=128, H=96)
+    pc.check_few_tile_backward_segments(hip, oracle64, oracle32, N=120000, W=256, H=192, seed=43)
+
+
 def test_two_segment_backward_at_the_reference_resolution(hip):
     """256 x 256 (the reference's default frames: 256 tiles), 150 k Gaussians, opaque enough that pixels stop at different depths: the
     backward that walks every quadrant's list in two segments (default for such images) against the one-walker kernel; forward outputs
