@@ -27,8 +27,9 @@ for seed in range(n0, n1):
             rv["scales"] = rv["scales"] * float(np.exp(r.uniform(-0.5, 1.5)))
         pc.check_forward(rs, rv, o32)
         if seed % 3 == 0:
-            pc.check_backward(rs, rv, o64, min_frac=0.99, oracle32=o32)
+            pc.check_backward(rs, rv, o64, oracle32=o32)          # the stated 0.995 bar; the fp32 hatch is tallied below
     except Exception as e:
         bad.append((seed, repr(e)[:300]))
         print("FAIL seed", seed, repr(e)[:300], flush=True)
 print("seeds %d..%d: %d failures" % (n0, n1, len(bad)))
+print("fp32 escape hatch: fired %d times in %d gradient comparisons" % (pc.HATCH["fired"], pc.HATCH["keys_checked"]), pc.HATCH["where"][:8])
