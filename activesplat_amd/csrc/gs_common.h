@@ -141,13 +141,10 @@ struct GeomPtrs {
     uint8_t* vis_seen;
 };
 
-// wait for every outstanding vector-memory operation of this wavefront (returning atomics included): the cheap way to order a
-// device-scope atomic behind earlier ones without a release fence (which writes the L2 back).  The host emulator defines both empty.
+// wait for every outstanding vector-memory operation of this wavefront: orders a device-scope atomic store behind earlier ones without a
+// release fence (which writes the L2 back: ~20 ns per workgroup when thousands issue them, profiles/README.md).  The host emulator defines it empty.
 #ifndef GS_WAIT_VMEM
 #define GS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#endif
-#ifndef GS_KEEP
-#define GS_KEEP(x) asm volatile("" ::"v"(x))          // keeps a returning atomic's result (and with it the "returning" form) alive
 #endif
 
 // ---- wave-64 helpers ---------------------------------------------------------------------------

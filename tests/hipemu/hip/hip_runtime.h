@@ -314,7 +314,6 @@ template <class T, class U> static inline void hipemu_atomic_store(T* p, U val, 
 static inline void hipemu_sleep() { struct timespec ts = {0, 2000}; nanosleep(&ts, nullptr); }
 #define __builtin_amdgcn_s_sleep(x) hipemu_sleep()
 #define GS_WAIT_VMEM() ((void)0)
-#define GS_KEEP(x) ((void)(x))
 static inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
