@@ -18,6 +18,9 @@ if seed % 4 == 1:
                         sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
     rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
     rv["scales"] = rv["scales"] * float(np.exp(r.uniform(-0.5, 1.5)))
+if os.environ.get("SEGS"):                                  # list segments of the few-tile backward (gs_set_backward_segments)
+    from activesplat_amd import _lib
+    _lib.get().gs_set_backward_segments(int(os.environ["SEGS"]))
 H, W = int(rs.image_height), int(rs.image_width)
 dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(0))
 got = util.run_product(rs, rv, dL)
