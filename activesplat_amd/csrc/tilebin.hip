@@ -427,13 +427,15 @@ constexpr int kBucketCap = 5632;          // keys per tile list the bucket kerne
 constexpr int kBuckets = 2048;           // 16-bit counters, two per LDS word (a list holds < 65536 keys)
 constexpr int kBucketThreads = 512;
 constexpr int kBucketRankMax = 64;
+constexpr int kBucketThreadsBig = 1024;  // lists of kBucketCap < n <= kBucketCapBig keys: eleven keys per thread of a 1024-thread workgroup
+constexpr int kBucketCapBig = 11 * kBucketThreadsBig;
+constexpr int kBucketsBig = 4096;
 
-template <int E>
+template <int E, int T, int NB, int CAP>
 __device__ __forceinline__ void bucket_sort_impl(const uint2 range, uint32_t n, const unsigned long long* __restrict__ pairs,
                                                  uint32_t* __restrict__ point_list, unsigned long long* s_keys, uint32_t* s_cnt, uint16_t* s_off,
                                                  float* s_redf, uint32_t* s_redu, int tid)
 {
-    constexpr int T = kBucketThreads;
     const int lane = tid & 63, wave = tid >> 6;
     unsigned long long k[E];
     float zmin = 3.0e38f, zmax = 0.0f;
@@ -447,7 +449,7 @@ __device__ __forceinline__ void bucket_sort_impl(const uint2 range, uint32_t n, 
         }
     }
     // short lists use fewer bins (fixed cost of zeroing and scanning them): ~2 keys per bin either way
-    const int nbins = n <= 1024u ? kBuckets / 4 : (n <= 2560u ? kBuckets / 2 : kBuckets);
+    const int nbins = n <= (uint32_t)NB / 2 ? NB / 4 : (n <= (uint32_t)(NB + NB / 4) ? NB / 2 : NB);
     for (int b = tid; b < nbins / 2; b += T) s_cnt[b] = 0u;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { zmin = fminf(zmin, __shfl_xor(zmin, m)); zmax = fmaxf(zmax, __shfl_xor(zmax, m)); }
@@ -456,7 +458,7 @@ __device__ __forceinline__ void bucket_sort_impl(const uint2 range, uint32_t n, 
     float zlo = s_redf[0], zhi = s_redf[T / kWave];
 #pragma unroll
     for (int w = 1; w < T / kWave; w++) { zlo = fminf(zlo, s_redf[w]); zhi = fmaxf(zhi, s_redf[T / kWave + w]); }
-    // bin = min(kBuckets - 1, (uint)((z - zlo) * scale)): monotone in z whatever the rounding (subtraction, product and conversion are)
+    // bin = min(nbins - 1, (uint)((z - zlo) * scale)): monotone in z whatever the rounding (subtraction, product and conversion are)
     const float span = zhi - zlo;
     const float scale = span > 0.0f ? (float)nbins / span : 0.0f;
     const uint32_t last_bin = (uint32_t)nbins - 1u;
@@ -475,7 +477,7 @@ __device__ __forceinline__ void bucket_sort_impl(const uint2 range, uint32_t n, 
     }
     __syncthreads();
     // exclusive scan of the counts (kBuckets / T consecutive bins per thread) and the fullest bin
-    constexpr int PB = kBuckets / T;
+    constexpr int PB = NB / T;
     static_assert(PB % 2 == 0, "a thread scans whole counter words");
     uint32_t c[PB], sum = 0, cmax = 0;
 #pragma unroll
@@ -536,7 +538,7 @@ __device__ __forceinline__ void bucket_sort_impl(const uint2 range, uint32_t n, 
         return;
     }
     constexpr int EB = 4;                                          // (kBucketCap - 8 T) / T = 3 keys per thread, as a power of two
-    static_assert(kBucketCap <= (8 + EB) * T && E <= 8 + EB, "run B holds the keys beyond run A");
+    static_assert(CAP <= (8 + EB) * T && E <= 8 + EB, "run B holds the keys beyond run A");
     double vb[EB];
 #pragma unroll
     for (int i = 0; i < EB; i++) vb[i] = key_to_f64((EA + i) < E ? k[(EA + i) < E ? (EA + i) : 0] : kPadKey);
@@ -546,7 +548,7 @@ __device__ __forceinline__ void bucket_sort_impl(const uint2 range, uint32_t n, 
 #pragma unroll
     for (int i = 0; i < EA; i++) s_keys[(uint32_t)tid * EA + i] = f64_to_key(va[i]);
 #pragma unroll
-    for (int i = 0; i < EB; i++) if ((uint32_t)(EA * T + tid * EB + i) < (uint32_t)kBucketCap) s_keys[EA * T + (uint32_t)tid * EB + i] = f64_to_key(vb[i]);
+    for (int i = 0; i < EB; i++) if ((uint32_t)(EA * T + tid * EB + i) < (uint32_t)CAP) s_keys[EA * T + (uint32_t)tid * EB + i] = f64_to_key(vb[i]);
     __syncthreads();
     // rank merge of the two sorted runs A = s_keys[0, nA), B = s_keys[EA T, EA T + nB): keys are unique
     const uint32_t nB = n - nA;
@@ -566,24 +568,29 @@ __device__ __forceinline__ void bucket_sort_impl(const uint2 range, uint32_t n, 
 
 // (launch bound: THREE workgroups per CU -- 24 wavefronts, 80 registers; the natural allocation of 92 admits two, i.e. 512 slots for the 1200 tiles of
 // a 640 x 480 image: 28.7 -> 25.4 us at 2 M Gaussians.  Two tiles per workgroup with both lists requested up front: 123 registers, 34.7 us.)
-__global__ __launch_bounds__(kBucketThreads, 6) void tile_bucket_sort_kernel(const uint2* __restrict__ ranges, const unsigned long long* __restrict__ pairs,
-                                                                           uint32_t* __restrict__ point_list, uint32_t cap)
+// BIG (round 4): lists of kBucketCap < n <= kBucketCapBig keys -- a 1 M-Gaussian map in the reference's 256 x 256 frame: ~9.4 k per tile -- in a
+// 1024-thread workgroup (eleven keys per thread, 4096 bins, 106 KB of LDS: one workgroup per CU, which is what a 256-tile image has) instead
+// of 4096-key bitonic runs + the LDS rank merge.
+template <bool BIG>
+__global__ __launch_bounds__(BIG ? kBucketThreadsBig : kBucketThreads, BIG ? 4 : 6) void tile_bucket_sort_kernel(
+    const uint2* __restrict__ ranges, const unsigned long long* __restrict__ pairs, uint32_t* __restrict__ point_list, uint32_t cap)
 {
-    __shared__ unsigned long long s_keys[kBucketCap];
-    __shared__ uint32_t s_cnt[kBuckets / 2];
-    __shared__ uint16_t s_off[kBuckets + 2];
-    __shared__ float s_redf[2 * kBucketThreads / kWave];
-    __shared__ uint32_t s_redu[2 * kBucketThreads / kWave];
+    constexpr int T = BIG ? kBucketThreadsBig : kBucketThreads, NB = BIG ? kBucketsBig : kBuckets, CAP = BIG ? kBucketCapBig : kBucketCap;
+    __shared__ unsigned long long s_keys[CAP];
+    __shared__ uint32_t s_cnt[NB / 2];
+    __shared__ uint16_t s_off[NB + 2];
+    __shared__ float s_redf[2 * T / kWave];
+    __shared__ uint32_t s_redu[2 * T / kWave];
     const int tid = threadIdx.x;
     uint2 range = ranges[blockIdx.x];
     range.x = min(range.x, cap); range.y = min(range.y, cap);   // workspace capacity (see tile_bin_kernel)
     const uint32_t n = range.y - range.x;
-    if (n == 0 || n > (uint32_t)kBucketCap) return;             // uniform
-    constexpr int T = kBucketThreads;
-    if (n <= 2u * T) bucket_sort_impl<2>(range, n, pairs, point_list, s_keys, s_cnt, s_off, s_redf, s_redu, tid);
-    else if (n <= 4u * T) bucket_sort_impl<4>(range, n, pairs, point_list, s_keys, s_cnt, s_off, s_redf, s_redu, tid);
-    else if (n <= 8u * T) bucket_sort_impl<8>(range, n, pairs, point_list, s_keys, s_cnt, s_off, s_redf, s_redu, tid);
-    else bucket_sort_impl<11>(range, n, pairs, point_list, s_keys, s_cnt, s_off, s_redf, s_redu, tid);
+    if (n == 0 || n > (uint32_t)CAP || (BIG && n <= (uint32_t)kBucketCap)) return;             // uniform (BIG: the shorter lists are the other instantiation's)
+    if (BIG) { bucket_sort_impl<11, T, NB, CAP>(range, n, pairs, point_list, s_keys, s_cnt, s_off, s_redf, s_redu, tid); return; }
+    if (n <= 2u * T) bucket_sort_impl<2, T, NB, CAP>(range, n, pairs, point_list, s_keys, s_cnt, s_off, s_redf, s_redu, tid);
+    else if (n <= 4u * T) bucket_sort_impl<4, T, NB, CAP>(range, n, pairs, point_list, s_keys, s_cnt, s_off, s_redf, s_redu, tid);
+    else if (n <= 8u * T) bucket_sort_impl<8, T, NB, CAP>(range, n, pairs, point_list, s_keys, s_cnt, s_off, s_redf, s_redu, tid);
+    else bucket_sort_impl<11, T, NB, CAP>(range, n, pairs, point_list, s_keys, s_cnt, s_off, s_redf, s_redu, tid);
 }
 
 // Tiles with CHUNK < n <= CAP: the CHUNK-sized sorted runs left by tile_sort_kernel are merged by RANK: the whole
@@ -736,10 +743,16 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
     // Lists of at most kBucketCap keys: the bucket sort, one workgroup per tile.  The choice is made PER TILE on the device (the caller's
     // max_tile_instances may be the capacity guess of an optimistic launch): when longer lists are possible the run sort + merges below
     // are launched as well and skip the tiles the bucket kernel took.
-    const uint32_t skip_le = max_tile_instances <= (uint32_t)kSortCapMax ? (uint32_t)kBucketCap : 0u;
+    // (lists of up to kBucketCapBig keys in images of at most 512 tiles -- one 1024-thread workgroup per CU, two rounds at most --: the big instantiation)
+    const bool big = max_tile_instances > (uint32_t)kBucketCap && max_tile_instances <= (uint32_t)kSortCapMax && tiles <= 512;
+    const uint32_t skip_le = max_tile_instances <= (uint32_t)kSortCapMax ? (uint32_t)(big ? kBucketCapBig : kBucketCap) : 0u;
     if (skip_le) {
-        hipLaunchKernelGGL(tile_bucket_sort_kernel, dim3(tiles), dim3(kBucketThreads), 0, st, ranges, pairs, point_list, cap);
+        hipLaunchKernelGGL(tile_bucket_sort_kernel<false>, dim3(tiles), dim3(kBucketThreads), 0, st, ranges, pairs, point_list, cap);
         if (max_tile_instances <= (uint32_t)kBucketCap) return hipGetLastError();
+        if (big) {
+            hipLaunchKernelGGL(tile_bucket_sort_kernel<true>, dim3(tiles), dim3(kBucketThreadsBig), 0, st, ranges, pairs, point_list, cap);
+            if (max_tile_instances <= (uint32_t)kBucketCapBig) return hipGetLastError();
+        }
     }
     if (max_tile_instances <= (uint32_t)kSortChunk) {
         hipLaunchKernelGGL((tile_sort_kernel<kSortChunk, 256>), dim3(tiles, 1), dim3(256), 0, st, ranges, pairs, pairs, point_list, cap, 0u);

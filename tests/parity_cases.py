@@ -60,11 +60,14 @@ def build_case(name, device):
     elif name == "merge_passes_even":       # > 32768 per tile: 4 passes (the run sort starts in the other buffer), ragged last runs
         W, H, N = 32, 32, 75000
         mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.01)  # noqa: E731
-    elif name in ("bucket_lists", "bucket_lists_long", "crowded_depth", "crowded_depth_long"):
+    elif name in ("bucket_lists", "bucket_lists_long", "crowded_depth", "crowded_depth_long", "bucket_lists_big", "crowded_depth_big"):
         # tile lists of ~3.5 k / ~4.6 k keys (one bucket-sort workgroup per tile, 8 / 10 keys per thread); "crowded": every depth but a
         # few outliers inside 1e-4 of each other, so one bin of the bucket sort holds the whole list -> its comparison-network branch
         # (one run / two runs + merge)
-        W, H, N = 48, 48, {"bucket_lists": 14000, "bucket_lists_long": 18000, "crowded_depth": 11000, "crowded_depth_long": 15500}[name]
+        # "_big": ~8-10 k keys per tile: the 1024-thread instantiation of the bucket sort (eleven keys per thread; crowded: its network branch,
+        # a run of 8192 + the rest + a rank merge)
+        W, H, N = 48, 48, {"bucket_lists": 14000, "bucket_lists_long": 18000, "crowded_depth": 11000, "crowded_depth_long": 15500,
+                           "bucket_lists_big": 34000, "crowded_depth_big": 30000}[name]
 
         def mutate(rv, crowded=name.startswith("crowded")):
             upd = dict(opacities=rv["opacities"] * 0.05)
@@ -138,7 +141,7 @@ def topdown_scene(N, device, seed=12, bg=(0.0, 0.0, 0.0), W=360, H=300):
 
 
 BIG_TILE_CASES = ["merge_tiles", "merge_tiles_large", "merge_passes", "merge_passes_even", "bucket_lists", "bucket_lists_long", "crowded_depth",
-                  "crowded_depth_long", "equal_depth"]
+                  "crowded_depth_long", "equal_depth", "bucket_lists_big", "crowded_depth_big"]
 CASES = ["basic", "ragged_image", "tiny_lookaround", "lookaround_intrinsics", "posed_white_bg", "scale_modifier", "scale_modifier_001", "topdown_1000m",
          "topdown_1000m_white", "behind_camera", "all_culled",
          "huge_gaussians", "dense_overdraw", "low_opacity", "one_gaussian", "not_multiple_of_block", "sh0", "sh1", "sh2",

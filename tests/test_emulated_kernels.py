@@ -20,7 +20,7 @@ def test_emulated_forward_matches_oracle(emu, oracle32, case):
 
 
 @pytest.mark.parametrize("case,path", [("merge_tiles", 1), ("merge_passes", 1), ("merge_passes_even", 1), ("bucket_lists", 1), ("bucket_lists_long", 1),
-                                       ("crowded_depth", 1), ("crowded_depth_long", 1), ("equal_depth", 1)])
+                                       ("crowded_depth", 1), ("crowded_depth_long", 1), ("equal_depth", 1), ("bucket_lists_big", 1), ("crowded_depth_big", 1)])
 def test_emulated_big_tile_lists(emu, oracle32, case, path):
     """tile lists beyond one sort chunk: sorted chunks + LDS rank-merge; beyond the LDS capacity: pairwise merge passes."""
     rs, rv = pc.build_case(case, emu)

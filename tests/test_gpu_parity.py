@@ -184,7 +184,7 @@ def test_fused_rgbd_matches_two_passes_and_oracle(hip, oracle64, case):
 
 
 @pytest.mark.parametrize("case,path", [("merge_tiles", 1), ("merge_tiles_large", 1), ("merge_passes", 1), ("merge_passes_even", 1), ("bucket_lists", 1),
-                                       ("bucket_lists_long", 1), ("crowded_depth", 1), ("crowded_depth_long", 1), ("equal_depth", 1)])
+                                       ("bucket_lists_long", 1), ("crowded_depth", 1), ("crowded_depth_long", 1), ("equal_depth", 1), ("bucket_lists_big", 1), ("crowded_depth_big", 1)])
 def test_big_tile_lists(hip, oracle32, oracle64, case, path):
     rs, rv = pc.build_case(case, hip)
     pc.check_forward(rs, rv, oracle32)
