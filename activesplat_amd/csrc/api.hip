@@ -216,7 +216,7 @@ int gs_image_layout(int32_t width, int32_t height, GsImageLayout* out)
     out->ranges = o; o = align_up(o + tiles * 8);
     out->final_T = o; o = align_up(o + hw * 4);
     out->n_contrib = o; o = align_up(o + hw * 4);
-    // (recorded only for images of few tiles: every pixel's state at the cut positions of the two-segment backward)
+    // (recorded only for images of few tiles: every pixel's state at the recorded list positions the segmented backward resumes from)
     // (images of many tiles: the hand-over state of the chained backward walks lives at the same offset)
     out->split_state = o; o = align_up(o + (tiles <= (uint64_t)gs::kFewTiles ? ((uint64_t)gs::kCutLevels * 5 + 4) * hw + 4
                                              : (uint64_t)gs::chain_state_words(tiles)) * 4);

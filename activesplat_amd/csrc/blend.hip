@@ -132,7 +132,7 @@ __device__ __forceinline__ void write_sentinel(float4* s0, float4* s1, float4* s
 //            product) and adds its colour / depth sums to the zero-initialised images with atomics; the last segment of a
 //            pixel that is not yet stopped at entry writes final_T, opacity and T*bg; n_contrib is an atomic max.
 //   SEG = 0: the whole list in one workgroup (the normal path; its code is untouched by the other two).
-// (images of at most 256 tiles take blend_forward_pc_kernel below, which also records the state the two-segment backward resumes from)
+// (images of at most 256 tiles take blend_forward_pc_kernel below, which also records the states the segmented backward resumes from)
 template <bool DEPTH_SQ, int NS, int SEG, int NW>     // DEPTH_SQ: also accumulate sum z^2 alpha T (third channel of the reference's depth/silhouette pass)
 __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
 //   LISTER   : fetches the tile's records (ids four chunks ahead, records three; the four listers share the gather: 16 records each, one
 //              gather per tile instead of four), stages chunk i+2, and builds the per-stream lists of chunk i+1;
 //   PRODUCER : alpha of every list entry of chunk i -> an LDS plane [trip][lane];
-//   CONSUMER : composites chunk i-1 from the plane (and records the state the two-segment backward resumes from).
+//   CONSUMER : composites chunk i-1 from the plane (and records the states the segmented backward resumes from).
 // One workgroup barrier per chunk; alpha planes double-buffered, lists triple-buffered, staged records in four buffers (written at step
 // i-2, read by the lister at i-1, the producer at i, the consumer at i+1).  Same arithmetic per entry as blend_forward_streams_kernel:
 // identical images.  LDS: 4 x 2 x 16 KB planes + lists + 4 x 3 KB records = 147 KB: one workgroup per CU, which is what a 256-tile image
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
 // images of at most this many tiles (gs_set_half_quadrants; the name dates from the first few-tile variant) take the few-tile kernels:
 // 256 tiles x 4 quadrants are one walker per SIMD of this chip and every walker's chunk-by-chunk chain is exposed.  Forward: producer /
 // consumer workgroups (blend_forward_pc_kernel: 256 x 256, 200 k Gaussians 80 -> 65 us, 1 M 87 -> 74 us; 120 x 150 76 -> 68 us); backward:
-// two list segments per quadrant from the state that forward records (134 -> 88 us).  Above 256 tiles the plain kernels win (400 tiles:
+// three list segments per quadrant from the states that forward records (134 -> 88 us with two segments, -> 65 us with three).  Above 256 tiles the plain kernels win (400 tiles:
 // backward 134 -> 172 us with the few-tile variant): hence 256
 int g_half_quadrant_tiles = 256;
 // pieces of a chained backward walk (images of more than kChainMinTiles tiles); 1 switches the chaining off (tests, A/B measurements)

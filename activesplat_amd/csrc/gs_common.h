@@ -34,7 +34,7 @@ struct Cam {
     const float* campos;
     // forward blend, images of few tiles: the producer / consumer kernel (set by the blend launchers)
     int half;
-    // backward blend, images of few tiles: every tile list is walked in TWO segments by two wavefronts per quadrant; the front
+    // backward blend, images of few tiles: every tile list is walked in `split` (2 or 3) segments by as many wavefronts per quadrant; the front
     // one starts from the per-pixel state the forward left at the boundary (set by the blend launchers)
     int split;
     // backward blend, images of MORE quadrants than the chip holds walkers (3 wavefronts x 1024 SIMDs): every quadrant's walk is cut into
@@ -531,7 +531,7 @@ extern int g_chain_pieces;
 extern int g_chain_min_tiles;
 extern int g_few_segments;
 // images of few tiles (at most kFewTiles; the knob above can only lower the limit): the forward records every pixel's running state
-// at the list positions 128 * 2^k, k < kCutLevels, for the two-segment backward.  Planes of H*W floats: [k][T, C0, C1, C2, D], then the
+// at the recorded list positions (cut_level below: every 256th up to 4096, then powers of two) for the segmented backward.  Planes of H*W floats: [level][T, C0, C1, C2, D], then the
 // four totals, then one word "recorded"
 constexpr int kFewTiles = 256;
 // chained backward walks (images of more than kChainMinTiles tiles): pieces per quadrant, and what the image workspace holds for them behind

@@ -133,7 +133,8 @@ int gs_set_sort_path(int32_t path);
 int gs_set_forward_segments(int32_t on);
 /* Images of at most max_tiles tiles (default 256; 0 = never) get twice the wavefronts: 256 tiles x 4 quadrants are one wavefront per SIMD of
  * an MI355X.  The forward's wavefronts take half an 8 x 8 quadrant each (half their lanes idle; results unchanged); the backward walks every
- * tile list in two segments, the front one from a per-pixel state the forward recorded at the cut (gradients agree to rounding). */
+ * tile list in up to three segments (gs_set_backward_segments), the front ones from per-pixel states the forward recorded at the cuts
+ * (gradients agree to rounding). */
 int gs_set_half_quadrants(int32_t max_tiles);
 /* Images of more than min_tiles tiles (default 768 = more quadrants than the chip holds backward walkers; negative: the default; values
  * below 256 act as 256): every quadrant's backward walk is cut into `pieces` consecutive pieces (default 3, the maximum; 1 = one walker per
