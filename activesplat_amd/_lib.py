@@ -54,7 +54,7 @@ SORT_AUTO, SORT_TILE_LDS, SORT_RADIX = 0, 1, 2
 
 # every symbol include/gsplat_hip.h declares (tests check the library exports all of them)
 #: the GS_ABI_VERSION of include/gsplat_hip.h this binding was written against (checked when a library is bound)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 SYMBOLS = ("gs_abi_version", "gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
            "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_set_half_quadrants", "gs_set_backward_chain", "gs_set_backward_segments", "gs_preprocess_forward", "gs_preprocess_forward_raw", "gs_render_forward", "gs_render_backward", "gs_render_backward_raw", "gs_render_backward_raw_adam", "gs_adam_step", "gs_adam_step_multi",
@@ -126,7 +126,7 @@ def _bind(lib):
     lib.gs_activate_backward_accumulate.restype = C.c_int
     lib.gs_mapping_loss_scratch_bytes.argtypes = [i32, i32]
     lib.gs_mapping_loss_scratch_bytes.restype = C.c_uint64
-    lib.gs_mapping_loss.argtypes = [i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]
+    lib.gs_mapping_loss.argtypes = [i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i64, vp]
     lib.gs_mapping_loss.restype = C.c_int
     lib.gs_compact_scratch_bytes.argtypes = [i64]
     lib.gs_compact_scratch_bytes.restype = C.c_uint64

@@ -640,17 +640,17 @@ int gs_activate_backward_accumulate(int32_t P, int32_t isotropic, const float* h
 
 uint64_t gs_mapping_loss_scratch_bytes(int32_t width, int32_t height)
 {
-    return align_up((uint64_t)(gs::kLossAccSlots * 16 + 9 * (uint64_t)(width > 0 ? width : 1) * (uint64_t)(height > 0 ? height : 1)) * 4);   // accumulator lines + 9 maps
+    return align_up((uint64_t)(2 * gs::kLossAccSlots * 16 + 9 * (uint64_t)(width > 0 ? width : 1) * (uint64_t)(height > 0 ? height : 1)) * 4);   // two sets of accumulator lines + 9 maps
 }
 
 int gs_mapping_loss(int32_t width, int32_t height, const float* im, const float* gt_im, const float* depth,
                     const float* depth_sq, const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
-                    float* dL_ddepth, void* scratch, gs_stream_t stream)
+                    float* dL_ddepth, void* scratch, int64_t persistent_call, gs_stream_t stream)
 {
-    if (width <= 0 || height <= 0 || !im || !gt_im || !depth || !gt_depth || !losses || !dL_dim || !dL_ddepth || !scratch)
+    if (width <= 0 || height <= 0 || !im || !gt_im || !depth || !gt_depth || !losses || !dL_dim || !dL_ddepth || !scratch || persistent_call < 0)
         return fail(GS_EINVAL, "gs_mapping_loss: bad argument");
     hipError_t e = gs::launch_mapping_loss(width, height, im, gt_im, depth, depth_sq, gt_depth, w_im, w_depth, losses, dL_dim,
-                                           dL_ddepth, (float*)scratch, (hipStream_t)stream);
+                                           dL_ddepth, (float*)scratch, persistent_call, (hipStream_t)stream);
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_mapping_loss: %s", hipGetErrorString(e));
     return GS_OK;
 }

@@ -597,7 +597,7 @@ hipError_t launch_activate_backward(int P, int iso, const float* pose7, const fl
 constexpr int kLossAccSlots = 256;          // 64-byte accumulator lines at the head of the mapping loss' scratch (loss.hip)
 hipError_t launch_mapping_loss(int W, int H, const float* im, const float* gt, const float* depth, const float* depth_sq,
                                const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
-                               float* dL_ddepth, float* scratch, hipStream_t st);
+                               float* dL_ddepth, float* scratch, int64_t persistent_call, hipStream_t st);
 hipError_t launch_visibility_stats(int P, const int32_t* radii, uint8_t* seen, float* max_radius, hipStream_t st);
 hipError_t launch_accumulate_grad2d(int P, const float* grad, const uint8_t* seen, float* accum, float* denom, hipStream_t st);
 uint64_t grow_scratch_bytes(int64_t npix);

@@ -140,13 +140,16 @@ __global__ __launch_bounds__(kBlock) void loss_grad_kernel(int W, int H, const f
                                                            const float* __restrict__ gt_depth, const float* __restrict__ partials,
                                                            const float* __restrict__ acc, float w_im, float w_depth,
                                                            float* __restrict__ dL_dim, float* __restrict__ dL_ddepth,
-                                                           float* __restrict__ losses)
+                                                           float* __restrict__ losses, float* __restrict__ acc_other)
 {
     __shared__ float s_p[3][kLP][kLP + 1];
     __shared__ float s_h[3][kLP][kLT + 1];
     __shared__ float s_tot[4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     acc_totals(acc, s_tot, tid);
+    // persistent scratch: the accumulator set of the NEXT call is zeroed here (nobody touches it during this call), so that no memset is needed
+    if (acc_other && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int e = tid; e < kAccFloats; e += kBlock) acc_other[e] = 0.0f;
     const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
     const int px = x0 + tx, py = y0 + ty;
     const bool inside = px < W && py < H;
@@ -210,16 +213,23 @@ __global__ __launch_bounds__(kBlock) void loss_grad_kernel(int W, int H, const f
 
 hipError_t launch_mapping_loss(int W, int H, const float* im, const float* gt, const float* depth, const float* depth_sq,
                                const float* gt_depth, float w_im, float w_depth, float* losses, float* dL_dim,
-                               float* dL_ddepth, float* scratch, hipStream_t st)
+                               float* dL_ddepth, float* scratch, int64_t persistent_call, hipStream_t st)
 {
-    float* acc = scratch;                         // kAccSlots x 4 accumulators (one 64-byte line each), then 9 partial maps
-    float* partials = scratch + kAccFloats;
-    hipError_t e = hipMemsetAsync(acc, 0, kAccFloats * sizeof(float), st);
-    if (e != hipSuccess) return e;
+    // two sets of kAccSlots x 4 accumulators (one 64-byte line each), then 9 partial maps.  persistent_call = 0: any scratch, set 0 is
+    // memset here.  persistent_call = k >= 1: the k-th call on a scratch its owner zeroed ONCE and keeps for this stream -- the call uses
+    // set k & 1 and its second kernel zeroes the other one for call k + 1 (no memset launch per call)
+    const int set = persistent_call > 0 ? (int)(persistent_call & 1) : 0;
+    float* acc = scratch + set * kAccFloats;
+    float* acc_other = persistent_call > 0 ? scratch + (1 - set) * kAccFloats : nullptr;
+    float* partials = scratch + 2 * kAccFloats;
+    if (persistent_call <= 0) {
+        hipError_t e = hipMemsetAsync(acc, 0, kAccFloats * sizeof(float), st);
+        if (e != hipSuccess) return e;
+    }
     const dim3 grid((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, 3);
     hipLaunchKernelGGL(loss_stats_kernel, grid, dim3(kBlock), 0, st, W, H, im, gt, depth, depth_sq, gt_depth, partials, acc);
     hipLaunchKernelGGL(loss_grad_kernel, grid, dim3(kBlock), 0, st, W, H, im, gt, depth, depth_sq, gt_depth, partials, acc, w_im,
-                       w_depth, dL_dim, dL_ddepth, losses);
+                       w_depth, dL_dim, dL_ddepth, losses, acc_other);
     return hipGetLastError();
 }
 

@@ -248,6 +248,23 @@ def unit_gradient(like: torch.Tensor) -> torch.Tensor:
     return t
 
 
+#: persistent scratch of the fused loss per (device, stream, W, H): [buffer, calls so far] -- zeroed ONCE here; every call's second kernel
+#: clears the accumulator set of the next call (gs_mapping_loss(persistent_call = k)), so no memset is launched per loss
+_LOSS_SCRATCH = {}
+
+
+def _loss_scratch(lib, dev, W, H):
+    from . import _lib
+    key = (dev.index, _lib.stream_handle(dev), W, H)
+    ent = _LOSS_SCRATCH.get(key)
+    if ent is None:
+        if len(_LOSS_SCRATCH) >= 32:
+            _LOSS_SCRATCH.pop(next(iter(_LOSS_SCRATCH)))
+        ent = _LOSS_SCRATCH[key] = [torch.zeros(int(lib.gs_mapping_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev), 0]
+    ent[1] += 1
+    return ent[0], ent[1]
+
+
 class _FusedMappingLoss(torch.autograd.Function):
     """gs_mapping_loss: value and gradients in two HIP launches (csrc/loss.hip)."""
 
@@ -265,9 +282,9 @@ class _FusedMappingLoss(torch.autograd.Function):
         d_im, d_depth = grads[:3], grads[3:]
         st = _lib.stream_ptr(dev)
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-        scratch = torch.empty(int(lib.gs_mapping_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
+        scratch, call = _loss_scratch(lib, dev, W, H)
         _lib.check(lib.gs_mapping_loss(W, H, p(im_), p(gt_), p(depth_), p(dsq_), p(gtd_), float(w_im), float(w_depth), p(buf),
-                                       p(d_im), p(d_depth), p(scratch), st))
+                                       p(d_im), p(d_depth), p(scratch), call, st))
         ctx.save_for_backward(grads)
         ctx.set_materialize_grads(False)
         losses, loss = buf[:3], buf[3]          # two views of one small buffer: no clone kernel for the scalar

@@ -154,7 +154,7 @@ const char* gs_version(void);
 /* Integer version of THIS binary interface: bumped whenever an entry point's argument list or a published record layout changes (e.g.
  * the seed argument of gs_densify_children, the 40-byte SH Jacobian record).  A host binding compares it with the GS_ABI_VERSION it was
  * written against before the first call, so that a stale prebuilt library fails at load time instead of misreading its arguments. */
-#define GS_ABI_VERSION 7
+#define GS_ABI_VERSION 8
 int32_t gs_abi_version(void);
 
 /* Optional per-stage timing (hipEvents recorded on the caller's stream around each stage's launches).
@@ -325,10 +325,13 @@ int gs_activate_backward_accumulate(int32_t P, int32_t isotropic, const float* h
  * im, gt_im [3,H,W]; depth, gt_depth [1,H,W]; depth_sq [1,H,W] nullable (only its NaN-ness enters the mask).
  * Writes losses[4] = {loss, weighted image term, weighted depth term, loss again} (device), dL_dim [3,H,W],
  * dL_ddepth [1,H,W]. */
+/* persistent_call = 0: `scratch` is any buffer of gs_mapping_loss_scratch_bytes bytes (its accumulators are cleared by a memset in front of the
+ * two kernels).  persistent_call = k >= 1: the k-th call (k counts up by one) on a scratch that its owner zeroed ONCE and keeps for this
+ * stream: the call accumulates in one of two accumulator sets and its second kernel zeroes the other for call k + 1 -- no memset launch. */
 uint64_t gs_mapping_loss_scratch_bytes(int32_t width, int32_t height);
 int gs_mapping_loss(int32_t width, int32_t height, const float* im, const float* gt_im, const float* depth,
                     const float* depth_sq, const float* gt_depth, float w_im, float w_depth, float* losses,
-                    float* dL_dim, float* dL_ddepth, void* scratch, gs_stream_t stream);
+                    float* dL_dim, float* dL_ddepth, void* scratch, int64_t persistent_call, gs_stream_t stream);
 
 
 /* Stream compaction for prune / densify surgery (replaces the boolean-mask gathers of

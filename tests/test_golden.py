@@ -434,6 +434,27 @@ def test_fused_loss_ragged_image_and_torch_mirror(backend):
     np.testing.assert_allclose(depth.grad.cpu().numpy(), d2.grad.cpu().numpy(), atol=1e-10, rtol=1e-5)
 
 
+def test_fused_loss_persistent_scratch_alternating_inputs(backend):
+    """The fused loss keeps ONE scratch per (device, stream, size) and never memsets it: call k accumulates in set k & 1 and zeroes the
+    other for call k + 1.  Two different image pairs in turn, five calls: every call reproduces the torch mirror of the reference loss for
+    ITS inputs (a stale accumulator would add the previous call's sums)."""
+    from activesplat_amd import mapping as M
+    g = torch.Generator().manual_seed(11)
+    H, W = 45, 52
+    pairs = []
+    for _ in range(2):
+        im = torch.rand(3, H, W, generator=g).to(backend); depth = (torch.rand(1, H, W, generator=g) * 3).to(backend)
+        gt_im = torch.rand(3, H, W, generator=g).to(backend); gt_d = (torch.rand(1, H, W, generator=g) * 3).to(backend)
+        gt_d[0, :2, :7] = 0.0
+        mask = gt_d > 0
+        ref = 1.0 * (gt_d - depth).abs()[mask].mean() + 0.5 * (0.8 * M.l1_loss_v1(im, gt_im) + 0.2 * (1.0 - M.calc_ssim(im, gt_im)))
+        pairs.append((im, depth, gt_im, gt_d, float(ref)))
+    for call in range(5):
+        im, depth, gt_im, gt_d, ref = pairs[call % 2]
+        loss, parts = M.fused_mapping_loss(im, depth, depth ** 2 + 0.1, gt_im, gt_d, dict(im=0.5, depth=1.0))
+        np.testing.assert_allclose(float(loss), ref, rtol=5e-6, err_msg=f"call {call}")
+
+
 def test_fused_loss_backward_with_the_cached_unit_gradient(backend):
     """loss.backward(mapping.unit_gradient(loss)) -- the root gradient the mapper and the keyframe batch pass -- skips the fused loss' scaling
     launch: same gradients as the plain loss.backward(); any other upstream gradient still scales."""
