@@ -50,6 +50,27 @@ METRIC = "render+backward frames/sec at 640x480, N Gaussians"
 _T0 = time.perf_counter()
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """stdout carries ONE JSON line and nothing else: from here on file descriptor 1 points at stderr, so that whatever a library prints there
+    (RCCL announces its version on stdout when a process group comes up) cannot end up next to the result; emit() writes to the real stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
+
+
 def note(msg):
     """progress line on stderr (the JSON line on stdout stays the only stdout output)"""
     print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
@@ -204,7 +225,7 @@ def pmc_file(pattern):
     return files[-1] if files else None
 
 
-def run_c4(args, dev, rank, world, emit=True, ranks_info=None):
+def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
     """BASELINE configs[3]: 64 keyframes sharded over the ranks, RCCL gradient exchange, sharded fused Adam."""
     import torch.distributed as dist
     from activesplat_amd import mapping as M, optim as O, parallel as PL, setup_camera
@@ -381,8 +402,8 @@ def run_c4(args, dev, rank, world, emit=True, ranks_info=None):
                 out["eight_gpu_prediction"] = {"error": str(e)}
     if world > 1:
         barrier()
-        if rank == 0 and emit:
-            print(json.dumps(out))
+        if rank == 0 and print_line:
+            emit(out)
         dist.destroy_process_group()
     return out
 
@@ -417,6 +438,7 @@ def main():
         # `python bench.py --gpus N` without a launcher's environment: start the N ranks ourselves (one process per GPU, RCCL) -- a bare run must
         # never measure one GPU and print it under --gpus N
         raise SystemExit(self_launch(args.gpus, same_dev))
+    claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -454,7 +476,7 @@ def main():
     if dist_on or args.workload == "c4":
         out = run_c4(args, dev, rank, world, ranks_info=ranks_info)
         if not dist_on:
-            print(json.dumps(out))
+            emit(out)
         return
 
     W, H, N = args.width, args.height, args.gaussians
@@ -766,7 +788,7 @@ def main():
         except Exception as e:
             out["mapping_iteration"] = {"error": str(e)}
     note("done")
-    print(json.dumps(out))
+    emit(out)
 
 
 if __name__ == "__main__":
