@@ -608,6 +608,7 @@ constexpr int kBT = 16;                // list positions per batch: 16 x 4 rows 
 constexpr int kMT = kWave + 4;         // floats per position in an exchange plane: +4 makes phase B's b128 reads conflict-free
 constexpr int kPairStride = 12;        // floats per pair / record slot in the sum exchanges: components 0-4 at [0,5), 5-9 at [6,11)
 constexpr int kMPlane = (kBT - 1) * kMT + kWave;   // floats of one exchange plane
+constexpr int kRoundSlack = 4;         // a round is closed after a chunk of n hit records if cnt + n + this many would not fit in the 64 staging slots
 
 template <bool DEPTH_GRAD, int NW, bool FEW = false>        // FEW: two or three list segments per quadrant (images of few tiles)
 __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
@@ -619,6 +620,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     __shared__ float4 s_rec[NW][3][kWave + 1];           // + the sentinel slot
     __shared__ __attribute__((aligned(16))) uint8_t s_list[NW][4 * kWave + 16];
     __shared__ __attribute__((aligned(16))) float s_m[NW][2][kMPlane];
+    __shared__ uint8_t s_flag[NW][kWave];                // per staging slot: which of the four blocks the record's box meets
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
     const int nseg = FEW ? cam.split : 0;                    // 0: one walker per quadrant; 2 / 3: list segments (walkers) per quadrant
@@ -772,35 +774,89 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
         S = __hip_atomic_load(in + kWave + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!handed) T = __builtin_nanf("");
     }
-    for (int ch = cmax; ch >= cmin; ch--) {
+    // ---- the walk: SCAN list chunks, STAGE only the records that hit the quadrant, PROCESS a round when the staging is (nearly) full ----
+    // A 64-record chunk of the tile's list holds ~21 records whose alpha-visible box meets this quadrant and its longest block list is ~14
+    // positions: processed chunk by chunk (rounds 1-4), the per-chunk work (lists, ranks, flush set-up) was spread over a third of the
+    // lanes and three of ten batches of phase B ran nearly empty (scripts/exp/bwd_work.py: 1.25 batches per chunk, 29 % of them full).
+    // Now a chunk is only scanned -- four block tests, one ballot -- and its hit records go to the next free staging slots (deepest first,
+    // with their list position and block flags); a ROUND (lists, phases A / B, gather, flush -- lane = staging slot) runs on ~45 records:
+    // two to three batches, nearly full, one flush of dense slots.  A round is closed after a chunk if another chunk like it would not fit;
+    // a chunk that does not fit all the same is SPLIT: its deepest hits complete the round and the chunk is fetched again for the rest.
+    int cnt = 0;                                                 // records staged (wave-uniform)
+    int skip = 0;                                                // split chunk: its `skip` deepest hits are done
+    const int cmin_u = __builtin_amdgcn_readfirstlane(cmin);     // (wave-uniform values the compiler cannot see as such: scalar registers)
+    for (int ch = __builtin_amdgcn_readfirstlane(cmax); ch >= cmin_u;) {
         const float4 q0 = r0, q1 = r1, q2 = r2;
         const uint32_t id_cur = id_next;
         id_next = id_next2;
-        id_next2 = ch >= cmin + 2 ? list[(ch - 2) * kWave + lane] : kNoId;
-        r2 = make_float4(0.f, 0.f, -1.f, -1.f);
-        if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
+        id_next2 = ch >= cmin_u + 2 ? list[(ch - 2) * kWave + lane] : kNoId;
+        {   // (unconditional loads: a lane beyond the walker's range fetches record 0 and is masked by its id in the scan)
+            const float4* gr = geom + (size_t)(id_next != kNoId ? id_next : 0u) * 3;
+            r0 = gr[0]; r1 = gr[1]; r2 = gr[2];
+        }
 
-        const bool live = id_cur != kNoId;
+        // scan: which of the four blocks does the record's alpha-visible box meet (and has the block contributors this deep)?  Wave masks
+        // in scalar registers; the block tests share their column / row halves
         const uint32_t cpos = (uint32_t)ch * kWave;                  // first list position of this chunk
-        const bool h0 = live && cpos < rm0 && subblock_hit(q0, q2, c.qx0, c.qy0), h1 = live && cpos < rm1 && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0);
-        const bool h2 = live && cpos < rm2 && subblock_hit(q0, q2, c.qx0, c.qy0 + 4.0f), h3 = live && cpos < rm3 && subblock_hit(q0, q2, c.qx0 + 4.0f, c.qy0 + 4.0f);
+        unsigned long long m_any;
+        unsigned hf;                                                 // bit r: block r
+        {
+            const float ex = q2.z, ey = q2.w;
+            const float xl = q0.x - ex, xh = q0.x + ex, yl = q0.y - ey, yh = q0.y + ey;
+            const unsigned long long vis = __ballot(id_cur != kNoId) & __ballot(ex >= 0.0f);
+            const unsigned long long cx0 = __ballot(xh >= c.qx0) & __ballot(xl <= c.qx0 + 3.0f), cx1 = __ballot(xh >= c.qx0 + 4.0f) & __ballot(xl <= c.qx0 + 4.0f + 3.0f);
+            const unsigned long long cy0 = vis & __ballot(yh >= c.qy0) & __ballot(yl <= c.qy0 + 3.0f), cy1 = vis & __ballot(yh >= c.qy0 + 4.0f) & __ballot(yl <= c.qy0 + 4.0f + 3.0f);
+            const unsigned long long b0 = cpos < rm0 ? cx0 & cy0 : 0ull, b1 = cpos < rm1 ? cx1 & cy0 : 0ull;
+            const unsigned long long b2 = cpos < rm2 ? cx0 & cy1 : 0ull, b3 = cpos < rm3 ? cx1 & cy1 : 0ull;
+            m_any = (b0 | b1) | (b2 | b3);
+            hf = (__builtin_amdgcn_inverse_ballot_w64(b0) ? 1u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b1) ? 2u : 0u) |
+                 (__builtin_amdgcn_inverse_ballot_w64(b2) ? 4u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b3) ? 8u : 0u);
+        }
+        const int n_hit = (int)__popcll(m_any);
+        bool split = false;
+        if (m_any != 0ull) {
+            const int todo = n_hit - skip, room = kWave - cnt;
+            split = todo > room;
+            const int n_stage = split ? room : todo;
+            // deepest first (the higher lane is the deeper list position)
+            const int rel = n_hit - 1 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_any, 0u)) - skip;
+            if (hf != 0u && (unsigned)rel < (unsigned)n_stage) {
+                const int slot = cnt + rel;
+                s0[slot] = make_float4(q0.x, q0.y, -0.5f * kLog2e * q0.z, -kLog2e * q0.w);
+                s1[slot] = make_float4(-0.5f * kLog2e * q1.x, q1.y, q1.z, q1.w);
+                s2[slot] = make_float4(q2.x, __uint_as_float(cpos + (uint32_t)lane), q2.y, __uint_as_float(id_cur));
+                s_flag[wave][slot] = (uint8_t)hf;
+            }
+            cnt = __builtin_amdgcn_readfirstlane(cnt + n_stage);
+            skip = __builtin_amdgcn_readfirstlane(split ? skip + n_stage : 0);
+        }
+        if (split) {
+            // (rare) the chunk goes back into the prefetch registers and is scanned again after the round for the rest of its hits; the
+            // records prefetched for the next chunk are dropped and fetched again
+            r0 = q0; r1 = q1; r2 = q2; id_next2 = id_next; id_next = id_cur;
+        } else {
+            ch--;
+        }
+        if (cnt == 0 || !(split || ch < cmin_u || (m_any != 0ull && cnt + n_hit + kRoundSlack > kWave))) continue;
+
+        // ---- a round: lane = staging slot ----
+        __builtin_amdgcn_wave_barrier();
+        const unsigned fl = lane < cnt ? (unsigned)s_flag[wave][lane] : 0u;
+        const bool h0 = (fl & 1u) != 0u, h1 = (fl & 2u) != 0u, h2 = (fl & 4u) != 0u, h3 = (fl & 8u) != 0u;
         const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
-        if ((m0 | m1 | m2 | m3) == 0ull) continue;
-        stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
         reinterpret_cast<uint32_t*>(s_list[wave])[lane] = 0x40404040u;          // sentinel fill: one store per lane = 4 x 64 bytes
         __builtin_amdgcn_wave_barrier();
         const int n0 = (int)__popcll(m0), n1 = (int)__popcll(m1), n2 = (int)__popcll(m2), n3 = (int)__popcll(m3);
 #define GS_RANK(m) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u)))
-        // deepest record first; the lane (= record) remembers where it sits in every row's list (0xff: not in that row's list)
-        const int p0 = h0 ? n0 - 1 - GS_RANK(m0) : 0xff, p1 = h1 ? n1 - 1 - GS_RANK(m1) : 0xff;
-        const int p2 = h2 ? n2 - 1 - GS_RANK(m2) : 0xff, p3 = h3 ? n3 - 1 - GS_RANK(m3) : 0xff;
+        // slots are in walk order (deepest first); the lane (= record) remembers where it sits in every row's list (0xff: not in that row's list)
+        const int p0 = h0 ? GS_RANK(m0) : 0xff, p1 = h1 ? GS_RANK(m1) : 0xff;
+        const int p2 = h2 ? GS_RANK(m2) : 0xff, p3 = h3 ? GS_RANK(m3) : 0xff;
         if (h0) s_list[wave][0 * kWave + p0] = (uint8_t)lane;
         if (h1) s_list[wave][1 * kWave + p1] = (uint8_t)lane;
         if (h2) s_list[wave][2 * kWave + p2] = (uint8_t)lane;
         if (h3) s_list[wave][3 * kWave + p3] = (uint8_t)lane;
 #undef GS_RANK
         float racc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    // this record's moments, summed over rows and batches
-        const int rel_last = (int)min(last, (uint32_t)(ch + 1) * kWave) - ch * kWave;   // this pixel's contributors end before slot rel_last of the chunk (<= 0: none)
         const int ntrips = max(max(n0, n1), max(n2, n3));
         __builtin_amdgcn_wave_barrier();
         for (int t0 = 0; t0 < ntrips; t0 += kBT) {
@@ -822,7 +878,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
                     const float p = (a0[u].z * dx[u] + a0[u].w * dy[u]) * dx[u] + (a1[u].x * dy[u]) * dy[u];
                     G[u] = __builtin_amdgcn_exp2f(p);
                     alpha[u] = fminf(0.99f, a1[u].y * G[u]);
-                    ok[u] = jj[u] < rel_last && p <= 0.0f && alpha[u] >= kAlphaMin;     // (list position ch * 64 + jj below this pixel's last contributor)
+                    ok[u] = __float_as_uint(a2[u].y) < last && p <= 0.0f && alpha[u] >= kAlphaMin;     // (list position below this pixel's last contributor)
                 }
                 float* w1 = m1p + (t * kMT + lane); float* w2 = m2p + (t * kMT + lane);
 #pragma unroll
@@ -833,7 +889,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
                     const float rcp = __builtin_amdgcn_rcpf(1.0f - a_eff);
                     T = T * rcp;                                      // transmittance in front of this record
                     float cd = a1[u].z * d0 + a1[u].w * d1 + a2[u].x * d2;
-                    if (DEPTH_GRAD) cd += a2[u].y * dz_;
+                    if (DEPTH_GRAD) cd += a2[u].z * dz_;
                     const float dot = cd - S;                         // (colour of this record - colour behind it) . dL
                     const float dL_dalpha = dot * T - tfbg * rcp;
                     S += a_eff * dot;
@@ -903,16 +959,12 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
             }
             __builtin_amdgcn_wave_barrier();
         }
-        // flush: the records some row hit (union of the four ballots) put their ten sums into the (now idle) exchange planes; then
-        // 6 records x 10 components per global atomic instruction, software-pipelined
+        // flush: the staged records (dense slots: every one of them hit some row) put their ten sums into the (now idle) exchange planes;
+        // then 6 records x 10 components per global atomic instruction, software-pipelined
         __builtin_amdgcn_wave_barrier();
         {
-            const unsigned long long many = m0 | m1 | m2 | m3;
-            const int n_any = (int)__popcll(many);
             float* fls = s_m[wave][0];                          // 64 x 12 floats <= 2 planes
-            uint8_t* ulist = s_list[wave];                     // the row lists are spent: reuse their space for the union list
-            if ((many >> lane) & 1ull) {
-                ulist[(int)__builtin_amdgcn_mbcnt_hi((uint32_t)(many >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)many, 0u))] = (uint8_t)lane;
+            if (lane < cnt) {
                 float4* f4 = reinterpret_cast<float4*>(fls + lane * kPairStride);
                 f4[0] = make_float4(racc[0], racc[1], racc[2], racc[3]);
                 f4[1] = make_float4(racc[4], 0.f, racc[5], racc[6]);
@@ -920,21 +972,20 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
             }
             __builtin_amdgcn_wave_barrier();
             const int krec = min(fl_rec, 5);                   // lanes 60..63 idle along with record 5's mapping (never valid)
-            int slot_c = (int)ulist[krec];
-            int slot_n = (int)ulist[6 + krec];
-            bool valid_c = lane < 60 && krec < n_any;
-            float val_c = valid_c ? fls[slot_c * kPairStride + fl_off] : 0.0f;
-            uint32_t id_c = valid_c ? __float_as_uint(s2[slot_c].z) : 0u;
-            for (int g = 0; g < n_any; g += 6) {
-                const bool valid_n = lane < 60 && g + 6 + krec < n_any;
+            bool valid_c = lane < 60 && krec < cnt;
+            float val_c = valid_c ? fls[krec * kPairStride + fl_off] : 0.0f;
+            uint32_t id_c = valid_c ? __float_as_uint(s2[krec].w) : 0u;
+            for (int g = 0; g < cnt; g += 6) {
+                const int slot_n = min(g + 6 + krec, kWave);           // (kWave: the sentinel slot)
+                const bool valid_n = lane < 60 && g + 6 + krec < cnt;
                 const float val_n = valid_n ? fls[slot_n * kPairStride + fl_off] : 0.0f;
-                const uint32_t id_n = valid_n ? __float_as_uint(s2[slot_n].z) : 0u;
-                const int slot_nn = (int)ulist[min(g + 12 + krec, 4 * kWave + 15)];
+                const uint32_t id_n = valid_n ? __float_as_uint(s2[slot_n].w) : 0u;
                 if (val_c != 0.0f) atomicAdd(grad2d + (size_t)id_c * kGradStride + fl_comp, val_c);
-                slot_c = slot_n; slot_n = slot_nn; val_c = val_n; id_c = id_n;
+                val_c = val_n; id_c = id_n;
             }
         }
         __builtin_amdgcn_wave_barrier();
+        cnt = 0;
     }
     if (pieces > 1 && piece < pieces - 1) {            // hand the state on (no exit between the range set-up above and this point)
         float* out = chain_st + piece * 2 * kWave;

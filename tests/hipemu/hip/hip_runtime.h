@@ -212,6 +212,8 @@ static inline unsigned hipemu_mbcnt_hi(unsigned mask, unsigned base)
 #define __builtin_amdgcn_mbcnt_lo(a, b) hipemu_mbcnt_lo(a, b)
 #define __builtin_amdgcn_mbcnt_hi(a, b) hipemu_mbcnt_hi(a, b)
 #define __lane_id() (hipemu::lane_id())
+// the lane's own bit of a wave-uniform mask (v_cndmask with the mask as its condition on the device)
+#define __builtin_amdgcn_inverse_ballot_w64(m) (((((unsigned long long)(m)) >> hipemu::lane_id()) & 1ull) != 0ull)
 
 // DPP emulation (the subset of controls the kernels use); semantics of v_mov_b32_dpp with
 // old=`old`, bound_ctrl as given, row_mask/bank_mask honoured.
