@@ -113,6 +113,25 @@ __device__ __forceinline__ void write_sentinel(float4* s0, float4* s1, float4* s
     __builtin_amdgcn_wave_barrier();
 }
 
+// SCAN of a 64-record chunk (one record per lane): which of the quadrant's four 4x4 blocks does the record's alpha-visible box meet?  g0..g3
+// (wave-uniform) switch a block off (forward: all its pixels have stopped; backward: no contributor of the block lies this deep).  The
+// tests are wave masks in scalar registers -- the blocks share their column / row halves -- and only the lane's four flag bits are vector
+// work.  Returns the flags (bit r: block r) and the mask of lanes with any.
+__device__ __forceinline__ unsigned scan_blocks(const float4& q0, const float4& q2, bool valid, float qx0, float qy0, bool g0, bool g1, bool g2, bool g3,
+                                                unsigned long long& m_any)
+{
+    const float ex = q2.z, ey = q2.w;
+    const float xl = q0.x - ex, xh = q0.x + ex, yl = q0.y - ey, yh = q0.y + ey;
+    const unsigned long long vis = __ballot(valid) & __ballot(ex >= 0.0f);
+    const unsigned long long cx0 = __ballot(xh >= qx0) & __ballot(xl <= qx0 + 3.0f), cx1 = __ballot(xh >= qx0 + 4.0f) & __ballot(xl <= qx0 + 4.0f + 3.0f);
+    const unsigned long long cy0 = vis & __ballot(yh >= qy0) & __ballot(yl <= qy0 + 3.0f), cy1 = vis & __ballot(yh >= qy0 + 4.0f) & __ballot(yl <= qy0 + 4.0f + 3.0f);
+    const unsigned long long b0 = g0 ? cx0 & cy0 : 0ull, b1 = g1 ? cx1 & cy0 : 0ull, b2 = g2 ? cx0 & cy1 : 0ull, b3 = g3 ? cx1 & cy1 : 0ull;
+    m_any = (b0 | b1) | (b2 | b3);
+    return (__builtin_amdgcn_inverse_ballot_w64(b0) ? 1u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b1) ? 2u : 0u) |
+           (__builtin_amdgcn_inverse_ballot_w64(b2) ? 4u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b3) ? 8u : 0u);
+}
+constexpr int kRoundSlack = 4;         // a round is closed after a chunk of n hit records if cnt + n + this many would not fit in the 64 staging slots
+
 // ---------------------------------------------------------------------------------------------------
 // Forward: the quadrant's 64 lanes form NS streams of 64/NS lanes (NS = 4: 4x4 pixel blocks,
 // NS = 8: 4x2 blocks), every stream walks ITS OWN list of the staged records whose alpha-visible box overlaps its
@@ -608,10 +627,9 @@ constexpr int kBT = 16;                // list positions per batch: 16 x 4 rows 
 constexpr int kMT = kWave + 4;         // floats per position in an exchange plane: +4 makes phase B's b128 reads conflict-free
 constexpr int kPairStride = 12;        // floats per pair / record slot in the sum exchanges: components 0-4 at [0,5), 5-9 at [6,11)
 constexpr int kMPlane = (kBT - 1) * kMT + kWave;   // floats of one exchange plane
-constexpr int kRoundSlack = 4;         // a round is closed after a chunk of n hit records if cnt + n + this many would not fit in the 64 staging slots
 
 template <bool DEPTH_GRAD, int NW, bool FEW = false>        // FEW: two or three list segments per quadrant (images of few tiles)
-__global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
+__global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void blend_backward_kernel(
     Cam cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ geom, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, float* __restrict__ grad2d,
@@ -621,6 +639,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     __shared__ __attribute__((aligned(16))) uint8_t s_list[NW][4 * kWave + 16];
     __shared__ __attribute__((aligned(16))) float s_m[NW][2][kMPlane];
     __shared__ uint8_t s_flag[NW][kWave];                // per staging slot: which of the four blocks the record's box meets
+    __shared__ __attribute__((aligned(16))) float s_ez[DEPTH_GRAD ? NW : 1][DEPTH_GRAD ? kWave : 4];      // dL/ddepth of the quadrant, (block, pixel) order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx c;
     const int nseg = FEW ? cam.split : 0;                    // 0: one walker per quadrant; 2 / 3: list segments (walkers) per quadrant
@@ -717,13 +736,15 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     // phase B role: the block of row rb at list position tb of the batch; its 16 pixels' dL/dcolour stay in registers
     const int tb = lane >> 2, rb = lane & 3;
     const int bxb = (int)c.qx0 + (rb & 1) * 4, byb = (int)c.qy0 + (rb >> 1) * 4;
-    float e0[16], e1[16], e2[16], ez[16];
-    if (!DEPTH_GRAD) {
+    float e0[16], e1[16], e2[16];
+    {
         // the quadrant's dL/dcolour is already in the wavefront, one pixel per lane in (block, pixel) order: it goes through the still idle
         // exchange planes instead of 48 more global loads with their address arithmetic per lane (the prologue is paid per chained piece).
-        // (Not for the fused RGB-D backward: with the fourth channel this path costs the kernel its third wavefront's registers.)
+        // The fused RGB-D backward's fourth channel, dL/ddepth, stays in LDS (256 bytes per wavefront) and is read per batch in phase B:
+        // sixteen more registers would cost the kernel its third wavefront per SIMD.
         float* xs = s_m[wave][0];
         xs[lane] = d0; xs[kWave + lane] = d1; xs[2 * kWave + lane] = d2;
+        if (DEPTH_GRAD) s_ez[wave][lane] = dz_;
         __builtin_amdgcn_wave_barrier();
         const float4* x4 = reinterpret_cast<const float4*>(xs + rb * 16);
 #pragma unroll
@@ -732,18 +753,8 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
             e0[4 * v] = a.x; e0[4 * v + 1] = a.y; e0[4 * v + 2] = a.z; e0[4 * v + 3] = a.w;
             e1[4 * v] = b.x; e1[4 * v + 1] = b.y; e1[4 * v + 2] = b.z; e1[4 * v + 3] = b.w;
             e2[4 * v] = cc.x; e2[4 * v + 1] = cc.y; e2[4 * v + 2] = cc.z; e2[4 * v + 3] = cc.w;
-            ez[4 * v] = ez[4 * v + 1] = ez[4 * v + 2] = ez[4 * v + 3] = 0.f;
         }
         __builtin_amdgcn_wave_barrier();           // (the planes are written again in the first batch)
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int x = bxb + (i & 3), y = byb + (i >> 2);
-            const bool in = x < cam.W && y < cam.H;
-            const size_t p = (size_t)y * cam.W + x;
-            e0[i] = in ? dL_dcolor[p] : 0.f; e1[i] = in ? dL_dcolor[HW + p] : 0.f; e2[i] = in ? dL_dcolor[2 * HW + p] : 0.f;
-            ez[i] = in ? dL_ddepth[p] : 0.f;
-        }
     }
     const float bxf = (float)bxb, byf = (float)byb;
     const int m_rd = tb * kMT + rb * 16;                         // phase B read offset inside a plane
@@ -783,7 +794,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
     // two to three batches, nearly full, one flush of dense slots.  A round is closed after a chunk if another chunk like it would not fit;
     // a chunk that does not fit all the same is SPLIT: its deepest hits complete the round and the chunk is fetched again for the rest.
     int cnt = 0;                                                 // records staged (wave-uniform)
-    int skip = 0;                                                // split chunk: its `skip` deepest hits are done
+    int upto = kWave;                                            // split chunk: its lanes from `upto` on (the deeper ones) are done
     const int cmin_u = __builtin_amdgcn_readfirstlane(cmin);     // (wave-uniform values the compiler cannot see as such: scalar registers)
     for (int ch = __builtin_amdgcn_readfirstlane(cmax); ch >= cmin_u;) {
         const float4 q0 = r0, q1 = r1, q2 = r2;
@@ -799,28 +810,17 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
         // in scalar registers; the block tests share their column / row halves
         const uint32_t cpos = (uint32_t)ch * kWave;                  // first list position of this chunk
         unsigned long long m_any;
-        unsigned hf;                                                 // bit r: block r
-        {
-            const float ex = q2.z, ey = q2.w;
-            const float xl = q0.x - ex, xh = q0.x + ex, yl = q0.y - ey, yh = q0.y + ey;
-            const unsigned long long vis = __ballot(id_cur != kNoId) & __ballot(ex >= 0.0f);
-            const unsigned long long cx0 = __ballot(xh >= c.qx0) & __ballot(xl <= c.qx0 + 3.0f), cx1 = __ballot(xh >= c.qx0 + 4.0f) & __ballot(xl <= c.qx0 + 4.0f + 3.0f);
-            const unsigned long long cy0 = vis & __ballot(yh >= c.qy0) & __ballot(yl <= c.qy0 + 3.0f), cy1 = vis & __ballot(yh >= c.qy0 + 4.0f) & __ballot(yl <= c.qy0 + 4.0f + 3.0f);
-            const unsigned long long b0 = cpos < rm0 ? cx0 & cy0 : 0ull, b1 = cpos < rm1 ? cx1 & cy0 : 0ull;
-            const unsigned long long b2 = cpos < rm2 ? cx0 & cy1 : 0ull, b3 = cpos < rm3 ? cx1 & cy1 : 0ull;
-            m_any = (b0 | b1) | (b2 | b3);
-            hf = (__builtin_amdgcn_inverse_ballot_w64(b0) ? 1u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b1) ? 2u : 0u) |
-                 (__builtin_amdgcn_inverse_ballot_w64(b2) ? 4u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b3) ? 8u : 0u);
-        }
+        const unsigned hf = scan_blocks(q0, q2, id_cur != kNoId && lane < upto, c.qx0, c.qy0, cpos < rm0, cpos < rm1, cpos < rm2, cpos < rm3, m_any);
         const int n_hit = (int)__popcll(m_any);
         bool split = false;
         if (m_any != 0ull) {
-            const int todo = n_hit - skip, room = kWave - cnt;
-            split = todo > room;
-            const int n_stage = split ? room : todo;
+            const int room = kWave - cnt;
+            split = n_hit > room;
+            const int n_stage = split ? room : n_hit;
             // deepest first (the higher lane is the deeper list position)
-            const int rel = n_hit - 1 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_any, 0u)) - skip;
-            if (hf != 0u && (unsigned)rel < (unsigned)n_stage) {
+            const int rel = n_hit - 1 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_any, 0u));
+            const bool stage = hf != 0u && rel < n_stage;
+            if (stage) {
                 const int slot = cnt + rel;
                 s0[slot] = make_float4(q0.x, q0.y, -0.5f * kLog2e * q0.z, -kLog2e * q0.w);
                 s1[slot] = make_float4(-0.5f * kLog2e * q1.x, q1.y, q1.z, q1.w);
@@ -828,8 +828,9 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
                 s_flag[wave][slot] = (uint8_t)hf;
             }
             cnt = __builtin_amdgcn_readfirstlane(cnt + n_stage);
-            skip = __builtin_amdgcn_readfirstlane(split ? skip + n_stage : 0);
+            if (split) upto = (int)__ffsll((unsigned long long)__ballot(stage)) - 1;           // (a split chunk is taken up again below its last staged lane)
         }
+        if (!split) upto = kWave;
         if (split) {
             // (rare) the chunk goes back into the prefetch registers and is scanned again after the round for the rest of its hits; the
             // records prefetched for the next chunk are dropped and fetched again
@@ -930,11 +931,18 @@ __global__ __launch_bounds__(NW * kWave) void blend_backward_kernel(
                 sm[3] = opb * fmaf(rx[3], ddy[3], fmaf(rx[2], ddy[2], fmaf(rx[1], ddy[1], rx[0] * ddy[0])));
                 sm[4] = opb * fmaf(u3, ddy[3], fmaf(u2, ddy[2], fmaf(u1, ddy[1], u0 * ddy[0])));
                 sm[5] = (gr[0] + gr[1]) + (gr[2] + gr[3]);
-                sm[6] = ww[0] * e0[0]; sm[7] = ww[0] * e1[0]; sm[8] = ww[0] * e2[0]; sm[9] = DEPTH_GRAD ? ww[0] * ez[0] : 0.0f;
+                sm[6] = ww[0] * e0[0]; sm[7] = ww[0] * e1[0]; sm[8] = ww[0] * e2[0]; sm[9] = 0.0f;
 #pragma unroll
                 for (int i = 1; i < 16; i++) {
                     sm[6] = fmaf(ww[i], e0[i], sm[6]); sm[7] = fmaf(ww[i], e1[i], sm[7]); sm[8] = fmaf(ww[i], e2[i], sm[8]);
-                    if (DEPTH_GRAD) sm[9] = fmaf(ww[i], ez[i], sm[9]);
+                }
+                if (DEPTH_GRAD) {
+                    const float4* z4 = reinterpret_cast<const float4*>(s_ez[wave] + rb * 16);
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const float4 z = z4[v];
+                        sm[9] = fmaf(ww[4 * v + 3], z.w, fmaf(ww[4 * v + 2], z.z, fmaf(ww[4 * v + 1], z.y, fmaf(ww[4 * v], z.x, sm[9]))));
+                    }
                 }
                 // pair sums -> LDS (over the scalars just consumed: every lane has issued its reads; LDS serves a wave in order),
                 // then every RECORD lane picks up the pairs of its record

@@ -21,7 +21,7 @@ geom, ranges, plist = art["geom"], art["ranges"].astype(np.int64), art["point_li
 gx, gy = (W + 15) // 16, (H + 15) // 16
 mx, my, ex, ey = geom[:, 0], geom[:, 1], geom[:, 10], geom[:, 11]
 
-SLACKS = (0, 4, 8, 12)
+SLACKS = ((4, 0), (4, 32), (4, 30), (2, 32), (4, 48), (0, 32))
 pol = {sl: dict(rounds=0, positions=0, batches=0, iters=0, flush_groups=0, scans=0, misses=0, pairs=0) for sl in SLACKS}
 PIECES = int(os.environ.get("PIECES", 3))          # chained pieces per quadrant walk (each ends with a partial round)
 rt = dict(rounds=0, positions=0, pairs=0, batches=0, iters=0, flush_groups=0, scans=0)
@@ -117,7 +117,7 @@ for t in range(gx * gy):
                         acc += (hm & ~first).sum(1); cnt = a - take
                     else:
                         cnt += a; acc += nr[:, chn]
-                    if cnt + a + sl > 64:
+                    if cnt + a + sl[0] > 64 or (sl[1] and int((acc + nr[:, chn]).max()) > sl[1]):
                         close2(); cnt = 0; acc[:] = 0
                 close2()
             hi = lo
@@ -145,5 +145,5 @@ for sl in SLACKS:
     parts = dict(phase_A=d["iters"] * A_ITER, phase_B=d["batches"] * B_BATCH, gather=d["batches"] * GATHER, scan=d["scans"] * SCAN, round=d["rounds"] * ROUND,
                  flush=d["rounds"] * FLUSH_SETUP + d["flush_groups"] * FLUSH_GROUP)
     s3 = sum(parts.values())
-    print("policy slack %2d: rounds %d, records per round %.1f, batches per round %.2f, row fill %.2f, split chunks %d (%.1f %% of scans): %.1f M (%.3f x)" % (
+    print("policy slack %s: rounds %d, records per round %.1f, batches per round %.2f, row fill %.2f, split chunks %d (%.1f %% of scans): %.1f M (%.3f x)" % (
         sl, d["rounds"], c["any_records"] / d["rounds"], d["batches"] / d["rounds"], d["pairs"] / (4.0 * d["positions"]), d["misses"], 100.0 * d["misses"] / d["scans"], s3 / 1e6, s3 / s))

@@ -48,6 +48,15 @@ def build_case(name, device):
     elif name == "dense_overdraw":          # early termination (T < 1e-4) everywhere
         W, H, N = 48, 48, 6000
         mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.5 + 0.5)  # noqa: E731
+    elif name == "mixed_sizes":
+        # depth bands of quadrant-covering splats between bands of small ones, all faint (no saturation): list chunks of ~15 and of 64 hit
+        # records in turn -> the blend kernels' compacted staging closes rounds early AND splits chunks (blend.hip)
+        W, H, N = 64, 64, 6000
+
+        def mutate(rv):
+            z = rv["means3D"][:, 2:3]
+            big = (torch.floor(z * 6.0).long() % 2 == 0)
+            rv.update(scales=torch.where(big, rv["scales"] * 25.0, rv["scales"]), opacities=rv["opacities"] * 0.04)
     elif name == "merge_tiles":             # ~5k instances per tile: chunk sort + LDS rank-merge (8192 variant)
         W, H, N = 48, 48, 20000
         mutate = lambda rv: rv.update(opacities=rv["opacities"] * 0.05)  # noqa: E731
@@ -144,7 +153,7 @@ BIG_TILE_CASES = ["merge_tiles", "merge_tiles_large", "merge_passes", "merge_pas
                   "crowded_depth_long", "equal_depth", "bucket_lists_big", "crowded_depth_big"]
 CASES = ["basic", "ragged_image", "tiny_lookaround", "lookaround_intrinsics", "posed_white_bg", "scale_modifier", "scale_modifier_001", "topdown_1000m",
          "topdown_1000m_white", "behind_camera", "all_culled",
-         "huge_gaussians", "dense_overdraw", "low_opacity", "one_gaussian", "not_multiple_of_block", "sh0", "sh1", "sh2",
+         "huge_gaussians", "dense_overdraw", "mixed_sizes", "low_opacity", "one_gaussian", "not_multiple_of_block", "sh0", "sh1", "sh2",
          "sh3", "sh2_ragged", "sh3_half_culled", "cov3d_precomp"]
 
 
@@ -160,7 +169,7 @@ def check_whole_quadrants_on_small_images(device, oracle32, oracle64):
     from activesplat_amd import _lib
     lib = _lib.get()
     try:
-        for name in ("basic", "ragged_image", "posed_white_bg", "dense_overdraw", "huge_gaussians", "sh3", "merge_tiles", "not_multiple_of_block"):
+        for name in ("basic", "ragged_image", "posed_white_bg", "dense_overdraw", "mixed_sizes", "huge_gaussians", "sh3", "merge_tiles", "not_multiple_of_block"):
             rs, rv = build_case(name, device)
             _lib.check(lib.gs_set_half_quadrants(256))
             halves = util.run_product(rs, rv)
@@ -168,7 +177,7 @@ def check_whole_quadrants_on_small_images(device, oracle32, oracle64):
             got, _ = check_forward(rs, rv, oracle32)
             for k in ("color", "depth", "opacity"):
                 assert np.array_equal(got[k], halves[k]), (name, k)
-            if name in ("basic", "ragged_image", "dense_overdraw", "sh3"):
+            if name in ("basic", "ragged_image", "dense_overdraw", "mixed_sizes", "sh3"):
                 check_backward(rs, rv, oracle64, oracle32=oracle32)
     finally:
         _lib.check(lib.gs_set_half_quadrants(256))

@@ -39,7 +39,7 @@ def test_emulated_forward_radix_path_matches_oracle(emu, oracle32, case):
         pc.set_sort_path("auto")
 
 
-@pytest.mark.parametrize("case", ["basic", "ragged_image", "posed_white_bg", "scale_modifier", "dense_overdraw",
+@pytest.mark.parametrize("case", ["basic", "ragged_image", "posed_white_bg", "scale_modifier", "dense_overdraw", "mixed_sizes",
                                   "huge_gaussians", "all_culled", "sh3", "sh2_ragged", "sh3_half_culled", "cov3d_precomp", "lookaround_intrinsics",
                                   "scale_modifier_001", "topdown_1000m", "topdown_1000m_white"])
 def test_emulated_backward_matches_fp64_oracle(emu, oracle64, case):
@@ -87,7 +87,7 @@ def test_emulated_multi_tensor_adam_equals_per_tensor_launches(emu):
     assert lib.gs_adam_step_multi(1, (_lib.GsAdamTensor * 1)(_lib.GsAdamTensor(4, None, None, None, None, 1e-3, 0.9, 0.999, 1e-15, 1, 0)), None) != 0
 
 
-@pytest.mark.parametrize("case", ["basic", "posed_white_bg", "ragged_image", "sh2", "dense_overdraw"])
+@pytest.mark.parametrize("case", ["basic", "posed_white_bg", "ragged_image", "sh2", "dense_overdraw", "mixed_sizes"])
 def test_emulated_fused_rgbd_matches_two_passes_and_oracle(emu, oracle64, case):
     rs, rv = pc.build_case(case, emu)
     pc.check_fused_rgbd(rs, rv, oracle64)

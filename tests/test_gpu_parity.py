@@ -177,7 +177,7 @@ def test_reference_call_pattern_two_passes(hip, oracle32):
         assert torch.isfinite(inp[k].grad).all() and inp[k].grad.abs().sum() > 0
 
 
-@pytest.mark.parametrize("case", ["basic", "posed_white_bg", "ragged_image", "sh2", "dense_overdraw", "huge_gaussians", "tiny_lookaround"])
+@pytest.mark.parametrize("case", ["basic", "posed_white_bg", "ragged_image", "sh2", "dense_overdraw", "mixed_sizes", "huge_gaussians", "tiny_lookaround"])
 def test_fused_rgbd_matches_two_passes_and_oracle(hip, oracle64, case):
     rs, rv = pc.build_case(case, hip)
     pc.check_fused_rgbd(rs, rv, oracle64)
