@@ -118,7 +118,7 @@ __device__ __forceinline__ void write_sentinel(float4* s0, float4* s1, float4* s
 // tests are wave masks in scalar registers -- the blocks share their column / row halves -- and only the lane's four flag bits are vector
 // work.  Returns the flags (bit r: block r) and the mask of lanes with any.
 __device__ __forceinline__ unsigned scan_blocks(const float4& q0, const float4& q2, bool valid, float qx0, float qy0, bool g0, bool g1, bool g2, bool g3,
-                                                unsigned long long& m_any)
+                                                unsigned long long& m_any, unsigned long long* masks = nullptr)
 {
     const float ex = q2.z, ey = q2.w;
     const float xl = q0.x - ex, xh = q0.x + ex, yl = q0.y - ey, yh = q0.y + ey;
@@ -127,6 +127,7 @@ __device__ __forceinline__ unsigned scan_blocks(const float4& q0, const float4& 
     const unsigned long long cy0 = vis & __ballot(yh >= qy0) & __ballot(yl <= qy0 + 3.0f), cy1 = vis & __ballot(yh >= qy0 + 4.0f) & __ballot(yl <= qy0 + 4.0f + 3.0f);
     const unsigned long long b0 = g0 ? cx0 & cy0 : 0ull, b1 = g1 ? cx1 & cy0 : 0ull, b2 = g2 ? cx0 & cy1 : 0ull, b3 = g3 ? cx1 & cy1 : 0ull;
     m_any = (b0 | b1) | (b2 | b3);
+    if (masks) { masks[0] = b0; masks[1] = b1; masks[2] = b2; masks[3] = b3; }
     return (__builtin_amdgcn_inverse_ballot_w64(b0) ? 1u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b1) ? 2u : 0u) |
            (__builtin_amdgcn_inverse_ballot_w64(b2) ? 4u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b3) ? 8u : 0u);
 }
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     __shared__ float4 s_rec[NW][3][kWave + 1];           // + the sentinel slot
     // NS rows of 64 entries per wave (+16 bytes so that the look-ahead read behind the last row stays inside the wave's slab)
     __shared__ __attribute__((aligned(16))) uint8_t s_list[NW][NS * kWave + 16];
+    static_assert(NS == 4 && kWave / NS == 16, "the scan tests the four 4x4 blocks of a quadrant");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // side job (SEG = 0 only): this workgroup's slice of the backward's gradient records is zero-filled here instead of by a fill launch
     // in front of the backward -- plain fire-and-forget 16-byte stores, kFillPerStep of them per trip of the chunk loop below.  (Issued
@@ -251,8 +253,15 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
             r2 = make_float4(0.f, 0.f, -1.f, -1.f);
             if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
 
-            const bool live = id_cur != kNoId;
-            if (!__any(live && quadrant_hit(q0, q2, c.qx0, c.qy0))) continue;
+            // a stream whose pixels have ALL stopped gets an empty list: the walk's trip count is the longest list of the streams that
+            // still blend (pixels of a quadrant saturate at different depths: at 2 M Gaussians the mean stop is at position ~900, the
+            // last pixel of a quadrant stops around 1400).  The four block tests are wave masks in scalar registers (scan_blocks): no
+            // branches, the lane's rank in a list is one mbcnt of the block's mask
+            const unsigned long long going = SEG == 1 ? ~0ull : ~__ballot(done);
+            unsigned long long m_any, mb[4];
+            scan_blocks(q0, q2, id_cur != kNoId, c.qx0, c.qy0, (going & 0xffffull) != 0ull, (going & 0xffff0000ull) != 0ull,
+                        (going & 0xffff00000000ull) != 0ull, (going >> 48) != 0ull, m_any, mb);
+            if (m_any == 0ull) continue;
             stage_record(s0, s1, s2, lane, q0, q1, q2, id_cur);
             // per-stream lists: sentinel fill (one store per lane covers NS x 64 bytes), then every hit lane drops its index
             {
@@ -262,20 +271,11 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
             }
             __builtin_amdgcn_wave_barrier();
             int ntrips = 0;
-            const float ex = q2.z, ey = q2.w;
-            // a stream whose pixels have ALL stopped gets an empty list: the walk's trip count is the longest list of the streams that
-            // still blend (pixels of a quadrant saturate at different depths: at 2 M Gaussians the mean stop is at position ~900, the
-            // last pixel of a quadrant stops around 1400)
-            const unsigned long long going = SEG == 1 ? ~0ull : ~__ballot(done);
 #pragma unroll
             for (int s = 0; s < NS; s++) {
-                const float x0 = c.qx0 + (float)((s & 1) * 4), y0 = c.qy0 + (float)((s >> 1) * BH);
-                const bool stream_going = ((going >> (s * LS)) & ((1ull << LS) - 1ull)) != 0ull;
-                const bool hit = live && stream_going && ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) &&
-                                 (q0.y - ey <= y0 + (float)(BH - 1));
-                const unsigned long long m = __ballot(hit);
+                const unsigned long long m = mb[s];
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (hit) s_list[wave][s * kWave + rank] = (uint8_t)lane;
+                if (__builtin_amdgcn_inverse_ballot_w64(m)) s_list[wave][s * kWave + rank] = (uint8_t)lane;
                 ntrips = max(ntrips, (int)__popcll(m));
             }
             __builtin_amdgcn_wave_barrier();
@@ -616,11 +616,17 @@ __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
 //           (48 registers, loaded once per kernel), factored into column / row sums; writes them as the pair's 12-float slot;
 //   gather : lane = staged record j knows its position in each row's list (its own mbcnt rank from the list build), so it reads the
 //           slots of its <= 4 pairs of this batch and adds them to ten REGISTER accumulators -- no LDS read-modify-write, no atomics;
-//   flush  : once per 64-record chunk the records some row hit put their sums into the idle exchange planes and leave with one
-//           global fp32 atomic request per (quadrant, record), 6 records x 10 components per instruction, into 64-byte-aligned
-//           gradient records (a device-scope atomic is a read-modify-write of a whole line at the memory side on this multi-XCD part).
-// Measured (profiles/README.md, round 2): 184 us on configs[1], 262 us at 2 M Gaussians; VALU wave-instructions per launch 99 M -> 70 M.
-// LDS 11.8 KB per wave; the wavefronts share nothing, so a workgroup is ONE wavefront (NW = 1): LDS and CU slots are handed out at
+//   flush  : once per ROUND the staged records put their sums into the idle exchange planes and leave with one global fp32 atomic
+//           request per (quadrant, record), 6 records x 10 components per instruction, into 64-byte-aligned gradient records (a
+//           device-scope atomic is a read-modify-write of a whole line at the memory side on this multi-XCD part).
+// A ROUND is not a list chunk (round 4): a 64-record chunk is only SCANNED (scan_blocks: four block tests as wave masks, one ballot) and the
+// ~21 records that meet the quadrant are staged -- with list position and block flags -- behind those of the chunks before; lists, phases,
+// gather and flush run when the 64 staging slots are (nearly) full.  Chunk by chunk, three of ten phase-B batches ran nearly empty and the
+// per-chunk set-up was paid per ~14 list positions; rounds hold ~45 records / ~30 positions (scripts/exp/bwd_work.py replays the control
+// flow from a frame's integer artefacts and prices it with the ISA's instruction counts: 91 M -> 78 M vector instructions at 2 M Gaussians).
+// Measured (profiles/README.md): round 2: 184 us on configs[1], 262 us at 2 M Gaussians; round 3 (chained pieces): 157 / 210; round 4
+// (rounds on compacted staging): 141 / 188.
+// LDS 12.1 KB per wave; the wavefronts share nothing, so a workgroup is ONE wavefront (NW = 1): LDS and CU slots are handed out at
 // that granularity and 4800 small workgroups drain more evenly than 1200 whole-tile ones.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kBT = 16;                // list positions per batch: 16 x 4 rows = one (row, position) pair per lane in phase B

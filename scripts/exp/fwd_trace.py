@@ -20,10 +20,10 @@ with torch.no_grad():
 torch.cuda.synchronize()
 lib = _lib.get()
 nw = ((W + 15) // 16) * ((H + 15) // 16) * 4
-buf = (C.c_uint64 * (6 * nw))()
+buf = (C.c_uint64 * (10 * nw))()
 lib.gs_debug_fwd_trace.argtypes = [C.c_void_p, C.c_int]
 assert lib.gs_debug_fwd_trace(buf, nw) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 6).astype(np.int64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 10).astype(np.int64)
 tick = 0.01                                                  # us per tick (100 MHz constant clock)
 s = (a[:, 0] - a[:, 0].min()) * tick; e = (a[:, 1] - a[:, 0].min()) * tick
 d = e - s
@@ -31,6 +31,9 @@ hw, xcc = a[:, 2], a[:, 3]
 simd, cu, shh, se = hw >> 4 & 3, hw >> 8 & 0xf, hw >> 12 & 1, hw >> 13 & 7
 print("waves %d, kernel span %.1f us; wave duration mean %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f; start p99 %.1f; scans per wave %.1f, rounds %.1f" % (
     nw, e.max(), d.mean(), *np.percentile(d, [10, 50, 90, 99]), d.max(), np.percentile(s, 99), a[:, 4].mean(), a[:, 5].mean()))
+cyc, ctr, ntr, cwt = a[:, 8].astype(np.float64), a[:, 6].astype(np.float64), a[:, 7].astype(np.float64), a[:, 9].astype(np.float64)
+print("shader clock from the waves' own counters: %.2f GHz (cycles / wall time); cycles per wave mean %.0f; in the trip loops %.0f %% (%.0f cycles per two-entry trip, %.1f trips per wave); waiting for the prefetched records %.1f %%" % (
+    (cyc / (d * 1e3)).mean(), cyc.mean(), 100.0 * ctr.sum() / cyc.sum(), ctr.sum() / ntr.sum(), ntr.mean(), 100.0 * cwt.sum() / cyc.sum()))
 for name, key in (("XCC", xcc), ("CU", xcc * 1000 + se * 100 + shh * 50 + cu), ("SIMD", (xcc * 1000 + se * 100 + shh * 50 + cu) * 4 + simd)):
     ks = np.unique(key)
     load = np.array([d[key == k].sum() for k in ks]); cnt = np.array([(key == k).sum() for k in ks]); last = np.array([e[key == k].max() for k in ks])
