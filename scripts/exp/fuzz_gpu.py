@@ -11,6 +11,8 @@ from tests.test_randomized import _draw
 
 o32, o64 = Oracle("f32"), Oracle("f64")
 lib = _lib.get()
+if os.environ.get("PLAIN"):          # the kernels of images of more than 256 / 768 tiles on the sweep's small images: streams forward, chained backward walks
+    _lib.check(lib.gs_set_half_quadrants(0)); _lib.check(lib.gs_set_backward_chain(3, 0))
 n0, n1 = int(os.environ.get("SEED0", 20000)), int(os.environ.get("SEED1", 20300))
 bad = []
 for seed in range(n0, n1):
@@ -25,6 +27,13 @@ for seed in range(n0, n1):
                                 sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
             rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
             rv["scales"] = rv["scales"] * float(np.exp(r.uniform(-0.5, 1.5)))
+        if os.environ.get("PLAIN") == "2":              # more than 256 tiles: the chained backward walks (three pieces per quadrant)
+            N = int(r.randint(5000, 40000))
+            W, H = int(r.randint(272, 400)), int(r.randint(256, 320))
+            rs, rv = util.scene(N, W, H, seed=seed, device="cuda", w2c=util.pose(float(r.uniform(-0.4, 0.4)), (0.0, 0.0, float(r.uniform(-1.0, 0.5)))),
+                                sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
+            rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
+            rv["scales"] = rv["scales"] * float(np.exp(r.uniform(0.0, 2.0)))
         pc.check_forward(rs, rv, o32)
         if seed % 3 == 0:
             pc.check_backward(rs, rv, o64, oracle32=o32)          # the stated 0.995 bar; the fp32 hatch is tallied below

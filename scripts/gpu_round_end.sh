@@ -33,6 +33,8 @@ BENCH_SAME_DEVICE=1 timeout 300 python bench.py --gpus 2 --steps 3 --warmup 1 --
 ELEMS=118000000 timeout 100 python scripts/adam_bench.py > gpurun_out/final/${TAG}_adam.txt 2>&1; tail -1 gpurun_out/final/${TAG}_adam.txt
 for mode in "ADAM=0 DIRECT=0" "ADAM=1 DIRECT=0" "ADAM=1 DIRECT=1"; do env $mode PROFILE=0 BATCHES=5 N=200000 W=256 H=256 timeout 120 taskset -c 4 python scripts/exp/map_iter.py 2>&1 | tail -1 | sed "s/^/$mode /"; done > gpurun_out/final/${TAG}_map_iter_256.txt; cat gpurun_out/final/${TAG}_map_iter_256.txt
 timeout 200 taskset -c 4 python scripts/exp/harness_time.py 2>&1 | grep "ms total" > gpurun_out/final/${TAG}_harness.txt; cat gpurun_out/final/${TAG}_harness.txt
+# where the backward blend's instructions go (control flow replayed from the frame's integer artefacts, priced from the ISA)
+(timeout 100 python scripts/exp/bwd_work.py 2>&1 | tail -12; N=500000 timeout 100 python scripts/exp/bwd_work.py 2>&1 | tail -12) > gpurun_out/final/${TAG}_bwd_work.txt
 # planner panorama, densify event
 timeout 200 python scripts/lookaround_times.py > gpurun_out/final/${TAG}_lookaround.txt 2>&1
 N=3000000 timeout 200 python scripts/densify_time.py > gpurun_out/final/${TAG}_densify.txt 2>&1
