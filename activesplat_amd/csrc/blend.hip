@@ -447,21 +447,20 @@ __global__ __launch_bounds__(kPcWaves * kWave) void blend_forward_pc_kernel(
         const int lb = chunk % 3, rb = chunk & 3;
         const float2 q0 = *reinterpret_cast<const float2*>(&s_rec[rb][0][lane]);                       // (x, y)
         const float2 q2 = *(reinterpret_cast<const float2*>(&s_rec[rb][1][lane]) + 1);                 // (ext_x, ext_y)
-        const float ex = q2.x, ey = q2.y;
         int ntrips = 0;
-        const bool qhit = ex >= 0.0f && (q0.x + ex >= qx0) && (q0.x - ex <= qx0 + 7.0f) && (q0.y + ey >= qy0) && (q0.y - ey <= qy0 + 7.0f);
-        if (__any(qhit)) {
+        // (the four block tests as wave masks in scalar registers: scan_blocks; a record slot behind the list's end was staged with extent -1)
+        const unsigned long long going = s_going[pair];
+        unsigned long long m_any, mb[4];
+        scan_blocks(make_float4(q0.x, q0.y, 0.f, 0.f), make_float4(0.f, 0.f, q2.x, q2.y), true, qx0, qy0, (going & 0xffffull) != 0ull,
+                    (going & 0xffff0000ull) != 0ull, (going & 0xffff00000000ull) != 0ull, (going >> 48) != 0ull, m_any, mb);
+        if (m_any != 0ull) {
             reinterpret_cast<uint32_t*>(s_list[pair][lb])[lane] = 0x40404040u;        // sentinel fill: 4 x 64 bytes
             __builtin_amdgcn_wave_barrier();
-            const unsigned long long going = s_going[pair];
 #pragma unroll
             for (int st = 0; st < 4; st++) {
-                const float x0 = qx0 + (float)((st & 1) * 4), y0 = qy0 + (float)((st >> 1) * 4);
-                const bool stream_going = ((going >> (st * 16)) & 0xffffull) != 0ull;
-                const bool hit = stream_going && ex >= 0.0f && (q0.x + ex >= x0) && (q0.x - ex <= x0 + 3.0f) && (q0.y + ey >= y0) && (q0.y - ey <= y0 + 3.0f);
-                const unsigned long long m = __ballot(hit);
+                const unsigned long long m = mb[st];
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (hit) s_list[pair][lb][st * kWave + rank] = (uint8_t)lane;
+                if (__builtin_amdgcn_inverse_ballot_w64(m)) s_list[pair][lb][st * kWave + rank] = (uint8_t)lane;
                 ntrips = max(ntrips, (int)__popcll(m));
             }
         }
