@@ -985,16 +985,23 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(3, 3
             }
             __builtin_amdgcn_wave_barrier();
             const int krec = min(fl_rec, 5);                   // lanes 60..63 idle along with record 5's mapping (never valid)
-            bool valid_c = lane < 60 && krec < cnt;
-            float val_c = valid_c ? fls[krec * kPairStride + fl_off] : 0.0f;
-            uint32_t id_c = valid_c ? __float_as_uint(s2[krec].w) : 0u;
-            for (int g = 0; g < cnt; g += 6) {
-                const int slot_n = min(g + 6 + krec, kWave);           // (kWave: the sentinel slot)
-                const bool valid_n = lane < 60 && g + 6 + krec < cnt;
-                const float val_n = valid_n ? fls[slot_n * kPairStride + fl_off] : 0.0f;
-                const uint32_t id_n = valid_n ? __float_as_uint(s2[slot_n].w) : 0u;
-                if (val_c != 0.0f) atomicAdd(grad2d + (size_t)id_c * kGradStride + fl_comp, val_c);
-                val_c = val_n; id_c = id_n;
+            // four groups per trip: eight unconditional LDS reads first (a slot behind the last staged record is clamped to the sentinel
+            // slot), then the atomics, each under one predicate -- the conditional reads of the first version were a taken branch each and an
+            // LDS round trip per group
+            for (int g = 0; g < cnt; g += 24) {
+                float val[4];
+                uint32_t id[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int slot = g + 6 * u + krec, sl = min(slot, kWave);
+                    const float v = fls[sl * kPairStride + fl_off];
+                    id[u] = __float_as_uint(s2[sl].w);
+                    val[u] = (lane < 60 && slot < cnt) ? v : 0.0f;
+                }
+                asm volatile("" ::: "memory");                 // (the reads stay in front of the atomics)
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (val[u] != 0.0f) atomicAdd(grad2d + (size_t)id[u] * kGradStride + fl_comp, val[u]);
             }
         }
         __builtin_amdgcn_wave_barrier();
