@@ -122,6 +122,8 @@ for t in range(gx * gy):
                 close2()
             hi = lo
 print(tot)
+print("Gaussians %d, visible (tiles touched > 0) %d = %.1f %%, contributing to some quadrant's staging %d" % (N, int((art["tiles_touched"] > 0).sum()), 100.0 * float((art["tiles_touched"] > 0).mean()),
+      tot["any_records"]))
 c = tot
 print("per visited chunk: positions %.1f (lane-rows filled %.2f), batches %.2f (%.0f %% full), union records %.1f, flush groups %.1f" % (
     c["positions"] / c["chunks"], c["pairs"] / (4.0 * c["positions"]), c["batches"] / c["chunks"], 100.0 * c["full_batches"] / c["batches"],
