@@ -1,3 +1,5 @@
+"""Development helper: what plain element-wise kernels reach on this box's HBM (PyTorch's own copy / fill / sum / mul / add on 256 MB ... 4 GB tensors,
+hipEvents): the yardstick for the per-Gaussian kernels' TB/s.  GPU box: python scripts/exp/hbm_bw_torch.py"""
 import torch, time
 dev='cuda'
 def t(fn, n=20):
