@@ -237,8 +237,13 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
         uint32_t id_next2 = first + (uint32_t)lane + 64u < n ? list[first + lane + 64] : kNoId;
         if (id_next >= P) id_next = kNoId;
         if (id_next2 >= P) id_next2 = kNoId;
+        // (unconditional record loads: a lane without a list entry fetches record 0 -- there is one: the list is not empty -- and is masked
+        // by its id in the scan; a conditional load keeps the old registers alive for the masked lanes: twelve moves and a branch per chunk)
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
-        if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
+        if (first < n) {
+            const float4* gr = geom + (size_t)(id_next != kNoId ? id_next : 0u) * 3;
+            r0 = gr[0]; r1 = gr[1]; r2 = gr[2];
+        }
         for (uint32_t base = first; base < n; base += kWave) {
             if (SEG == 0) {
 #pragma unroll
@@ -250,8 +255,10 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
             id_next = id_next2;
             id_next2 = base + 128u + (uint32_t)lane < n ? list[base + 128u + lane] : kNoId;
             if (id_next2 >= P) id_next2 = kNoId;
-            r2 = make_float4(0.f, 0.f, -1.f, -1.f);
-            if (id_next != kNoId) { r0 = geom[(size_t)id_next * 3]; r1 = geom[(size_t)id_next * 3 + 1]; r2 = geom[(size_t)id_next * 3 + 2]; }
+            {
+                const float4* gr = geom + (size_t)(id_next != kNoId ? id_next : 0u) * 3;
+                r0 = gr[0]; r1 = gr[1]; r2 = gr[2];
+            }
 
             // a stream whose pixels have ALL stopped gets an empty list: the walk's trip count is the longest list of the streams that
             // still blend (pixels of a quadrant saturate at different depths: at 2 M Gaussians the mean stop is at position ~900, the
