@@ -10,11 +10,12 @@
 //     simply finishes.  Sharing a workgroup keeps the four walkers of a tile on one CU, so the 48-byte
 //     record gathers of three of them hit that CU's L1.
 //   * 64 records at a time: every lane gathers one record, stages it in the wave's private LDS slice (3 KiB)
-//     and tests ITS alpha>=1/255 bounding box against the four 4x4-pixel blocks of the quadrant; per block
-//     a 64-bit __ballot plus an mbcnt rank turn the hits into a LIST of record slots in LDS.  The 16 lanes
-//     of a block (one DPP row) then walk only their own list -- four record streams per wavefront, no
-//     scalar bookkeeping in the loop.  Skipped records can never pass the alpha>=1/255 test, so the result
-//     is identical to evaluating all of them.
+//     and tests ITS alpha>=1/255 bounding box against the four 4x4-pixel blocks of the quadrant (scan_blocks:
+//     the tests are wave masks in scalar registers, no branches); per block an mbcnt rank of its mask turns
+//     the hits into a LIST of record slots in LDS.  The 16 lanes of a block (one DPP row) then walk only their
+//     own list -- four record streams per wavefront, no scalar bookkeeping in the loop.  Skipped records can
+//     never pass the alpha>=1/255 test, so the result is identical to evaluating all of them.  (The backward
+//     stages only the records that hit and runs its phases on nearly full staging: see there.)
 //   * the loop is software-pipelined: ids two chunks ahead, records one chunk ahead.
 //   * blockIdx -> tile mapping is XCD-aware: the dispatcher places block b on XCD b%8, so XCD x is
 //     given the contiguous band of tiles [x*ceil(T/8), (x+1)*ceil(T/8)) and neighbouring tiles (which
