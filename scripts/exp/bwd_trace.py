@@ -30,6 +30,8 @@ s, e = (a[:, 0] - t0) * 0.01, (a[:, 1] - t0) * 0.01
 cyc = a[:, 2].astype(np.float64)
 print("walkers traced %d, kernel span %.1f us, walker duration mean %.1f p90 %.1f max %.1f us; shader clock %.2f GHz" % (
     len(a), e.max(), (e - s).mean(), np.percentile(e - s, 90), (e - s).max(), (cyc / ((e - s) * 1e3)).mean()))
+zero = (a[:, 9] >> 40).sum(); staged = ((a[:, 9] >> 20) & 0xfffff).sum(); a[:, 9] &= (1 << 20) - 1
+print("  staged records %d, of which with ten zero sums at the flush %d (%.1f %%)" % (staged, zero, 100.0 * zero / max(staged, 1)))
 names = ["scan", "round set-up (flags, ballots, lists)", "phase A", "phase B + gather", "flush"]
 tot = cyc.sum()
 acc = 0.0

@@ -66,6 +66,9 @@ sub('''        __builtin_amdgcn_wave_barrier();
 sub('''    if (pieces > 1 && piece < pieces - 1) {            // hand the state on''', '''    const unsigned long long c_e0 = __builtin_readcyclecounter();
     struct EpiEnd { unsigned long long c0; unsigned long long* cy; __device__ ~EpiEnd() { cy[4] = cy[4]; cy[0] = cy[0]; cy[6] |= (__builtin_readcyclecounter() - c0) << 32; } } epi_end{c_e0, cy};
     if (pieces > 1 && piece < pieces - 1) {            // hand the state on''')
+sub('''            float* fls = s_m[wave][0];                          // 64 x 12 floats <= 2 planes''', '''            float* fls = s_m[wave][0];                          // 64 x 12 floats <= 2 planes
+            { bool z = true; for (int k_ = 0; k_ < 10; k_++) z = z && racc[k_] == 0.0f;
+              nn[1] += ((unsigned long long)__popcll(__ballot(lane < cnt && z)) << 40) | ((unsigned long long)cnt << 20); }''')
 s += '''
 extern "C" int gs_debug_bwd_trace(unsigned long long* out, int n)
 {
