@@ -37,6 +37,8 @@ for seed in range(n0, n1):
         pc.check_forward(rs, rv, o32)
         if seed % 3 == 0:
             pc.check_backward(rs, rv, o64, oracle32=o32)          # the stated 0.995 bar; the fp32 hatch is tallied below
+        if os.environ.get("RGBD") and seed % 3 == 1 and "colors_precomp" in rv and "cov3D_precomp" not in rv:
+            pc.check_fused_rgbd(rs, rv, o64, seed=seed, oracle32=o32)           # the single-pass RGB-D render and its backward (DEPTH_GRAD kernels)
     except Exception as e:
         bad.append((seed, repr(e)[:300]))
         print("FAIL seed", seed, repr(e)[:300], flush=True)

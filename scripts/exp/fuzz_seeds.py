@@ -1,0 +1,37 @@
+"""Development helper (uses the oracle: a checker run): the checks of scripts/exp/fuzz_gpu.py on a given list of seeds, one line per seed -- to
+compare two builds of the library on the scenes a sweep flagged.  GPU box: SEEDS=122026,122050 RGBD=1 PLAIN=2 python scripts/exp/fuzz_seeds.py"""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.gs_oracle import Oracle
+from activesplat_amd import _lib
+from tests import parity_cases as pc, util
+from tests.test_randomized import _draw
+
+o32, o64 = Oracle("f32"), Oracle("f64")
+lib = _lib.get()
+plain = os.environ.get("PLAIN")
+if plain:
+    _lib.check(lib.gs_set_half_quadrants(0)); _lib.check(lib.gs_set_backward_chain(3, 0))
+for seed in [int(x) for x in os.environ["SEEDS"].split(",")]:
+    r = np.random.RandomState(seed)
+    rs, rv = _draw(seed, "cuda")
+    mode = seed % 4
+    if mode == 1:
+        N = int(r.randint(3000, 30000)); W, H = int(r.randint(40, 200)), int(r.randint(40, 160))
+        rs, rv = util.scene(N, W, H, seed=seed, device="cuda", w2c=util.pose(float(r.uniform(-0.4, 0.4)), (0.0, 0.0, float(r.uniform(-1.0, 0.5)))),
+                            sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
+        rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
+        rv["scales"] = rv["scales"] * float(np.exp(r.uniform(-0.5, 1.5)))
+    if plain == "2":
+        N = int(r.randint(5000, 40000)); W, H = int(r.randint(272, 400)), int(r.randint(256, 320))
+        rs, rv = util.scene(N, W, H, seed=seed, device="cuda", w2c=util.pose(float(r.uniform(-0.4, 0.4)), (0.0, 0.0, float(r.uniform(-1.0, 0.5)))),
+                            sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
+        rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
+        rv["scales"] = rv["scales"] * float(np.exp(r.uniform(0.0, 2.0)))
+    try:
+        pc.check_fused_rgbd(rs, rv, o64, seed=seed, oracle32=o32)
+        print("seed", seed, "P", rv["means3D"].shape[0], "ok", flush=True)
+    except Exception as e:
+        print("seed", seed, "P", rv["means3D"].shape[0], "FAIL", repr(e)[:160].replace("\n", " "), flush=True)

@@ -532,9 +532,10 @@ def check_backward(rs, rv, oracle64, seed=0, min_frac=0.995, oracle32=None):
     return got, ref
 
 
-def check_fused_rgbd(rs, rv, oracle64, seed=0):
+def check_fused_rgbd(rs, rv, oracle64, seed=0, oracle32=None):
     """rasterizer.render_rgbd (one pass) vs (a) the two reference-style passes of the same library and
-    (b) the fp64 oracle with a depth gradient."""
+    (b) the fp64 oracle with a depth gradient.  With `oracle32` (the random sweeps of scripts/exp: scenes of tens of thousands of Gaussians)
+    a gradient that misses the 1e-3 bar against fp64 is judged against the fp32 oracle's own error, as in check_backward."""
     from activesplat_amd import rasterizer as R
     H, W = int(rs.image_height), int(rs.image_width)
     dev = rv["means3D"].device
@@ -564,7 +565,12 @@ def check_fused_rgbd(rs, rv, oracle64, seed=0):
     ((c1 * dLc).sum() + (c2[0:1] * dLd).sum()).backward()
     n = lambda t: t.detach().cpu().numpy()  # noqa: E731
     assert np.array_equal(n(radii), n(r1))
-    np.testing.assert_array_equal(n(color), n(c1))
+    if R.last_stats.get("max_tile_instances", 0) >= 8192 and not np.array_equal(n(color), n(c1)):
+        # (tile lists of 8192 and more in a small image take the SEGMENTED forward, whose segments add their sums with atomics: two renders
+        # of one scene agree to the last bits only)
+        assert np.abs(n(color) - n(c1)).max() <= 2e-6 * max(1.0, float(np.abs(n(c1)).max()))
+    else:
+        np.testing.assert_array_equal(n(color), n(c1))
     for a, b, name in ((depth[0], c2[0], "depth"), (sil[0], c2[1], "silhouette"), (dsq[0], c2[2], "depth_sq")):
         sc = max(1.0, float(n(b).max()))
         assert close_frac(n(a), n(b), 1e-5, 2e-6 * sc) > 0.9999, name
@@ -575,9 +581,19 @@ def check_fused_rgbd(rs, rv, oracle64, seed=0):
     # (3) fp64 oracle
     ref = util.run_oracle(oracle64, rs, rv)
     go = oracle64.backward(ref, dLc.cpu().numpy(), dLd.cpu().numpy())
+    go32 = None
     for k, gq in gf.items():
         r = go[k].reshape(gq.shape)
         rel = np.linalg.norm(gq.astype(np.float64) - r) / max(np.linalg.norm(r), 1e-30)
+        HATCH["keys_checked"] += 1
+        if rel >= 1e-3 and oracle32 is not None:
+            HATCH["fired"] += 1
+            HATCH["where"].append((k + " (fused RGB-D)", float(rel), 1.0, int(gq.shape[0])))
+            if go32 is None:
+                go32 = oracle32.backward(util.run_oracle(oracle32, rs, rv), dLc.cpu().numpy(), dLd.cpu().numpy())
+            rel32 = np.linalg.norm(go32[k].reshape(gq.shape).astype(np.float64) - r) / max(np.linalg.norm(r), 1e-30)
+            assert rel <= 1.5 * rel32 + 1e-6, (k, rel, rel32)
+            continue
         assert rel < 1e-3, (k, rel)
     sc = max(1.0, float(ref["depth_sq"].max()))
     assert close_frac(n(dsq), ref["depth_sq"], FWD_RTOL, FWD_ATOL * sc) >= 0.999
