@@ -1,0 +1,40 @@
+"""The scene generator of the wide random sweeps (scripts/exp/fuzz_gpu.py and friends), kept here so that a scene a sweep flagged can be
+pinned in the test suite by its seed alone (tests/test_gpu_parity.py: `test_flagged_sweep_scene_*`).
+
+`sweep_scene(seed, device, plain)` reproduces what the sweep drew for `seed`:
+  * seed % 4 != 1: the small draw of tests/test_randomized._draw (17..130 x 17..110 pixels, 1..1500 Gaussians);
+  * seed % 4 == 1: 3 000..30 000 Gaussians on 40..200 x 40..160 pixels (several binning chunks, tile lists of thousands);
+  * plain == "2" (any seed): 5 000..40 000 Gaussians on 272..400 x 256..320 pixels -- more than 256 tiles, i.e. the streams forward and the
+    chained backward walks of the full-size frames (the caller also sets gs_set_half_quadrants(0) / gs_set_backward_chain(3, 0)).
+"""
+import numpy as np
+
+from tests import util
+from tests.test_randomized import _draw
+
+
+def sweep_scene(seed, device, plain=None):
+    r = np.random.RandomState(seed)
+    rs, rv = _draw(seed, device)
+    if seed % 4 == 1:                                   # bigger scene: more chunks, longer lists
+        N = int(r.randint(3000, 30000))
+        W, H = int(r.randint(40, 200)), int(r.randint(40, 160))
+        rs, rv = util.scene(N, W, H, seed=seed, device=device, w2c=util.pose(float(r.uniform(-0.4, 0.4)), (0.0, 0.0, float(r.uniform(-1.0, 0.5)))),
+                            sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
+        rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
+        rv["scales"] = rv["scales"] * float(np.exp(r.uniform(-0.5, 1.5)))
+    if plain == "2":                                    # more than 256 tiles: the chained backward walks (three pieces per quadrant)
+        N = int(r.randint(5000, 40000))
+        W, H = int(r.randint(272, 400)), int(r.randint(256, 320))
+        rs, rv = util.scene(N, W, H, seed=seed, device=device, w2c=util.pose(float(r.uniform(-0.4, 0.4)), (0.0, 0.0, float(r.uniform(-1.0, 0.5)))),
+                            sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
+        rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
+        rv["scales"] = rv["scales"] * float(np.exp(r.uniform(0.0, 2.0)))
+    return rs, rv
+
+
+#: scenes the round-4 sweeps flagged (profiles/r04_fuzz5.txt): (seed, plain).  Ten pass under the operative gradient rule of DESIGN section 6
+#: (the fp64 bar, or at most 1.5 x the fp32 oracle's own error); 120013 is the alpha = 1/255 threshold scene analysed in
+#: profiles/README.md ("seed 120013") and is checked with the decision-aware rule of parity_cases.check_fused_rgbd(flip_aware=True).
+FLAGGED_RGBD = [(122026, "2"), (122050, "2"), (122083, "2"), (122086, "2"), (122095, "2"), (122131, "2"), (122184, "2"), (122236, "2"),
+                (120013, None), (120229, None), (120517, None)]

@@ -15,6 +15,8 @@ What is pinned:
   adam.npz       initialize_optimizer + Adam steps   (splatam.py:118-124)
   prune.npz      prune_gaussians, remove_points, cat_params_to_optimizer, update_params_and_optimizer,
                  accumulate_mean2d_gradient, densify (isotropic, no timestep)  (slam_external.py:100-247)
+  densify_t.npz  the second executable densify variant: gs_external.densify, isotropic WITH `timestep` inherited by clones and
+                 split children, [N,3] means2D through its accumulate_mean2d_gradient (no early return)   (gs_external.py:100-105,191-253)
   pointcloud.npz get_pointcloud, initialize_params, initialize_new_params, add_new_gaussians
                                                      (splatam.py:25-115,304-379)
   keyframe.npz   keyframe_selection_overlap          (keyframe_selection.py:40-95)
@@ -308,6 +310,57 @@ def main():
         out.update(den_accum1=n(variables["means2D_gradient_accum"]), den_denom1=n(variables["denom"]),
                    den_max2d1=n(variables["max_2D_radius"]))
         np.savez_compressed(os.path.join(HERE, "prune.npz"), **out)
+
+        # ---------------- densify, second executable variant: gs_external.densify (isotropic, WITH timestep) ----------------
+        from mapper.splatam.utils import gs_external
+        g = torch.Generator().manual_seed(15)
+        N = 320
+        raw = dict(means3D=torch.randn(N, 3, generator=g), rgb_colors=torch.rand(N, 3, generator=g),
+                   unnorm_rotations=torch.randn(N, 4, generator=g), logit_opacities=torch.randn(N, 1, generator=g) * 2,
+                   log_scales=torch.randn(N, 1, generator=g) * 0.7 - 4.0, cam_unnorm_rots=torch.randn(1, 4, 2, generator=g),
+                   cam_trans=torch.randn(1, 3, 2, generator=g))
+        params = {k: torch.nn.Parameter(v.clone()) for k, v in raw.items()}
+        opt = sp.initialize_optimizer(params, lrs, tracking=False)
+        for k, p in params.items():
+            if not k.startswith("cam_"):
+                p.grad = torch.randn(p.shape, generator=g)
+        opt.step()
+        m2d = torch.zeros(N, 3, requires_grad=True)                       # the [P,3] carrier the rasteriser's callers pass
+        m2d.grad = torch.randn(N, 3, generator=g) * 3e-4
+        seen = torch.rand(N, generator=g) > 0.3
+        variables = dict(means2D=m2d, seen=seen, means2D_gradient_accum=torch.rand(N, generator=g) * 4e-4,
+                         denom=(torch.rand(N, generator=g) * 3).floor(), max_2D_radius=torch.rand(N, generator=g) * 5,
+                         timestep=torch.randint(0, 40, (N,), generator=g).float(), scene_radius=torch.tensor(2.0))
+        ddict = dict(start_after=0, remove_big_after=0, stop_after=100, densify_every=10, grad_thresh=0.0002, num_to_split_into=2,
+                     removal_opacity_threshold=0.005, final_removal_opacity_threshold=0.005, reset_opacities=False,
+                     reset_opacities_every=3000)
+        out = {f"p0_{k}": n(v) for k, v in params.items()}
+        for k, p in params.items():
+            st = opt.state.get(p, None)
+            if st:
+                out[f"m0_{k}"] = n(st["exp_avg"]); out[f"v0_{k}"] = n(st["exp_avg_sq"])
+        out.update(m2d_grad=n(m2d.grad), seen=n(seen), accum0=n(variables["means2D_gradient_accum"]), denom0=n(variables["denom"]),
+                   max2d0=n(variables["max_2D_radius"]), timestep0=n(variables["timestep"]), scene_radius=np.array(2.0))
+        out.update({f"ddict_{k}": np.array(v) for k, v in ddict.items()})
+        captured = {}
+
+        def spy_normal_t(*a, **k):
+            r = real_normal(*a, **k)
+            captured["samples"] = r.detach().clone()
+            return r
+        torch.normal = spy_normal_t
+        torch.manual_seed(321)
+        params, variables = gs_external.densify(params, variables, opt, 10, ddict)
+        torch.normal = real_normal
+        out["samples"] = n(captured["samples"])
+        out.update({f"p1_{k}": n(v) for k, v in params.items()})
+        for k, p in params.items():
+            st = opt.state.get(p, None)
+            if st:
+                out[f"m1_{k}"] = n(st["exp_avg"]); out[f"v1_{k}"] = n(st["exp_avg_sq"]); out[f"t1_{k}"] = n(st["step"])
+        out.update(accum1=n(variables["means2D_gradient_accum"]), denom1=n(variables["denom"]), max2d1=n(variables["max_2D_radius"]),
+                   timestep1=n(variables["timestep"]))
+        np.savez_compressed(os.path.join(HERE, "densify_t.npz"), **out)
 
         # ---------------- pointcloud / new gaussians ----------------
         g = torch.Generator().manual_seed(6)

@@ -212,6 +212,35 @@ def test_densify_matches_reference_isotropic(backend):
         np.testing.assert_array_equal(variables[k].cpu().numpy(), d[g])
 
 
+def test_densify_with_timestep_matches_reference_second_variant(backend):
+    """SURVEY 8c(7)'s second executable variant: gs_external.densify (gs_external.py:191-253) -- isotropic map, `timestep` inherited by clones and
+    split children, the [N,3] means2D carrier going through ITS accumulate_mean2d_gradient (gs_external.py:100-105: no early return, norm of the first two
+    columns) -- with the recorded normal samples injected.  tests/golden/densify_t.npz, captured by make_golden.py from the imported reference."""
+    from activesplat_amd import optim as O
+    d = load("densify_t.npz")
+    params, opt = _optimizer_from(d, "")
+    _seed_state(opt, params, d, "", "p0")
+    N = params["means3D"].shape[0]
+    m2d = torch.zeros(N, 3, requires_grad=True, device=backend)
+    m2d.grad = T(d["m2d_grad"])
+    variables = dict(means2D=m2d, seen=T(d["seen"]), means2D_gradient_accum=T(d["accum0"]).clone(), denom=T(d["denom0"]).clone(),
+                     max_2D_radius=T(d["max2d0"]).clone(), timestep=T(d["timestep0"]).clone(), scene_radius=T(d["scene_radius"]))
+    ddict = {k: d[f"ddict_{k}"].item() for k in ("start_after", "remove_big_after", "stop_after", "densify_every", "grad_thresh", "num_to_split_into",
+                                                "removal_opacity_threshold", "final_removal_opacity_threshold", "reset_opacities", "reset_opacities_every")}
+    params, variables = O.densify(params, variables, opt, 10, ddict, samples=T(d["samples"]))
+    assert params["means3D"].shape[0] == d["p1_means3D"].shape[0] != N
+    for k in KEYS:
+        np.testing.assert_allclose(params[k].detach().cpu().numpy(), d[f"p1_{k}"], rtol=1e-6, atol=1e-7, err_msg=k)
+        if not k.startswith("cam_"):
+            st = opt.state[params[k]]
+            np.testing.assert_array_equal(st["exp_avg"].cpu().numpy(), d[f"m1_{k}"])
+            np.testing.assert_array_equal(st["exp_avg_sq"].cpu().numpy(), d[f"v1_{k}"])
+            assert float(st["step"]) == float(d[f"t1_{k}"])
+    for k, g in (("means2D_gradient_accum", "accum1"), ("denom", "denom1"), ("max_2D_radius", "max2d1"), ("timestep", "timestep1")):
+        np.testing.assert_array_equal(variables[k].cpu().numpy(), d[g], err_msg=k)
+    assert len(np.unique(d["timestep1"])) > 5 and d["timestep1"].shape[0] == d["p1_means3D"].shape[0]
+
+
 def test_densify_anisotropic_with_timestep_runs(backend):
     """The cases the reference cannot execute: per-axis split noise, timestep inherited."""
     from activesplat_amd import optim as O
