@@ -384,7 +384,7 @@ def prune_gaussians(params, variables, optimizer, iter, prune_dict, fused=True):
     return params, variables
 
 
-def _densify_fused(params, variables, optimizer, iter, densify_dict, samples):
+def _densify_fused(params, variables, optimizer, iter, densify_dict, samples, seed=None):
     """One classification, one index, one gather per tensor.  Output rows, as the reference orders them: surviving originals
     (split parents gone), surviving clones, then num_to_split_into blocks of surviving children (parents ascending in a block)."""
     lib = _lib.get()
@@ -410,8 +410,9 @@ def _densify_fused(params, variables, optimizer, iter, densify_dict, samples):
         kid_samples, seed = None, 0
         if samples is None:
             # drawn inside the kernel (counter-based): the event's seed comes from torch's CPU generator, so torch.manual_seed makes a run
-            # repeatable; no sample tensor, no torch.normal / exp / repeat launches
-            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            # repeatable; no sample tensor, no torch.normal / exp / repeat launches.  A keyframe-sharded loop hands in `seed` -- a function of
+            # replicated state (parallel.event_seed) -- so that every rank draws the same offsets without a broadcast
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()) if seed is None else int(seed) & (2 ** 62 - 1)
         else:
             # injected offsets are indexed like the reference's un-culled split list: block c, rank of the parent among ALL split parents
             rank = torch.cumsum(masks[3].to(torch.int64), 0) - 1
@@ -427,16 +428,19 @@ def _densify_fused(params, variables, optimizer, iter, densify_dict, samples):
     return params, variables
 
 
-def densify(params, variables, optimizer, iter, densify_dict, samples=None, fused=True):
+def densify(params, variables, optimizer, iter, densify_dict, samples=None, fused=True, seed=None, accumulate=True):
     """Clone small / split large high-gradient Gaussians, then cull (slam_external.py:195-247).
     `samples` optionally injects the N(0, scale) split offsets ([n_split * num_to_split_into, 3]) so that a run
-    can be replayed exactly; otherwise torch.normal draws them.  fused=False runs the reference's step-by-step call pattern."""
+    can be replayed exactly; otherwise they are drawn in the kernel from `seed` (None: a seed from torch's CPU generator).
+    accumulate=False: the caller has already added this iteration's mean-2D gradient statistics (parallel.sharded_densify, whose
+    accumulators are rank-local partial sums until the event's all-reduce)."""
     if iter > densify_dict["stop_after"]:
         return params, variables
-    variables = accumulate_mean2d_gradient(variables)
+    if accumulate:
+        variables = accumulate_mean2d_gradient(variables)
     grad_thresh = densify_dict["grad_thresh"]
     if fused and iter >= densify_dict["start_after"] and iter % densify_dict["densify_every"] == 0:
-        params, variables = _densify_fused(params, variables, optimizer, iter, densify_dict, samples)
+        params, variables = _densify_fused(params, variables, optimizer, iter, densify_dict, samples, seed)
     elif iter >= densify_dict["start_after"] and iter % densify_dict["densify_every"] == 0:
         keys = [k for k in params.keys() if k not in _SKIP]
         dev = params["means3D"].device

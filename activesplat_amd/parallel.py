@@ -140,7 +140,8 @@ def all_reduce_gradients(params, buf: FlatGradBuffer | None = None, group=None, 
 
 
 def all_reduce_statistics(variables, group=None):
-    """Densification statistics live per rank; combine them before densify (sum, sum, max)."""
+    """Densification statistics live per rank as PARTIAL sums (every rank adds what its own keyframes saw); combine them -- once -- right before
+    a densify event (sum, sum, max): sharded_densify does.  (Reducing accumulators that already hold reduced values would count them world times.)"""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return variables
     for k, op in (("means2D_gradient_accum", dist.ReduceOp.SUM), ("denom", dist.ReduceOp.SUM), ("max_2D_radius", dist.ReduceOp.MAX)):
@@ -150,7 +151,7 @@ def all_reduce_statistics(variables, group=None):
 
 
 def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank=None, world=None, buf=None,
-                          sharded_adam=False, streams=1, densify_statistics=False, timing=False):
+                          sharded_adam=False, streams=1, densify_statistics=False, timing=False, accumulate_statistics=False, partition=None):
     """One optimiser step over a batch of keyframes sharded across ranks.
     loss_fn(params, keyframe, variables) -> (loss, variables).  Returns the local loss sum.
 
@@ -161,12 +162,17 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
     for frames that do not, e.g. the reference's 256 x 256).  Each keyframe's
     gradients are taken with autograd.grad on its own stream and summed after the streams have joined.
     autograd.grad does not populate `means2D.grad`, which the densifier's statistics read (optim.accumulate_mean2d_gradient):
-    a caller that densifies from this step's statistics passes densify_statistics=True and gets the serial walk."""
+    a caller that densifies from this step's statistics passes densify_statistics=True and gets the serial walk.
+    accumulate_statistics=True (implies the serial walk): EVERY keyframe of this rank adds its mean-2D gradient norm and visibility to the
+    densifier's accumulators right after its backward (optim.accumulate_mean2d_gradient) -- the batch's statistic is then the sum over all of its
+    keyframes whatever the number of ranks; the accumulators are rank-local partial sums until parallel.sharded_densify all-reduces them.
+    partition: list of this step's keyframe indices per rank (parallel.balanced_partition); default: contiguous blocks (shard_keyframes)."""
     on = dist.is_available() and dist.is_initialized()
     rank = (dist.get_rank() if on else 0) if rank is None else rank
     world = (dist.get_world_size() if on else 1) if world is None else world
     optimizer.zero_grad(set_to_none=True)
-    mine = list(shard_keyframes(len(keyframes), rank, world))
+    mine = list(shard_keyframes(len(keyframes), rank, world)) if partition is None else list(partition[rank])
+    densify_statistics = densify_statistics or accumulate_statistics
     keys = grad_keys(params)
     dev = params[keys[0]].device
     rev = None
@@ -224,6 +230,9 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
             # launch for this very tensor); autograd accumulates into .grad across this rank's keyframes
             loss.backward(unit_gradient(loss) if loss.dim() == 0 else None)
             losses.append(loss.detach())          # (read after the loop: a float() here would stall the host once per keyframe)
+            if accumulate_statistics:
+                from .optim import accumulate_mean2d_gradient
+                variables = accumulate_mean2d_gradient(variables)
         total = float(torch.stack(losses).sum()) if losses else 0.0
     if rev is not None:
         rev[1].record()
@@ -346,3 +355,55 @@ def gather_moments(params, optimizer, group=None):
             full = torch.empty(rows * world, t.shape[1], dtype=t.dtype, device=t.device)
             _all_gather_rows(full, mine, group)
             st[name].copy_(full[:n].reshape(st[name].shape))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Row surgery in a keyframe-sharded loop ("decisions are deterministic functions of replicated state").
+# Between events the densifier's accumulators are rank-local PARTIAL sums (every rank adds what its own keyframes saw) and the Adam moments
+# are current only on the owner's row block; an event first makes both complete and identical everywhere -- all-reduce (sum, sum, max),
+# gather_moments -- then every rank takes the same decisions on the same numbers and draws the split offsets from the same counter-based
+# seed.  The accumulators come out of a densify event as zeros (a valid partial sum), the shard plan is rebuilt for the new N by the next step.
+# ------------------------------------------------------------------------------------------------------------
+def event_seed(base_seed: int, iter: int, n: int) -> int:
+    """62-bit seed of an event's in-kernel split offsets: a splitmix64 mix of (run seed, iteration, Gaussian count) -- replicated state only."""
+    x = (int(base_seed) ^ (int(iter) * 0x9E3779B97F4A7C15) ^ (int(n) * 0xD1B54A32D192ED03)) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return (x ^ (x >> 31)) & (2 ** 62 - 1)
+
+
+def _world(group, world):
+    if world is not None:
+        return int(world)
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def sharded_densify(params, variables, optimizer, iter, densify_dict, group=None, base_seed=0x5EED, accumulate=True, world=None):
+    """optim.densify for a keyframe-sharded loop (call it on EVERY rank at the same iteration; slam_external.py:195-247).
+    accumulate=True: this rank's most recent keyframe adds its statistics first (the reference's per-iteration accumulation; pass False when
+    sharded_keyframe_step(accumulate_statistics=True) already added every keyframe's).  world=1 skips the collectives (one rank running alone)."""
+    from . import optim as O
+    if iter > densify_dict["stop_after"]:
+        return params, variables
+    if accumulate:
+        variables = O.accumulate_mean2d_gradient(variables)
+    if O.densify_event(iter, densify_dict):
+        if _world(group, world) > 1:
+            all_reduce_statistics(variables, group)
+            gather_moments(params, optimizer, group)
+        n = int(params["means3D"].shape[0])
+        params, variables = O.densify(params, variables, optimizer, iter, densify_dict, seed=event_seed(base_seed, iter, n), accumulate=False)
+        optimizer._shard_plan = None
+    return params, variables
+
+
+def sharded_prune(params, variables, optimizer, iter, prune_dict, group=None, world=None):
+    """optim.prune_gaussians for a keyframe-sharded loop (slam_external.py:171-192): the moments are completed on every rank before rows move;
+    the decisions read parameters only (opacity, scale), which are replicated.  The statistics stay rank-local partial sums, compacted like the rest."""
+    from . import optim as O
+    if O.prune_event(iter, prune_dict):
+        if _world(group, world) > 1:
+            gather_moments(params, optimizer, group)
+        params, variables = O.prune_gaussians(params, variables, optimizer, iter, prune_dict)
+        optimizer._shard_plan = None
+    return params, variables

@@ -387,3 +387,152 @@ def test_rccl_one_rank_group_runs_the_sharded_step_at_configs3_size(hip):
     assert ex["bytes"] == 2_000_000 * 14 * 4 and ms is not None and ms > 0
     print(f"RCCL 1-rank exchange + sharded Adam at [2M,14]: {ms:.3f} ms")
     assert ar_same and ar["backend"] == "nccl" and ar["reduce"] == "all_reduce" and mx == 3.0
+
+
+# ---- row surgery in a keyframe-sharded loop: sharded steps -> densify -> prune -> sharded steps on two ranks ----------
+_DDICT = dict(start_after=0, remove_big_after=0, stop_after=100, densify_every=3, grad_thresh=2e-5, num_to_split_into=2,
+              removal_opacity_threshold=0.02, final_removal_opacity_threshold=0.02, reset_opacities=False, reset_opacities_every=3000)
+_PDICT = dict(start_after=0, remove_big_after=0, stop_after=100, prune_every=4, removal_opacity_threshold=0.05,
+              final_removal_opacity_threshold=0.05, reset_opacities=False, reset_opacities_every=3000)
+
+
+def _surgery_loop(device, rank, world, n, W, H, log=None):
+    """Three sharded steps (statistics of every keyframe accumulated) -> densify event (iteration 3) -> prune event (iteration 4) -> two more
+    sharded steps; world = 1 runs the same loop alone, without collectives.  -> (params, optimizer, variables, trace)"""
+    from activesplat_amd import optim as O, parallel as PL
+    params, kfs = _scene(n=n, W=W, H=H, K=4, device=device)
+    with torch.no_grad():                                          # a map on which every branch of the event fires: small and large splats, faint ones
+        g = torch.Generator().manual_seed(21)
+        params["log_scales"] += (torch.randn(params["log_scales"].shape, generator=g) * 1.2).to(device)
+        params["logit_opacities"] -= (torch.rand(params["logit_opacities"].shape, generator=g) * 4.0).to(device)
+    N0 = params["means3D"].shape[0]
+    variables = {k: torch.zeros(N0, device=device) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+    variables["scene_radius"] = torch.tensor(3.0, device=device)
+    lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
+    opt = O.initialize_optimizer(params, lrs)
+    trace = []
+    for it in range(1, 7):
+        _, variables, _ = PL.sharded_keyframe_step(params, variables, kfs, opt, _loss_fn_raw, rank=rank, world=world, sharded_adam=True,
+                                                   accumulate_statistics=True)
+        n_before = params["means3D"].shape[0]
+        if O.densify_event(it, _DDICT):
+            partial = float(variables["denom"].sum())
+        params, variables = PL.sharded_densify(params, variables, opt, it, _DDICT, accumulate=False, world=world)
+        if O.densify_event(it, _DDICT):
+            trace.append(("densify", it, n_before, int(params["means3D"].shape[0]), partial))
+            assert float(variables["denom"].abs().sum()) == 0.0 and variables["denom"].shape[0] == params["means3D"].shape[0]
+        n_mid = params["means3D"].shape[0]
+        params, variables = PL.sharded_prune(params, variables, opt, it, _PDICT, world=world)
+        if O.prune_event(it, _PDICT):
+            trace.append(("prune", it, n_mid, int(params["means3D"].shape[0])))
+        if it == 5 and world > 1:                                   # the first sharded step after the events rebuilt plan and buffers for the new N
+            plan = opt._shard_plan
+            assert plan is not None and plan["n"] == params["means3D"].shape[0] and plan["buf"].n == plan["n"]
+            assert plan["rows"] * world >= plan["n"] and plan["gshard"].shape[0] == plan["rows"]
+    if world > 1:
+        PL.gather_moments(params, opt)
+    return params, opt, variables, trace
+
+
+def _flat_state(params, opt):
+    from activesplat_amd import parallel as PL
+    keys = PL.grad_keys(params)
+    return torch.cat([params[k].detach().reshape(-1) for k in keys] + [opt.state[params[k]][m].reshape(-1) for k in keys for m in ("exp_avg", "exp_avg_sq")])
+
+
+def _worker_surgery(rank, world, port, emu_path, q, device="cpu", n=900, W=64, H=48):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from activesplat_amd import parallel as PL
+        if device == "cpu":
+            from tests import util
+            util.use_emulated_kernels(emu_path)
+        params, opt, variables, trace = _surgery_loop(device, rank, world, n, W, H)
+        flat = _flat_state(params, opt)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([flat.numel()], dtype=torch.int64, device=device))
+        same_n = all(int(s) == flat.numel() for s in sizes)
+        same = False
+        if same_n:
+            gathered = [torch.zeros_like(flat) for _ in range(world)]
+            dist.all_gather(gathered, flat)
+            same = all(torch.equal(gathered[0], t) for t in gathered)
+        steps = sorted({int(opt.state[params[k]]["step"]) for k in PL.grad_keys(params)})
+        ts_ok = variables["timestep"].shape[0] == params["means3D"].shape[0]
+        res = dict(rank=rank, same_n=same_n, same=same, trace=trace, steps=steps, ts_ok=ts_ok, N=int(params["means3D"].shape[0]))
+        if rank == 0:
+            # the same loop on one rank alone (no collectives): same decisions, same rows, parameters equal up to the order of the gradient sums
+            p1, o1, v1, t1 = _surgery_loop(device, 0, 1, n, W, H)
+            res["single_trace"] = t1
+            a, b = _flat_state(p1, o1), flat
+            res["single_same_n"] = a.numel() == b.numel()
+            if res["single_same_n"]:
+                res["single_maxdiff"] = float((a - b).abs().max())
+                res["single_rel"] = float((a - b).norm() / b.norm())
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def _check_surgery(res):
+    res = sorted(res, key=lambda r: r["rank"])
+    for r in res:
+        assert r["same_n"] and r["same"], r                        # identical N, parameters AND moments on both ranks, to the bit
+        assert r["steps"] == [6] and r["ts_ok"], r
+    t = res[0]["trace"]
+    assert [x[:4] for x in t] == [x[:4] for x in res[1]["trace"]]
+    kinds = [x[0] for x in t]
+    assert kinds == ["densify", "prune", "densify"], kinds        # iterations 3 (densify), 4 (prune), 6 (densify)
+    d = t[0]
+    assert d[3] != d[2], d                                         # the event changed N
+    # the ranks' accumulators were PARTIAL sums before the event: each holds only its own keyframes' visibility counts
+    assert res[0]["trace"][0][4] + res[1]["trace"][0][4] == res[0]["single_trace"][0][4] > 0, (res[0]["trace"], res[0]["single_trace"])
+    assert t[1][3] < t[1][2], t                                    # the prune removed rows
+    # against the loop run by one rank alone: the same N after every event, the same state up to fp32 summation order
+    assert [x[:4] for x in res[0]["single_trace"]] == [x[:4] for x in t], (res[0]["single_trace"], t)
+    assert res[0]["single_same_n"] and res[0]["single_rel"] < 1e-5, res[0]
+
+
+def test_two_rank_sharded_steps_densify_prune_sharded_steps(emu_lib_path):
+    """Sharded Adam steps -> all-reduced statistics -> gathered moments -> fused densify (split offsets drawn in the kernel from a seed that is a
+    function of replicated state) -> prune -> sharded steps again, on two gloo ranks (emulated kernels): identical N / parameters / moments on
+    both ranks, a rebuilt shard plan, and agreement with the same loop run by one rank alone (slam_external.py:143-247 under SURVEY 8e)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_surgery, args=(r, 2, port, emu_lib_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _check_surgery(res)
+
+
+@pytest.mark.gpu
+def test_two_rank_row_surgery_on_the_device(hip):
+    """The same on the real library: both ranks on the one GPU of the test box, gloo for the exchange (the development layout of bench.py)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_surgery, args=(r, 2, port, None, q, "cuda", 30000, 160, 128)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res = sorted(res, key=lambda r: r["rank"])
+    for r in res:
+        assert r["same_n"] and r["same"] and r["steps"] == [6] and r["ts_ok"], r
+    assert [x[:4] for x in res[0]["trace"]] == [x[:4] for x in res[1]["trace"]]
+    assert [x[0] for x in res[0]["trace"]] == ["densify", "prune", "densify"] and res[0]["trace"][0][3] != res[0]["trace"][0][2]
+    # one rank alone: the device's atomics order the gradient sums differently from run to run, so a Gaussian within rounding of a threshold may
+    # decide differently -- N within 0.2 %, and the state compared only when N agrees
+    n2, n1 = res[0]["trace"][-1][3], res[0]["single_trace"][-1][3]
+    assert abs(n2 - n1) <= max(2, 0.002 * n1), (n2, n1)
+    if res[0]["single_same_n"]:
+        assert res[0]["single_rel"] < 1e-3, res[0]
