@@ -54,10 +54,10 @@ SORT_AUTO, SORT_TILE_LDS, SORT_RADIX = 0, 1, 2
 
 # every symbol include/gsplat_hip.h declares (tests check the library exports all of them)
 #: the GS_ABI_VERSION of include/gsplat_hip.h this binding was written against (checked when a library is bound)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 SYMBOLS = ("gs_abi_version", "gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
-           "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_set_half_quadrants", "gs_set_backward_chain", "gs_set_backward_segments", "gs_preprocess_forward", "gs_preprocess_forward_raw", "gs_render_forward", "gs_render_backward", "gs_render_backward_raw", "gs_render_backward_raw_adam", "gs_adam_step", "gs_adam_step_multi",
+           "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_set_half_quadrants", "gs_set_backward_chain", "gs_set_backward_chain_tickets", "gs_set_backward_chain_polls", "gs_async_status_word", "gs_recorded_cut", "gs_set_backward_segments", "gs_preprocess_forward", "gs_preprocess_forward_raw", "gs_render_forward", "gs_render_backward", "gs_render_backward_raw", "gs_render_backward_raw_adam", "gs_adam_step", "gs_adam_step_multi",
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
            "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward", "gs_activate_backward_accumulate",
            "gs_grow_scratch_bytes", "gs_grow_gaussians", "gs_keyframe_overlap", "gs_visibility_stats", "gs_accumulate_grad2d",
@@ -88,6 +88,14 @@ def _bind(lib):
     lib.gs_set_backward_chain.restype = C.c_int
     lib.gs_set_backward_segments.argtypes = [i32]
     lib.gs_set_backward_segments.restype = C.c_int
+    lib.gs_set_backward_chain_tickets.argtypes = [i32]
+    lib.gs_set_backward_chain_tickets.restype = C.c_int
+    lib.gs_set_backward_chain_polls.argtypes = [i32]
+    lib.gs_set_backward_chain_polls.restype = C.c_int
+    lib.gs_async_status_word.argtypes = [C.POINTER(C.POINTER(C.c_uint32))]
+    lib.gs_async_status_word.restype = C.c_int
+    lib.gs_recorded_cut.argtypes = [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(i32)]
+    lib.gs_recorded_cut.restype = C.c_int
     lib.gs_set_forward_segments.restype = C.c_int
     lib.gs_image_layout.argtypes = [i32, i32, C.POINTER(GsImageLayout)]
     lib.gs_bin_layout.argtypes = [i64, C.c_uint32, i32, i32, C.POINTER(GsBinLayout)]
@@ -181,16 +189,38 @@ def get():
 
 def load_for_tests(path: str):
     """TEST HOOK ONLY: bind an alternative build of the same C ABI (the host-emulated kernels)."""
-    global _lib, _emulated
+    global _lib, _emulated, _status
     _lib = _bind(C.CDLL(path))
     _emulated = True
+    _status = None
     return _lib
 
 
 def unload_for_tests():
-    global _lib, _emulated
+    global _lib, _emulated, _status
     _lib = None
     _emulated = False
+    _status = None
+
+
+#: the library's host-mapped status word (gs_async_status_word), as a ctypes view: a plain host load per poll
+_status = None
+
+
+def poll_async_status():
+    """Called in front of every render: has a chained backward walk of an EARLIER launch run out of its bounded wait (include/gsplat_hip.h,
+    gs_set_backward_chain_polls)?  Then that backward's gradients hold NaNs: the word is cleared, chaining is switched off for the rest of the
+    process (every quadrant walked by one wavefront again: slower at 640 x 480, no hand-over to wait for) and the caller is told."""
+    global _status
+    if _status is None:
+        w = C.POINTER(C.c_uint32)()
+        check(get().gs_async_status_word(C.byref(w)))
+        _status = w
+    if _status[0]:
+        _status[0] = 0
+        check(get().gs_set_backward_chain(1, -1))
+        raise RuntimeError("activesplat_amd: a chained backward walk timed out waiting for the piece in front of it -- the gradients of the previous "
+                           "backward on this process are invalid (NaN).  Chained walks are now off (gs_set_backward_chain(1, -1)); render that frame again.")
 
 
 def emulated() -> bool:

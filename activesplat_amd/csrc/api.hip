@@ -161,6 +161,46 @@ int gs_set_backward_chain(int32_t pieces, int32_t min_tiles)
     return GS_OK;
 }
 
+int gs_set_backward_chain_tickets(int32_t on)
+{
+    gs::g_chain_tickets = on != 0;
+    return GS_OK;
+}
+
+int gs_set_backward_chain_polls(int32_t polls)
+{
+    gs::g_chain_polls = polls == -1 ? gs::kChainPollsDefault : polls;      // (below -1: every waiting piece gives up at once -- tests)
+    return GS_OK;
+}
+
+int gs_async_status_word(uint32_t** host_word)
+{
+    // one host-mapped word per process (portable: every device can raise it); plain host reads see it once the raising kernel has ended
+    static uint32_t* word = nullptr;
+    if (!word) {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(GS_ELAUNCH, "gs_async_status_word: hipHostMalloc failed");
+        }
+        memset(h, 0, 64);
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); return fail(GS_ELAUNCH, "gs_async_status_word: no device view of the host word"); }
+        word = (uint32_t*)h;
+        gs::g_async_status_dev = (uint32_t*)d;
+    }
+    if (host_word) *host_word = word;
+    return GS_OK;
+}
+
+int gs_recorded_cut(uint32_t target, uint32_t* nearest, int32_t* level)
+{
+    const uint32_t pos = gs::cut_nearest(target);
+    if (nearest) *nearest = pos;
+    if (level) *level = pos ? gs::cut_level(pos) : -1;
+    return GS_OK;
+}
+
 int gs_set_backward_segments(int32_t segments)
 {
     if (segments < 1 || segments > gs::kFewSegmentsMax) return fail(GS_EINVAL, "gs_set_backward_segments: 1, 2 or 3");

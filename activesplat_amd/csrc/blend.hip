@@ -182,6 +182,9 @@ __global__ __launch_bounds__(NW * kWave) void blend_forward_streams_kernel(
     }
 #define GS_FILL_REST() if (SEG == 0) { for (; zf < zf_end; zf += NW * kWave) zero_fill[zf] = make_float4(0.f, 0.f, 0.f, 0.f); }
     TileCtx c;
+    // chained backward walks: the ticket counters (behind the hand-over flags) start from zero with every forward
+    if (SEG == 0 && cam.chain > 1 && split_state && blockIdx.x == 0 && tid < 8)
+        reinterpret_cast<uint32_t*>(split_state)[(size_t)cam.gx * cam.gy * 4 * (kChainStateFloats + kChainPieces - 1) + (size_t)tid * kChainTicketStride] = 0u;
     if (!tile_ctx_nw<NW>(cam, wave, lane, c)) { GS_FILL_REST(); return; }
     // chained backward walks: the quadrant's hand-over flags start from zero with every forward (the backward's epoch is never zero)
     if (SEG == 0 && cam.chain > 1 && split_state && lane < kChainPieces - 1)
@@ -664,8 +667,22 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(3, 3
     // index order and a piece only ever waits for a LOWER index (same XCD: the group size is a multiple of 8), so the wait cannot deadlock.
     const int pieces = (!FEW && cam.chain > 1) ? cam.chain : 1;
     const unsigned group = gridDim.x / (unsigned)pieces;
-    const int piece = pieces > 1 ? (int)(blockIdx.x / group) : 0;
-    if (!tile_ctx_at<NW>(cam, pieces > 1 ? blockIdx.x - (unsigned)piece * group : blockIdx.x, wave, lane, c, nseg)) return;
+    // ORDERED TICKETS (cam.chain_ticket): the workgroup's place in the chain order is the ticket it draws NOW, from the counter of its index class
+    // (blockIdx & 7 -- on this part the XCD it runs on), so "the piece in front" is by construction a workgroup that drew earlier: running or
+    // done.  The index order of the dispatcher is then an optimisation (the chains start in list order), no longer a correctness assumption.
+    // The last drawer of a class puts its counter back to zero for the next launch on this workspace.
+    unsigned vb = blockIdx.x;
+    if (pieces > 1 && cam.chain_ticket) {
+        uint32_t* ctr = reinterpret_cast<uint32_t*>(const_cast<float*>(split_state)) + (size_t)cam.gx * cam.gy * 4 * (kChainStateFloats + kChainPieces - 1) +
+                        (size_t)(blockIdx.x & 7u) * kChainTicketStride;
+        unsigned t = 0u;
+        if (lane == 0) t = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        if (t == (gridDim.x >> 3) - 1u && lane == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vb = (t << 3) | (blockIdx.x & 7u);
+    }
+    const int piece = pieces > 1 ? (int)(vb / group) : 0;
+    if (!tile_ctx_at<NW>(cam, pieces > 1 ? vb - (unsigned)piece * group : vb, wave, lane, c, nseg)) return;
     // phase A role: row (lane>>4) = 4x4 sub-block, (lane&15) = pixel inside it
     const int row = lane >> 4, l16 = lane & 15;
     const int px = (int)c.qx0 + (row & 1) * 4 + (l16 & 3), py = (int)c.qy0 + (row >> 1) * 4 + (l16 >> 2);
@@ -782,16 +799,18 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(3, 3
         // (as late as possible: this walker's own loads are in flight while the piece in front of it finishes)
         // (state and flag travel as device-scope atomics, which bypass the non-coherent cache levels: no acquire on the poll -- a cache
         // invalidate per poll of thousands of waiting wavefronts costs everybody's record gathers their hits)
-        // HARDWARE ASSUMPTION: workgroups of one launch start in index order, so the piece in front (a lower index on
-        // this XCD) is resident or done when this one polls.  The poll is BOUNDED all the same (~0.3 s of polling): if the assumption ever
-        // failed, the walk goes on with NaN state -- NaN gradients for this quadrant's Gaussians, loud in every consumer -- instead of hanging
-        // the device.
+        // With ordered tickets (gs_set_backward_chain_tickets(1)) the piece in front drew its ticket before this one: it is resident or done.
+        // Without them (the default: the ticket costs 2.5-5 % of this kernel) that rests on workgroups starting in index order.  The poll is BOUNDED either way (~0.3 s): a wait
+        // that runs out raises the host-visible status bit and the walk goes on with NaN state -- NaN gradients for this quadrant's
+        // Gaussians, loud in every consumer -- instead of hanging the device.
         int polls = 0;
-        bool handed = true;
-        while (__hip_atomic_load(chain_fl + piece - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cam.chain_epoch) {
+        bool handed = cam.chain_polls >= 0;                 // (negative: give up without looking -- the tests' way to take the timeout path)
+        while (handed && __hip_atomic_load(chain_fl + piece - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cam.chain_epoch) {
             __builtin_amdgcn_s_sleep(16);
-            if (++polls > (1 << 21)) { handed = false; break; }
+            if (++polls > cam.chain_polls) handed = false;
         }
+        if (!handed && lane == 0 && cam.async_status)       // (host-mapped word: rasterizer.py reads it before the next launch and stops chaining)
+            __hip_atomic_fetch_or(cam.async_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         GS_WAIT_VMEM();
         const float* in = chain_st + (piece - 1) * 2 * kWave;
         T = __hip_atomic_load(in + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1034,6 +1053,12 @@ int g_half_quadrant_tiles = 256;
 // pieces of a chained backward walk (images of more than kChainMinTiles tiles); 1 switches the chaining off (tests, A/B measurements)
 int g_chain_pieces = kChainPieces;
 int g_chain_min_tiles = kChainMinTiles;
+// ordered tickets for the chained walks (gs_set_backward_chain_tickets): OFF by default -- the ticket is a fourth dependent round trip in front of a
+// walker's prologue and measured +4-6 us on the 2 M frame's 182 us, +7 us on configs[1]'s 135 us (profiles/r05_ab_tickets.txt); without them the
+// chain order is the workgroup index, which the dispatcher hands out in order.  Either way a wait is bounded and a timeout is reported.
+int g_chain_tickets = 0;
+int g_chain_polls = kChainPollsDefault;      // bound of a piece's wait for the piece in front (gs_set_backward_chain_polls: tests)
+uint32_t* g_async_status_dev = nullptr;      // device view of the host-mapped status word (api.hip: gs_async_status_word)
 // list segments (walkers) per quadrant in the few-tile backward: 3 x 256 tiles x 4 quadrants = the chip's 3072 walker slots (gs_set_backward_segments)
 int g_few_segments = kFewSegmentsMax;
 
@@ -1068,7 +1093,7 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
         if (e == hipSuccess && split_state && cam.gx * cam.gy <= kFewTiles)
             e = hipMemsetAsync(split_state + (kCutLevels * 5 + 4) * HW, 0, sizeof(uint32_t), st);    // nothing recorded
         if (e == hipSuccess && cam.chain > 1)      // (the segmented kernels do not clear the chained backward's hand-over flags)
-            e = hipMemsetAsync(split_state + (size_t)cam.gx * cam.gy * 4 * kChainStateFloats, 0, (size_t)cam.gx * cam.gy * 4 * (kChainPieces - 1) * sizeof(uint32_t), st);
+            e = hipMemsetAsync(split_state + (size_t)cam.gx * cam.gy * 4 * kChainStateFloats, 0, chain_flag_words((size_t)cam.gx * cam.gy) * sizeof(uint32_t), st);
         if (e != hipSuccess) return e;
         const dim3 grid(nb, segments);
         if (out_depth_sq) { GS_FWD(true, 1, grid); GS_FWD(true, 2, grid); }
@@ -1076,7 +1101,7 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
     } else if (cam.half || cam.split) {
         // images of few tiles: one producer / consumer workgroup per tile
         if (cam.chain > 1) {      // (an image of more than kFewTiles tiles sent here by gs_set_half_quadrants: this kernel does not clear the hand-over flags)
-            hipError_t e = hipMemsetAsync(split_state + (size_t)cam.gx * cam.gy * 4 * kChainStateFloats, 0, (size_t)cam.gx * cam.gy * 4 * (kChainPieces - 1) * sizeof(uint32_t), st);
+            hipError_t e = hipMemsetAsync(split_state + (size_t)cam.gx * cam.gy * 4 * kChainStateFloats, 0, chain_flag_words((size_t)cam.gx * cam.gy) * sizeof(uint32_t), st);
             if (e != hipSuccess) return e;
         }
         const dim3 grid(((cam.gx * cam.gy + 7) >> 3) << 3), block(kPcWaves * kWave);
@@ -1109,6 +1134,7 @@ hipError_t launch_blend_backward(const Cam& cam_in, const uint2* ranges, const u
     cam.chain = (cam.V == 1 && split_state && cam.gx * cam.gy > max(g_chain_min_tiles, kFewTiles) && g_chain_pieces > 1) ? g_chain_pieces : 0;
     static std::atomic<unsigned> epoch{0};
     do { cam.chain_epoch = ++epoch; } while (cam.chain_epoch == 0u);          // (the forward leaves zero in the hand-over flags)
+    cam.chain_ticket = g_chain_tickets; cam.chain_polls = g_chain_polls; cam.async_status = g_async_status_dev;
     const int per = ((cam.gx * cam.gy + 7) >> 3) * (cam.split ? cam.split : cam.chain > 1 ? cam.chain : 1);
 #define GS_BWD(DG, FEW)                                                                                                          \
     hipLaunchKernelGGL((blend_backward_kernel<DG, 1, FEW>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom, final_T, \

@@ -42,6 +42,12 @@ struct Cam {
     // launchers; 0 / 1: one walker per quadrant)
     int chain;
     unsigned chain_epoch;
+    // chained walks, robustness: chain_ticket != 0: a workgroup's (quadrant, piece) comes from an ORDERED TICKET it draws when it starts (one counter
+    // per blockIdx & 7), not from its index -- a piece then only ever waits for a workgroup that is already running or done, whatever order the
+    // hardware starts workgroups in; chain_polls bounds the wait all the same; a walker whose wait runs out sets bit 0 of *async_status
+    // (host-mapped, gs_async_status) and goes on with NaN state
+    int chain_ticket, chain_polls;
+    uint32_t* async_status;
     // raw-parameter mode of the per-Gaussian kernels (gs_preprocess_forward_raw / gs_render_backward_raw): the inputs are the mapper's
     // PARAMETERS -- world-frame means, unnormalised quaternions, logit opacities, log scales ([P,1] when act_iso) -- and the frame transform
     // + activations of slam_helpers.py:252-304,124-139 (activate.hip) happen inside the kernels; act_accumulate: the backward ADDS its
@@ -529,6 +535,9 @@ hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t
 extern int g_half_quadrant_tiles;
 extern int g_chain_pieces;
 extern int g_chain_min_tiles;
+extern int g_chain_tickets;
+extern int g_chain_polls;
+extern uint32_t* g_async_status_dev;
 extern int g_few_segments;
 // images of few tiles (at most kFewTiles; the knob above can only lower the limit): the forward records every pixel's running state
 // at the recorded list positions (cut_level below: every 256th up to 4096, then powers of two) for the segmented backward.  Planes of H*W floats: [level][T, C0, C1, C2, D], then the
@@ -539,7 +548,11 @@ constexpr int kFewTiles = 256;
 constexpr int kChainPieces = 3;
 constexpr int kChainMinTiles = 768;                       // default threshold: 3072 resident walkers / 4 quadrants (gs_set_backward_chain lowers it for tests)
 constexpr int kChainStateFloats = (kChainPieces - 1) * 2 * kWave;
-inline size_t chain_state_words(size_t tiles) { return tiles * 4 * (kChainStateFloats + (kChainPieces - 1)); }
+constexpr int kChainTicketStride = 32;                    // words between the eight ticket counters: one 128-byte line each
+constexpr int kChainTicketWords = 8 * kChainTicketStride; // ... behind the hand-over flags (zeroed with them by every forward)
+inline size_t chain_flag_words(size_t tiles) { return tiles * 4 * (kChainPieces - 1) + kChainTicketWords; }
+inline size_t chain_state_words(size_t tiles) { return tiles * 4 * kChainStateFloats + chain_flag_words(tiles); }
+constexpr int kChainPollsDefault = 1 << 21;               // ~0.3 s of polling
 // Recorded list positions (all multiples of the 64-record chunk): every kCutStep-th position up to kCutLinear (levels 0 .. kCutLinear /
 // kCutStep - 1), then the powers of two up to kCutLast.  (Round 3 recorded 128 * 2^k only: a list of 1900 could be cut at 1024 and nowhere
 // near a third or two thirds of it.)
@@ -570,8 +583,9 @@ __host__ __device__ inline uint32_t cut_nearest(uint32_t target)
         return k * kCutStep;
     }
     uint32_t pos = kCutLinear;
-    // the next power of two is nearer (in ratio) once target >= pos * sqrt(2)
-    while (pos < (uint32_t)kCutLast && (unsigned long long)target * 46341ull >= ((unsigned long long)pos << 17)) pos <<= 1;       // target >= 2 pos / sqrt 2
+    // the next power of two is nearer (in ratio) once target >= pos * sqrt(2): 46341 / 65536 = 1 / sqrt 2
+    // (round 4 shifted by 17: targets up to 2.83 pos stayed at pos, so that cuts above 4096 came out one level low -- results correct, walkers unbalanced)
+    while (pos < (uint32_t)kCutLast && (unsigned long long)target * 46341ull >= ((unsigned long long)pos << 16)) pos <<= 1;
     return pos;
 }
 hipError_t launch_emit(const Cam& cam, int P, GeomPtrs gp, uint64_t* keys, uint32_t* vals, hipStream_t st);

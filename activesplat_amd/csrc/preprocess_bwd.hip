@@ -26,14 +26,19 @@ namespace gs {
 #ifndef GS_PBWD_RAW_SH_WGS
 #define GS_PBWD_RAW_SH_WGS 4
 #endif
+// The parameter inputs are `__restrict__` only where nothing writes them: in the ADAM instantiation they ALIAS ad.p[0..4], which the same kernel
+// updates in place (every read of an element precedes its write through a data dependence, but a no-alias promise there would be a false one).
+template <bool NOALIAS> struct ParamPtr { typedef const float* __restrict__ type; };
+template <> struct ParamPtr<false> { typedef const float* type; };
+
 template <int SH, bool ACT = false, bool ADAM = false>
 __global__ __launch_bounds__(kBlock, (ACT && SH == 3) ? GS_PBWD_RAW_SH_WGS : 4) void preprocess_backward_kernel(
-    Cam cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
-    const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov3Dp,
+    Cam cam, int P, typename ParamPtr<!ADAM>::type means3D, typename ParamPtr<!ADAM>::type shs,
+    typename ParamPtr<!ADAM>::type scales, typename ParamPtr<!ADAM>::type rots, const float* __restrict__ cov3Dp,
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const float2* __restrict__ sh_jac,
     const float* __restrict__ grad2d, float* __restrict__ dmeans2D, float* __restrict__ dmeans3D, float* __restrict__ dopac,
     float* __restrict__ dcolors, float* __restrict__ dshs, float* __restrict__ dscales,
-    float* __restrict__ drots, float* __restrict__ dcov3D, const float* __restrict__ logit, FusedAdam ad)
+    float* __restrict__ drots, float* __restrict__ dcov3D, typename ParamPtr<!ADAM>::type logit, FusedAdam ad)
 {
     // per-wave slabs: 32 coefficient rows in, their gradients written back IN PLACE (each element is read before it is overwritten)
     constexpr bool HAS_SH = SH != 0;

@@ -253,16 +253,37 @@ def unit_gradient(like: torch.Tensor) -> torch.Tensor:
 _LOSS_SCRATCH = {}
 
 
+#: bound on the bytes the cache pins (a 640 x 480 entry is 11 MB; streams and sizes come and go): oldest entries leave first
+_LOSS_SCRATCH_MAX_BYTES = 256 << 20
+
+
 def _loss_scratch(lib, dev, W, H):
+    """-> (key, scratch, persistent_call).  The entry's call counter is advanced by _loss_scratch_done() only AFTER the call succeeded: a call that
+    raises drops its entry (the accumulator set it was to use may be half-written, and the next call's set was not cleared), so the next call starts
+    from a freshly zeroed scratch.  While the stream is being captured into a graph the persistent protocol is not used at all (a replay would bake one
+    parity in and never clear the set it accumulates into): persistent_call = 0, the library's memset form, on a private buffer."""
     from . import _lib
+    if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        return None, torch.empty(int(lib.gs_mapping_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev), 0
     key = (dev.index, _lib.stream_handle(dev), W, H)
     ent = _LOSS_SCRATCH.get(key)
     if ent is None:
-        if len(_LOSS_SCRATCH) >= 32:
+        nbytes = int(lib.gs_mapping_loss_scratch_bytes(W, H))
+        while _LOSS_SCRATCH and (len(_LOSS_SCRATCH) >= 32 or sum(e[0].numel() for e in _LOSS_SCRATCH.values()) + nbytes > _LOSS_SCRATCH_MAX_BYTES):
             _LOSS_SCRATCH.pop(next(iter(_LOSS_SCRATCH)))
-        ent = _LOSS_SCRATCH[key] = [torch.zeros(int(lib.gs_mapping_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev), 0]
-    ent[1] += 1
-    return ent[0], ent[1]
+        ent = _LOSS_SCRATCH[key] = [torch.zeros(nbytes, dtype=torch.uint8, device=dev), 0]
+    return key, ent[0], ent[1] + 1
+
+
+def _loss_scratch_done(key, ok):
+    if key is None:
+        return
+    if ok:
+        ent = _LOSS_SCRATCH.get(key)
+        if ent is not None:
+            ent[1] += 1
+    else:
+        _LOSS_SCRATCH.pop(key, None)
 
 
 class _FusedMappingLoss(torch.autograd.Function):
@@ -282,9 +303,14 @@ class _FusedMappingLoss(torch.autograd.Function):
         d_im, d_depth = grads[:3], grads[3:]
         st = _lib.stream_ptr(dev)
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-        scratch, call = _loss_scratch(lib, dev, W, H)
-        _lib.check(lib.gs_mapping_loss(W, H, p(im_), p(gt_), p(depth_), p(dsq_), p(gtd_), float(w_im), float(w_depth), p(buf),
-                                       p(d_im), p(d_depth), p(scratch), call, st))
+        key, scratch, call = _loss_scratch(lib, dev, W, H)
+        try:
+            _lib.check(lib.gs_mapping_loss(W, H, p(im_), p(gt_), p(depth_), p(dsq_), p(gtd_), float(w_im), float(w_depth), p(buf),
+                                           p(d_im), p(d_depth), p(scratch), call, st))
+        except Exception:
+            _loss_scratch_done(key, False)
+            raise
+        _loss_scratch_done(key, True)
         ctx.save_for_backward(grads)
         ctx.set_materialize_grads(False)
         losses, loss = buf[:3], buf[3]          # two views of one small buffer: no clone kernel for the scalar

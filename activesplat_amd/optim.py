@@ -152,6 +152,14 @@ class GaussianAdam:
             t.lr = float(g["lr"]); t.beta1 = float(b1); t.beta2 = float(b2); t.eps = float(g["eps"]); t.step = int(st["step"])
         return arr
 
+    def rollback_backward_step(self, tensors):
+        """Undo the bookkeeping of backward_step_descriptors(tensors) for a launch that failed: the step counters go back by one, so that moments
+        and counters stay in step."""
+        for p in tensors:
+            st = self.state.get(p)
+            if st:
+                st["step"] = int(st["step"]) - 1
+
 
 def densify_event(iter, densify_dict) -> bool:
     """Does densify(..., iter, densify_dict) restructure the map or reset parameters at this iteration (as opposed to only accumulating

@@ -378,10 +378,12 @@ def _world(group, world):
     return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
 
-def sharded_densify(params, variables, optimizer, iter, densify_dict, group=None, base_seed=0x5EED, accumulate=True, world=None):
+def sharded_densify(params, variables, optimizer, iter, densify_dict, group=None, base_seed=0x5EED, accumulate=True, world=None, before_event=None):
     """optim.densify for a keyframe-sharded loop (call it on EVERY rank at the same iteration; slam_external.py:195-247).
     accumulate=True: this rank's most recent keyframe adds its statistics first (the reference's per-iteration accumulation; pass False when
-    sharded_keyframe_step(accumulate_statistics=True) already added every keyframe's).  world=1 skips the collectives (one rank running alone)."""
+    sharded_keyframe_step(accumulate_statistics=True) already added every keyframe's).  world=1 skips the collectives (one rank running alone).
+    before_event(params, variables, densify_dict) -> densify_dict: called on event iterations once the statistics are complete and identical on
+    every rank (an adaptive gradient threshold, logging); whatever it decides must be a function of those replicated values."""
     from . import optim as O
     if iter > densify_dict["stop_after"]:
         return params, variables
@@ -391,6 +393,8 @@ def sharded_densify(params, variables, optimizer, iter, densify_dict, group=None
         if _world(group, world) > 1:
             all_reduce_statistics(variables, group)
             gather_moments(params, optimizer, group)
+        if before_event is not None:
+            densify_dict = before_event(params, variables, densify_dict)
         n = int(params["means3D"].shape[0])
         params, variables = O.densify(params, variables, optimizer, iter, densify_dict, seed=event_seed(base_seed, iter, n), accumulate=False)
         optimizer._shard_plan = None

@@ -158,6 +158,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         leaves = (means3D, opacities, scales, rotations, colors_precomp)     # (raw + accumulate: the backward adds into these tensors' .grad)
         shs_in = shs
         _require_rocm(device)
+        _lib.poll_async_status()                 # (a plain host load: did a chained backward of an earlier launch give up its wait?)
         P = int(means3D.shape[0])
         means3D = _f32(means3D, device)
         shs, colors_precomp = _f32(shs, device), _f32(colors_precomp, device)
@@ -292,14 +293,27 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                          # takes a fresh buffer plus a memset
         if ctx.raw is not None and ctx.adam is not None:
             # single-keyframe step: Adam on the five per-Gaussian tensors rides in the per-Gaussian backward kernel (no gradient tensors)
+            if ctx.adam == "stepped":
+                # (retain_graph + a second backward through this render would apply the optimiser step twice, on already-stepped parameters)
+                raise RuntimeError("render_rgbd_raw(adam=...): this render's backward has already applied its optimiser step; a second backward "
+                                   "through the same graph is refused -- render again, or use accumulate_grads / a separate optimizer.step()")
             pose, iso, _acc, logit = ctx.raw
             d_m2d = torch.empty(P, 3, dtype=torch.float32, device=device)
             opt, tensors = ctx.adam
-            desc = opt.backward_step_descriptors(tensors)
-            _lib.check(lib.gs_render_backward_raw_adam(
-                C.byref(cam), P, ctx.D, _ptr(means3D), _ptr(shs if has_sh else None), _ptr(colors if has_col else None), _ptr(logit),
-                _ptr(scales), _ptr(rots), pose, iso, _ptr(radii), _ptr(geom), _ptr(point_list), _ptr(image), _ptr(grad_color),
-                _ptr(grad_depth), _ptr(d_m2d), _ptr(scratch), 1 if clean else 0, int(ctx.sh_jac), desc, _stream(device)))
+            ctx.adam = "stepped"
+            desc = opt.backward_step_descriptors(tensors)                 # (advances the step counters ...)
+            try:
+                _lib.check(lib.gs_render_backward_raw_adam(
+                    C.byref(cam), P, ctx.D, _ptr(means3D), _ptr(shs if has_sh else None), _ptr(colors if has_col else None), _ptr(logit),
+                    _ptr(scales), _ptr(rots), pose, iso, _ptr(radii), _ptr(geom), _ptr(point_list), _ptr(image), _ptr(grad_color),
+                    _ptr(grad_depth), _ptr(d_m2d), _ptr(scratch), 1 if clean else 0, int(ctx.sh_jac), desc, _stream(device)))
+            except Exception:
+                opt.rollback_backward_step(tensors)                       # (... which a launch that did not happen must not keep)
+                raise
+            # the parameters changed in place behind autograd's back: bump their version counters, so that any other graph that saved them
+            # (a regulariser on the same parameters, a second keyframe rendered before this backward) fails loudly in ITS backward instead of
+            # differentiating through stepped values -- and note that such a branch gets no rasteriser gradient from this render
+            torch.autograd.graph.increment_version([t for t in tensors if t is not None])
             return None, d_m2d, None, None, None, None, None, None, None, None, None
         z = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731  (kernel writes every row)
         d_m2d, d_m3d, d_op = z(P, 3), z(P, 3), z(P, 1)

@@ -248,7 +248,9 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
         prm = {k: torch.nn.Parameter(v.to(dev)) for k, v in raw.items()}
         prm["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([1.0, 0, 0, 0], device=dev).reshape(1, 4, 1))
         prm["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 1, device=dev))
-        return prm, O.initialize_optimizer(prm, lrs), {k: torch.zeros(N, device=dev) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+        var = {k: torch.zeros(N, device=dev) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+        var["scene_radius"] = torch.tensor(10.0, device=dev)
+        return prm, O.initialize_optimizer(prm, lrs), var
     params, opt, variables = fresh()
     cam = setup_camera(W, H, K, np.eye(4), device=dev, sh_degree=max(args.c4_sh_degree, 0))
     mine = set(PL.shard_keyframes(KF, rank, world)) if world > 1 else set(range(KF))
@@ -277,21 +279,45 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
 
     state = dict(v=variables, it=0)
     ex_ms, rd_ms = [], []
+    every = int(args.c4_densify_every)
+    ddict = dict(start_after=0, remove_big_after=0, stop_after=10 ** 9, densify_every=max(every, 1), grad_thresh=0.0, num_to_split_into=2,
+                 removal_opacity_threshold=0.005, final_removal_opacity_threshold=0.005, reset_opacities=False, reset_opacities_every=10 ** 9)
+    events = []
+
+    def threshold_from_statistics(p, v, dd):
+        # (the statistics are complete and identical on every rank here: the quantile is a function of replicated values)
+        g = v["means2D_gradient_accum"] / v["denom"].clamp_min(1.0)
+        k = max(1, min(g.numel(), int(round(args.c4_densify_quantile * g.numel()))))
+        return dict(dd, grad_thresh=float(torch.kthvalue(g, k).values))
+
+    def densify_step(prm, o, st, w):
+        """the event of step st['it'], if one is due: -> (N before, N after, grad_thresh) or None"""
+        if not every or st["it"] % every:
+            return None
+        n0 = int(prm["means3D"].shape[0])
+        seen_thr = {}
+
+        def hook(p, v, dd):
+            dd = threshold_from_statistics(p, v, dd); seen_thr["t"] = dd["grad_thresh"]
+            return dd
+        _, st["v"] = PL.sharded_densify(prm, st["v"], o, st["it"], ddict, accumulate=False, world=w, before_event=hook)
+        return (n0, int(prm["means3D"].shape[0]), seen_thr.get("t"))
 
     def step():
         _, state["v"], _ = PL.sharded_keyframe_step(params, state["v"], keyframes, opt, loss_fn, rank=rank, world=world,
-                                                    sharded_adam=True, streams=args.streams, timing=True)
+                                                    sharded_adam=True, streams=args.streams, timing=True, accumulate_statistics=bool(every))
         state["it"] += 1
         if world > 1:
-            if state["it"] % args.stats_every == 0:            # the densifier's statistics are combined (sum, sum, max) every k-th step
-                PL.all_reduce_statistics(state["v"])
             ex_ms.append(PL.last_exchange.get("events"))
             rd_ms.append(PL.last_exchange.get("render_events"))
+            ev = densify_step(params, opt, state, world)       # every k-th step: statistics all-reduced, moments gathered, rows moved, plan rebuilt
+            if ev is not None:
+                events.append(ev)
     if world > 1:
         for _ in range(args.warmup):
             step()
         barrier()
-        ex_ms.clear(); rd_ms.clear()
+        ex_ms.clear(); rd_ms.clear(); events.clear()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -321,7 +347,8 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
                        "gaussians": N, "width": W, "height": H, "keyframes_per_step": KF, "keyframes_per_rank_per_step": KF // max(world, 1),
                        "tile_instances_D_last_keyframe": D, "streams": args.streams, "exchange_floats_per_gaussian": 59 if sh else 14,
                        "grad_exchange": dict(exch, note="the collectives that actually ran (activesplat_amd.parallel.last_exchange)"),
-                       "statistics_all_reduce_every": args.stats_every,
+                       "densify_every": every, "densify_events_in_timed_region": [dict(n_before=a, n_after=b, grad_thresh=c) for a, b, c in events],
+                       "gaussians_at_end": int(params["means3D"].shape[0]),
                        "loss": "fused mapping loss (L1 + SSIM + masked depth) through the single-pass RGB-D render",
                        "parallelism": f"keyframe-sharded x{world}"},
             "exchange_plus_adam_ms": round(float(np.mean(ex)), 4) if ex else None,
@@ -348,14 +375,27 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
         for _ in range(n_ref):
             step1()
         torch.cuda.synchronize()
-        ref = KF * n_ref / (time.perf_counter() - t1)
+        t_steps = time.perf_counter() - t1
+        ev1 = None
+        if every:
+            # the single-GPU figure carries the same densify cadence as the sharded run: one event timed here (statistics of one more batch
+            # accumulated first), its time spread over `every` steps
+            _, s1["v"], _ = PL.sharded_keyframe_step(p1, s1["v"], keyframes, o1, loss_fn, rank=0, world=1, sharded_adam=True, streams=1, accumulate_statistics=True)
+            s1["it"] = every
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            ev1 = densify_step(p1, o1, s1, 1)
+            torch.cuda.synchronize()
+            t_event = time.perf_counter() - t2
+            t_steps += t_event * n_ref / every
+        ref = KF * n_ref / t_steps
         if world > 1:
             out["single_gpu_same_workload_fps"] = round(ref, 2)
             out["speedup_vs_single_gpu_same_workload"] = round(out["value"] / ref, 3)
         else:
             out = {"workload": f"BASELINE configs[3] on ONE GPU: {N} Gaussians, {KF} keyframes per optimiser step (activations inside the per-Gaussian kernels of the RGB-D render -> "
                                "fused loss -> backward per keyframe, fused Adam), no collective", "keyframes_per_s": round(ref, 2),
-                   "ms_per_optimiser_step": round(KF / ref * 1e3, 3), "streams": args.streams}
+                   "ms_per_optimiser_step": round(KF / ref * 1e3, 3), "streams": args.streams,
+                   "densify_every": every, "densify_event": None if ev1 is None else dict(n_before=ev1[0], n_after=ev1[1], grad_thresh=ev1[2], ms=round(t_event * 1e3, 3))}
             # ---- what ONE device can say about the 8-GPU run: every rank's shard of the batch timed alone (load balance: D differs per
             # view), and the exchange as a ONE-rank RCCL group runs it (pack -> reduce_scatter_tensor -> Adam -> all_gather_into_tensor ->
             # unpack; there the Adam still covers ALL rows and nothing crosses xGMI) ----
@@ -428,7 +468,10 @@ def main():
     ap.add_argument("--c4-sh-degree", type=int, default=-1, help="configs[3]: -1 = `rgb_colors` (the reference mapper's map, G = 14 floats per Gaussian "
                                                                  "in the exchange); 0..3 = 16-coefficient SH rows (`shs`, G = 59)")
     ap.add_argument("--predict-ranks", type=int, default=8, help="configs[3] on one GPU: ranks of the load-balance / exchange prediction leg")
-    ap.add_argument("--stats-every", type=int, default=10, help="configs[3]: all-reduce the densifier's statistics every k-th step")
+    ap.add_argument("--c4-densify-every", type=int, default=10, help="configs[3]: a densify event (all-reduced statistics -> gathered moments -> fused clone / "
+                    "split / cull with the split offsets drawn from a replicated seed -> rebuilt shard plan) every k-th optimiser step; 0: never")
+    ap.add_argument("--c4-densify-quantile", type=float, default=0.995, help="configs[3]: the event's gradient threshold is this quantile of the batch's "
+                    "reduced mean-2D gradient statistic, so that an event clones / splits ~0.5 %% of the map and the workload stays configs[3]'s")
     ap.add_argument("--workload", choices=("auto", "c4"), default="auto", help="auto: configs[2]'s render on one GPU, configs[3] on several")
     args = ap.parse_args()
 

@@ -141,6 +141,22 @@ int gs_set_half_quadrants(int32_t max_tiles);
  * quadrant) that run as separate workgroups in dispatch order and hand the per-pixel running state on through the image workspace.  The
  * arithmetic per pixel is the same sequence either way (gradients differ only by the order of the atomic sums). */
 int gs_set_backward_chain(int32_t pieces, int32_t min_tiles);
+/* Chained walks, robustness.  Ordered tickets (gs_set_backward_chain_tickets(1); default OFF: one more dependent round trip per walker, measured
+ * +2.5-5 % of the backward blend): a workgroup's place in the chain order is a ticket it draws when it starts, so the piece it waits for is by
+ * construction already running or done -- no assumption about the order in which the hardware starts workgroups.  Off: the place is the
+ * workgroup index, which the dispatcher hands out in order (a piece only ever waits for a lower index of its own XCD class).
+ * gs_set_backward_chain_polls: bound of a piece's wait, in polls (-1: the default, 2^21 ~ 0.3 s; below -1: every piece gives up without
+ * looking -- the tests' way to take the timeout path).
+ * A wait that runs out sets bit 0 of the process' host-mapped status word and the walk continues with NaN state (NaN gradients for that
+ * quadrant's Gaussians).  gs_async_status_word returns the word's HOST address (created on first call; call it once before the first
+ * backward): the caller reads it -- a plain load -- before its next launch; non-zero = the previous chained backward's gradients are invalid:
+ * clear the word, gs_set_backward_chain(1, -1), and render again (activesplat_amd/rasterizer.py does exactly that). */
+int gs_set_backward_chain_tickets(int32_t on);
+int gs_set_backward_chain_polls(int32_t polls);
+int gs_async_status_word(uint32_t** host_word);
+/* Introspection of the few-tile backward's cuts: the recorded list position nearest to `target` (0: none below it) and its level (-1: none) --
+ * every 256th position up to 4096, then the powers of two up to 131072, nearest in ratio above 4096. */
+int gs_recorded_cut(uint32_t target, uint32_t* nearest, int32_t* level);
 /* Test / tuning knob: list segments (walkers) per quadrant in the backward blend of images of few tiles (at most 256): 3 (default: 3 x 256
  * tiles x 4 quadrants = the chip's 3072 walker slots), 2, or 1 (one walker per quadrant; the forward then records nothing).  The walkers
  * of a quadrant resume from the per-pixel state the forward recorded at every 256th list position up to 4096 and at the powers of two
@@ -154,7 +170,7 @@ const char* gs_version(void);
 /* Integer version of THIS binary interface: bumped whenever an entry point's argument list or a published record layout changes (e.g.
  * the seed argument of gs_densify_children, the 40-byte SH Jacobian record).  A host binding compares it with the GS_ABI_VERSION it was
  * written against before the first call, so that a stale prebuilt library fails at load time instead of misreading its arguments. */
-#define GS_ABI_VERSION 8
+#define GS_ABI_VERSION 9
 int32_t gs_abi_version(void);
 
 /* Optional per-stage timing (hipEvents recorded on the caller's stream around each stage's launches).

@@ -311,6 +311,9 @@ template <class T> static inline T hipemu_atomic_load(const T* p, int order) { T
 template <class T, class U> static inline void hipemu_atomic_store(T* p, U val, int order) { T v = (T)val; __atomic_store(p, &v, order); }
 #define __hip_atomic_load(p, order, scope) hipemu_atomic_load(p, order)
 #define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store(p, v, order)
+#define __HIP_MEMORY_SCOPE_SYSTEM 1
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, order)
+#define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or(p, v, order)
 // a waiting wavefront on the device sleeps ~64 x clocks per s_sleep; here the poller gives its host thread away for a moment, so that a bounded
 // poll loop of the kernels (2^21..2^22 polls) stays a bound of seconds, as on the device, instead of milliseconds
 static inline void hipemu_sleep() { struct timespec ts = {0, 2000}; nanosleep(&ts, nullptr); }
@@ -324,6 +327,9 @@ static inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_C
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memmove(d, s, n); return 0; }
 static inline hipError_t hipHostGetDevicePointer(void** dp, void* hp, unsigned) { *dp = hp; return 0; }   // host memory IS device memory here
+#define hipHostMallocMapped 2u
+#define hipHostMallocPortable 1u
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n); return *p ? 0 : 2; }
 typedef void* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }

@@ -323,6 +323,64 @@ def check_adam_inside_the_backward(device, n=600, W=64, H=48, steps=3, exact=Tru
                 assert float((d > 1e-6 * float(b[0][k].abs().max())).float().mean()) < 1e-3, (k, sh, iso, it, float(d.max()))
 
 
+def check_adam_backward_guards(device, n=400, W=64, H=48):
+    """The in-kernel optimiser step is applied at most once per render and never silently: a second backward through the same graph is
+    refused; the stepped parameters' version counters move, so a graph that saved them before the step fails in ITS backward; a launch that fails
+    leaves step counters and moments in step."""
+    from activesplat_amd import _lib, optim as O, rasterizer as R
+    from activesplat_amd import synthetic as syn
+    from activesplat_amd.camera import setup_camera
+    pose = [1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    p0 = syn.make_params(n, W, H, seed=2)
+    cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=device)
+    prm = {k: torch.nn.Parameter(v.clone().to(device)) for k, v in p0.items()}
+    opt = O.initialize_optimizer(prm, {k: 1e-3 for k in prm})
+
+    def render():
+        m2d = torch.empty_like(prm["means3D"], requires_grad=True)
+        return R.render_rgbd_raw(cam, prm["means3D"], m2d, prm["logit_opacities"], prm["log_scales"], prm["unnorm_rotations"], pose, adam=opt,
+                                 colors_precomp=prm["rgb_colors"])
+    im = render()[0]
+    reg = (prm["means3D"] ** 2).sum()                       # another branch that saved the parameter before the step
+    v0 = prm["means3D"]._version
+    before = prm["means3D"].detach().clone()
+    im.sum().backward(retain_graph=True)
+    assert prm["means3D"]._version > v0 and not torch.equal(before, prm["means3D"].detach())
+    steps = {k: int(opt.state[v]["step"]) for k, v in prm.items()}
+    assert set(steps.values()) == {1}
+    after = prm["means3D"].detach().clone()
+    try:
+        im.sum().backward()
+        raise AssertionError("a second backward through a stepped render must be refused")
+    except RuntimeError as e:
+        assert "already applied its optimiser step" in str(e) or "modified by an inplace operation" in str(e), e
+    assert torch.equal(after, prm["means3D"].detach()) and {k: int(opt.state[v]["step"]) for k, v in prm.items()} == steps
+    try:
+        reg.backward()
+        raise AssertionError("a graph that saved the parameters before the in-kernel step must not differentiate through stepped values silently")
+    except RuntimeError as e:
+        assert "modified by an inplace operation" in str(e), e
+    # a failing launch: the step counters are rolled back
+    im = render()[0]
+    real = _lib.check
+
+    def failing(code):
+        raise RuntimeError("injected launch failure")
+    _lib.check = failing
+    try:
+        try:
+            im.sum().backward()
+            raise AssertionError("the injected failure must surface")
+        except RuntimeError as e:
+            assert "injected launch failure" in str(e)
+    finally:
+        _lib.check = real
+    assert {k: int(opt.state[v]["step"]) for k, v in prm.items()} == steps
+    im = render()[0]
+    im.sum().backward()
+    assert set(int(opt.state[v]["step"]) for v in prm.values()) == {2}
+
+
 def check_mapping_iteration_without_autograd(device, n=500, exact=True):
     """mapping.mapping_iteration (the iteration's four library calls issued directly) against get_loss(fused..., fused_adam=) + backward + step +
     zero_grad through autograd: parameters, moments, loss, means2D.grad, seen, max_2D_radius after three iterations on three keyframes;
@@ -444,6 +502,53 @@ def check_chained_backward(device, oracle64, N=5000, W=288, H=272, oracle32=None
         check_backward(rs._replace(debug=True), rv, oracle64, seed=7, oracle32=oracle32)
     finally:
         _lib.check(lib.gs_set_backward_chain(3, -1))
+
+
+def check_chained_backward_fails_safe(device, N=5000, W=288, H=272, seed=33):
+    """VERDICT r4 item 6.  (a) ordered tickets on / off give the same gradients (the arithmetic per pixel is the same sequence); (b) a wait that
+    runs out (provoked: gs_set_backward_chain_polls(-2)) raises the host-visible status word: the next render raises, chaining is off afterwards
+    and the frame rendered again is right; nothing hangs."""
+    from activesplat_amd import _lib
+    lib = _lib.get()
+    rs, rv = util.scene(N, W, H, seed=seed, device=device, scale_jitter=0.5)
+    rs = rs._replace(debug=False)
+    rv["opacities"] = (rv["opacities"] * 0.15).clamp(0, 1)
+    rv["scales"] = rv["scales"] * 3.0
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(7))
+    sync = (lambda: torch.cuda.synchronize()) if device != "cpu" else (lambda: None)
+    try:
+        _lib.check(lib.gs_set_backward_chain(3, 256)); _lib.check(lib.gs_set_backward_chain_tickets(0))
+        plain = util.run_product(rs, rv, dL)
+        _lib.check(lib.gs_set_backward_chain_tickets(1))
+        tick = util.run_product(rs, rv, dL)
+        tick2 = util.run_product(rs, rv, dL)                      # (a second launch: the last drawer put the counters back)
+        for k, g in tick["grads"].items():
+            for other in (plain, tick2):
+                r = other["grads"][k]
+                assert np.isfinite(g).all() and np.linalg.norm(g.astype(np.float64) - r) <= 2e-5 * max(np.linalg.norm(r), 1e-30), k
+        # (b) the timeout path
+        _lib.poll_async_status()
+        _lib.check(lib.gs_set_backward_chain_polls(-2))
+        bad = util.run_product(rs, rv, dL)
+        sync()
+        assert not all(np.isfinite(g).all() for g in bad["grads"].values())      # NaN state went through the pieces behind the first
+        try:
+            util.run_product(rs, rv, dL)
+            raise AssertionError("the render after a timed-out chained backward must raise")
+        except RuntimeError as e:
+            assert "timed out" in str(e), e
+        _lib.check(lib.gs_set_backward_chain_polls(-1))
+        again = util.run_product(rs, rv, dL)                       # chaining is off now (one walker per quadrant): finite and equal
+        sync()
+        _lib.poll_async_status()
+        for k, g in again["grads"].items():
+            r = plain["grads"][k]
+            assert np.isfinite(g).all() and np.linalg.norm(g.astype(np.float64) - r) <= 2e-5 * max(np.linalg.norm(r), 1e-30), k
+    finally:
+        _lib.check(lib.gs_set_backward_chain_polls(-1)); _lib.check(lib.gs_set_backward_chain_tickets(0))
+        _lib.check(lib.gs_set_backward_chain(3, -1))
+        if _lib._status is not None:
+            _lib._status[0] = 0
 
 
 #: tally of check_backward's fp32 escape hatch over the session (printed by tests/conftest.py); "decisions": how often the third tier -- rows of

@@ -85,3 +85,23 @@ def test_dropin_module_name_and_settings_tuple():
     assert Camera._fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
                               "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
     assert issubclass(Renderer, torch.nn.Module) and hasattr(d, "rasterize_gaussians")
+
+
+def test_recorded_cut_positions_are_nearest_in_ratio():
+    """cut_nearest chose the lower power of two for every target up to 2.83 x it (a shift by 17 where 16 was meant): the nearest recorded
+    position in RATIO switches at sqrt(2) x.  gs_recorded_cut exposes the device function (the few-tile backward cuts its walks there)."""
+    import ctypes as C
+    from activesplat_amd import _lib
+    lib = C.CDLL(_lib.LIB_PATH)
+    lib.gs_recorded_cut.argtypes = [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+
+    def cut(t):
+        pos, lvl = C.c_uint32(), C.c_int32()
+        assert lib.gs_recorded_cut(t, C.byref(pos), C.byref(lvl)) == 0
+        return pos.value, lvl.value
+    assert cut(100) == (0, -1) and cut(128) == (256, 0) and cut(1000) == (1024, 3) and cut(4096) == (4096, 15)
+    assert cut(5000) == (4096, 15) and cut(5792) == (4096, 15) and cut(5794) == (8192, 16)          # 4096 sqrt 2 = 5792.6
+    assert cut(6000) == (8192, 16) and cut(11585) == (8192, 16) and cut(11586) == (16384, 17)
+    assert cut(12000) == (16384, 17) and cut(24000) == (32768, 18) and cut(10 ** 9) == (131072, 20)
+    # three walkers of a 30 000-deep list: cuts at 8192 and 16384 (round 4: 4096 and 8192 -- the last walker took 73 % of the walk)
+    assert cut(30000 // 3)[0] == 8192 and cut(2 * 30000 // 3)[0] == 16384

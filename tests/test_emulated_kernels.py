@@ -133,6 +133,10 @@ def test_emulated_adam_inside_the_backward_equals_backward_plus_step(emu):
         omp.omp_set_num_threads(before)
 
 
+def test_emulated_adam_inside_the_backward_is_applied_once_and_never_silently(emu):
+    pc.check_adam_backward_guards(emu)
+
+
 def test_emulated_mapping_iteration_without_autograd_equals_the_autograd_path(emu):
     import ctypes
     omp = ctypes.CDLL("libgomp.so.1")
@@ -184,6 +188,10 @@ def test_whole_quadrants_on_small_images(emu, oracle32, oracle64):
 
 def test_emulated_chained_backward(emu, oracle64, oracle32):
     pc.check_chained_backward(emu, oracle64, oracle32=oracle32)
+
+
+def test_emulated_chained_backward_fails_safe(emu):
+    pc.check_chained_backward_fails_safe(emu, N=2500)
 
 
 def test_emulated_few_tile_backward_segments(emu, oracle64, oracle32):

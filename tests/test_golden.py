@@ -482,6 +482,25 @@ def test_fused_loss_persistent_scratch_alternating_inputs(backend):
         im, depth, gt_im, gt_d, ref = pairs[call % 2]
         loss, parts = M.fused_mapping_loss(im, depth, depth ** 2 + 0.1, gt_im, gt_d, dict(im=0.5, depth=1.0))
         np.testing.assert_allclose(float(loss), ref, rtol=5e-6, err_msg=f"call {call}")
+    # a call that raises: its cache entry is dropped, so the call after it starts from a zeroed scratch instead of accumulating into a set
+    # that the failed call's second kernel never cleared
+    from activesplat_amd import _lib
+    real = _lib.check
+    n_entries = len(M._LOSS_SCRATCH)
+
+    def failing(code):
+        raise RuntimeError("injected launch failure")
+    _lib.check = failing
+    try:
+        with pytest.raises(RuntimeError, match="injected"):
+            M.fused_mapping_loss(*pairs[1][:2], pairs[1][1] ** 2 + 0.1, *pairs[1][2:4], dict(im=0.5, depth=1.0))
+    finally:
+        _lib.check = real
+    assert len(M._LOSS_SCRATCH) == n_entries - 1
+    for call in range(3):
+        im, depth, gt_im, gt_d, ref = pairs[call % 2]
+        loss, parts = M.fused_mapping_loss(im, depth, depth ** 2 + 0.1, gt_im, gt_d, dict(im=0.5, depth=1.0))
+        np.testing.assert_allclose(float(loss), ref, rtol=5e-6, err_msg=f"call {call} after the failure")
 
 
 def test_fused_loss_backward_with_the_cached_unit_gradient(backend):

@@ -370,6 +370,56 @@ def test_chained_backward_small(hip, oracle64, oracle32, seed, N, W, H):
     pc.check_chained_backward(hip, oracle64, N=N, W=W, H=H, oracle32=oracle32, seed=seed)
 
 
+def test_chained_backward_fails_safe(hip):
+    pc.check_chained_backward_fails_safe(hip, N=20000, W=400, H=304, seed=36)
+
+
+@pytest.mark.parametrize("tickets", [0, 1], ids=["index-order", "ordered-tickets"])
+def test_chained_backward_on_two_streams_concurrently(hip, tickets):
+    """the chained backward at 640 x 480 (1200 tiles: the default there) on two HIP streams at once, 100 iterations -- each
+    stream's gradients finite and equal to its serial run to 2e-5, the status word silent.  Two launches share the chip's walker slots, so a
+    piece's predecessor may be queued behind the other launch's workgroups: the case ordered tickets exist for."""
+    from activesplat_amd import _lib, GaussianRasterizer
+    _lib.poll_async_status()
+    _lib.check(_lib.get().gs_set_backward_chain_tickets(tickets))
+    scenes = []
+    for seed in (0, 1):
+        rs, rv = util.scene(150_000, 640, 480, seed=seed, device=hip)
+        rs = rs._replace(debug=False)
+        dL = torch.randn(3, 480, 640, generator=torch.Generator().manual_seed(5 + seed)).to(hip)
+        scenes.append((rs, rv, dL))
+
+    def fwd_bwd(rs, rv, dL):
+        inp = {k: v.detach().clone().requires_grad_(True) for k, v in rv.items()}
+        m2d = torch.zeros(rv["means3D"].shape[0], 3, device=hip, requires_grad=True)
+        color = GaussianRasterizer(raster_settings=rs)(means2D=m2d, **inp)[0]
+        color.backward(dL)
+        return {k: v.grad for k, v in inp.items()}
+    serial = [fwd_bwd(*s) for s in scenes]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=hip) for _ in scenes]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    worst = 0.0
+    for it in range(100):
+        got = []
+        for s, sc in zip(streams, scenes):
+            with torch.cuda.stream(s):
+                got.append(fwd_bwd(*sc))
+        if it % 10 == 9 or it == 0:
+            torch.cuda.synchronize()
+            for g, r in zip(got, serial):
+                for k in g:
+                    assert torch.isfinite(g[k]).all(), (it, k)
+                    rel = float((g[k].double() - r[k].double()).norm() / r[k].double().norm().clamp_min(1e-30))
+                    worst = max(worst, rel)
+                    assert rel <= 2e-5, (it, k, rel)
+    torch.cuda.synchronize()
+    _lib.check(_lib.get().gs_set_backward_chain_tickets(0))
+    _lib.poll_async_status()                                      # silent: no wait ran out
+    print(f"two concurrent chained backwards, 100 iterations: worst relative difference to the serial run {worst:.2e}")
+
+
 def test_chained_backward_at_full_size_equals_one_walker_per_quadrant(hip):
     """BASELINE configs[1]'s frame (640 x 480: 1200 tiles, the chained backward is the default there): three pieces per quadrant against
     one walker per quadrant -- forward identical, gradients equal up to the order of the atomic sums."""
@@ -395,6 +445,10 @@ def test_chained_backward_at_full_size_equals_one_walker_per_quadrant(hip):
 
 def test_adam_inside_the_backward_equals_backward_plus_step(hip):
     pc.check_adam_inside_the_backward(hip, n=30000, W=160, H=128, exact=False)
+
+
+def test_adam_inside_the_backward_is_applied_once_and_never_silently(hip):
+    pc.check_adam_backward_guards(hip, n=5000, W=96, H=64)
 
 
 def test_mapping_iteration_without_autograd_equals_the_autograd_path(hip):

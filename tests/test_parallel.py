@@ -260,7 +260,7 @@ def test_bench_configs3_workload_two_ranks_on_one_device(hip, n_gauss, kf):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    BENCH_SAME_DEVICE="1", BENCH_BACKEND="gloo")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                                       "--c4-gaussians", str(n_gauss), "--keyframes", str(kf)], env=env, stdout=subprocess.PIPE,
+                                       "--c4-gaussians", str(n_gauss), "--keyframes", str(kf), "--c4-densify-every", "2"], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
@@ -271,6 +271,12 @@ def test_bench_configs3_workload_two_ranks_on_one_device(hip, n_gauss, kf):
     assert d["config"]["gaussians"] == n_gauss and d["config"]["grad_exchange"]["backend"] == "gloo"
     assert d["config"]["grad_exchange"]["reduce"] == "all_reduce+slice"             # what actually ran (gloo has no reduce-scatter)
     assert d["exchange_plus_adam_ms"] > 0
+    # one densify event inside the timed region (step 2 of warm-up + timed steps): statistics all-reduced, moments gathered, rows moved on both
+    # ranks, and the step after it ran on the rebuilt shard plan
+    ev = d["config"]["densify_events_in_timed_region"]
+    assert len(ev) == 1 and ev[0]["n_before"] == n_gauss and ev[0]["n_after"] != n_gauss and ev[0]["grad_thresh"] > 0, ev
+    assert d["config"]["gaussians_at_end"] == ev[0]["n_after"] and abs(ev[0]["n_after"] - n_gauss) < 0.05 * n_gauss
+    assert d["config"]["grad_exchange"]["bytes"] // (14 * 4) in (ev[0]["n_after"], ev[0]["n_after"] + 1)
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]          # only rank 0 prints
 
 
@@ -320,11 +326,13 @@ def test_bench_configs3_with_sh_rows_exchanges_59_floats(hip):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(BENCH_SAME_DEVICE="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--c4-gaussians", "100000",
-                        "--keyframes", "4", "--c4-sh-degree", "3", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+                        "--keyframes", "4", "--c4-sh-degree", "3", "--no-extras", "--c4-densify-every", "2"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["exchange_floats_per_gaussian"] == 59
-    assert d["config"]["grad_exchange"]["bytes"] == 100000 * 59 * 4 and d["value"] > 0
+    n_end = d["config"]["gaussians_at_end"]                      # (one densify event in the timed region: the [N,16,3] rows and their moments moved too)
+    assert len(d["config"]["densify_events_in_timed_region"]) == 1 and n_end != 100000
+    assert d["config"]["grad_exchange"]["bytes"] // (59 * 4) in (n_end, n_end + 1) and d["value"] > 0
 
 
 def _worker_nccl_one_rank(port, q):
