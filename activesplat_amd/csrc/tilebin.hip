@@ -14,8 +14,16 @@
 //   tile_scan    : exclusive scan of the per-tile totals -> ranges[tile], D, max instances per tile.
 //   tile_scatter : same expansion; LDS returning atomics hand out slots inside the reserved slices;
 //                  one 8-byte (depth_bits<<32 | id) store per instance.
-//   tile_sort    : one workgroup per tile, bitonic sort of the 64-bit pairs in LDS (keys are unique, so
-//                  the result does not depend on the atomics' arrival order), writes point_list.
+//   per-tile sort, chosen PER TILE on the device (keys are unique, so the result does not depend on the atomics' arrival order):
+//     tile_bucket_sort        : lists of at most 5632 keys (every list of a 640 x 480 frame up to ~2.3 M Gaussians): ONE 512-thread workgroup per
+//                               tile, keys in registers; a tile's depths lie in a narrow interval, so a LINEAR map onto up to 2048 bins is a
+//                               monotone coarse key: min / max -> one returning LDS atomic per key (bin count + arrival index) -> scan -> scatter
+//                               by bin -> rank inside the bin's handful of keys; writes ONLY the ids (point_list).  <BIG>: up to 11264 keys in a
+//                               1024-thread workgroup for images of at most 512 tiles (a 1 M-Gaussian map in the reference's 256 x 256 frame).
+//                               A tile whose fullest bin exceeds 64 keys (clustered depths + an outlier) takes the comparison network instead,
+//                               from the same registers.
+//     tile_sort + tile_merge  : longer lists (the planner's multi-view atlas: up to 78 k per tile): register-blocked bitonic run sort of
+//                               2048-key chunks, rank merge in LDS up to 16384 keys, pairwise merge passes through global memory beyond.
 #include "gs_common.h"
 
 

@@ -53,7 +53,7 @@ DEFAULT_CONFIG = dict(
     fused_iteration=False,   # ... and the whole iteration (get_loss + backward + step + zero_grad) as four library calls without autograd
                              # (mapping.mapping_iteration; needs fused_render, fused_loss, fused_preprocess; event iterations take the usual path)
     fused_growth=False,      # add_new_gaussians: one forward + gs_grow_gaussians
-    fused_keyframes=False,   # keyframe overlap scores by gs_keyframe_overlap (one launch for all keyframes)
+    fused_keyframes=True,    # (accepted for older configs; no effect: the keyframe overlap scores always come from gs_keyframe_overlap, one launch)
     high_loss_samples=True,  # the per-frame no-grad render of get_high_loss_samples (__init__.py:184-258) before mapping a frame
     mapping=dict(
         loss_weights=dict(im=0.5, depth=1.0), sil_thres=0.98, use_sil_for_loss=False, use_l1=True,
@@ -178,7 +178,7 @@ class SplatMapper:
                                                                   + [float(v) for v in pos_h.tolist()] if cfg.get("fused_growth", False) else None)
             with torch.no_grad():
                 sel = keyframe_selection_overlap(depth, self._w2c(fid), self.intrinsics, self.keyframe_list[:-1],
-                                                 cfg["mapping_window_size"] - 2, fused=cfg.get("fused_keyframes", False))
+                                                 cfg["mapping_window_size"] - 2)
                 self.selected_keyframes = [int(s) for s in sel]
                 if len(self.keyframe_list) > 0:
                     self.selected_keyframes.append(len(self.keyframe_list) - 1)
@@ -193,19 +193,25 @@ class SplatMapper:
             else:
                 kf = self.keyframe_list[pick]
                 it_id, it_color, it_depth = kf["id"], kf["color"], kf["depth"]
-            in_backward = cfg.get("fused_adam", False) and cfg.get("fused_preprocess", False) and cfg["fused_render"] \
-                and not (mc["prune_gaussians"] and O.prune_event(it, mc["pruning_dict"])) \
-                and not (mc["use_gaussian_splatting_densification"] and O.densify_event(it, mc["densify_dict"]))
-            direct = cfg.get("fused_iteration", False) and cfg.get("fused_preprocess", False) and cfg["fused_render"] and cfg["fused_loss"] \
-                and mc["use_l1"] and not mc["ignore_outlier_depth_loss"] \
-                and not (mc["prune_gaussians"] and O.prune_event(it, mc["pruning_dict"])) \
-                and not (mc["use_gaussian_splatting_densification"] and O.densify_event(it, mc["densify_dict"]))
+            # ONE predicate for both fused forms: does this iteration's prune / densify call move rows or reset parameters (then the tensors are
+            # replaced between backward and step, and the separate step is taken, as the reference's loop effectively does)?
+            event = (mc["prune_gaussians"] and O.prune_event(it, mc["pruning_dict"])) \
+                or (mc["use_gaussian_splatting_densification"] and O.densify_event(it, mc["densify_dict"]))
+            fused_path = cfg.get("fused_preprocess", False) and cfg["fused_render"] and not event
+            in_backward = cfg.get("fused_adam", False) and fused_path
+            # (fused_iteration IS the Adam-inside-the-backward form without autograd: it implies fused_adam whatever the config says)
+            direct = cfg.get("fused_iteration", False) and fused_path and cfg["fused_loss"] and mc["use_l1"] and not mc["ignore_outlier_depth_loss"]
             if direct:
-                # the whole iteration without autograd; a densify iteration that only accumulates statistics still does so below
+                # the whole iteration without autograd.  No event here, so prune_gaussians is a no-op by its own predicate (prune_event) and
+                # densify only accumulates this iteration's statistics; nothing holds a gradient afterwards, so step() / zero_grad() have
+                # nothing to do -- asserted, so that a parameter that starts receiving gradients (camera learning rates > 0) cannot be skipped
                 loss, self.variables, losses = M.mapping_iteration(self.params, self._data(it_color, it_depth, it_id), self.variables, it_id,
                                                                    mc["loss_weights"], self.optimizer)
                 if mc["use_gaussian_splatting_densification"]:
                     self.params, self.variables = O.densify(self.params, self.variables, self.optimizer, it, mc["densify_dict"])
+                if any(p.grad is not None for p in self.params.values()):
+                    raise RuntimeError("SplatMapper(fused_iteration=True): a parameter holds a gradient after the autograd-free iteration -- "
+                                       "this loop would never step it; use fused_iteration=False")
                 self._last_losses = {k: v.detach() for k, v in losses.items()}
                 self.stats["iters"] += 1
                 self.stats["iter_time"] += time.perf_counter() - t0

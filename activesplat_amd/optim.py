@@ -17,12 +17,12 @@ gs_compact_index + gs_gather_rows pair shared by the parameter, both Adam moment
 statistics.  The optimiser keeps torch.optim's `param_groups` / `state[param]` layout so that code written
 against the reference's surgery functions keeps working.
 
-Fused surgery (default, `fused=True`): the clone / split / cull decisions of one densify or prune event are taken by ONE kernel
+Fused surgery: the clone / split / cull decisions of one densify or prune event are taken by ONE kernel
 (gs_densify_classify), their three masks become index lists through the ballot/popcount compaction, and every tensor --
 parameter, both Adam moments, statistics -- is produced by ONE row gather (gs_gather_rows_zero_tail: rows of new Gaussians
 zero-filled in the moments); the split children's offset and scale are applied in place by gs_densify_children.  Same rows in
-the same order as the step-by-step formulation (`fused=False`: clone -> cat -> split -> cat -> remove -> cull -> remove, the
-reference's call pattern, four index builds and ~40 torch launches per event).
+the same order as the step-by-step formulation (clone -> cat -> split -> cat -> remove -> cull -> remove, the reference's call pattern: four
+index builds and ~40 torch launches per event; kept in tests/reference_pattern.py as the comparison baseline of the parity tests).
 
 densify: the reference's slam_external.densify only executes for isotropic scales without a 'timestep'
 variable.  This mirror reproduces that case exactly and defines the missing ones the way
@@ -367,25 +367,15 @@ def remove_points(to_remove, params, variables, optimizer):
     return params, variables
 
 
-def _too_big(params, variables, factor):
-    return torch.exp(params["log_scales"]).max(dim=1).values > factor * variables["scene_radius"]
-
-
-def prune_gaussians(params, variables, optimizer, iter, prune_dict, fused=True):
+def prune_gaussians(params, variables, optimizer, iter, prune_dict):
     if iter <= prune_dict["stop_after"]:
         if iter >= prune_dict["start_after"] and iter % prune_dict["prune_every"] == 0:
             thr = prune_dict["final_removal_opacity_threshold"] if iter == prune_dict["stop_after"] \
                 else prune_dict["removal_opacity_threshold"]
             remove_big = iter >= prune_dict["remove_big_after"]
-            if fused:
-                idx, cnt = _index_of(_classify(params, variables, thr, remove_big)[0])
-                n = int(cnt.item())
-                params, variables = _apply_index(idx[:n], n, params, variables, optimizer, zero_stats=False)
-            else:
-                to_remove = (torch.sigmoid(params["logit_opacities"]) < thr).squeeze(-1)
-                if remove_big:
-                    to_remove = to_remove | _too_big(params, variables, 0.1)
-                params, variables = remove_points(to_remove, params, variables, optimizer)
+            idx, cnt = _index_of(_classify(params, variables, thr, remove_big)[0])
+            n = int(cnt.item())
+            params, variables = _apply_index(idx[:n], n, params, variables, optimizer, zero_stats=False)
         if iter > 0 and iter % prune_dict["reset_opacities_every"] == 0 and prune_dict["reset_opacities"]:
             new = {"logit_opacities": inverse_sigmoid(torch.ones_like(params["logit_opacities"]) * 0.01)}
             params = update_params_and_optimizer(new, params, optimizer)
@@ -436,8 +426,9 @@ def _densify_fused(params, variables, optimizer, iter, densify_dict, samples, se
     return params, variables
 
 
-def densify(params, variables, optimizer, iter, densify_dict, samples=None, fused=True, seed=None, accumulate=True):
-    """Clone small / split large high-gradient Gaussians, then cull (slam_external.py:195-247).
+def densify(params, variables, optimizer, iter, densify_dict, samples=None, seed=None, accumulate=True):
+    """Clone small / split large high-gradient Gaussians, then cull (slam_external.py:195-247): one classification kernel, one index, one row
+    gather per tensor (the reference's step-by-step call pattern lives in tests/reference_pattern.py as the comparison baseline).
     `samples` optionally injects the N(0, scale) split offsets ([n_split * num_to_split_into, 3]) so that a run
     can be replayed exactly; otherwise they are drawn in the kernel from `seed` (None: a seed from torch's CPU generator).
     accumulate=False: the caller has already added this iteration's mean-2D gradient statistics (parallel.sharded_densify, whose
@@ -446,60 +437,9 @@ def densify(params, variables, optimizer, iter, densify_dict, samples=None, fuse
         return params, variables
     if accumulate:
         variables = accumulate_mean2d_gradient(variables)
-    grad_thresh = densify_dict["grad_thresh"]
-    if fused and iter >= densify_dict["start_after"] and iter % densify_dict["densify_every"] == 0:
+    if iter >= densify_dict["start_after"] and iter % densify_dict["densify_every"] == 0:
         params, variables = _densify_fused(params, variables, optimizer, iter, densify_dict, samples, seed)
-    elif iter >= densify_dict["start_after"] and iter % densify_dict["densify_every"] == 0:
-        keys = [k for k in params.keys() if k not in _SKIP]
-        dev = params["means3D"].device
-        grads = variables["means2D_gradient_accum"] / variables["denom"]
-        grads[grads.isnan()] = 0.0
-        small = torch.exp(params["log_scales"]).max(dim=1).values <= 0.01 * variables["scene_radius"]
-        to_clone = (grads >= grad_thresh) & small
-        clone_idx = build_index(to_clone)
-        new_params = {k: gather_rows(params[k], clone_idx) for k in keys}
-        ts = variables.get("timestep")
-        if ts is not None:
-            ts = torch.cat((ts, gather_rows(ts, clone_idx)))
-        params = cat_params_to_optimizer(new_params, params, optimizer)
-        num_pts = params["means3D"].shape[0]
-        padded = torch.zeros(num_pts, device=dev)
-        padded[: grads.shape[0]] = grads
-        to_split = (padded >= grad_thresh) & (torch.exp(params["log_scales"]).max(dim=1).values > 0.01 * variables["scene_radius"])
-        n = densify_dict["num_to_split_into"]
-        split_idx = build_index(to_split).repeat(n)
-        new_params = {k: gather_rows(params[k], split_idx) for k in keys}
-        stds = torch.exp(new_params["log_scales"])
-        stds = stds.repeat(1, 3) if stds.shape[1] == 1 else stds          # anisotropic: per-axis
-        if samples is None:
-            samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
-        rots = build_rotation_from(new_params["unnorm_rotations"])
-        # R * sample as an element-wise product-sum: a [n,3,3] x [n,3,1] bmm would pull in rocBLAS (hundreds of ms of
-        # one-time library initialisation at the first densify event) for 9 multiply-adds per row
-        new_params["means3D"] = new_params["means3D"] + (rots * samples.to(dev).unsqueeze(1)).sum(dim=-1)
-        new_params["log_scales"] = torch.log(torch.exp(new_params["log_scales"]) / (0.8 * n))
-        if ts is not None:
-            ts = torch.cat((ts, gather_rows(ts, split_idx)))
-        params = cat_params_to_optimizer(new_params, params, optimizer)
-        num_pts = params["means3D"].shape[0]
-        for k in ("means2D_gradient_accum", "denom", "max_2D_radius"):
-            variables[k] = torch.zeros(num_pts, device=dev)
-        if ts is not None:
-            variables["timestep"] = ts
-        to_remove = torch.cat((to_split, torch.zeros(split_idx.numel(), dtype=torch.bool, device=dev)))
-        params, variables = remove_points(to_remove, params, variables, optimizer)
-        thr = densify_dict["final_removal_opacity_threshold"] if iter == densify_dict["stop_after"] \
-            else densify_dict["removal_opacity_threshold"]
-        to_remove = (torch.sigmoid(params["logit_opacities"]) < thr).squeeze(-1)
-        if iter >= densify_dict["remove_big_after"]:
-            to_remove = to_remove | _too_big(params, variables, 0.1)
-        params, variables = remove_points(to_remove, params, variables, optimizer)
     if iter > 0 and iter % densify_dict["reset_opacities_every"] == 0 and densify_dict.get("reset_opacities", False):
         new = {"logit_opacities": inverse_sigmoid(torch.ones_like(params["logit_opacities"]) * 0.01)}
         params = update_params_and_optimizer(new, params, optimizer)
     return params, variables
-
-
-def build_rotation_from(q):
-    from .mapping import build_rotation
-    return build_rotation(q)

@@ -9,12 +9,13 @@ from . import synthetic as syn
 from .camera import setup_camera
 
 
-def configs2_optimise_loop(N, iters, device, fused_densify=True, densify_every=50, sh_degree=3, W=640, H=480, seed=0, time_it=False, raw=True,
+def configs2_optimise_loop(N, iters, device, densify_fn=None, densify_every=50, sh_degree=3, W=640, H=480, seed=0, time_it=False, raw=True,
                            fused_adam=True):
     """BASELINE configs[2]: N Gaussians with SH coefficients, one 640x480 target, `iters` iterations of
     fused activations -> single-pass RGB-D render -> fused loss -> backward -> densify (every `densify_every`) -> fused Adam.
     fused_adam (with raw): on iterations without a densify event the Adam step rides in the backward's per-Gaussian kernel
     (render_rgbd_raw(adam=...)); same parameters afterwards, bit for bit.
+    densify_fn: optim.densify unless a caller compares another implementation of the same call (the tests' step-by-step baseline).
     Returns dict(losses=[first, last], counts=[N after every densify event], seconds)."""
     import time
     from activesplat_amd import mapping as M, optim as O
@@ -59,7 +60,7 @@ def configs2_optimise_loop(N, iters, device, fused_densify=True, densify_every=5
                 event = it % densify_every == 0
                 if event and time_it:
                     torch.cuda.synchronize(); t1 = time.perf_counter()
-                params, variables = O.densify(params, variables, opt, it, ddict, fused=fused_densify)
+                params, variables = (densify_fn or O.densify)(params, variables, opt, it, ddict)
                 if event and time_it:
                     torch.cuda.synchronize(); densify_s.append(time.perf_counter() - t1)
                 if params["means3D"].shape[0] != n0:

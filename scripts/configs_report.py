@@ -21,7 +21,7 @@ from tests import util  # noqa: E402
 N, ITERS = int(os.environ.get("N", 2_000_000)), 100
 util.configs2_optimise_loop(4096, 12, "cuda", densify_every=5)          # one-time code-object loads of every kernel / torch op involved
 torch.manual_seed(0)
-r = util.configs2_optimise_loop(N, ITERS, "cuda", fused_densify=True, time_it=True)
+r = util.configs2_optimise_loop(N, ITERS, "cuda", time_it=True)
 out["configs2_optimise_loop"] = dict(gaussians_start=N, gaussians_after_densify=r["counts"], sh_degree=3, iters=ITERS, seconds=round(r["seconds"], 4),
                                      iters_per_s=round(ITERS / r["seconds"], 2), loss_first=r["losses"][0], loss_last=r["losses"][1],
                                      densify_event_ms=[round(x * 1e3, 3) for x in r["densify_seconds"]],

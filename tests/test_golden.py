@@ -293,14 +293,15 @@ def _random_map(backend, N, iso, seed):
 
 @pytest.mark.parametrize("iso", [True, False])
 def test_fused_densify_and_prune_equal_the_stepwise_call_pattern(backend, iso):
-    """One classification + one gather per tensor (optim.densify / prune_gaussians, fused=True) against the reference's
-    clone -> cat -> split -> cat -> remove -> cull -> remove sequence (fused=False) on a map where every branch fires:
+    """One classification + one gather per tensor (optim.densify / prune_gaussians) against the reference's
+    clone -> cat -> split -> cat -> remove -> cull -> remove sequence (tests/reference_pattern.py) on a map where every branch fires:
     clones, splits, opacity culls, too-big culls (of originals AND of freshly split children), 0/0 gradients."""
     check_fused_densify_and_prune(backend, iso, 3000, 11)
 
 
 def check_fused_densify_and_prune(backend, iso, N, seed):
     from activesplat_amd import optim as O
+    from tests import reference_pattern as RP
     ddict = dict(start_after=0, remove_big_after=0, stop_after=100, densify_every=10, grad_thresh=0.0002, num_to_split_into=2,
                  removal_opacity_threshold=0.05, final_removal_opacity_threshold=0.05, reset_opacities=False, reset_opacities_every=3000)
     out = []
@@ -314,7 +315,7 @@ def check_fused_densify_and_prune(backend, iso, N, seed):
             den = var["denom"] + var["seen"].float()
             gr = acc / den; gr[gr.isnan()] = 0.0
             n_all = int(((gr >= 0.0002) & (torch.exp(params["log_scales"]).max(dim=1).values > 0.01 * 1.7)).sum())
-        p2, v2 = O.densify(params, var, opt, 10, ddict, samples=samples[: 2 * n_all], fused=fused)
+        p2, v2 = (O.densify if fused else RP.densify_stepwise)(params, var, opt, 10, ddict, samples=samples[: 2 * n_all])
         out.append((p2, v2, opt))
     (pa, va, oa), (pb, vb, ob) = out
     n = pa["means3D"].shape[0]
@@ -333,7 +334,7 @@ def check_fused_densify_and_prune(backend, iso, N, seed):
     res = []
     for fused in (True, False):
         params, var, opt, _ = _random_map(backend, N, iso, seed + 1)
-        res.append(O.prune_gaussians(params, var, opt, 5, pdict, fused=fused) + (opt,))
+        res.append((O.prune_gaussians if fused else RP.prune_stepwise)(params, var, opt, 5, pdict) + (opt,))
     (pa, va, oa), (pb, vb, ob) = res
     assert pa["means3D"].shape[0] == pb["means3D"].shape[0] and (0 < pa["means3D"].shape[0] < N or N < 500)
     for k in KEYS[:5]:
@@ -380,25 +381,39 @@ def test_pointcloud_and_growth_match_reference(monkeypatch):
         np.testing.assert_array_equal(v2[k].cpu().numpy(), d[f"add_var1_{k}"])
 
 
-def test_keyframe_selection_matches_reference():
-    from activesplat_amd.keyframes import keyframe_selection_overlap
-    d = load("keyframe.npz")
-    kfs = [{"id": i, "est_w2c": T(w)} for i, w in enumerate(d["kf_w2c"])]
-    sel = keyframe_selection_overlap(T(d["gt_depth"]), T(d["w2c"]), T(d["K"]), kfs, 4, pixels=200, sampled=T(d["sampled"]), shuffle=False)
-    assert [int(s) for s in sel] == [int(s) for s in d["selected"]]
-
-
-def test_keyframe_overlap_kernel_matches_reference(backend):
-    from activesplat_amd.keyframes import keyframe_selection_overlap
+def test_keyframe_selection_matches_reference(backend):
+    """keyframe.npz (keyframe_selection.py:40-95 run by the imported reference with the sampler's draw recorded): the same selection in the same
+    order, and per keyframe the fraction the reference's scoring loop computes (tests/reference_pattern.keyframe_overlap_torch on the same points)."""
+    from activesplat_amd import keyframes as KF
+    from tests import reference_pattern as RP
     d = load("keyframe.npz")
     kfs = [{"id": i, "est_w2c": T(w)} for i, w in enumerate(d["kf_w2c"])]
     args = (T(d["gt_depth"]), T(d["w2c"]), T(d["K"]), kfs, 4)
-    sel, ranked = keyframe_selection_overlap(*args, pixels=200, sampled=T(d["sampled"]), shuffle=False, fused=True, return_percent=True)
+    sel, ranked = KF.keyframe_selection_overlap(*args, pixels=200, sampled=T(d["sampled"]), shuffle=False, return_percent=True)
     assert [int(s) for s in sel] == [int(s) for s in d["selected"]]
-    _, ranked_t = keyframe_selection_overlap(*args, pixels=200, sampled=T(d["sampled"]), shuffle=False, return_percent=True)
-    assert [(r["id"], round(float(r["percent_inside"]), 6)) for r in ranked] == \
-           [(r["id"], round(float(r["percent_inside"]), 6)) for r in ranked_t]
-    assert keyframe_selection_overlap(*args[:3], [], 4, pixels=200, sampled=T(d["sampled"]), shuffle=False, fused=True) == []
+    depth, w2c, K = args[:3]
+    valid = torch.stack(torch.where(depth[0] > 0), dim=1)
+    pts = KF.drop_repeated_points(KF.world_points(depth, K, w2c, valid[T(d["sampled"]).to(valid.device)]))
+    ref = RP.keyframe_overlap_torch(pts, kfs, K, depth.shape[2], depth.shape[1])
+    assert {r["id"]: round(float(r["percent_inside"]), 6) for r in ranked} == {i: round(c / pts.shape[0], 6) for i, c in enumerate(ref)}
+    assert KF.keyframe_selection_overlap(*args[:3], [], 4, pixels=200, sampled=T(d["sampled"]), shuffle=False) == []
+
+
+def test_repeated_points_filter_equals_the_reference_formulation():
+    """drop_repeated_points (one sort of packed integer keys) against the reference's formulation of the same filter (keyframe_selection.py:28-36:
+    unique rows of the rounded magnitudes plus the origin, every row that occurs more than once is invalid) -- duplicates drawn by the sampler,
+    mirrored points (magnitudes equal), points within rounding of each other, a point at the origin, and the beyond-209 m branch."""
+    from activesplat_amd.keyframes import drop_repeated_points
+    g = torch.Generator().manual_seed(0)
+    for scale in (3.0, 500.0):
+        pts = torch.randn(400, 3, generator=g) * scale
+        pts[10] = pts[3]; pts[11] = -pts[4]; pts[12] = pts[5] + 2e-5; pts[13] = 0.0; pts[14] = torch.tensor([1e-5, -2e-5, 0.0])
+        pts[15] = pts[6] + torch.tensor([6e-5, 0.0, 0.0])
+        A = torch.abs(torch.round(pts, decimals=4))
+        _, idx, counts = torch.cat([A, torch.zeros(1, 3)], dim=0).unique(dim=0, return_inverse=True, return_counts=True)
+        keep = ~torch.isin(idx, torch.where(counts.gt(1))[0])[: len(A)]
+        got = drop_repeated_points(pts)
+        assert torch.equal(got, pts[keep]) and 380 < got.shape[0] < 400 and not keep[13] and not keep[3] and not keep[10]
 
 
 def test_growth_kernel_matches_reference_add_new_gaussians(backend):

@@ -247,10 +247,15 @@ def test_keyframe_overlap_kernel_equals_torch_on_gpu(hip):
     kfs = [{"id": i, "est_w2c": torch.tensor(syn.keyframe_w2c(i, 24), dtype=torch.float32, device=hip)} for i in range(24)]
     sampled = torch.randint(H * W, (1600,), generator=g)
     args = (depth, torch.eye(4, device=hip), K, kfs, 8)
-    a, ra = keyframe_selection_overlap(*args, sampled=sampled, shuffle=False, fused=True, return_percent=True)
-    b, rb = keyframe_selection_overlap(*args, sampled=sampled, shuffle=False, return_percent=True)
+    a, ra = keyframe_selection_overlap(*args, sampled=sampled, shuffle=False, return_percent=True)
+    from activesplat_amd import keyframes as KF
+    from tests import reference_pattern as RP
+    valid = torch.stack(torch.where(depth[0] > 0), dim=1)
+    pts = KF.drop_repeated_points(KF.world_points(depth, K, args[1], valid[sampled.to(hip)]))
+    cnt = RP.keyframe_overlap_torch(pts, kfs, K, W, H)
+    b = [i for i, c in sorted(enumerate(cnt), key=lambda t: -t[1]) if c > 0][:8]
     pa = {r["id"]: float(r["percent_inside"]) for r in ra}
-    pb = {r["id"]: float(r["percent_inside"]) for r in rb}
+    pb = {i: c / pts.shape[0] for i, c in enumerate(cnt)}
     assert max(abs(pa[i] - pb[i]) for i in pa) <= 2 / 1600            # at most a borderline point or two per keyframe
     assert len(a) == len(b) == 8
 
@@ -279,9 +284,10 @@ def test_configs2_optimise_loop_2m_sh3(hip):
     pattern.  Both must end with the same number of Gaussians after the event and a lower loss than they started with."""
     from tests import util
     torch.manual_seed(0)
-    a = util.configs2_optimise_loop(2_000_000, 100, "cuda", fused_densify=True)
+    a = util.configs2_optimise_loop(2_000_000, 100, "cuda")
     torch.manual_seed(0)
-    b = util.configs2_optimise_loop(2_000_000, 100, "cuda", fused_densify=False)
+    from tests import reference_pattern as RP
+    b = util.configs2_optimise_loop(2_000_000, 100, "cuda", densify_fn=RP.densify_stepwise)
     assert a["counts"] and a["counts"] == b["counts"], (a["counts"], b["counts"])
     assert a["counts"][0] != 2_000_000
     for r in (a, b):
