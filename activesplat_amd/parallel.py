@@ -40,6 +40,58 @@ def shard_keyframes(num_keyframes: int, rank: int, world: int) -> range:
     return range(start, start + base + (1 if rank < extra else 0))
 
 
+def balanced_partition(costs, world: int):
+    """Longest-processing-time assignment of keyframes to ranks: keyframes in descending cost (ties by index) each go to the rank with the
+    smallest load so far (ties by rank).  Deterministic in `costs` -- every rank computes the same lists from replicated costs (KeyframeCosts).
+    -> list (per rank) of ascending keyframe indices.  Real keyframes differ in their tile-instance count by integer factors (a wall at one
+    metre against a view down a corridor), which contiguous blocks (shard_keyframes) hand to the ranks as they come: SURVEY section 8e's >= 6x
+    at 8 GPUs hinges on the slowest rank."""
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+    load = [0.0] * world
+    out = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda j: (load[j], len(out[j]), j))
+        out[r].append(i)
+        load[r] += float(costs[i])
+    return [sorted(x) for x in out]
+
+
+class KeyframeCosts:
+    """Per-keyframe cost estimates for balanced_partition, kept identical on every rank: the owner of a keyframe records what its last render
+    cost (`record`: tile instances D, plus `gaussian_weight` instance-equivalents per Gaussian for the per-Gaussian stages -- at 2 M Gaussians /
+    4.84 M instances the per-Gaussian kernels are 265 us of a 660 us frame: 1.6), `sync` combines the ranks' records (one all-reduce of K
+    floats: every keyframe has exactly one owner per step), `partition` is the LPT assignment.  Before any record: contiguous blocks."""
+
+    def __init__(self, num_keyframes: int, gaussian_weight: float = 1.6):
+        self.k, self.gw = int(num_keyframes), float(gaussian_weight)
+        self.cost = [0.0] * self.k
+        self._fresh = {}
+
+    def record(self, index: int, tile_instances: int, gaussians: int = 0):
+        self._fresh[int(index)] = float(tile_instances) + self.gw * float(gaussians)
+
+    def sync(self, device="cpu", group=None):
+        t = torch.zeros(self.k, dtype=torch.float64)
+        for i, c in self._fresh.items():
+            t[i] = c
+        self._fresh = {}
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            t = t.to(device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            t = t.cpu()
+        for i in range(self.k):
+            if float(t[i]) > 0.0:
+                self.cost[i] = float(t[i])
+        return self
+
+    def partition(self, world: int):
+        if not any(c > 0.0 for c in self.cost):
+            return [list(shard_keyframes(self.k, r, world)) for r in range(world)]
+        known = [c for c in self.cost if c > 0.0]
+        fill = sum(known) / len(known)                    # a keyframe nobody has rendered yet counts as an average one
+        return balanced_partition([c if c > 0.0 else fill for c in self.cost], world)
+
+
 #: what the most recent gradient exchange of this process actually ran (bench.py prints it): backend, the collectives, and -- with
 #: `timing=True` -- CUDA events around exchange + Adam
 last_exchange = {}
@@ -151,7 +203,8 @@ def all_reduce_statistics(variables, group=None):
 
 
 def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank=None, world=None, buf=None,
-                          sharded_adam=False, streams=1, densify_statistics=False, timing=False, accumulate_statistics=False, partition=None):
+                          sharded_adam=False, streams=1, densify_statistics=False, timing=False, accumulate_statistics=False, partition=None,
+                          costs=None):
     """One optimiser step over a batch of keyframes sharded across ranks.
     loss_fn(params, keyframe, variables) -> (loss, variables).  Returns the local loss sum.
 
@@ -166,7 +219,8 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
     accumulate_statistics=True (implies the serial walk): EVERY keyframe of this rank adds its mean-2D gradient norm and visibility to the
     densifier's accumulators right after its backward (optim.accumulate_mean2d_gradient) -- the batch's statistic is then the sum over all of its
     keyframes whatever the number of ranks; the accumulators are rank-local partial sums until parallel.sharded_densify all-reduces them.
-    partition: list of this step's keyframe indices per rank (parallel.balanced_partition); default: contiguous blocks (shard_keyframes)."""
+    partition: list of this step's keyframe indices per rank (parallel.balanced_partition); default: contiguous blocks (shard_keyframes).
+    costs: a KeyframeCosts that the serial walk feeds with every rendered keyframe's tile-instance count (sync + partition are the caller's)."""
     on = dist.is_available() and dist.is_initialized()
     rank = (dist.get_rank() if on else 0) if rank is None else rank
     world = (dist.get_world_size() if on else 1) if world is None else world
@@ -226,6 +280,9 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
         losses = []
         for i in mine:
             loss, variables = loss_fn(params, keyframes[i], variables)
+            if costs is not None:                 # (the forward has read its counters back already: a host number, no sync)
+                from . import rasterizer as _R
+                costs.record(i, _R.last_stats.get("num_rendered", 0), _R.last_stats.get("P", 0))
             # dL/dloss = 1 from the cache (autograd would fill a fresh one per keyframe: a launch each; the fused loss skips its scaling
             # launch for this very tensor); autograd accumulates into .grad across this rank's keyframes
             loss.backward(unit_gradient(loss) if loss.dim() == 0 else None)

@@ -361,8 +361,57 @@ class _RasterizeGaussians(torch.autograd.Function):
         return d_m3d, d_m2d, d_shs, d_col, d_op, d_sc, d_rot, d_cov, None, None, None
 
 
+#: the drop-in call goes through the C++ autograd front-end (csrc/torch_frontend.cpp: the same library calls in the same order as
+#: _RasterizeGaussians above, without the interpreter in the way -- host time of a forward + backward ~240 -> ~90 us, which is what makes the reference's own
+#: 256 x 256 frames GPU-bound).  False: the Python twin (A/B measurements, tests of the twin).  Inside a capture() block and on the
+#: host-emulated test build the Python twin runs regardless.
+use_frontend = True
+
+
+def _frontend_apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, fused):
+    """The drop-in forward through the C++ front-end; None when this call is not one for it (then the Python twin takes it)."""
+    if not use_frontend or _lib.emulated() or means3D.device.type != "cuda":
+        return None
+    caps = getattr(_tls, "captures", None)
+    from . import _frontend
+    ext = _frontend.get()                               # (raises when it has not been built: no silent slow path on a GPU box)
+    device = means3D.device
+    P, W, H = int(means3D.shape[0]), int(rs.image_width), int(rs.image_height)
+    key = (P, W, H, device.index)
+    with _capacity_lock:
+        guess = _capacity.get(key) if optimistic else None
+    out, D, max_tile, hit, state, off = ext.rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs.bg,
+                                                      rs.viewmatrix, rs.projmatrix, rs.campos, W, H, float(rs.tanfovx), float(rs.tanfovy),
+                                                      float(rs.scale_modifier), int(rs.sh_degree), bool(fused), guess[0] if guess else 0,
+                                                      guess[1] if guess else 0, bool(caps))
+    if caps:
+        # capture(): views of the one workspace (and of the exact re-render's buffers after a miss), under the names the Python twin publishes
+        lib = _lib.get()
+        gl, il, _ = _frame_layouts(lib, P, W, H)
+        ws, bin2, plist2 = state
+        cap_d, cap_tile = (guess if hit else (D, max_tile))
+        bl = _lib.GsBinLayout(); _lib.check(lib.gs_bin_layout(cap_d, cap_tile, W, H, C.byref(bl)))
+        caps[-1].update(geom=ws[off[0]:off[0] + off[1]], image=ws[off[2]:off[2] + off[3]], gl=gl, il=il, bl=bl, D=D, P=P, W=W, H=H,
+                        binning=ws[off[4]:off[4] + off[5]] if hit else bin2,
+                        point_list=ws[off[6]:off[6] + 4 * off[7]].view(torch.int32) if hit else plist2)
+    if hit:
+        last_stats["optimistic_hits"] = last_stats.get("optimistic_hits", 0) + 1
+    else:
+        last_stats["optimistic_misses"] = last_stats.get("optimistic_misses", 0) + (1 if guess is not None else 0)
+    with _capacity_lock:
+        old = _capacity.get(key, (0, 0))
+        if len(_capacity) >= 64 and key not in _capacity:
+            _capacity.pop(next(iter(_capacity)))
+        _capacity[key] = (max(old[0], int(D * 1.25) + 4096), max(old[1], max_tile + max_tile // 16 + 64))
+    last_stats["num_rendered"], last_stats["P"], last_stats["max_tile_instances"] = D, P, max_tile
+    return tuple(out)
+
+
 def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                         raster_settings):
+    out = _frontend_apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, raster_settings, False)
+    if out is not None:
+        return out
     return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                      cov3D_precomp, raster_settings)
 
@@ -386,6 +435,9 @@ def render_rgbd(raster_settings, means3D, means2D, opacities, shs=None, colors_p
     if ((scales is None or rotations is None) and cov3D_precomp is None) or \
             ((scales is not None or rotations is not None) and cov3D_precomp is not None):
         raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+    out = _frontend_apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, raster_settings, True)
+    if out is not None:
+        return out
     return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                      raster_settings, True)
 

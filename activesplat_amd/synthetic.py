@@ -78,6 +78,20 @@ def shell_scene(N, seed=0, W=640, H=480):
                 logit_opacities=torch.randn(N, 1, generator=g).float(), log_scales=log_scales.float())
 
 
+def uneven_shell_scene(N, seed=0, W=640, H=480, dense_share=0.75):
+    """shell_scene with `dense_share` of the Gaussians in HALF of the azimuth range: the keyframes that look into the dense half (yaw in (0, pi))
+    see dense_share / (1 - dense_share) = 3 times the tile instances of the others -- the load imbalance of real keyframes (a wall at one metre
+    against a view down a corridor), which contiguous keyframe blocks hand to the ranks as they come."""
+    d = shell_scene(N, seed, W, H)
+    g = torch.Generator().manual_seed(seed + 7919)
+    dense = torch.rand(N, generator=g) < dense_share
+    yaw = torch.rand(N, generator=g) * math.pi + torch.where(dense, torch.zeros(N), torch.full((N,), math.pi))
+    m = d["means3D"]
+    r_xz = torch.sqrt(m[:, 0] ** 2 + m[:, 2] ** 2)
+    d["means3D"] = torch.stack([r_xz * torch.sin(yaw), m[:, 1], r_xz * torch.cos(yaw)], 1).float()
+    return d
+
+
 def keyframe_w2c(i, K):
     """In-place rotation about +y by yaw 2*pi*i/K (Habitat-like bootstrap spin)."""
     a = 2 * math.pi * i / K

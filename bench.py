@@ -273,7 +273,8 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
     for i in range(KF):
         a = 2 * np.pi * i / KF
         kf = dict(id=i, cam=cam, w2c=torch.eye(4, device=dev), pose7=[float(v) for v in syn.quat_from_yaw(a)] + [0.0, 0.0, 0.0])
-        if i in mine or rank == 0:                             # rank 0 also runs the whole batch alone afterwards
+        if i in mine or rank == 0 or (world > 1 and args.c4_partition == "lpt"):     # rank 0 also runs the whole batch alone afterwards; a
+            # re-balanced partition can hand any keyframe to any rank (64 targets are 315 MB)
             im, depth = syn.make_targets(W, H, seed=100 + i)
             kf.update(im=im.to(dev), depth=depth.to(dev))
         keyframes.append(kf)
@@ -301,9 +302,15 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
 
     def threshold_from_statistics(p, v, dd):
         # (the statistics are complete and identical on every rank here: the quantile is a function of replicated values)
+        # a 4096-bin histogram instead of a selection (torch.kthvalue sorts: 10 ms at 2 M): the threshold is the upper edge of the bin in which
+        # the cumulative count passes the quantile -- three small launches and one host read
         g = v["means2D_gradient_accum"] / v["denom"].clamp_min(1.0)
-        k = max(1, min(g.numel(), int(round(args.c4_densify_quantile * g.numel()))))
-        return dict(dd, grad_thresh=float(torch.kthvalue(g, k).values))
+        hi = float(g.max())
+        if not hi > 0.0:
+            return dict(dd, grad_thresh=float("inf"))
+        c = torch.cumsum(torch.histc(g, bins=4096, min=0.0, max=hi), 0)
+        b = int(torch.searchsorted(c, torch.tensor([args.c4_densify_quantile * g.numel()], device=c.device, dtype=c.dtype)).clamp_max(4095))
+        return dict(dd, grad_thresh=(b + 1) * hi / 4096.0)
 
     def densify_step(prm, o, st, w):
         """the event of step st['it'], if one is due: -> (N before, N after, grad_thresh) or None"""
@@ -318,10 +325,33 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
         _, st["v"] = PL.sharded_densify(prm, st["v"], o, st["it"], ddict, accumulate=False, world=w, before_event=hook)
         return (n0, int(prm["means3D"].shape[0]), seen_thr.get("t"))
 
+    if every:
+        # one-time costs of the event path (code-object loads of the torch ops behind kthvalue / the index builds, allocator growth): paid on a
+        # throwaway 4 k-Gaussian map before anything is timed -- a mapper that has densified once finds them paid
+        try:
+            small = {k: torch.nn.Parameter(v[:4096].detach().clone()) for k, v in params.items() if not k.startswith("cam_")}
+            o_s = O.initialize_optimizer(small, {k: v for k, v in lrs.items() if k in small})
+            for v_ in small.values():
+                v_.grad = torch.zeros_like(v_)
+            o_s.step(); o_s.zero_grad(set_to_none=True)
+            v_s = {k: torch.rand(4096, device=dev) for k in ("max_2D_radius", "means2D_gradient_accum", "timestep")}
+            v_s.update(denom=torch.ones(4096, device=dev), scene_radius=torch.tensor(10.0, device=dev))
+            densify_step(small, o_s, dict(v=v_s, it=every), 1)
+            del small, o_s, v_s
+        except Exception as e:
+            note(f"densify warm-up failed: {e}")
+    lpt = world > 1 and args.c4_partition == "lpt" and args.streams <= 1
+    costs = PL.KeyframeCosts(KF) if lpt else None
+    state["part"] = None
+
     def step():
         _, state["v"], _ = PL.sharded_keyframe_step(params, state["v"], keyframes, opt, loss_fn, rank=rank, world=world,
-                                                    sharded_adam=True, streams=args.streams, timing=True, accumulate_statistics=bool(every))
+                                                    sharded_adam=True, streams=args.streams, timing=True, accumulate_statistics=bool(every),
+                                                    partition=state["part"], costs=costs)
         state["it"] += 1
+        if lpt and (state["it"] == 1 or state["it"] % max(args.c4_rebalance_every, 1) == 0):
+            # every rank has recorded its own keyframes' tile-instance counts: one all-reduce of 64 floats, then the same LPT assignment everywhere
+            state["part"] = costs.sync(dev).partition(world)
         if world > 1:
             ex_ms.append(PL.last_exchange.get("events"))
             rd_ms.append(PL.last_exchange.get("render_events"))
@@ -362,6 +392,8 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
                        "gaussians": N, "width": W, "height": H, "keyframes_per_step": KF, "keyframes_per_rank_per_step": KF // max(world, 1),
                        "tile_instances_D_last_keyframe": D, "streams": args.streams, "exchange_floats_per_gaussian": 59 if sh else 14,
                        "grad_exchange": dict(exch, note="the collectives that actually ran (activesplat_amd.parallel.last_exchange)"),
+                       "partition": args.c4_partition if lpt or args.c4_partition == "contiguous" else "contiguous (streams > 1)",
+                       "keyframes_per_rank_last_step": [len(p_) for p_ in state["part"]] if state["part"] else [len(PL.shard_keyframes(KF, r, world)) for r in range(world)],
                        "densify_every": every, "densify_events_in_timed_region": [dict(n_before=a, n_after=b, grad_thresh=c) for a, b, c in events],
                        "gaussians_at_end": int(params["means3D"].shape[0]),
                        "loss": "fused mapping loss (L1 + SSIM + masked depth) through the single-pass RGB-D render",
@@ -452,6 +484,37 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
                         dist.destroy_process_group()
                 except Exception as e:
                     pred["exchange_error"] = str(e)
+                # ---- the same on a NON-uniform scene (three quarters of the Gaussians in half of the azimuth range: half the views see 3x the
+                # tile instances): contiguous keyframe blocks against the LPT assignment on each keyframe's measured instance count ----
+                try:
+                    raw_u = syn.uneven_shell_scene(N, seed=0, W=W, H=H)
+                    pu = {k: torch.nn.Parameter(v.to(dev)) for k, v in raw_u.items()}
+                    pu["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([1.0, 0, 0, 0], device=dev).reshape(1, 4, 1))
+                    pu["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 1, device=dev))
+                    ou = O.initialize_optimizer(pu, {k: v for k, v in lrs.items() if k in pu})
+                    vu = {k: torch.zeros(N, device=dev) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+                    kc = PL.KeyframeCosts(KF)
+                    PL.sharded_keyframe_step(pu, vu, keyframes, ou, loss_fn, rank=0, world=1, sharded_adam=True, streams=1, costs=kc)   # one pass: every keyframe's D
+                    kc.sync()
+                    d_per = [c - kc.gw * N for c in kc.cost]
+                    policies = {"contiguous": [list(PL.shard_keyframes(KF, r, R8)) for r in range(R8)], "lpt": kc.partition(R8)}
+                    un = {"scene": "three quarters of the Gaussians in half of the azimuth range", "tile_instances_per_keyframe": {"min": int(min(d_per)), "max": int(max(d_per)),
+                          "mean": int(np.mean(d_per))}}
+                    for name, part in policies.items():
+                        per_u = []
+                        for r in range(R8):
+                            ms = []
+                            for rep in range(3):
+                                PL.sharded_keyframe_step(pu, vu, keyframes, ou, loss_fn, rank=r, world=R8, sharded_adam=True, streams=1, timing=True, partition=part)
+                                if rep:
+                                    ms.append(PL.render_ms())
+                            per_u.append(round(float(np.mean(ms)), 3))
+                        un[name] = {"per_rank_ms": per_u, "keyframes_per_rank": [len(p_) for p_ in part], "max_over_mean": round(max(per_u) / float(np.mean(per_u)), 4)}
+                    un["slowest_rank_speedup_lpt_vs_contiguous"] = round(max(un["contiguous"]["per_rank_ms"]) / max(un["lpt"]["per_rank_ms"]), 3)
+                    pred["nonuniform_scene"] = un
+                    del pu, ou, vu
+                except Exception as e:
+                    pred["nonuniform_scene"] = {"error": str(e)}
                 out["eight_gpu_prediction"] = pred
             except Exception as e:
                 out["eight_gpu_prediction"] = {"error": str(e)}
@@ -483,7 +546,10 @@ def main():
     ap.add_argument("--c4-sh-degree", type=int, default=-1, help="configs[3]: -1 = `rgb_colors` (the reference mapper's map, G = 14 floats per Gaussian "
                                                                  "in the exchange); 0..3 = 16-coefficient SH rows (`shs`, G = 59)")
     ap.add_argument("--predict-ranks", type=int, default=8, help="configs[3] on one GPU: ranks of the load-balance / exchange prediction leg")
-    ap.add_argument("--c4-densify-every", type=int, default=10, help="configs[3]: a densify event (all-reduced statistics -> gathered moments -> fused clone / "
+    ap.add_argument("--c4-partition", choices=("lpt", "contiguous"), default="lpt", help="configs[3]: keyframes to ranks by longest-processing-time "
+                    "assignment on every keyframe's last tile-instance count (costs all-reduced every --c4-rebalance-every steps), or contiguous blocks")
+    ap.add_argument("--c4-rebalance-every", type=int, default=10)
+    ap.add_argument("--c4-densify-every", type=int, default=20, help="configs[3]: a densify event (all-reduced statistics -> gathered moments -> fused clone / "
                     "split / cull with the split offsets drawn from a replicated seed -> rebuilt shard plan) every k-th optimiser step; 0: never")
     ap.add_argument("--c4-densify-quantile", type=float, default=0.995, help="configs[3]: the event's gradient threshold is this quantile of the batch's "
                     "reduced mean-2D gradient statistic, so that an event clones / splits ~0.5 %% of the map and the workload stays configs[3]'s")

@@ -219,6 +219,69 @@ def test_optimistic_launch_hit_and_miss_equal_exact_launch(hip):
     pc.check_optimistic_tile_list_growth(hip)
 
 
+@pytest.fixture()
+def python_twin(hip):
+    """The drop-in call through rasterizer._RasterizeGaussians (the Python twin of the C++ front-end) for the duration of one test."""
+    from activesplat_amd import rasterizer as R
+    R.use_frontend = False
+    yield hip
+    R.use_frontend = True
+
+
+def test_optimistic_launch_through_the_python_twin(python_twin):
+    pc.check_optimistic_launch(python_twin)
+    pc.check_optimistic_tile_list_growth(python_twin)
+
+
+@pytest.mark.parametrize("case", ["basic", "posed_white_bg", "ragged_image", "sh3", "cov3d_precomp", "all_culled", "one_gaussian", "topdown_1000m", "huge_gaussians"])
+def test_python_twin_matches_oracle_and_the_frontend(hip, oracle32, oracle64, case):
+    """The drop-in call has two hosts above the C ABI: the C++ autograd front-end (csrc/torch_frontend.cpp, the default) and its Python twin
+    (rasterizer._RasterizeGaussians).  Same library calls in the same order: forward outputs and integer artefacts bit-identical, gradients equal up
+    to the order of the atomic sums -- and the twin passes the oracle checks the front-end passes in every other test of this file."""
+    from activesplat_amd import rasterizer as R
+    if case not in pc.CASES:
+        pytest.skip(f"no case {case}")
+    rs, rv = pc.build_case(case, hip)
+    dL = torch.randn(3, int(rs.image_height), int(rs.image_width), generator=torch.Generator().manual_seed(2))
+    front = util.run_product(rs, rv, dL)
+    art_f = util.artefacts()
+    R.use_frontend = False
+    try:
+        twin = util.run_product(rs, rv, dL)
+        art_t = util.artefacts()
+        pc.check_forward(rs, rv, oracle32)
+        pc.check_backward(rs, rv, oracle64, oracle32=oracle32 if case.startswith("topdown") else None)
+    finally:
+        R.use_frontend = True
+    for k in ("color", "depth", "opacity", "radii"):
+        assert np.array_equal(front[k], twin[k]), k
+    assert front["D"] == twin["D"]
+    for k in ("point_list", "ranges", "n_contrib", "tiles_touched", "keys_sorted"):
+        assert np.array_equal(art_f[k], art_t[k]), k
+    for k, g in front["grads"].items():
+        r = twin["grads"][k]
+        assert np.linalg.norm(g.astype(np.float64) - r) <= 2e-5 * max(np.linalg.norm(r), 1e-30), k
+
+
+def test_frontend_second_backward_and_no_grad(hip):
+    """retain_graph: a second backward through one front-end forward finds its gradient records dirty and has the library fill them (same
+    gradients); under no_grad nothing is saved and no records are allocated; means2D = None is accepted (render_views' single-view form)."""
+    from activesplat_amd import GaussianRasterizer
+    rs, rv = util.scene(8000, 128, 96, seed=3, device=hip)
+    rs = rs._replace(debug=False)
+    inp = {k: v.clone().requires_grad_(True) for k, v in rv.items()}
+    m2d = torch.zeros(8000, 3, device=hip, requires_grad=True)
+    color = GaussianRasterizer(raster_settings=rs)(means2D=m2d, **inp)[0]
+    dL = torch.randn_like(color)
+    g1 = torch.autograd.grad(color, list(inp.values()) + [m2d], dL, retain_graph=True)
+    g2 = torch.autograd.grad(color, list(inp.values()) + [m2d], dL)
+    for a, b in zip(g1, g2):
+        assert torch.isfinite(a).all() and float((a - b).norm()) <= 2e-5 * float(b.norm().clamp_min(1e-30))
+    with torch.no_grad():
+        c2, r2, d2, o2 = GaussianRasterizer(raster_settings=rs)(means2D=None, **rv)
+    assert torch.equal(c2, color.detach()) and not c2.requires_grad
+
+
 def test_full_size_config2_sh3_against_oracle_and_properties(hip, oracle32, oracle64):
     """BASELINE configs[2]'s render: 2 M Gaussians, SH degree 3, 640x480 -- forward vs the fp32 oracle (integer artefacts
     exact), gradients vs the oracle's fp32 build, plus permutation invariance (a shuffled scene renders the same

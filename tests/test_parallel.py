@@ -52,7 +52,7 @@ def _loss_fn_raw(params, kf, variables):
     return loss, variables
 
 
-def _worker(rank, world, port, emu_path, q, device="cpu", raw=False):
+def _worker(rank, world, port, emu_path, q, device="cpu", raw=False, lpt=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -76,7 +76,21 @@ def _worker(rank, world, port, emu_path, q, device="cpu", raw=False):
                 seq[k] += params[k].grad
         opt = O.initialize_optimizer(params, lrs)
         assert list(PL.shard_keyframes(len(kfs), rank, world)) == [2 * rank, 2 * rank + 1]
-        _, variables, buf = PL.sharded_keyframe_step(params, variables, kfs, opt, _loss_fn_raw if raw else _loss_fn)
+        part = None
+        if lpt:
+            # every rank records what ITS keyframes cost; one all-reduce later every rank holds all costs and computes the same assignment
+            costs = PL.KeyframeCosts(len(kfs), gaussian_weight=0.0)
+            assert costs.partition(world) == [[0, 1], [2, 3]]                  # nothing known yet: contiguous blocks
+            for i in PL.shard_keyframes(len(kfs), rank, world):
+                costs.record(i, 1000 * (i + 1))
+            part = costs.sync(device).partition(world)
+            assert part == [[0, 3], [1, 2]], part                             # LPT on (1000, 2000, 3000, 4000): 4000 + 1000 | 3000 + 2000
+            enc = torch.tensor([i for p_ in part for i in p_], device=device)
+            got = [torch.zeros_like(enc) for _ in range(world)]
+            dist.all_gather(got, enc)
+            assert all(torch.equal(got[0], g_) for g_ in got)
+        _, variables, buf = PL.sharded_keyframe_step(params, variables, kfs, opt, _loss_fn_raw if raw else _loss_fn, partition=part,
+                                                     costs=PL.KeyframeCosts(len(kfs)) if lpt else None)
         assert buf.flat.shape == (n, 14)
         err = max(float((buf.flat[:, c0:c0 + w] - seq[k]).abs().max() / (seq[k].abs().max() + 1e-12))
                   for k, w, c0 in zip(buf.keys, buf.widths, np.cumsum([0] + buf.widths[:-1])))
@@ -96,6 +110,44 @@ def test_shard_keyframes_partition():
     assert [list(shard_keyframes(64, r, 8)) for r in (0, 7)] == [list(range(0, 8)), list(range(56, 64))]
     got = sorted(i for r in range(3) for i in shard_keyframes(10, r, 3))
     assert got == list(range(10)) and len(shard_keyframes(10, 0, 3)) == 4
+
+
+def test_balanced_partition_is_a_partition_and_balances():
+    from activesplat_amd.parallel import KeyframeCosts, balanced_partition, shard_keyframes
+    costs = [3.0 if i < 32 else 1.0 for i in range(64)]                 # half the views see three times the instances
+    part = balanced_partition(costs, 8)
+    assert sorted(i for p in part for i in p) == list(range(64)) and all(p == sorted(p) for p in part)
+    load = lambda pp: [sum(costs[i] for i in p) for p in pp]  # noqa: E731
+    contiguous = [list(shard_keyframes(64, r, 8)) for r in range(8)]
+    assert max(load(contiguous)) / (sum(costs) / 8) == 1.5 and max(load(part)) / (sum(costs) / 8) == 1.0
+    assert balanced_partition(costs, 8) == part                         # deterministic
+    rng = np.random.RandomState(0)
+    for _ in range(20):                                                 # LPT's bound: max load <= (4/3 - 1/(3 m)) x optimum <= that x max(mean, largest)
+        c = rng.lognormal(0.0, 0.7, size=int(rng.randint(8, 80))).tolist()
+        m = int(rng.randint(2, 9))
+        pp = balanced_partition(c, m)
+        assert sorted(i for p in pp for i in p) == list(range(len(c)))
+        assert max(load_ for load_ in [sum(c[i] for i in p) for p in pp]) <= (4 / 3) * max(sum(c) / m, max(c)) + 1e-9
+    kc = KeyframeCosts(6)
+    kc.record(2, 5_000_000, 2_000_000); kc.sync()
+    assert kc.cost[2] == 5_000_000 + 1.6 * 2_000_000 and sum(len(p) for p in kc.partition(4)) == 6
+
+
+def test_two_rank_step_on_a_cost_balanced_partition(emu_lib_path):
+    """sharded_keyframe_step(partition=...) with the LPT assignment computed from costs that each rank recorded for its own keyframes and one
+    all-reduce made common: same partition on both ranks, the all-reduced gradient still the sequential sum over ALL keyframes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu_lib_path, q, "cpu", False, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, same, mx, den in res:
+        assert err < 1e-5 and same, (rank, err, same)
 
 
 def test_two_rank_gradient_allreduce_equals_sequential_sum(emu_lib_path):
