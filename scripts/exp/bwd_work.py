@@ -25,6 +25,10 @@ SLACKS = ((4, 0), (4, 32), (4, 30), (2, 32), (4, 48), (0, 32))
 pol = {sl: dict(rounds=0, positions=0, batches=0, iters=0, flush_groups=0, scans=0, misses=0, pairs=0) for sl in SLACKS}
 PIECES = int(os.environ.get("PIECES", 3))          # chained pieces per quadrant walk (each ends with a partial round)
 rt = dict(rounds=0, positions=0, pairs=0, batches=0, iters=0, flush_groups=0, scans=0)
+# DECOUPLED STREAMS (priced before building): per-stream ring queues -- a stream whose list for one round is short goes on with the
+# next round's entries instead of idling to the longest list.  Upper bound of what that buys: per walker (piece) the trip count becomes the LONGEST
+# stream's total over the whole piece instead of the sum over rounds of each round's longest list; scans, gathers per batch and flushes stay.
+dec = dict(positions=0, pairs=0, batches=0, iters=0)
 tot = dict(walkers=0, chunks=0, skipped=0, iters=0, batches=0, positions=0, pairs=0, flush_groups=0, any_records=0, records=0, full_batches=0)
 hist_ntrips = np.zeros(66, np.int64)
 for t in range(gx * gy):
@@ -75,6 +79,11 @@ for t in range(gx * gy):
         bounds = [nch - (nch * (p + 1)) // PIECES for p in range(PIECES)]      # piece p covers chunks [bounds[p], previous bound)
         hi = nch
         for lo in bounds:
+            S_ = nr[:, lo:hi].sum(1)
+            if int(S_.max()) > 0:
+                nt_ = int(S_.max())
+                dec["positions"] += nt_; dec["pairs"] += int(S_.sum()); dec["batches"] += (nt_ + 15) // 16
+                dec["iters"] += (nt_ // 16) * 8 + ((nt_ % 16) + 1) // 2
             cnt = 0; acc = np.zeros(4, np.int64)
             def close():
                 global rt
@@ -149,3 +158,15 @@ for sl in SLACKS:
     s3 = sum(parts.values())
     print("policy slack %s: rounds %d, records per round %.1f, batches per round %.2f, row fill %.2f, split chunks %d (%.1f %% of scans): %.1f M (%.3f x)" % (
         sl, d["rounds"], c["any_records"] / d["rounds"], d["batches"] / d["rounds"], d["pairs"] / (4.0 * d["positions"]), d["misses"], 100.0 * d["misses"] / d["scans"], s3 / 1e6, s3 / s))
+
+# decoupled streams, priced on top of the shipped policy (4, 0): its scans / rounds / flushes, the decoupled trip counts, and RING instructions of
+# bookkeeping per scan (per-stream head / tail, a record's "all four streams done" count before its slot is flushed and freed)
+d = pol[(4, 0)]
+base = dict(phase_A=d["iters"] * A_ITER, phase_B=d["batches"] * B_BATCH, gather=d["batches"] * GATHER, scan=d["scans"] * SCAN, round=d["rounds"] * ROUND,
+            flush=d["rounds"] * FLUSH_SETUP + d["flush_groups"] * FLUSH_GROUP)
+sb = sum(base.values())
+for RING in (0, 40, 80):
+    parts = dict(base, phase_A=dec["iters"] * A_ITER, phase_B=dec["batches"] * B_BATCH, gather=dec["batches"] * GATHER, ring=d["scans"] * RING)
+    sd_ = sum(parts.values())
+    print("decoupled streams (upper bound, %d ring instructions per scan): row fill %.3f (shipped %.3f), positions %d (shipped %d): %.1f M = %.3f x the shipped %.1f M" % (
+        RING, dec["pairs"] / (4.0 * dec["positions"]), d["pairs"] / (4.0 * d["positions"]), dec["positions"], d["positions"], sd_ / 1e6, sd_ / sb, sb / 1e6))

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 from oracle.gs_oracle import Oracle
 from activesplat_amd import _lib
 from tests import parity_cases as pc, util
-from tests.test_randomized import _draw
+from tests.fuzz_scenes import sweep_scene
 
 o32, o64 = Oracle("f32"), Oracle("f64")
 lib = _lib.get()
@@ -16,24 +16,8 @@ if os.environ.get("PLAIN"):          # the kernels of images of more than 256 / 
 n0, n1 = int(os.environ.get("SEED0", 20000)), int(os.environ.get("SEED1", 20300))
 bad = []
 for seed in range(n0, n1):
-    r = np.random.RandomState(seed)
     try:
-        rs, rv = _draw(seed, "cuda")
-        mode = seed % 4
-        if mode == 1:                                   # bigger scene: more chunks, longer lists
-            N = int(r.randint(3000, 30000))
-            W, H = int(r.randint(40, 200)), int(r.randint(40, 160))
-            rs, rv = util.scene(N, W, H, seed=seed, device="cuda", w2c=util.pose(float(r.uniform(-0.4, 0.4)), (0.0, 0.0, float(r.uniform(-1.0, 0.5)))),
-                                sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
-            rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
-            rv["scales"] = rv["scales"] * float(np.exp(r.uniform(-0.5, 1.5)))
-        if os.environ.get("PLAIN") == "2":              # more than 256 tiles: the chained backward walks (three pieces per quadrant)
-            N = int(r.randint(5000, 40000))
-            W, H = int(r.randint(272, 400)), int(r.randint(256, 320))
-            rs, rv = util.scene(N, W, H, seed=seed, device="cuda", w2c=util.pose(float(r.uniform(-0.4, 0.4)), (0.0, 0.0, float(r.uniform(-1.0, 0.5)))),
-                                sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
-            rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
-            rv["scales"] = rv["scales"] * float(np.exp(r.uniform(0.0, 2.0)))
+        rs, rv = sweep_scene(seed, "cuda", os.environ.get("PLAIN"))
         pc.check_forward(rs, rv, o32)
         if seed % 3 == 0:
             pc.check_backward(rs, rv, o64, oracle32=o32)          # the stated 0.995 bar; the fp32 hatch is tallied below
@@ -43,4 +27,4 @@ for seed in range(n0, n1):
         bad.append((seed, repr(e)[:300]))
         print("FAIL seed", seed, repr(e)[:300], flush=True)
 print("seeds %d..%d: %d failures" % (n0, n1, len(bad)))
-print("fp32 escape hatch: fired %d times in %d gradient comparisons" % (pc.HATCH["fired"], pc.HATCH["keys_checked"]), pc.HATCH["where"][:8])
+print("fp32 escape hatch: fired %d times in %d gradient comparisons; decision-aware rule decided %d times" % (pc.HATCH["fired"], pc.HATCH["keys_checked"], pc.HATCH["decisions"]), pc.HATCH["where"][:6], [(k, [g for g, _, _, _ in w]) for k, w, _, _ in pc.HATCH["decision_where"][:8]])

@@ -6,18 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle.gs_oracle import Oracle
 from tests import util
-from tests.test_randomized import _draw
+from tests.fuzz_scenes import sweep_scene
 
 seed = int(os.environ.get("SEED", 50310))
 o32, o64 = Oracle("f32"), Oracle("f64")
-r = np.random.RandomState(seed)
-rs, rv = _draw(seed, "cuda")
-if seed % 4 == 1:
-    N = int(r.randint(3000, 30000)); W, H = int(r.randint(40, 200)), int(r.randint(40, 160))
-    rs, rv = util.scene(N, W, H, seed=seed, device="cuda", w2c=util.pose(float(r.uniform(-0.4, 0.4)), (0.0, 0.0, float(r.uniform(-1.0, 0.5)))),
-                        sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
-    rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
-    rv["scales"] = rv["scales"] * float(np.exp(r.uniform(-0.5, 1.5)))
+rs, rv = sweep_scene(seed, "cuda", os.environ.get("PLAIN"))
 if os.environ.get("SEGS"):                                  # list segments of the few-tile backward (gs_set_backward_segments)
     from activesplat_amd import _lib
     _lib.get().gs_set_backward_segments(int(os.environ["SEGS"]))

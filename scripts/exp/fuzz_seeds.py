@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 from oracle.gs_oracle import Oracle
 from activesplat_amd import _lib
 from tests import parity_cases as pc, util
-from tests.test_randomized import _draw
+from tests.fuzz_scenes import sweep_scene
 
 o32, o64 = Oracle("f32"), Oracle("f64")
 lib = _lib.get()
@@ -15,21 +15,7 @@ plain = os.environ.get("PLAIN")
 if plain:
     _lib.check(lib.gs_set_half_quadrants(0)); _lib.check(lib.gs_set_backward_chain(3, 0))
 for seed in [int(x) for x in os.environ["SEEDS"].split(",")]:
-    r = np.random.RandomState(seed)
-    rs, rv = _draw(seed, "cuda")
-    mode = seed % 4
-    if mode == 1:
-        N = int(r.randint(3000, 30000)); W, H = int(r.randint(40, 200)), int(r.randint(40, 160))
-        rs, rv = util.scene(N, W, H, seed=seed, device="cuda", w2c=util.pose(float(r.uniform(-0.4, 0.4)), (0.0, 0.0, float(r.uniform(-1.0, 0.5)))),
-                            sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
-        rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
-        rv["scales"] = rv["scales"] * float(np.exp(r.uniform(-0.5, 1.5)))
-    if plain == "2":
-        N = int(r.randint(5000, 40000)); W, H = int(r.randint(272, 400)), int(r.randint(256, 320))
-        rs, rv = util.scene(N, W, H, seed=seed, device="cuda", w2c=util.pose(float(r.uniform(-0.4, 0.4)), (0.0, 0.0, float(r.uniform(-1.0, 0.5)))),
-                            sh_degree=[None, 3][seed % 8 == 1], scale_jitter=0.5)
-        rv["opacities"] = (rv["opacities"] * float(r.uniform(0.02, 0.6))).clamp(0, 1)
-        rv["scales"] = rv["scales"] * float(np.exp(r.uniform(0.0, 2.0)))
+    rs, rv = sweep_scene(seed, "cuda", plain)
     try:
         pc.check_fused_rgbd(rs, rv, o64, seed=seed, oracle32=o32)
         print("seed", seed, "P", rv["means3D"].shape[0], "ok", flush=True)
