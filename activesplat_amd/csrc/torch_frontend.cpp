@@ -153,7 +153,9 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
         bool optimistic = guess_d > 0;
         if (optimistic) {
             check(gs_bin_layout(guess_d, (uint32_t)guess_tile, (int32_t)W, (int32_t)H, &bl));
-            optimistic = bl.path == GS_SORT_TILE_LDS;
+            // (never optimistic where the capacities would CHOOSE the algorithm: the segmented compositing of few-tile images is switched on, and its
+            // segment count set, by the tile-list bound -- an inflated guess would make the image depend on the call history)
+            optimistic = bl.path == GS_SORT_TILE_LDS && bl.segments <= 1;
         }
         const uint64_t o_geom = 0, o_image = up256(L.gl.total_bytes), o_num = o_image + up256(L.il.total_bytes), o_scratch = o_num + 256;
         const uint64_t o_bin = o_scratch + (need_scratch ? up256(L.scratch) : 0);

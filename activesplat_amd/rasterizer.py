@@ -220,7 +220,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 ev = torch.cuda.Event()
                 ev.record(cur)
             bl_g = _lib.GsBinLayout(); _lib.check(lib.gs_bin_layout(guess[0], guess[1], W, H, C.byref(bl_g)))
-            if bl_g.path == 1:
+            # (never optimistic where the capacities would CHOOSE the algorithm: the segmented compositing of few-tile images is switched on, and
+            # its segment count set, by the tile-list bound -- an inflated guess would make the image depend on the call history; such frames
+            # take the exact launch, whose choice follows the true counts)
+            if bl_g.path == 1 and bl_g.segments <= 1:
                 done = render(*guess)
             if device.type == "cuda":
                 ev.synchronize()                                # counters are on the host; the render is still in flight

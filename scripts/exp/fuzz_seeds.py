@@ -18,6 +18,8 @@ for seed in [int(x) for x in os.environ["SEEDS"].split(",")]:
     rs, rv = sweep_scene(seed, "cuda", plain)
     try:
         pc.check_fused_rgbd(rs, rv, o64, seed=seed, oracle32=o32)
-        print("seed", seed, "P", rv["means3D"].shape[0], "ok", flush=True)
+        from activesplat_amd import rasterizer as R
+        print("seed", seed, "P", rv["means3D"].shape[0], "ok", "max tile list", R.last_stats.get("max_tile_instances"), flush=True)
     except Exception as e:
-        print("seed", seed, "P", rv["means3D"].shape[0], "FAIL", repr(e)[:160].replace("\n", " "), flush=True)
+        from activesplat_amd import rasterizer as R
+        print("seed", seed, "P", rv["means3D"].shape[0], "max tile list", R.last_stats.get("max_tile_instances"), "FAIL", repr(e)[:160].replace("\n", " "), flush=True)
