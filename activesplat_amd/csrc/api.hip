@@ -21,8 +21,8 @@ uint64_t align_up(uint64_t v, uint64_t a = 256) { return (v + a - 1) / a * a; }
 enum Stage { ST_PREPROCESS = 0, ST_TILE_COUNT, ST_EMIT, ST_SORT, ST_RANGES, ST_TILE_SCATTER_SORT, ST_BLEND_FWD, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_ADAM, ST_COUNT };
 const char* kStageNames[ST_COUNT] = {"preprocess_forward+scan", "tile_count+scan", "emit", "sort", "ranges",
                                      "tile_scatter+sort", "blend_forward", "blend_backward", "preprocess_backward", "adam"};
-int g_sort_path = GS_SORT_AUTO;
-bool g_segments_enabled = true;
+std::atomic<int> g_sort_path{GS_SORT_AUTO};          // (development knobs: atomics, read once per decision -- see the header's note on threads)
+std::atomic<bool> g_segments_enabled{true};
 
 int choose_path(int tiles, uint32_t max_tile_instances)
 {

@@ -1049,18 +1049,18 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(3, 3
 // consumer workgroups (blend_forward_pc_kernel: 256 x 256, 200 k Gaussians 80 -> 65 us, 1 M 87 -> 74 us; 120 x 150 76 -> 68 us); backward:
 // three list segments per quadrant from the states that forward records (134 -> 88 us with two segments, -> 65 us with three).  Above 256 tiles the plain kernels win (400 tiles:
 // backward 134 -> 172 us with the few-tile variant): hence 256
-int g_half_quadrant_tiles = 256;
+std::atomic<int> g_half_quadrant_tiles{256};
 // pieces of a chained backward walk (images of more than kChainMinTiles tiles); 1 switches the chaining off (tests, A/B measurements)
-int g_chain_pieces = kChainPieces;
-int g_chain_min_tiles = kChainMinTiles;
+std::atomic<int> g_chain_pieces{kChainPieces};
+std::atomic<int> g_chain_min_tiles{kChainMinTiles};
 // ordered tickets for the chained walks (gs_set_backward_chain_tickets): OFF by default -- the ticket is a fourth dependent round trip in front of a
 // walker's prologue and measured +4-6 us on the 2 M frame's 182 us, +7 us on configs[1]'s 135 us (profiles/r05_ab_tickets.txt); without them the
 // chain order is the workgroup index, which the dispatcher hands out in order.  Either way a wait is bounded and a timeout is reported.
-int g_chain_tickets = 0;
-int g_chain_polls = kChainPollsDefault;      // bound of a piece's wait for the piece in front (gs_set_backward_chain_polls: tests)
+std::atomic<int> g_chain_tickets{0};
+std::atomic<int> g_chain_polls{kChainPollsDefault};      // bound of a piece's wait for the piece in front (gs_set_backward_chain_polls: tests)
 uint32_t* g_async_status_dev = nullptr;      // device view of the host-mapped status word (api.hip: gs_async_status_word)
 // list segments (walkers) per quadrant in the few-tile backward: 3 x 256 tiles x 4 quadrants = the chip's 3072 walker slots (gs_set_backward_segments)
-int g_few_segments = kFewSegmentsMax;
+std::atomic<int> g_few_segments{kFewSegmentsMax};
 
 hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const uint32_t* point_list, const float4* geom,
                                 float* out_color, float* out_depth, float* out_opacity, float* final_T,
@@ -1070,8 +1070,11 @@ hipError_t launch_blend_forward(const Cam& cam_in, const uint2* ranges, const ui
     // whole-tile workgroups (NW = 4) here: one-wavefront workgroups measured 85 vs 80 us on configs[1] and the same at 2 M -- the
     // four walkers of a tile gather the same records, and on one CU three of them hit its L1
     Cam cam = cam_in;
-    cam.half = (segments <= 1 || !seg_T) && cam.gx * cam.gy <= g_half_quadrant_tiles;          // few tiles: the producer / consumer forward
-    cam.split = (cam.V == 1 && split_state && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles)) && g_few_segments > 1 ? g_few_segments : 0;      // (the backward refuses atlases; > 0 makes the forward record)
+    // (the development knobs are atomics read ONCE per launch: a knob changed on another thread -- the reference runs a visualiser thread next to the
+    // mapper -- takes effect at a launch boundary, never inside one decision)
+    const int k_half = g_half_quadrant_tiles.load(std::memory_order_relaxed), k_fseg = g_few_segments.load(std::memory_order_relaxed);
+    cam.half = (segments <= 1 || !seg_T) && cam.gx * cam.gy <= k_half;          // few tiles: the producer / consumer forward
+    cam.split = (cam.V == 1 && split_state && cam.gx * cam.gy <= min(k_half, kFewTiles)) && k_fseg > 1 ? k_fseg : 0;      // (the backward refuses atlases; > 0 makes the forward record)
     // (the forward's only use of `chain` is to zero the hand-over flags of the chained backward walks.  It does so for EVERY image whose
     // workspace holds them -- more than kFewTiles tiles -- whatever gs_set_backward_chain says at this moment: the backward takes its own
     // decision from the knob when IT is launched, and must find zeroed flags even if the knob changed in between)
@@ -1130,11 +1133,14 @@ hipError_t launch_blend_backward(const Cam& cam_in, const uint2* ranges, const u
     // segments (the forward of such an image has recorded the state at the cut; if it has not, the back walkers exit at once)
     Cam cam = cam_in;
     cam.half = 0;
-    cam.split = (split_state != nullptr && cam.gx * cam.gy <= min(g_half_quadrant_tiles, kFewTiles) && g_few_segments > 1) ? g_few_segments : 0;
-    cam.chain = (cam.V == 1 && split_state && cam.gx * cam.gy > max(g_chain_min_tiles, kFewTiles) && g_chain_pieces > 1) ? g_chain_pieces : 0;
+    const int k_half = g_half_quadrant_tiles.load(std::memory_order_relaxed), k_fseg = g_few_segments.load(std::memory_order_relaxed);
+    const int k_pieces = g_chain_pieces.load(std::memory_order_relaxed), k_min = g_chain_min_tiles.load(std::memory_order_relaxed);
+    cam.split = (split_state != nullptr && cam.gx * cam.gy <= min(k_half, kFewTiles) && k_fseg > 1) ? k_fseg : 0;
+    cam.chain = (cam.V == 1 && split_state && cam.gx * cam.gy > max(k_min, kFewTiles) && k_pieces > 1) ? k_pieces : 0;
     static std::atomic<unsigned> epoch{0};
     do { cam.chain_epoch = ++epoch; } while (cam.chain_epoch == 0u);          // (the forward leaves zero in the hand-over flags)
-    cam.chain_ticket = g_chain_tickets; cam.chain_polls = g_chain_polls; cam.async_status = g_async_status_dev;
+    cam.chain_ticket = g_chain_tickets.load(std::memory_order_relaxed); cam.chain_polls = g_chain_polls.load(std::memory_order_relaxed);
+    cam.async_status = g_async_status_dev;
     const int per = ((cam.gx * cam.gy + 7) >> 3) * (cam.split ? cam.split : cam.chain > 1 ? cam.chain : 1);
 #define GS_BWD(DG, FEW)                                                                                                          \
     hipLaunchKernelGGL((blend_backward_kernel<DG, 1, FEW>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom, final_T, \

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <math.h>
 
+#include <atomic>
+
 #include "../../include/gsplat_hip.h"
 
 namespace gs {
@@ -532,13 +534,13 @@ hipError_t launch_tile_count(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_
 hipError_t launch_tile_scatter_sort(const Cam& cam, int P, GeomPtrs gp, uint32_t* tile_base, const uint2* ranges,
                                     uint32_t max_tile_instances, unsigned long long* pairs, unsigned long long* pairs_alt,
                                     uint32_t* point_list, uint32_t cap, hipStream_t st);
-extern int g_half_quadrant_tiles;
-extern int g_chain_pieces;
-extern int g_chain_min_tiles;
-extern int g_chain_tickets;
-extern int g_chain_polls;
+extern std::atomic<int> g_half_quadrant_tiles;
+extern std::atomic<int> g_chain_pieces;
+extern std::atomic<int> g_chain_min_tiles;
+extern std::atomic<int> g_chain_tickets;
+extern std::atomic<int> g_chain_polls;
 extern uint32_t* g_async_status_dev;
-extern int g_few_segments;
+extern std::atomic<int> g_few_segments;
 // images of few tiles (at most kFewTiles; the knob above can only lower the limit): the forward records every pixel's running state
 // at the recorded list positions (cut_level below: every 256th up to 4096, then powers of two) for the segmented backward.  Planes of H*W floats: [level][T, C0, C1, C2, D], then the
 // four totals, then one word "recorded"

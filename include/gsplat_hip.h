@@ -19,9 +19,13 @@
  *      rotations [P,4] (w,x,y,z), cov3D_precomp [P,6]); base pointers 16-byte aligned;
  *   - `stream` is a hipStream_t; every entry point only enqueues work on it (no implicit sync);
  *   - return value 0 = success, otherwise a GS_E* code; gs_last_error() gives the message;
- *   - no torch types.  Process-wide state: the last-error string (thread-local), and three development knobs that are NOT
- *     synchronised with rendering calls on other threads -- set them while nothing is in flight: gs_set_sort_path,
- *     gs_set_forward_segments, gs_set_half_quadrants, gs_set_backward_chain (defaults: automatic path choice, segments on, few-tile kernels up to 256 tiles) and the gs_profile_* event log (off).
+ *   - no torch types.  Process-wide state: the last-error string (thread-local), the host-mapped status word (gs_async_status_word) and the
+ *     development knobs gs_set_sort_path, gs_set_forward_segments, gs_set_half_quadrants, gs_set_backward_chain[_tickets|_polls],
+ *     gs_set_backward_segments (defaults: automatic path choice, segments on, few-tile kernels up to 256 tiles, three chained pieces above 768 tiles).
+ *     The knobs are atomics that every launch reads ONCE: set from another thread (the reference runs a visualiser thread next to the mapper) a
+ *     new value takes effect at a launch boundary of the other threads, never inside one launch's decisions; a forward and the backward that
+ *     consumes its state tolerate a change in between (the forward clears the hand-over flags and records its "recorded" word whatever the
+ *     knobs say).  The gs_profile_* event log (off by default) is not thread-safe: one profiling thread at a time.
  *
  * Call sequence for one forward:
  *     gs_preprocess_forward(...)            // per-Gaussian stage + tile counting; writes the counts

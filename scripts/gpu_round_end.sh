@@ -1,8 +1,8 @@
 # End-of-round evidence run: parity tests, bench line, rocprof kernel summaries, PMC passes.  Run via gpurun from the repo root:
-#   gpurun --timeout 1800 -- 'bash scripts/gpu_round_end.sh r04'
+#   gpurun --timeout 1800 -- 'bash scripts/gpu_round_end.sh r05'
 # Every step is bounded by its own timeout; outputs land in gpurun_out/final (copy what is to be judged into profiles/).
 # The headline workload (bench.py, N = 1) is BASELINE configs[2]'s render: 2 M Gaussians, SH degree 3, 640x480, forward + backward.
-R=$PWD; TAG=${1:-r04}
+R=$PWD; TAG=${1:-r05}
 mkdir -p gpurun_out/final
 timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/final/build_smoke.log 2>&1; echo build+smoke rc=$?
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -40 > gpurun_out/final/${TAG}_pytest_gpu.log; tail -4 gpurun_out/final/${TAG}_pytest_gpu.log

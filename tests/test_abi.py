@@ -105,3 +105,18 @@ def test_recorded_cut_positions_are_nearest_in_ratio():
     assert cut(12000) == (16384, 17) and cut(24000) == (32768, 18) and cut(10 ** 9) == (131072, 20)
     # three walkers of a 30 000-deep list: cuts at 8192 and 16384 (round 4: 4096 and 8192 -- the last walker took 73 % of the walk)
     assert cut(30000 // 3)[0] == 8192 and cut(2 * 30000 // 3)[0] == 16384
+
+
+def test_frontend_builds_loads_and_refuses_host_tensors():
+    """The C++ autograd front-end of the drop-in call (csrc/torch_frontend.cpp): builds with g++ against this interpreter's torch and the C ABI library,
+    loads without a GPU, reports the ABI version it was linked against, and -- like the Python twin -- has no CPU fallback."""
+    import pytest
+    import torch
+    from activesplat_amd import _frontend, _lib
+    _frontend.build()
+    ext = _frontend.get()
+    assert int(ext.abi_version()) == _lib.ABI_VERSION
+    z = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ext.rasterize(z, None, None, z, torch.zeros(4, 1), z, torch.zeros(4, 4), None, torch.zeros(3), torch.eye(4), torch.eye(4), torch.zeros(3),
+                      32, 32, 1.0, 1.0, 1.0, 0, False, 0, 0, False)
