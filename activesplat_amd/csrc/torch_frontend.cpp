@@ -147,8 +147,9 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
         const Layouts L = layouts(P, (int)W, (int)H);
         const bool need_scratch = want_bwd && P > 0;
 
-        // ONE allocation for everything only the library reads: geom state | image state | device counters | gradient records | (with a capacity
-        // guess) binning workspace | point list
+        // ONE allocation for everything the backward needs again: geom state | image state | device counters | gradient records | (with a capacity
+        // guess) point list.  The binning workspace (8 bytes per tile instance: 39 MB at 2 M Gaussians) is scratch of this forward only and goes back
+        // to the allocator when it returns
         GsBinLayout bl{};
         bool optimistic = guess_d > 0;
         if (optimistic) {
@@ -158,12 +159,12 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
             optimistic = bl.path == GS_SORT_TILE_LDS && bl.segments <= 1;
         }
         const uint64_t o_geom = 0, o_image = up256(L.gl.total_bytes), o_num = o_image + up256(L.il.total_bytes), o_scratch = o_num + 256;
-        const uint64_t o_bin = o_scratch + (need_scratch ? up256(L.scratch) : 0);
-        const uint64_t o_plist = o_bin + (optimistic ? up256(bl.total_bytes) : 0);
+        const uint64_t o_plist = o_scratch + (need_scratch ? up256(L.scratch) : 0);
         const uint64_t total = o_plist + (optimistic ? up256(4 * (uint64_t)std::max<int64_t>(guess_d, 1)) : 0);
         auto bytes = at::TensorOptions().dtype(at::kByte).device(dev);
         Tensor ws = at::empty({(int64_t)total}, bytes);
         uint8_t* base = ws.data_ptr<uint8_t>();
+        Tensor bin1 = optimistic ? at::empty({(int64_t)bl.total_bytes}, bytes) : Tensor();
         auto f_opts = at::TensorOptions().dtype(at::kFloat).device(dev);
         Tensor radii = at::empty({P}, at::TensorOptions().dtype(at::kInt).device(dev));
         Tensor color = at::empty({3, H, W}, f_opts), depth = at::empty({1, H, W}, f_opts), opacity = at::empty({1, H, W}, f_opts);
@@ -175,7 +176,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
         // then does the host wait for the two counters; a frame that outgrew them is rendered again with exact sizes.
         if (optimistic) {
             if (hipEventRecord(ps.ev, st) != hipSuccess) throw std::runtime_error("frontend: hipEventRecord failed");
-            check(gs_render_forward(&cam, P, guess_d, (uint32_t)guess_tile, base + o_geom, base + o_bin, (uint32_t*)(base + o_plist), base + o_image,
+            check(gs_render_forward(&cam, P, guess_d, (uint32_t)guess_tile, base + o_geom, bin1.data_ptr(), (uint32_t*)(base + o_plist), base + o_image,
                                     color.data_ptr<float>(), depth.data_ptr<float>(), opacity.data_ptr<float>(), fused ? depth_sq.data_ptr<float>() : nullptr,
                                     need_scratch ? base + o_scratch : nullptr, st));
             if (hipEventSynchronize(ps.ev) != hipSuccess) throw std::runtime_error("frontend: hipEventSynchronize failed");
@@ -198,9 +199,8 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
         }
         tl_D = D; tl_max_tile = max_tile; tl_hit = hit ? 1 : 0;
         if (tl_want_state) {
-            tl_state = {ws, bin2, plist2};
-            tl_offsets = {(int64_t)o_geom, (int64_t)L.gl.total_bytes, (int64_t)o_image, (int64_t)L.il.total_bytes, (int64_t)o_bin, (int64_t)bl.total_bytes,
-                          (int64_t)o_plist, std::max<int64_t>(guess_d, 1)};
+            tl_state = {ws, hit ? bin1 : bin2, plist2};
+            tl_offsets = {(int64_t)o_geom, (int64_t)L.gl.total_bytes, (int64_t)o_image, (int64_t)L.il.total_bytes, (int64_t)o_plist, std::max<int64_t>(guess_d, 1)};
         }
 
         ctx->save_for_backward({means3D, shs, colors, scales, rotations, cov3D, radii, ws, plist2, bg, view, proj, campos});

@@ -391,12 +391,11 @@ def _frontend_apply(means3D, means2D, shs, colors_precomp, opacities, scales, ro
         # capture(): views of the one workspace (and of the exact re-render's buffers after a miss), under the names the Python twin publishes
         lib = _lib.get()
         gl, il, _ = _frame_layouts(lib, P, W, H)
-        ws, bin2, plist2 = state
+        ws, binning, plist2 = state
         cap_d, cap_tile = (guess if hit else (D, max_tile))
         bl = _lib.GsBinLayout(); _lib.check(lib.gs_bin_layout(cap_d, cap_tile, W, H, C.byref(bl)))
-        caps[-1].update(geom=ws[off[0]:off[0] + off[1]], image=ws[off[2]:off[2] + off[3]], gl=gl, il=il, bl=bl, D=D, P=P, W=W, H=H,
-                        binning=ws[off[4]:off[4] + off[5]] if hit else bin2,
-                        point_list=ws[off[6]:off[6] + 4 * off[7]].view(torch.int32) if hit else plist2)
+        caps[-1].update(geom=ws[off[0]:off[0] + off[1]], image=ws[off[2]:off[2] + off[3]], gl=gl, il=il, bl=bl, D=D, P=P, W=W, H=H, binning=binning,
+                        point_list=ws[off[4]:off[4] + 4 * off[5]].view(torch.int32) if hit else plist2)
     if hit:
         last_stats["optimistic_hits"] = last_stats.get("optimistic_hits", 0) + 1
     else:

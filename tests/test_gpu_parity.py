@@ -247,6 +247,52 @@ def test_render_does_not_depend_on_the_capacity_history(hip, frontend):
         R._capacity.clear()
 
 
+def test_frontend_from_two_host_threads(hip):
+    """The reference's threaded layout (a visualiser / planner thread rendering next to the mapper's, visualizer.py:157-160): two host threads, each on
+    its own HIP stream, render and back-propagate different scenes through the C++ front-end at the same time (the GIL is released inside it; pinned
+    counters and events are per thread and stream, the layout cache is locked).  Every result equals the thread's own serial result."""
+    import threading
+    from activesplat_amd import GaussianRasterizer
+    jobs = []
+    for seed, (n, w, h) in enumerate(((30_000, 256, 256), (12_000, 120, 150))):
+        rs, rv = util.scene(n, w, h, seed=seed, device=hip)
+        rs = rs._replace(debug=False)
+        dL = torch.randn(3, h, w, generator=torch.Generator().manual_seed(seed)).to(hip)
+        jobs.append((rs, rv, dL))
+
+    def run(rs, rv, dL):
+        inp = {k: v.detach().clone().requires_grad_(True) for k, v in rv.items()}
+        m2d = torch.zeros(rv["means3D"].shape[0], 3, device=hip, requires_grad=True)
+        out = GaussianRasterizer(raster_settings=rs)(means2D=m2d, **inp)
+        out[0].backward(dL)
+        return [t.detach().clone() for t in out], {k: v.grad.clone() for k, v in inp.items()}
+    serial = [run(*j) for j in jobs]
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+
+    def worker(i):
+        try:
+            s = torch.cuda.Stream(device=hip)
+            with torch.cuda.stream(s):
+                for _ in range(30):
+                    results[i] = run(*jobs[i])
+            s.synchronize()
+        except Exception as e:                       # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for (o_s, g_s), (o_t, g_t) in zip(serial, results):
+        for a, b in zip(o_s, o_t):
+            assert torch.equal(a, b)
+        for k in g_s:
+            assert float((g_s[k] - g_t[k]).norm()) <= 2e-5 * float(g_s[k].norm().clamp_min(1e-30)), k
+
+
 @pytest.fixture()
 def python_twin(hip):
     """The drop-in call through rasterizer._RasterizeGaussians (the Python twin of the C++ front-end) for the duration of one test."""
