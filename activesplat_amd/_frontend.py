@@ -1,7 +1,8 @@
 """The C++ autograd front-end of the drop-in call (csrc/torch_frontend.cpp): build recipe and loader.
 
 build() compiles it with g++ (host code only: the kernels live in libgsplat_hip.so) into activesplat_amd/_gs_frontend.so, in-tree, linked against
-the C ABI library next to it and against this interpreter's torch.  get() imports it -- and fails loudly when it has not been built."""
+the C ABI library next to it and against this interpreter's torch.  get() imports it (building it first if it is missing) -- and fails loudly
+when that is not possible."""
 from __future__ import annotations
 
 import importlib.machinery
@@ -37,7 +38,12 @@ def get():
     global _mod
     if _mod is None:
         if not os.path.exists(SO):
-            raise RuntimeError(f"{SO} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+            # host code only (g++, ~25 s): built in place on first use when build() has not run here; a failing build raises -- there is no
+            # silent fall-back to the slower Python twin on a GPU box
+            try:
+                build()
+            except Exception as e:
+                raise RuntimeError(f"{SO} is missing and could not be built ({e}): run `python -c 'import __graft_entry__ as g; g.build()'`") from e
         import torch  # noqa: F401  (its libraries must be loaded first)
         from . import _lib
         _lib.get()                                         # libgsplat_hip.so is resolved through the rpath; load it explicitly for a clear error

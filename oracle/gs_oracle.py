@@ -58,6 +58,11 @@ class Oracle:
         """Host threads of the pixel loops (default 1 = the deterministic sequential order the parity tests use)."""
         self.lib.gso_set_threads(int(n))
 
+    def set_threshold_scale(self, per_gaussian=None) -> None:
+        """TEST HOOK: per-Gaussian factor on the alpha >= 1/255 threshold (None: the published algorithm) -- see gso_set_threshold_scale."""
+        self._thresh = None if per_gaussian is None else np.ascontiguousarray(np.asarray(per_gaussian, dtype=self.real))
+        self.lib.gso_set_threshold_scale(_ptr(self._thresh))
+
     def _r(self, a):
         return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=self.real))
 

@@ -27,4 +27,4 @@ for seed in range(n0, n1):
         bad.append((seed, repr(e)[:300]))
         print("FAIL seed", seed, repr(e)[:300], flush=True)
 print("seeds %d..%d: %d failures" % (n0, n1, len(bad)))
-print("fp32 escape hatch: fired %d times in %d gradient comparisons; decision-aware rule decided %d times" % (pc.HATCH["fired"], pc.HATCH["keys_checked"], pc.HATCH["decisions"]), pc.HATCH["where"][:6], [(k, [g for g, _, _, _ in w]) for k, w, _, _ in pc.HATCH["decision_where"][:8]])
+print("fp32 escape hatch: fired %d times in %d gradient comparisons; decision-matched comparison decided %d times" % (pc.HATCH["fired"], pc.HATCH["keys_checked"], pc.HATCH["decisions"]), pc.HATCH["where"][:6], [(k, [g for g, _, _, _ in w]) for k, w, _, _ in pc.HATCH["decision_where"][:8]])

@@ -28,3 +28,13 @@ for k, g in got["grads"].items():
     print(k, "rel", np.linalg.norm(g - a) / np.linalg.norm(a), "rel32", np.linalg.norm(b - a) / np.linalg.norm(a), "|g|max", np.abs(a).max())
     for i in top:
         print("   gaussian", i, "err", d[i], "fp32-oracle err", d32[i], "radius", got["radii"][i])
+    # the elements outside the stated tolerance (rtol 1e-3, atol 1e-6 |g|inf): how large are they, and how much cancellation is behind them?
+    gmax = float(np.abs(a).max())
+    out = np.abs(g - a) > 1e-6 * gmax + 1e-3 * np.abs(a)
+    out32 = np.abs(b - a) > 1e-6 * gmax + 1e-3 * np.abs(a)
+    print("   elements outside the tolerance: kernel %d, fp32 oracle %d of %d" % (int(out.sum()), int(out32.sum()), out.size))
+    idx = np.argwhere(out)[:8]
+    for ix in idx:
+        ix = tuple(ix)
+        print("      element", ix, "fp64 %.3e kernel %.3e fp32-oracle %.3e  |value| / |g|inf = %.1e  kernel err / |g|inf = %.1e" % (
+            a[ix], g[ix], b[ix], abs(a[ix]) / gmax, abs(g[ix] - a[ix]) / gmax), "scales", rv["scales"][ix[0]].tolist() if "scales" in rv else None, "radius", got["radii"][ix[0]])

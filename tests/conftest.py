@@ -63,5 +63,5 @@ def pytest_terminal_summary(terminalreporter):
     if h["keys_checked"]:
         terminalreporter.write_line(f"check_backward: {h['keys_checked']} gradient tensors compared with the fp64 oracle at the stated tolerance; "
                                     f"fp32 escape hatch fired {h['fired']} time(s)" + (": " + ", ".join(f"{k} rel={r:.2e} frac={f:.4f} P={n}" for k, r, f, n in h["where"][:12]) if h["fired"] else "")
-                                    + f"; decision-aware rule (rows of Gaussians with a proven alpha = 1/255 threshold pixel taken out) decided {h['decisions']} time(s)"
+                                    + f"; decision-matched comparison (oracles re-run with the other decision at a proven alpha = 1/255 threshold pixel) decided {h['decisions']} time(s)"
                                     + (": " + ", ".join(f"{k} gaussians {[i for i, _, _, _ in w]}" for k, w, _, _ in h["decision_where"][:8]) if h["decisions"] else ""))

@@ -35,6 +35,12 @@ def sweep_scene(seed, device, plain=None):
 
 #: scenes the round-4 sweeps flagged (profiles/r04_fuzz5.txt): (seed, plain).  Ten pass under the operative gradient rule of DESIGN section 6
 #: (the fp64 bar, or at most 1.5 x the fp32 oracle's own error); 120013 is the alpha = 1/255 threshold scene analysed in
-#: profiles/README.md ("seed 120013") and is checked with the decision-aware rule of parity_cases.check_fused_rgbd(flip_aware=True).
+#: profiles/README.md ("seed 120013"): it passes through the decision-matched third tier of parity_cases.check_fused_rgbd.
 FLAGGED_RGBD = [(122026, "2"), (122050, "2"), (122083, "2"), (122086, "2"), (122095, "2"), (122131, "2"), (122184, "2"), (122236, "2"),
                 (120013, None), (120229, None), (120517, None)]
+
+#: scenes the round-5 sweeps flagged (profiles/r05_fuzz.txt, r05_fuzz2.txt): 130045 / 130237 (a render depended on the capacity history: fixed),
+#: 130378 (tiny scene, fused-vs-two-pass at 2.3e-4 in one run of two), 142132 (rotations one pass against two at 1.36e-4) through check_fused_rgbd;
+#: 140658 (one alpha = 1/255 decision, Gaussian 112 at pixel (0,39): the decision-matched tier) through check_backward
+FLAGGED_R05_RGBD = [(130045, None), (130237, None), (130378, None), (142132, "2")]
+FLAGGED_R05_BACKWARD = [(140658, None)]

@@ -551,8 +551,8 @@ def check_chained_backward_fails_safe(device, N=5000, W=288, H=272, seed=33):
             _lib._status[0] = 0
 
 
-#: tally of check_backward's fp32 escape hatch over the session (printed by tests/conftest.py); "decisions": how often the third tier -- rows of
-#: Gaussians with a PROVEN alpha = 1/255 threshold pixel taken out of the comparison -- decided
+#: tally of check_backward's fp32 escape hatch over the session (printed by tests/conftest.py); "decisions": how often the third tier -- the
+#: comparison against the oracles run with the other decision at a PROVEN alpha = 1/255 threshold pixel -- decided
 HATCH = {"keys_checked": 0, "fired": 0, "where": [], "decisions": 0, "decision_where": []}
 
 #: relative half-width of the window around 1/255 inside which a visibility decision may legitimately differ between two fp32 evaluation orders
@@ -584,37 +584,62 @@ def threshold_gaussians(f64, idx, W, H, window=THRESHOLD_WINDOW):
     return out
 
 
-def _rows_out(a, rows):
-    a = np.array(a, dtype=np.float64, copy=True)
-    a[rows] = 0.0
-    return a
+#: margin by which the oracle's threshold factor of a proven Gaussian is moved past its alpha (relative): above the few 1e-6 by which two fp32
+#: evaluation orders of alpha differ, below the 1e-5 window of the proof
+DECISION_MARGIN = 5e-6
 
 
-def decision_aware(k, g, r, o32, f64, W, H, min_frac=None, top=3):
-    """Third tier of the gradient rule.  `g` (kernel), `r` (fp64 oracle), `o32` (fp32 oracle) are one gradient tensor [P, ...] that
-    failed both the fp64 bar and the fp32-oracle rule.  If the error sits in at most `top` Gaussians AND each of those provably owns a pixel at the
-    alpha = 1/255 threshold (threshold_gaussians), their rows are taken out of all three tensors and the rest is judged by the first two tiers again.
-    Returns True when that passes (tallied), False otherwise."""
+def decision_aware(k, g, f64, W, H, rerun, oracle64, oracle32, min_frac=None, top=3):
+    """Third tier of the gradient rule: the DECISION-MATCHED comparison.  `g` [P, ...] is one gradient tensor of the kernel that
+    failed both the fp64 bar and the fp32-oracle rule.  Among the `top` Gaussians that carry most of its squared error, those that provably own a pixel
+    at the alpha = 1/255 threshold (threshold_gaussians) are candidates for "the kernel's arithmetic took the other decision there".  For every
+    non-empty subset of them the two oracles are run AGAIN with the visibility threshold of exactly those Gaussians moved past their alpha
+    (gso_set_threshold_scale: by the distance of alpha to the threshold plus 5e-6) -- the same algorithm with the kernel's decision at those
+    pixels -- and the WHOLE tensor is judged by tiers 1 and 2 against those references: nothing is excluded, and the side effects of the flipped pixel
+    on every other Gaussian that blends there (their transmittance and behind-colour change by alpha = 1/255) are part of the reference.
+    `rerun(oracle) -> {key: gradient}` repeats the caller's oracle run.  Returns True when a subset passes (tallied), False otherwise."""
+    import itertools
     P = g.shape[0]
+    key = k.split(" ")[0]                                     # ("means3D (fused RGB-D)" -> the oracle's key)
+    r = np.asarray(rerun.base64[key], np.float64).reshape(g.shape)
     e = ((g.astype(np.float64) - r).reshape(P, -1) ** 2).sum(1)
-    cand = np.argsort(-e)[:top]
-    proven = threshold_gaussians(f64, cand, W, H)
+    proven = threshold_gaussians(f64, np.argsort(-e)[:top], W, H)
     if not proven:
         return False
-    rows = [i for i, _, _, _ in proven]
-    g2, r2, o2 = _rows_out(g, rows), _rows_out(r, rows), _rows_out(o32, rows)
-    nr = max(np.linalg.norm(r2), 1e-30); gmax = float(np.abs(r2).max())
-    rel, rel32 = np.linalg.norm(g2 - r2) / nr, np.linalg.norm(o2 - r2) / nr
-    ok = rel < 1e-3 or rel <= 1.5 * rel32 + 1e-6
-    if min_frac is not None:
-        frac, frac32 = util.close_frac(g2, r2, GRAD_RTOL, 1e-6 * gmax), util.close_frac(o2, r2, GRAD_RTOL, 1e-6 * gmax)
-        ok = ok and (frac >= min_frac or (1.0 - frac) <= 1.5 * (1.0 - frac32) + 1e-3)
-    if ok:
-        HATCH["decisions"] += 1
-        HATCH["decision_where"].append((k, [(i, x, y, d) for i, x, y, d in proven], float(rel), float(rel32)))
-        print(f"decision-aware rule for {k}: rows of Gaussians {rows} out (threshold pixels {[(x, y, f'{d:+.1e}') for _, x, y, d in proven]}): "
-              f"rel {rel:.3e}, fp32 oracle {rel32:.3e}")
-    return ok
+    subsets = [c for n in range(len(proven), 0, -1) for c in itertools.combinations(proven, n)]
+    try:
+        for combo in subsets:
+            scale = np.ones(P)
+            for i, _, _, d in combo:
+                scale[i] = 1.0 + d + (DECISION_MARGIN if d >= 0 else -DECISION_MARGIN)
+            oracle64.set_threshold_scale(scale); oracle32.set_threshold_scale(scale)
+            r2 = np.asarray(rerun(oracle64)[key], np.float64).reshape(g.shape)
+            o2 = np.asarray(rerun(oracle32)[key], np.float64).reshape(g.shape)
+            nr = max(np.linalg.norm(r2), 1e-30); gmax = float(np.abs(r2).max())
+            rel, rel32 = np.linalg.norm(g - r2) / nr, np.linalg.norm(o2 - r2) / nr
+            ok = rel < 1e-3 or rel <= 1.5 * rel32 + 1e-6
+            if min_frac is not None:
+                frac, frac32 = util.close_frac(g, r2, GRAD_RTOL, 1e-6 * gmax), util.close_frac(o2, r2, GRAD_RTOL, 1e-6 * gmax)
+                ok = ok and (frac >= min_frac or (1.0 - frac) <= 1.5 * (1.0 - frac32) + 1e-3)
+            if ok:
+                HATCH["decisions"] += 1
+                HATCH["decision_where"].append((k, [(i, x, y, d) for i, x, y, d in combo], float(rel), float(rel32)))
+                print(f"decision-matched comparison for {k}: with the oracle's decision flipped at {[(i, (x, y), f'{d:+.1e}') for i, x, y, d in combo]} "
+                      f"(Gaussian, pixel, 255 alpha - 1): rel {rel:.3e}, fp32 oracle {rel32:.3e}")
+                return True
+        return False
+    finally:
+        oracle64.set_threshold_scale(None); oracle32.set_threshold_scale(None)
+
+
+class _Rerun:
+    """callable that repeats an oracle run for decision_aware; `base64`: the fp64 oracle's gradients of the undisturbed run"""
+
+    def __init__(self, fn, base64):
+        self.fn, self.base64 = fn, base64
+
+    def __call__(self, oracle):
+        return self.fn(oracle)
 
 
 def check_forward(rs, rv, oracle32, exact_float=False):
@@ -665,7 +690,7 @@ def check_backward(rs, rv, oracle64, seed=0, min_frac=0.995, oracle32=None):
     accepted when the fp32 ORACLE misses it by as much (ill-conditioned scenes: the limit is the arithmetic, not the kernel):
     the kernel's error must then stay within 1.5x the fp32 oracle's own error against fp64.  Third tier (decision_aware): when the miss sits in at
     most three Gaussians that provably own a pixel whose alpha is within 1e-5 of the 1/255 visibility threshold (one arithmetic blends it, another
-    skips it), those rows are taken out and the rest is judged by the first two tiers."""
+    skips it), the oracles are run again with the OTHER decision at those pixels and the whole tensor is judged by the first two tiers against them."""
     H, W = int(rs.image_height), int(rs.image_width)
     dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(seed))
     got = util.run_product(rs, rv, dL)
@@ -695,7 +720,8 @@ def check_backward(rs, rv, oracle64, seed=0, min_frac=0.995, oracle32=None):
             rel32 = np.linalg.norm(o - r) / np.linalg.norm(r)
             frac32 = util.close_frac(o, r, GRAD_RTOL, 1e-6 * gmax)
             if not (rel <= 1.5 * rel32 + 1e-6 and (1.0 - frac) <= 1.5 * (1.0 - frac32) + 1e-3):
-                assert decision_aware(k, g, r, o, ref, W, H, min_frac=min_frac), (k, rel, rel32, frac, frac32)
+                rerun = _Rerun(lambda orc: util.run_oracle(orc, rs, rv, dL)["grads"], ref["grads"])
+                assert decision_aware(k, g, ref, W, H, rerun, oracle64, oracle32, min_frac=min_frac), (k, rel, rel32, frac, frac32)
             continue
         assert frac >= min_frac, (k, frac)
         assert rel < 1e-3, (k, rel)
@@ -705,8 +731,8 @@ def check_backward(rs, rv, oracle64, seed=0, min_frac=0.995, oracle32=None):
 def check_fused_rgbd(rs, rv, oracle64, seed=0, oracle32=None):
     """rasterizer.render_rgbd (one pass) vs (a) the two reference-style passes of the same library and
     (b) the fp64 oracle with a depth gradient.  With `oracle32` (the random sweeps of scripts/exp: scenes of tens of thousands of Gaussians)
-    a gradient that misses the 1e-3 bar against fp64 is judged against the fp32 oracle's own error, as in check_backward, and -- third tier -- with the
-    rows of Gaussians that provably own a pixel at the alpha = 1/255 threshold taken out (decision_aware)."""
+    a gradient that misses the 1e-3 bar against fp64 is judged against the fp32 oracle's own error, as in check_backward, and -- third tier -- against
+    the oracles run with the other decision at proven alpha = 1/255 threshold pixels (decision_aware)."""
     from activesplat_amd import rasterizer as R
     H, W = int(rs.image_height), int(rs.image_width)
     dev = rv["means3D"].device
@@ -751,7 +777,9 @@ def check_fused_rgbd(rs, rv, oracle64, seed=0, oracle32=None):
         # (one pass against the SUM of two passes' gradients: where the colour pass' and the depth pass' contributions cancel, fp32 rounding of the
         # parts shows in the sum -- a scene of a few dozen Gaussians reached 2.3e-4 in one of two runs of the round-5 sweep (seed 130378, P = 63);
         # scenes below 400 Gaussians get 1e-3, the others 1e-4)
-        assert rel < (1e-4 if P >= 400 else 1e-3), (k, rel)
+        # (rotations / scales: the least well-conditioned of the gradients -- both formulations sit at ~1e-3 of the fp64 oracle on the sweeps' scenes --,
+        # one pass against two differs by up to 1.4e-4 there (seed 142132 of the round-5 sweep): 3e-4)
+        assert rel < (1e-3 if P < 400 else 3e-4 if k in ("rotations", "scales") else 1e-4), (k, rel)
     # (3) fp64 oracle
     ref = util.run_oracle(oracle64, rs, rv)
     go = oracle64.backward(ref, dLc.cpu().numpy(), dLd.cpu().numpy())
@@ -768,7 +796,8 @@ def check_fused_rgbd(rs, rv, oracle64, seed=0, oracle32=None):
             o = go32[k].reshape(gq.shape).astype(np.float64)
             rel32 = np.linalg.norm(o - r) / max(np.linalg.norm(r), 1e-30)
             if not rel <= 1.5 * rel32 + 1e-6:
-                assert decision_aware(k + " (fused RGB-D)", gq, r, o, ref, W, H), (k, rel, rel32)
+                rerun = _Rerun(lambda orc: orc.backward(util.run_oracle(orc, rs, rv), dLc.cpu().numpy(), dLd.cpu().numpy()), go)
+                assert decision_aware(k + " (fused RGB-D)", gq, ref, W, H, rerun, oracle64, oracle32), (k, rel, rel32)
             continue
         assert rel < 1e-3, (k, rel)
     sc = max(1.0, float(ref["depth_sq"].max()))

@@ -411,6 +411,36 @@ def test_flagged_sweep_scene_fused_rgbd(hip, oracle32, oracle64, seed, plain):
         _lib.check(lib.gs_set_half_quadrants(256)); _lib.check(lib.gs_set_backward_chain(3, -1))
 
 
+@pytest.mark.parametrize("seed,plain", __import__("tests.fuzz_scenes", fromlist=["FLAGGED_R05_RGBD"]).FLAGGED_R05_RGBD)
+def test_flagged_round5_sweep_scene_fused_rgbd(hip, oracle32, oracle64, seed, plain):
+    from activesplat_amd import _lib
+    from tests.fuzz_scenes import sweep_scene
+    lib = _lib.get()
+    rs, rv = sweep_scene(seed, hip, plain)
+    try:
+        if plain:
+            _lib.check(lib.gs_set_half_quadrants(0)); _lib.check(lib.gs_set_backward_chain(3, 0))
+        pc.check_forward(rs, rv, oracle32)
+        for _ in range(2):                                           # (twice: the second pass runs on the optimistic launch's capacities)
+            pc.check_fused_rgbd(rs, rv, oracle64, seed=seed, oracle32=oracle32)
+    finally:
+        _lib.check(lib.gs_set_half_quadrants(256)); _lib.check(lib.gs_set_backward_chain(3, -1))
+
+
+@pytest.mark.parametrize("seed,plain", __import__("tests.fuzz_scenes", fromlist=["FLAGGED_R05_BACKWARD"]).FLAGGED_R05_BACKWARD)
+def test_flagged_round5_sweep_scene_backward(hip, oracle32, oracle64, seed, plain):
+    """Seed 140658: 10 of 1024 rotation elements outside the element-wise tolerance at a relative L2 of 4.7e-5 -- ONE alpha = 1/255 decision (Gaussian 112,
+    pixel (0,39), 255 alpha - 1 = -5.9e-7) that the kernel takes the other way; it moves that Gaussian's row and, by alpha, every Gaussian that blends
+    at the pixel.  Passes through the decision-matched tier, for Gaussian 112 and nothing else."""
+    from tests.fuzz_scenes import sweep_scene
+    rs, rv = sweep_scene(seed, hip, plain)
+    pc.check_forward(rs, rv, oracle32)
+    before = pc.HATCH["decisions"]
+    pc.check_backward(rs, rv, oracle64, oracle32=oracle32)
+    where = pc.HATCH["decision_where"][before:]
+    assert where and all([i for i, _, _, _ in combo] == [112] for _, combo, _, _ in where), where
+
+
 def test_fused_rgbd_at_configs1_size(hip, oracle32, oracle64):
     """BASELINE configs[1]'s frame (500 k Gaussians, 640 x 480) through the single-pass RGB-D render: colour bit-equal to the plain render, depth /
     silhouette / depth^2 equal to the second reference-style pass, gradients (colour AND depth gradient) vs the two-pass formulation and vs the

@@ -1,6 +1,8 @@
 """CPU: the tiered gradient rule of tests/parity_cases.py is itself tested -- the threshold-pixel finder on the scene the
-round-4 sweep flagged (seed 120013; device analysis in profiles/README.md) and the decision-aware tier on synthetic errors."""
+round-4 sweep flagged (seed 120013; device analysis in profiles/README.md), and the DECISION-MATCHED third tier end to end on the host-emulated
+kernels with the scene the round-5 sweep flagged (seed 140658: the emulated build reproduces the device's decision there)."""
 import numpy as np
+import torch
 
 from tests import parity_cases as pc
 from tests import util
@@ -19,20 +21,58 @@ def test_threshold_pixels_of_the_flagged_scene(oracle64):
     assert n <= 0.02 * (14329 / 7), n
 
 
-def test_decision_aware_tier_takes_out_proven_rows_only(oracle64):
-    rs, rv = sweep_scene(120013, "cpu")
+def test_threshold_factor_of_the_oracle_flips_exactly_one_decision(oracle64):
+    """gso_set_threshold_scale: the factor of ONE Gaussian moved past its alpha flips its decision at its threshold pixel and nowhere else; None
+    restores the published algorithm."""
+    rs, rv = sweep_scene(140658, "cpu")
     W, H = int(rs.image_width), int(rs.image_height)
-    f = util.run_oracle(oracle64, rs, rv)
-    r = np.random.RandomState(0).randn(14329, 3)
-    o32 = r * (1 + 1e-4 * np.random.RandomState(1).randn(14329, 3))          # an "fp32 oracle" at 1e-4
-    g = r * (1 + 1e-4 * np.random.RandomState(2).randn(14329, 3))
-    bad = g.copy(); bad[14305] += 5.0                                        # one threshold-pixel Gaussian carries the whole miss
-    assert np.linalg.norm(bad - r) / np.linalg.norm(r) > 1e-3
-    before = pc.HATCH["decisions"]
-    assert pc.decision_aware("scales", bad, r, o32, f, W, H, min_frac=0.995)
-    assert pc.HATCH["decisions"] == before + 1 and pc.HATCH["decision_where"][-1][1][0][:3] == (14305, 71, 18)
-    worse = g.copy(); worse[3586] += 5.0                                     # the same miss on a Gaussian with no threshold pixel: a defect
-    assert not pc.decision_aware("scales", worse, r, o32, f, W, H, min_frac=0.995)
-    spread = g + 0.01 * np.random.RandomState(3).randn(14329, 3)             # an error everywhere is not rescued by taking three rows out
-    assert not pc.decision_aware("scales", spread, r, o32, f, W, H, min_frac=0.995)
-    pc.HATCH["decisions"] = before; pc.HATCH["decision_where"].pop()         # (keep the session tally for real comparisons)
+    base = util.run_oracle(oracle64, rs, rv)
+    (i, x, y, d), = pc.threshold_gaussians(base, [112], W, H)
+    assert (i, x, y) == (112, 0, 39) and -1e-5 < d < 0                       # fp64: a hair below 1/255 -> skipped
+    scale = np.ones(256); scale[112] = 1.0 + d - pc.DECISION_MARGIN
+    try:
+        oracle64.set_threshold_scale(scale)
+        flipped = util.run_oracle(oracle64, rs, rv)
+    finally:
+        oracle64.set_threshold_scale(None)
+    diff = np.abs(flipped["color"] - base["color"]).max(0)
+    assert diff[39, 0] > 0 and np.count_nonzero(diff) == 1                   # one pixel of the image changed
+    again = util.run_oracle(oracle64, rs, rv)
+    assert np.array_equal(again["color"], base["color"])
+
+
+def test_decision_matched_tier_end_to_end_on_the_emulated_kernels(emu, oracle32, oracle64):
+    """Seed 140658 (round-5 sweep, 256 Gaussians on 44 x 65 pixels): Gaussian 112 -- radius 50, faint -- owns pixel (0,39) at 255 alpha - 1 = -5.9e-7.
+    Both oracles skip it; the kernel's FMA / exp2 form (device AND emulated build) blends it, which moves Gaussian 112's row by a whole pixel's
+    contribution and every Gaussian that blends at that pixel by alpha = 1/255 of theirs: 10 of 1024 rotation elements outside the element-wise
+    tolerance at a relative L2 of 4.7e-5.  Tiers 1 and 2 fail; the oracles re-run with the other decision at that one pixel agree with the kernel."""
+    rs, rv = sweep_scene(140658, emu)
+    before = (pc.HATCH["fired"], pc.HATCH["decisions"])
+    pc.check_backward(rs, rv, oracle64, oracle32=oracle32)
+    assert pc.HATCH["decisions"] > before[1]
+    where = pc.HATCH["decision_where"][before[1]:]
+    assert all([(i, x, y) for i, x, y, _ in combo] == [(112, 0, 39)] for _, combo, _, _ in where), where
+    assert all(rel < 1e-5 for _, _, rel, _ in where)                          # with the decision matched: 6e-7, the fp32 oracle's own level
+
+
+def test_decision_matched_tier_does_not_rescue_a_defect(emu, oracle32, oracle64, monkeypatch):
+    """The same scene with a DEFECT injected into the kernel's result (a Gaussian without any threshold pixel gets a wrong gradient row; and,
+    separately, an error spread over all rows): no subset of flipped decisions explains either, the check fails."""
+    import pytest
+    rs, rv = sweep_scene(140658, emu)
+    real = util.run_product
+
+    def broken(row_scale, noise):
+        def run(rs_, rv_, dL=None):
+            out = real(rs_, rv_, dL)
+            if dL is not None:
+                g = out["grads"]["rotations"]
+                g[54] = g[54] * row_scale                                     # Gaussian 54: large gradient, no pixel near the threshold
+                g += noise * np.abs(g).max() * np.random.RandomState(0).randn(*g.shape).astype(g.dtype)
+            return out
+        return run
+    for row_scale, noise in ((1.5, 0.0), (1.0, 3e-3)):
+        monkeypatch.setattr(util, "run_product", broken(row_scale, noise))
+        with pytest.raises(AssertionError):
+            pc.check_backward(rs, rv, oracle64, oracle32=oracle32)
+    assert oracle64._thresh is None and oracle32._thresh is None              # the hook is always reset
