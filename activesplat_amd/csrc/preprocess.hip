@@ -159,10 +159,15 @@ __device__ __forceinline__ uint32_t project_gaussian(const Cam& cam, int P, int 
         }
         radii[io] = radius;
         if (radius_out) *radius_out = radius;
-        gp.geom[(size_t)io * 3] = g0; gp.geom[(size_t)io * 3 + 1] = g1; gp.geom[(size_t)io * 3 + 2] = g2;
-        gp.rect[io] = rc;
+        // a culled Gaussian leaves radius 0 and tile count 0 behind and nothing else: its 48-byte record, rect and depth bits are only ever read
+        // through a tile instance (binning reads rect / depth bits behind `tiles > 0`, the blend gathers records by the ids of the tile lists).  A
+        // mapper's keyframe sees a fraction of the map: 60 of the 68 bytes a culled Gaussian used to write
+        if (ntiles) {
+            gp.geom[(size_t)io * 3] = g0; gp.geom[(size_t)io * 3 + 1] = g1; gp.geom[(size_t)io * 3 + 2] = g2;
+            gp.rect[io] = rc;
+            gp.depth_bits[io] = __float_as_uint(g2.y);
+        }
         gp.tiles[io] = ntiles;
-        gp.depth_bits[io] = __float_as_uint(g2.y);
         if (HAS_SH && !gp.sh_jac) gp.clamped[io] = clampbits;     // (with a saved Jacobian the flags travel in its record)
     } else if (cam.V > 1) {                            // padding rows of a view's last block: never visible
         radii[io] = 0;
