@@ -51,7 +51,21 @@ __global__ __launch_bounds__(kBlock, (ACT && SH == 3) ? GS_PBWD_RAW_SH_WGS : 4) 
     const int ic = in_range ? i : P - 1;                       // clamped index: out-of-range lanes only help with the SH slabs
     const bool live = in_range && radii[ic] > 0;
     const float4* gr4 = reinterpret_cast<const float4*>(grad2d + (size_t)ic * kGradStride);
-    const float4 ga = gr4[0], gb = gr4[1], gc = gr4[2];
+    // Keyframe batches (raw parameters, gradients ADDED to the buffers: rows of Gaussians that were not rendered stay untouched): a keyframe sees a
+    // fraction of the map, and a Gaussian it does not see needs none of this kernel's reads.  There -- and only there -- the radius is waited for
+    // first: a wavefront none of whose Gaussians was rendered leaves at once (a map grown frame by frame is coherent in memory), and the 64-byte
+    // gradient records -- half of what the kernel reads -- are requested by the rendered lanes only (at the 27 % visibility of configs[3]'s random
+    // shell scene about half of their lines).  Everywhere else every request stays up front in one round trip.
+    const bool gate = ACT && !ADAM && !SLAB && cam.act_accumulate;
+    float4 ga, gb, gc;
+    if (gate) {
+        if (!__any(live)) return;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        ga = z4; gb = z4; gc = z4;
+        if (live) { ga = gr4[0]; gb = gr4[1]; gc = gr4[2]; }
+    } else {
+        ga = gr4[0]; gb = gr4[1]; gc = gr4[2];
+    }
     float dmean[3] = {0.f, 0.f, 0.f};
     // record (raw moments from blend_backward_kernel, Z = G dL/dG, d = mean - pixel):
     //   ga = (sum Z dx, sum Z dy, sum Z dx dx, sum Z dx dy)  gb = (sum Z dy dy, sum G dL/dalpha, dr, dg)  gc = (db, -, -, -)

@@ -249,6 +249,11 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
     W, H, N, KF = args.width, args.height, args.c4_gaussians, args.keyframes
     K = syn.intrinsics(W, H)
     raw = syn.shell_scene(N, seed=0, W=W, H=H)
+    if args.c4_coherent:
+        # a map grown frame by frame (add_new_gaussians appends the rows a frame sees) is coherent in memory: neighbours in the tensors are neighbours
+        # in space.  The default scene is the pessimistic one (rows in random order: every wavefront of the per-Gaussian kernels holds some visible row)
+        order = torch.argsort(torch.atan2(raw["means3D"][:, 0], raw["means3D"][:, 2]))
+        raw = {k: v[order].contiguous() for k, v in raw.items()}
     lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
     sh = args.c4_sh_degree >= 0
     if sh:
@@ -546,6 +551,7 @@ def main():
     ap.add_argument("--c4-sh-degree", type=int, default=-1, help="configs[3]: -1 = `rgb_colors` (the reference mapper's map, G = 14 floats per Gaussian "
                                                                  "in the exchange); 0..3 = 16-coefficient SH rows (`shs`, G = 59)")
     ap.add_argument("--predict-ranks", type=int, default=8, help="configs[3] on one GPU: ranks of the load-balance / exchange prediction leg")
+    ap.add_argument("--c4-coherent", action="store_true", help="configs[3]: the map's rows ordered by azimuth (a map grown frame by frame) instead of randomly")
     ap.add_argument("--c4-partition", choices=("lpt", "contiguous"), default="lpt", help="configs[3]: keyframes to ranks by longest-processing-time "
                     "assignment on every keyframe's last tile-instance count (costs all-reduced every --c4-rebalance-every steps), or contiguous blocks")
     ap.add_argument("--c4-rebalance-every", type=int, default=10)
