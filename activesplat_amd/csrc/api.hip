@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "gs_common.h"
 
 namespace {
@@ -177,6 +179,8 @@ int gs_async_status_word(uint32_t** host_word)
 {
     // one host-mapped word per process (portable: every device can raise it); plain host reads see it once the raising kernel has ended
     static uint32_t* word = nullptr;
+    static std::mutex mu;                               // (both hosts above the ABI may ask for it first, from different threads)
+    std::lock_guard<std::mutex> lock(mu);
     if (!word) {
         void* h = nullptr;
         if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
