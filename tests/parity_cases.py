@@ -751,16 +751,30 @@ def check_fused_rgbd(rs, rv, oracle64, seed=0, oracle32=None):
     gf = {k: v.grad.detach().cpu().numpy() for k, v in inp.items()}
     gf["means2D"] = m2d.grad.detach().cpu().numpy()
     # (2) two passes, the second with colours [z_cam, 1, z_cam^2] built from means3D (viewmatrix row-vector convention)
-    inp2, m2a = leaves()
-    m2b = torch.zeros(P, 3, device=dev, requires_grad=True)
-    c1, r1, _, _ = R.GaussianRasterizer(raster_settings=rs)(means2D=m2a, **inp2)
-    V = rs.viewmatrix.reshape(4, 4).to(dev)
-    z = inp2["means3D"] @ V[:3, 2] + V[3, 2]
-    second = {k: v for k, v in inp2.items() if k not in ("colors_precomp", "shs")}
-    c2, _, _, _ = R.GaussianRasterizer(raster_settings=rs._replace(bg=torch.zeros(3, device=dev)))(
-        means2D=m2b, colors_precomp=torch.stack([z, torch.ones_like(z), z * z], 1), **second)
-    ((c1 * dLc).sum() + (c2[0:1] * dLd).sum()).backward()
     n = lambda t: t.detach().cpu().numpy()  # noqa: E731
+
+    def two_passes():
+        """-> (c1, r1, c2, {key: (gradient of the colour pass, gradient of the depth pass)}): the two passes' gradients SEPARATELY -- their sum is
+        what the fused pass must reproduce, the sum of their norms is the scale its rounding is measured against"""
+        inp2, m2a = leaves()
+        m2b = torch.zeros(P, 3, device=dev, requires_grad=True)
+        c1, r1, _, _ = R.GaussianRasterizer(raster_settings=rs)(means2D=m2a, **inp2)
+        V = rs.viewmatrix.reshape(4, 4).to(dev)
+        z = inp2["means3D"] @ V[:3, 2] + V[3, 2]
+        second = {k: v for k, v in inp2.items() if k not in ("colors_precomp", "shs")}
+        c2, _, _, _ = R.GaussianRasterizer(raster_settings=rs._replace(bg=torch.zeros(3, device=dev)))(
+            means2D=m2b, colors_precomp=torch.stack([z, torch.ones_like(z), z * z], 1), **second)
+        leaves2 = list(inp2.items()) + [("means2D", m2a)]
+        g_col = torch.autograd.grad((c1 * dLc).sum(), [v for _, v in leaves2], allow_unused=True)
+        leaves3 = [(k, v) for k, v in inp2.items() if k not in ("colors_precomp", "shs")] + [("means2D", m2b)]
+        g_dep = dict(zip([k for k, _ in leaves3], torch.autograd.grad((c2[0:1] * dLd).sum(), [v for _, v in leaves3], allow_unused=True)))
+        out = {}
+        for (k, _), gc_ in zip(leaves2, g_col):
+            a_ = np.zeros(gf[k].shape, np.float64) if gc_ is None else n(gc_).astype(np.float64)
+            gd_ = g_dep.get(k)
+            out[k] = (a_, np.zeros(gf[k].shape, np.float64) if gd_ is None else n(gd_).astype(np.float64))
+        return c1, r1, c2, out
+    c1, r1, c2, parts = two_passes()
     assert np.array_equal(n(radii), n(r1))
     if R.last_stats.get("max_tile_instances", 0) >= 8192 and not np.array_equal(n(color), n(c1)):
         # (tile lists of 8192 and more in a small image take the SEGMENTED forward, whose segments add their sums with atomics: two renders
@@ -772,14 +786,18 @@ def check_fused_rgbd(rs, rv, oracle64, seed=0, oracle32=None):
         sc = max(1.0, float(n(b).max()))
         assert close_frac(n(a), n(b), 1e-5, 2e-6 * sc) > 0.9999, name
     for k in gf:
-        two = n(inp2[k].grad) if k != "means2D" else n(m2a.grad) + n(m2b.grad)
-        rel = np.linalg.norm(gf[k].astype(np.float64) - two) / max(np.linalg.norm(two), 1e-30)
-        # (one pass against the SUM of two passes' gradients: where the colour pass' and the depth pass' contributions cancel, fp32 rounding of the
-        # parts shows in the sum -- a scene of a few dozen Gaussians reached 2.3e-4 in one of two runs of the round-5 sweep (seed 130378, P = 63);
-        # scenes below 400 Gaussians get 1e-3, the others 1e-4)
-        # (rotations / scales: the least well-conditioned of the gradients -- both formulations sit at ~1e-3 of the fp64 oracle on the sweeps' scenes --,
-        # one pass against two differs by up to 1.4e-4 there (seed 142132 of the round-5 sweep): 3e-4)
-        assert rel < (1e-3 if P < 400 else 3e-4 if k in ("rotations", "scales") else 1e-4), (k, rel)
+        a_, b_ = parts[k]
+        d_ = (gf[k].astype(np.float64) - (a_ + b_)).reshape(P, -1) if P else np.zeros((0, 1))
+        e2 = (d_ ** 2).sum(1)
+        scale = max(np.linalg.norm(a_) + np.linalg.norm(b_), 1e-30)
+        # 1e-4 of the two parts' magnitudes for the tensor WITHOUT its two worst rows, 1e-3 with them.  The device's atomics sum in a different order
+        # every run, and one kind of Gaussian carries a run-to-run spread of up to 2e-4 of the whole tensor all by itself: a screen-filling splat
+        # centred far outside the image (raw moments with pixel offsets of hundreds, combinations that nearly cancel in the chain to the 3-D
+        # parameters) -- seeds 130378, 142132, 150586 of the round-5 sweeps; `scripts/exp/rgbd_variance.py`: 99-100 % of the spread in ONE Gaussian,
+        # two runs of the SAME formulation 5e-5 ... 2e-4 apart.  A wrong term in the fused pass would show in every row.
+        worst = np.sort(e2)[-2:].sum() if P > 8 else 0.0
+        assert np.sqrt(max(e2.sum() - worst, 0.0)) < 1e-4 * scale, (k, float(np.sqrt(e2.sum())) / scale)
+        assert np.sqrt(e2.sum()) < 1e-3 * scale, (k, float(np.sqrt(e2.sum())) / scale)
     # (3) fp64 oracle
     ref = util.run_oracle(oracle64, rs, rv)
     go = oracle64.backward(ref, dLc.cpu().numpy(), dLd.cpu().numpy())
