@@ -1,6 +1,8 @@
 """Development helper (checker only: runs the two oracle builds, no product code): WHERE does an fp32 rasteriser lose the stated gradient tolerance on the scenes that
 the fp32-oracle tier decides?  The 2-D gradients of the per-pixel replay are mixed across precisions with the per-Gaussian chain to the 3-D parameters.
-usage: python scripts/exp/prec_mix.py 122050 2"""
+usage: python scripts/exp/prec_mix.py 122050 2
+(A third variant -- fp32 replay with the sums over the pixels in fp64: the oracle source with the five accumulator arrays of gso_blend_backward retyped to double, built
+to a scratch library -- gave the all-fp32 error to three digits: the loss is per pixel, not in the sums.)"""
 import sys, numpy as np, torch, ctypes as C
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle.gs_oracle import Oracle, _ptr
