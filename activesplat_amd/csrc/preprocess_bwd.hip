@@ -232,15 +232,21 @@ __global__ __launch_bounds__(kBlock, (ACT && SH == 3) ? GS_PBWD_RAW_SH_WGS : 4) 
             ST0[a] = S[a][0] * T0[0] + S[a][1] * T0[1] + S[a][2] * T0[2];
             ST1[a] = S[a][0] * T1[0] + S[a][1] * T1[1] + S[a][2] * T1[2];
         }
-        const float p_ = T0[0] * ST0[0] + T0[1] * ST0[1] + T0[2] * ST0[2] + 0.3f;
-        const float q_ = T1[0] * ST0[0] + T1[1] * ST0[1] + T1[2] * ST0[2];
-        const float r_ = T1[0] * ST1[0] + T1[1] * ST1[1] + T1[2] * ST1[2] + 0.3f;
-        const float det = p_ * r_ - q_ * q_;
-        const float d2 = 1.0f / (det * det);
-        const float dA = -0.5f * ga.z, dB = -ga.w, dC = -0.5f * gb.x;      // true partials w.r.t. conic (a, b, c)
-        const float dp = (-r_ * r_ * dA + q_ * r_ * dB - q_ * q_ * dC) * d2;
-        const float dq = (2.f * q_ * r_ * dA - (p_ * r_ + q_ * q_) * dB + 2.f * p_ * q_ * dC) * d2;
-        const float dr = (-q_ * q_ * dA + p_ * q_ * dB - p_ * p_ * dC) * d2;
+        // The ONE ill-conditioned block of the chain, in fp64: for an elongated splat the determinant of the 2-D covariance lies orders of magnitude
+        // below its entries (seed 160050 of the round-5 sweep: p, q, r = 74, -208, 590, det = 396), and the conic-to-covariance gradient divides
+        // by its square -- in fp32 this block alone put 3.5e-3 of relative error on that Gaussian's rotation gradient (the fp32 oracle: 3.4e-4); with
+        // the block in fp64 the row is at 2.8e-5.  ~25 double-precision operations per Gaussian in an HBM-bound kernel: no measurable time
+        // (profiles/README.md).
+        const double p_d = (double)T0[0] * ST0[0] + (double)T0[1] * ST0[1] + (double)T0[2] * ST0[2] + 0.3;
+        const double q_d = (double)T1[0] * ST0[0] + (double)T1[1] * ST0[1] + (double)T1[2] * ST0[2];
+        const double r_d = (double)T1[0] * ST1[0] + (double)T1[1] * ST1[1] + (double)T1[2] * ST1[2] + 0.3;
+        const double det_d = p_d * r_d - q_d * q_d;
+        const double d2_d = 1.0 / (det_d * det_d);
+        const double dA = -0.5 * ga.z, dB = -(double)ga.w, dC = -0.5 * gb.x;      // true partials w.r.t. conic (a, b, c)
+        const float dp = (float)((-r_d * r_d * dA + q_d * r_d * dB - q_d * q_d * dC) * d2_d);
+        const float dq = (float)((2.0 * q_d * r_d * dA - (p_d * r_d + q_d * q_d) * dB + 2.0 * p_d * q_d * dC) * d2_d);
+        const float dr = (float)((-q_d * q_d * dA + p_d * q_d * dB - p_d * p_d * dC) * d2_d);
+        const float p_ = (float)p_d, q_ = (float)q_d, r_ = (float)r_d, det = (float)det_d;
         const float h = 0.5f * dq;
         // dL/dSigma = T^T G2 T,  G2 = [[dp,h],[h,dr]]
         float dS[3][3];

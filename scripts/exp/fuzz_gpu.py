@@ -11,6 +11,9 @@ from tests.fuzz_scenes import sweep_scene
 
 o32, o64 = Oracle("f32"), Oracle("f64")
 lib = _lib.get()
+if os.environ.get("TWIN"):           # the drop-in call through the Python twin of the C++ front-end
+    from activesplat_amd import rasterizer as _R
+    _R.use_frontend = False
 if os.environ.get("PLAIN"):          # the kernels of images of more than 256 / 768 tiles on the sweep's small images: streams forward, chained backward walks
     _lib.check(lib.gs_set_half_quadrants(0)); _lib.check(lib.gs_set_backward_chain(3, 0))
 n0, n1 = int(os.environ.get("SEED0", 20000)), int(os.environ.get("SEED1", 20300))

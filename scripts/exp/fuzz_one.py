@@ -9,8 +9,13 @@ from tests import util
 from tests.fuzz_scenes import sweep_scene
 
 seed = int(os.environ.get("SEED", 50310))
+dev = os.environ.get("DEVICE", "cuda")
+if dev == "cpu":                                            # the host-emulated kernels (tests/hipemu), for comparison
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hipemu"), "-j8"], stdout=subprocess.DEVNULL)
+    util.use_emulated_kernels(os.path.join(ROOT, "tests", "hipemu", "libgsplat_emu.so"))
 o32, o64 = Oracle("f32"), Oracle("f64")
-rs, rv = sweep_scene(seed, "cuda", os.environ.get("PLAIN"))
+rs, rv = sweep_scene(seed, dev, os.environ.get("PLAIN"))
 if os.environ.get("SEGS"):                                  # list segments of the few-tile backward (gs_set_backward_segments)
     from activesplat_amd import _lib
     _lib.get().gs_set_backward_segments(int(os.environ["SEGS"]))

@@ -44,3 +44,9 @@ for k in ("means3D", "scales", "rotations"):
     print(f"{k:10s} all-fp32 {np.linalg.norm(g32[k] - r) / n:.2e}   fp32 accumulation + fp64 chain {np.linalg.norm(mixA[k] - r) / n:.2e}   fp64 accumulation + fp32 chain {np.linalg.norm(mixB[k] - r) / n:.2e}")
 for nm, i in (("dxy", 0), ("dconic", 1)):
     r = b64[i]; print(f"2-D {nm}: fp32 accumulation rel {np.linalg.norm(b32[i] - r) / np.linalg.norm(r):.2e}")
+if len(sys.argv) > 3:                                       # one Gaussian in detail
+    i = int(sys.argv[3])
+    for k in ("means3D", "scales", "rotations"):
+        r = g64[k][i]
+        print(f"Gaussian {i} {k:10s} fp64 {np.round(r, 5)}  |err| all-fp32 {np.abs(g32[k][i] - r).max():.2e}  fp32 replay + fp64 chain {np.abs(mixA[k][i] - r).max():.2e}  fp64 replay + fp32 chain {np.abs(mixB[k][i] - r).max():.2e}")
+    print("   2-D: dconic fp64", b64[1][i], " fp32 replay error", np.abs(b32[1][i] - b64[1][i]), " conic", f64["conic_opacity"][i][:3], "cov2d", f64["cov2d"][i])

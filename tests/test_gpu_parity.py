@@ -442,7 +442,10 @@ def test_flagged_round5_sweep_scene_backward(hip, oracle32, oracle64, seed, plai
     before = pc.HATCH["decisions"]
     pc.check_backward(rs, rv, oracle64, oracle32=oracle32)
     where = pc.HATCH["decision_where"][before:]
-    assert where and all([i for i, _, _, _ in combo] == [112] for _, combo, _, _ in where), where
+    if seed == 140658:
+        assert where and all([i for i, _, _, _ in combo] == [112] for _, combo, _, _ in where), where
+    else:
+        assert not where                                           # (160050: inside the stated bar since the conic-gradient block runs in fp64)
 
 
 def test_fused_rgbd_at_configs1_size(hip, oracle32, oracle64):
