@@ -642,7 +642,11 @@ class _Rerun:
         return self.fn(oracle)
 
 
-def check_forward(rs, rv, oracle32, exact_float=False):
+def check_forward(rs, rv, oracle32, exact_float=False, oracle64=None):
+    """oracle64 (the sweeps of scripts/exp only): an image that misses the tolerance against the fp32 oracle is judged like a gradient of tier 2 --
+    against the fp64 oracle, where it must be no further out than the fp32 oracle itself is.  (Strongly anisotropic splats: the quadratic form of
+    the exponent is a difference of large products, and two fp32 evaluation orders of it differ by more than the tolerance -- on such scenes the
+    kernel is usually CLOSER to fp64 than the fp32 oracle, `scripts/exp/fwd_hard.py`.)  The suite's calls do not pass it: there the bar is the plain one."""
     got = util.run_product(rs, rv)
     art = util.artefacts()
     ref = util.run_oracle(oracle32, rs, rv)
@@ -675,7 +679,17 @@ def check_forward(rs, rv, oracle32, exact_float=False):
             # >= 99.9 % of the values inside the tolerance; on tiny images (a few hundred pixels) two pixels' worth of
             # alpha = 1/255 / T = 1e-4 threshold flips are allowed instead (each bounded by the 0.02 limit below)
             n_bad = int(round((1.0 - util.close_frac(a, b, FWD_RTOL, FWD_ATOL * scale)) * a.size))
-            assert n_bad <= max(0.001 * a.size, 6 if k_got == "color" else 2), (k_got, n_bad, a.size)
+            allowed = max(0.001 * a.size, 6 if k_got == "color" else 2)
+            if n_bad > allowed and oracle64 is not None:
+                ref64 = util.run_oracle(oracle64, rs, rv) if "_ref64" not in got else got["_ref64"]
+                got["_ref64"] = ref64
+                c = np.asarray(ref64[k_ref], np.float64).reshape(a.shape)
+                bad_k = int(round((1.0 - util.close_frac(a, c, FWD_RTOL, FWD_ATOL * scale)) * a.size))
+                bad_o = int(round((1.0 - util.close_frac(b, c, FWD_RTOL, FWD_ATOL * scale)) * a.size))
+                HATCH["forward_fired"] = HATCH.get("forward_fired", 0) + 1
+                assert bad_k <= 1.5 * bad_o + allowed, (k_got, n_bad, bad_k, bad_o, a.size)
+            else:
+                assert n_bad <= allowed, (k_got, n_bad, a.size)
             assert np.abs(a - b).max() <= 0.02 * scale, k_got
     # PSNR >= 60 dB; an image of a few hundred pixels is exempt (one threshold-flipped pixel of 0.02 in 500 pixels is 58 dB --
     # those are bounded by the per-value checks above)
