@@ -261,6 +261,110 @@ def check_raw_parameter_mode_sh(device, n=400, W=64, H=48):
     assert float((a[4] - b[4]).norm() / a[4].norm()) < 3e-4
 
 
+def _depth_ties_cover(prm_means, pose, rv_means, radius, d, W, H, tol):
+    """True when every pixel of `d` above `tol` lies in the footprints of a pair of Gaussians whose view depths are within four ulps in fp32 (or ordered the other
+    way in fp64): the depth order of such a pair is not decided in fp32, the two entries evaluate the frame transform with different roundings, and either order is a
+    valid rendering (scripts/exp/fuzz_raw_diag.py prints the pairs)."""
+    from activesplat_amd import synthetic as syn
+    K = syn.intrinsics(W, H)
+    z32 = rv_means[:, 2].cpu()
+    px = (rv_means[:, 0] / rv_means[:, 2] * K[0][0] + K[0][2]).cpu(); py = (rv_means[:, 1] / rv_means[:, 2] * K[1][1] + K[1][2]).cpu()
+    q = torch.tensor(pose[:4], dtype=torch.float64); t = torch.tensor(pose[4:], dtype=torch.float64)
+    w, x, y, z = q / q.norm()
+    Rm = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]], dtype=torch.float64)
+    z64 = (prm_means.double().cpu() @ Rm.T + t)[:, 2]
+    order = torch.argsort(z32, stable=True)
+    zs, zz = z32[order], z64[order]
+    near = torch.nonzero((zz[1:] < zz[:-1]) | ((zs[1:] - zs[:-1]) <= 4 * torch.finfo(torch.float32).eps * zs[1:].abs()))[:, 0]
+    ra = radius.cpu().float()
+    ys, xs = torch.nonzero(d.cpu() > tol, as_tuple=True)
+    covered = torch.zeros(len(ys), dtype=torch.bool)
+    for j in near.tolist():
+        i0, i1 = int(order[j]), int(order[j + 1])
+        if ra[i0] > 0 and ra[i1] > 0:
+            both = torch.ones(len(ys), dtype=torch.bool)
+            for i in (i0, i1):
+                both &= ((xs - px[i]).abs() <= ra[i] + 1) & ((ys - py[i]).abs() <= ra[i] + 1)
+            covered |= both
+    return bool(covered.all()), int(covered.sum()), len(ys)
+
+
+def check_raw_entry_random_draw(seed, device, rows_detail=False):
+    """One draw of the raw-parameter sweep (scripts/exp/fuzz_raw.py; profiles/r05_fuzz_raw.txt): render_rgbd_raw (frame transform + activations inside the per-Gaussian
+    kernels, gradients w.r.t. the PARAMETERS) against fused_rendervar + render_rgbd on a random map (50..40 000 Gaussians, colours or 16 SH rows, isotropic or
+    anisotropic), image size (both sides of the few-tile / chained-kernel thresholds) and pose.  Radii within one on a handful of boundary Gaussians; images equal up to
+    bounded threshold flips; parameter gradients within 3e-4 relative L2 without the two worst rows.
+    -> "ok" | "depth tie" (the two entries blend a pair of splats whose view depths are within four fp32 ulps in different orders and every differing pixel lies in the
+    pair's footprints: both are valid fp32 renderings, the gradients are not compared) | ("rows", key, row, relative difference) (two rows carry more than 3e-3 of
+    the norm: one per-pixel alpha = 1/255 decision)."""
+    from activesplat_amd import mapping as M, rasterizer as R
+    from activesplat_amd import synthetic as syn
+    from activesplat_amd.camera import setup_camera
+    r = np.random.RandomState(seed)
+    n = int(r.choice([int(r.randint(50, 2000)), int(r.randint(2000, 40000))]))
+    W, H = (int(r.randint(24, 200)), int(r.randint(24, 160))) if seed % 3 else (int(r.randint(272, 420)), int(r.randint(256, 330)))
+    sh, iso = seed % 4 == 0, bool(seed % 2)
+    p = syn.make_params(n, W, H, seed=seed, sh_degree=3 if sh else None)
+    if sh:
+        p.pop("rgb_colors", None)
+    if iso:
+        p["log_scales"] = p["log_scales"][:, :1].contiguous()
+    p["log_scales"] = p["log_scales"] + float(r.uniform(-0.5, 1.2))
+    cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=device, sh_degree=3 if sh else 0)
+    a = float(r.uniform(-0.4, 0.4))
+    pose = [float(np.cos(a / 2)), 0.0, float(np.sin(a / 2)), 0.0, float(r.uniform(-0.2, 0.2)), float(r.uniform(-0.1, 0.1)), float(r.uniform(-0.8, 0.4))]
+    g = torch.Generator().manual_seed(seed)
+    dLc, dLd = torch.randn(3, H, W, generator=g).to(device), torch.randn(1, H, W, generator=g).to(device)
+    out = []
+    for raw in (False, True):
+        prm = {k: torch.nn.Parameter(v.clone().to(device)) for k, v in p.items()}
+        col = dict(shs=prm["shs"]) if sh else dict(colors_precomp=prm["rgb_colors"])
+        if raw:
+            m2d = torch.empty_like(prm["means3D"], requires_grad=True)
+            im, radius, depth, sil, dsq = R.render_rgbd_raw(cam, prm["means3D"], m2d, prm["logit_opacities"], prm["log_scales"], prm["unnorm_rotations"], pose, **col)
+        else:
+            rv = M.fused_rendervar(dict(prm, rgb_colors=prm["shs"]) if sh else prm, 0, pose)
+            rv.pop("colors_precomp")
+            m2d = rv["means2D"]
+            tm = rv["means3D"].detach().clone()
+            im, radius, depth, sil, dsq = R.render_rgbd(cam, **col, **rv)
+        ((im * dLc).sum() + (depth * dLd).sum()).backward()
+        out.append((im.detach(), depth.detach(), radius.clone(), {k: v.grad.double() for k, v in prm.items() if v.grad is not None}, m2d.grad.double()))
+    x, y = out
+    dr = (x[2] - y[2]).abs()
+    assert int(dr.max()) <= 1 and float((dr > 0).float().mean()) < 2e-3 + 2.0 / n, ("radii", int(dr.max()), int((dr > 0).sum()))
+    for u, v, tol, nm in ((x[0], y[0], 5e-5, "colour"), (x[1], y[1], 5e-4, "depth")):
+        d = (u - v).abs()
+        if not (float((d > tol).float().mean()) < 2e-3 and float(d.max()) < 0.03 * max(1.0, float(v.abs().max()))):
+            ok, c, m = _depth_ties_cover(p["means3D"], pose, tm, x[2], d.amax(0), W, H, tol)
+            assert ok, (nm, float(d.max()), int((d > tol).sum()), "pixels in depth-tie footprints: %d of %d" % (c, m))
+            return "depth tie"
+    verdict = "ok"
+    for k in x[3]:
+        if iso and k == "unnorm_rotations":                 # equal scales: the rotation's gradient is rounding noise
+            continue
+        e2 = ((x[3][k] - y[3][k]).reshape(n, -1) ** 2).sum(1)
+        nr = float(x[3][k].norm().clamp_min(1e-30))
+        rest = float((e2.sum() - e2.sort().values[-2:].sum()).clamp_min(0).sqrt()) if n > 8 else 0.0
+        assert rest < 3e-4 * nr, (k, rest / nr, float(e2.sum().sqrt()) / nr)
+        if not float(e2.sum().sqrt()) < 3e-3 * nr and verdict == "ok":
+            w = int(e2.argmax())
+            verdict = ("rows", k, w, round(float(e2.sum().sqrt()) / nr, 5))
+            if rows_detail:                                 # the one pixel inside that Gaussian's footprint where the two forward images differ
+                K = syn.intrinsics(W, H)
+                cx, cy = float(tm[w, 0] / tm[w, 2] * K[0][0] + K[0][2]), float(tm[w, 1] / tm[w, 2] * K[1][1] + K[1][2])
+                dd = (x[0] - y[0]).abs().amax(0)
+                rr = int(x[2][w]) + 1
+                x0, x1, y0, y1 = max(0, int(cx) - rr), min(W, int(cx) + rr + 2), max(0, int(cy) - rr), min(H, int(cy) + rr + 2)
+                box = dd[y0:y1, x0:x1]
+                top = torch.topk(box.flatten(), min(5, box.numel()))
+                print("   seed", seed, k, "row", w, "radius", int(x[2][w]), "centre (%.1f, %.1f); largest colour differences inside its footprint:" % (cx, cy),
+                      [(x0 + int(i) % (x1 - x0), y0 + int(i) // (x1 - x0), "%.2e" % float(v)) for v, i in zip(top.values, top.indices)],
+                      "; median over the image %.2e, maximum %.2e" % (float(dd.median()), float(dd.max())),
+                      "\n      activation kernels:", x[3][k][w].tolist(), "\n      raw entry:         ", y[3][k][w].tolist())
+    return verdict
+
+
 def check_adam_inside_the_backward(device, n=600, W=64, H=48, steps=3, exact=True, seed=6, pose=None, visible=(0.2, 0.95)):
     """render_rgbd_raw(adam=optimizer) -- the Adam step of the five per-Gaussian tensors inside the per-Gaussian backward kernel
     (gs_render_backward_raw_adam) -- against backward + GaussianAdam.step() (whose arithmetic the golden adam.npz fixture pins): parameters,

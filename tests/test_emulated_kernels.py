@@ -118,6 +118,7 @@ def test_emulated_fused_loss_equals_two_pass_loss(emu):
 def test_emulated_raw_parameter_rasteriser_equals_the_activation_kernels(emu):
     pc.check_raw_parameter_mode("cpu")
     pc.check_raw_parameter_mode_sh("cpu")
+    assert pc.check_raw_entry_random_draw(1, "cpu") == "ok"                 # one draw of the device sweep (1111 Gaussians, 96 x 157): the same checker code
 
 
 def test_emulated_adam_inside_the_backward_equals_backward_plus_step(emu):

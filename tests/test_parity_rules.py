@@ -76,3 +76,28 @@ def test_decision_matched_tier_does_not_rescue_a_defect(emu, oracle32, oracle64,
         with pytest.raises(AssertionError):
             pc.check_backward(rs, rv, oracle64, oracle32=oracle32)
     assert oracle64._thresh is None and oracle32._thresh is None              # the hook is always reset
+
+
+def test_depth_tie_rule_covers_only_the_pair_s_footprints():
+    """The depth-tie class of the raw-parameter sweep (check_raw_entry_random_draw): differing pixels are excused only inside the footprints of BOTH splats of a pair
+    whose view depths are within four fp32 ulps; a pixel outside, or a pair eight ulps apart, is a failure."""
+    import torch
+    from activesplat_amd import synthetic as syn
+    W, H = 64, 48
+    K = syn.intrinsics(W, H)
+    eps = float(np.finfo(np.float32).eps)
+
+    def at(px, py, z):                                      # camera-frame point projecting to pixel (px, py) at depth z
+        return [(px - K[0][2]) / K[0][0] * z, (py - K[1][2]) / K[1][1] * z, z]
+    for gap, expect in ((1.0, True), (8.0, False)):
+        z0 = 2.0
+        z1 = float(np.float32(z0 * (1.0 + gap * eps)))
+        means = torch.tensor([at(20, 20, z0), at(22, 21, z1), at(50, 30, 3.0)], dtype=torch.float32)
+        radius = torch.tensor([5, 6, 4])
+        pose = [1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]          # identity: the fp64 transform of the parameters is the parameters
+        d = torch.zeros(H, W)
+        d[21, 21] = 0.1                                     # inside both footprints
+        assert pc._depth_ties_cover(means, pose, means, radius, d, W, H, 1e-3)[0] is expect
+        d[30, 50] = 0.1                                     # inside the third splat only: never excused
+        ok, covered, total = pc._depth_ties_cover(means, pose, means, radius, d, W, H, 1e-3)
+        assert not ok and total == 2 and covered == (1 if expect else 0)
