@@ -1,15 +1,11 @@
-"""Development helper: random sweep of the mapper's loss call.  get_loss as the reference runs it (slam_helpers activations in torch -> two raster passes through the drop-in
-GaussianRasterizer -> masked depth L1 + L1 + SSIM in ~40 torch kernels; src/mapper/splatam/__init__.py:300-400) against the fully fused form of the same call
-(fused=True, fused_loss=True, fused_preprocess=True: raw-parameter single-pass RGB-D render + gs_mapping_loss): loss value, loss parts and the gradients of the five
-per-Gaussian parameters, on random maps, ragged image sizes and poses.  `means2D.grad` differs by design (the fused pass carries the depth term too) and is not compared.
-GPU box: SEED0=0 SEED1=300 python scripts/exp/fuzz_get_loss.py     (DEVICE=cpu: the host-emulated kernels)"""
+"""Development helper: random sweep of the mapper's loss call -- get_loss as the reference runs it against the fully fused form of the same call
+(tests/parity_cases.check_get_loss_random_draw on many seeds; the suite runs a handful, tests/test_gpu_parity.py).  profiles/r05_fuzz_get_loss.txt.
+GPU box: SEED0=0 SEED1=300 python scripts/exp/fuzz_get_loss.py     (SEEDS=135,444: those draws; DEVICE=cpu: the host-emulated kernels)"""
 import os, sys
-import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from activesplat_amd import mapping as M, rasterizer as R
-from activesplat_amd import synthetic as syn
-from activesplat_amd.camera import setup_camera
+from activesplat_amd import rasterizer as R
+from tests import parity_cases as pc
 
 dev = os.environ.get("DEVICE", "cuda")
 if dev == "cpu":
@@ -18,94 +14,18 @@ if dev == "cpu":
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hipemu"), "-j8"], stdout=subprocess.DEVNULL)
     util.use_emulated_kernels(os.path.join(ROOT, "tests", "hipemu", "libgsplat_emu.so"))
     R.use_frontend = False
-bad, rows, kinks = [], [], []
-
-
-def classify(p, q, t, kf, cam, W, H):
-    """Why the two calls' gradients differ by more than rounding: the two renders (inputs one ulp apart: torch activations in front of the plain render / activations inside
-    the raw entry's kernels) are compared.  -> ("L1 kink", flips): sign(im - gt), the gradient of the reference's L1 colour term, differs at a pixel-channel -- one flip moves
-    dL/dC there by 2 * 0.5 * 0.8 / (3 H W) for every Gaussian blended at the pixel;  ("depth L1 kink", flips): the same for sign(depth - gt) of the masked depth term
-    (2 / number of masked pixels);  ("depth tie", n): every pixel that differs by more than 5e-5 lies in the footprints of a
-    pair of splats whose view depths are within four fp32 ulps (parity_cases._depth_ties_cover) -- through the SSIM window every Gaussian around sees another dL/dC;  else None."""
-    from tests import parity_cases as pc
-    with torch.no_grad():
-        prm = {k: v.clone().to(dev) for k, v in p.items()}
-        prm["cam_unnorm_rots"] = q.reshape(1, 4, 1).clone().to(dev); prm["cam_trans"] = t.reshape(1, 3, 1).clone().to(dev)
-        rv0 = M.transformed_params2rendervar(prm, M.transform_to_frame(prm, 0, gaussians_grad=False, camera_grad=False))
-        pose7 = torch.cat([torch.nn.functional.normalize(q, dim=0), t]).tolist()
-        a = R.render_rgbd(cam, **{k: v.detach() for k, v in rv0.items()})
-        b = R.render_rgbd_raw(cam, prm["means3D"], torch.empty_like(prm["means3D"]), prm["logit_opacities"], prm["log_scales"], prm["unnorm_rotations"], pose7,
-                              colors_precomp=prm["rgb_colors"])
-    flips = [(int(c), int(x_), int(y_), "%.1e / %.1e" % (float(a[0][c, y_, x_] - kf["im"][c, y_, x_]), float(b[0][c, y_, x_] - kf["im"][c, y_, x_])))
-             for c, y_, x_ in torch.nonzero(torch.sign(a[0] - kf["im"]) != torch.sign(b[0] - kf["im"]))[:4]]
-    if flips:
-        return "L1 kink", flips
-    msk = kf["depth"] > 0
-    flips = [(int(x_), int(y_), "%.1e / %.1e" % (float(a[2][0, y_, x_] - kf["depth"][0, y_, x_]), float(b[2][0, y_, x_] - kf["depth"][0, y_, x_])))
-             for _, y_, x_ in torch.nonzero((torch.sign(a[2] - kf["depth"]) != torch.sign(b[2] - kf["depth"])) & msk)[:4]]
-    if flips:
-        return "depth L1 kink", flips
-    d = (a[0] - b[0]).abs().amax(0)
-    if int((d > 5e-5).sum()):
-        ok, c, m = pc._depth_ties_cover(p["means3D"], pose7, rv0["means3D"].detach(), a[1], d, W, H, 5e-5)
-        if ok:
-            return "depth tie", "%d pixels differ by more than 5e-5 (max %.1e), all in the footprints of depth-tied pairs" % (m, float(d.max()))
-        return None, "%d pixels differ by more than 5e-5 (max %.1e), %d of them in depth-tie footprints" % (m, float(d.max()), c)
-    return None, "images equal to 5e-5"
-
-
+bad, rows, events = [], [], []
 seeds = [int(v) for v in os.environ["SEEDS"].split(",")] if os.environ.get("SEEDS") else range(int(os.environ.get("SEED0", 0)), int(os.environ.get("SEED1", 300)))
 for seed in seeds:
-    r = np.random.RandomState(seed)
-    n = int(r.choice([int(r.randint(50, 2000)), int(r.randint(2000, 30000))]))
-    W, H = (int(r.randint(24, 200)), int(r.randint(24, 160))) if seed % 3 else (int(r.randint(272, 420)), int(r.randint(256, 330)))
-    iso = bool(seed % 2)
     try:
-        p = syn.make_params(n, W, H, seed=seed)
-        if iso:
-            p["log_scales"] = p["log_scales"][:, :1].contiguous()
-        p["log_scales"] = p["log_scales"] + float(r.uniform(0.0, 1.5))                      # larger splats: a silhouette above 0.99 somewhere
-        a = float(r.uniform(-0.3, 0.3))
-        q = torch.tensor([np.cos(a / 2), 0.0, np.sin(a / 2), 0.0], dtype=torch.float32)
-        t = torch.tensor([r.uniform(-0.2, 0.2), r.uniform(-0.1, 0.1), r.uniform(-0.6, 0.3)], dtype=torch.float32)
-        cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=dev)
-        g = torch.Generator().manual_seed(seed)
-        kf = dict(cam=cam, id=0, im=torch.rand(3, H, W, generator=g).to(dev), depth=(torch.rand(1, H, W, generator=g) * 3 + 0.5).to(dev), w2c=torch.eye(4, device=dev))
-        kf["depth"][0, : H // 7] = 0.0                                                      # a band without depth: the loss' depth mask
-        out = []
-        for fused in (False, True):
-            prm = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in p.items()}
-            prm["cam_unnorm_rots"] = torch.nn.Parameter(q.reshape(1, 4, 1).clone().to(dev))
-            prm["cam_trans"] = torch.nn.Parameter(t.reshape(1, 3, 1).clone().to(dev))
-            var = {k: torch.zeros(n, device=dev) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
-            kw = dict(fused=True, fused_loss=True, fused_preprocess=True) if fused else {}
-            loss, var, parts = M.get_loss(prm, kf, var, 0, dict(im=0.5, depth=1.0), **kw)
-            loss.backward(M.unit_gradient(loss)) if fused else loss.backward()
-            out.append((float(loss.detach()), {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in parts.items()}, {k: v.grad.double() for k, v in prm.items() if v.grad is not None and not k.startswith("cam_")},
-                        var["seen"].clone(), var["max_2D_radius"].clone()))
-        x, y = out
-        assert abs(x[0] - y[0]) <= 2e-5 * abs(x[0]) + 1e-7, ("loss", x[0], y[0])
-        for k in x[1]:
-            assert abs(x[1][k] - y[1][k]) <= 5e-5 * abs(x[1][k]) + 1e-7, ("part", k, x[1][k], y[1][k])
-        assert int((x[3] != y[3]).sum()) <= 1 + n // 2000 and float((x[4] - y[4]).abs().max()) <= 1.0, ("seen / max radius", int((x[3] != y[3]).sum()), float((x[4] - y[4]).abs().max()))
-        for k in x[2]:
-            if iso and k == "unnorm_rotations":
-                continue
-            e2 = ((x[2][k] - y[2][k]).reshape(n, -1) ** 2).sum(1)
-            nr = float(x[2][k].norm().clamp_min(1e-30))
-            rest = float((e2.sum() - e2.sort().values[-2:].sum()).clamp_min(0).sqrt()) if n > 8 else 0.0
-            if not rest < 3e-4 * nr:
-                why, detail = classify(p, q, t, kf, cam, W, H)
-                assert why, (k, rest / nr, float(e2.sum().sqrt()) / nr, detail)
-                kinks.append((seed, k, round(rest / nr, 6), why, detail))
-                break
-            if not float(e2.sum().sqrt()) < 3e-3 * nr:
-                rows.append((seed, k, int(e2.argmax()), round(float(e2.sum().sqrt()) / nr, 5)))
+        v = pc.check_get_loss_random_draw(seed, dev)
+        if v != "ok":
+            (rows if v[0] == "rows" else events).append((seed,) + tuple(v))
     except Exception as e:
         bad.append(seed)
-        print("FAIL seed", seed, "n", n, f"{W}x{H}", "iso" if iso else "aniso", repr(e)[:260], flush=True)
+        print("FAIL seed", seed, repr(e)[:300], flush=True)
 print("get_loss sweep (reference call pattern against the fully fused call): seeds %s..%s, %d failures %s" % (seeds[0], seeds[-1] + 1, len(bad), bad[:30]))
-print("   scenes whose gradients differ because the two renders differ by a discrete event (seed, first key above 3e-4, its relative difference, class, detail):")
-for kk in kinks:
-    print("     ", kk)
-print("   rows above 3e-3 of the norm while the rest agrees to 3e-4 (seed, key, row, relative difference):", rows)
+print("   scenes whose gradients differ because the two renders differ by a discrete event (seed, class, first key above 3e-4, its relative difference, detail):")
+for ev in events:
+    print("     ", ev)
+print("   rows above 3e-3 of the norm while the rest agrees to 3e-4 (seed, 'rows', key, row, relative difference):", rows)

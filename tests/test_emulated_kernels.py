@@ -121,6 +121,14 @@ def test_emulated_raw_parameter_rasteriser_equals_the_activation_kernels(emu):
     assert pc.check_raw_entry_random_draw(1, "cpu") == "ok"                 # one draw of the device sweep (1111 Gaussians, 96 x 157): the same checker code
 
 
+def test_emulated_loss_call_fully_fused_equals_the_reference_call_pattern(emu):
+    """Two draws of the device sweep of profiles/r05_fuzz_get_loss.txt: 1 (1111 Gaussians, 96 x 157) agrees outright; 604 (11 384 large splats on 31 x 33 pixels) is the
+    sweep's depth-tie scene, which the emulated kernels reproduce with the device's numbers -- the classifier, not a tolerance, lets it through."""
+    assert pc.check_get_loss_random_draw(1, "cpu") == "ok"
+    v = pc.check_get_loss_random_draw(604, "cpu")
+    assert v[0] == "depth tie" and v[1] == "unnorm_rotations", v
+
+
 def test_emulated_adam_inside_the_backward_equals_backward_plus_step(emu):
     """(one OpenMP thread for the emulator's block loop: the blend backward's float atomics then sum in a fixed order and the two loops can be
     compared bit for bit)"""

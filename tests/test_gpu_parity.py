@@ -634,6 +634,16 @@ def test_raw_parameter_rasteriser_equals_the_activation_kernels(hip):
     pc.check_raw_parameter_mode_sh(hip, n=20000, W=160, H=128)
 
 
+@pytest.mark.parametrize("seed", list(range(12)) + [135, 444, 604, 630, 812])
+def test_loss_call_fully_fused_equals_the_reference_call_pattern_on_random_draws(hip, seed):
+    """A dozen draws of the 1200-draw sweep of profiles/r05_fuzz_get_loss.txt (scripts/exp/fuzz_get_loss.py) plus five it flagged: get_loss as the reference runs it
+    (torch activations, two raster passes, torch loss) against get_loss(fused=True, fused_loss=True, fused_preprocess=True).  135 / 812: sign(im - gt) of the reference's
+    L1 colour term differs at one pixel-channel between the two renders; 444: the same for the depth term; 604: a depth tie; 630: one alpha = 1/255 decision.  The draw
+    asserts that a difference above rounding is one of these classes (which one hangs on the last bit of the device's arithmetic and is not asserted)."""
+    v = pc.check_get_loss_random_draw(seed, hip)
+    assert v == "ok" or v[0] in ("L1 kink", "depth L1 kink", "depth tie", "rows")
+
+
 @pytest.mark.parametrize("seed", list(range(24)) + [1782, 3452, 3570, 3988])
 def test_raw_parameter_rasteriser_on_random_draws(hip, seed):
     """Two dozen draws of the 4000-scene sweep of profiles/r05_fuzz_raw.txt (scripts/exp/fuzz_raw.py), plus four it flagged: 1782 / 3452 (two overlapping splats
