@@ -172,6 +172,12 @@ def densify_event(iter, densify_dict) -> bool:
     return bool(iter > 0 and iter % densify_dict["reset_opacities_every"] == 0 and densify_dict.get("reset_opacities", False))
 
 
+def densify_restructures(iter, densify_dict) -> bool:
+    """The clone / split / remove branch of densify_event alone (slam_external.py:199): the one that consumes AND zeroes the accumulators.  An
+    opacity-reset-only iteration (slam_external.py:243-246) leaves them standing."""
+    return bool(iter <= densify_dict["stop_after"] and iter >= densify_dict["start_after"] and iter % densify_dict["densify_every"] == 0)
+
+
 def prune_event(iter, prune_dict) -> bool:
     """Does prune_gaussians(..., iter, prune_dict) remove rows or reset opacities at this iteration?  (see densify_event)"""
     if iter > prune_dict["stop_after"]:

@@ -447,7 +447,10 @@ def sharded_densify(params, variables, optimizer, iter, densify_dict, group=None
     if accumulate:
         variables = O.accumulate_mean2d_gradient(variables)
     if O.densify_event(iter, densify_dict):
-        if _world(group, world) > 1:
+        # only the restructuring branch consumes -- and zeroes -- the accumulators.  An opacity-reset-only iteration leaves them standing: reducing
+        # them there would turn the partial sums into full ones on every rank, and the next real event would count them `world` times.  (The reset
+        # writes one constant into every row of the opacities and zeroes their moments: nothing rank-local survives it, no gather either.)
+        if _world(group, world) > 1 and O.densify_restructures(iter, densify_dict):
             all_reduce_statistics(variables, group)
             gather_moments(params, optimizer, group)
         if before_event is not None:

@@ -44,6 +44,8 @@ CPU_SECONDS = 12.0           # CPU work the cpu_baseline leg is bounded to (whol
 VALU_ISSUE_PEAK = 890e9      # wave64 plain-fp32 VALU instructions/s of the chip, MEASURED (scripts/exp/valu_issue.hip, profiles/r02_valu_issue.txt:
                              # v_mul/v_add_f32 at 8 waves per SIMD; DPP / v_cndmask / v_cmp / packed fp32 issue at 0.45-0.65x of this)
 FP32_PEAK = 157.3e12         # MI355X_MICROARCH.md: fp32 vector peak
+XGMI_LINK = 153e9            # MI355X_MICROARCH.md / SURVEY App. B: one xGMI link, one direction; 7 links per GPU, fully connected
+XGMI_PEAK = 7 * XGMI_LINK
 METRIC = "render+backward frames/sec at 640x480, N Gaussians"
 
 
@@ -98,6 +100,35 @@ def stage_bytes(P, D, npix, sh=False):
 
 def frame_bytes(P, D, npix, sh=False):
     return P * (832 if sh else 292) + D * 160 + npix * 48
+
+
+def c4_roofline(n_gauss, D, npix, sh, world, KF, step_s, exchange_ms, exchange_bytes, single_fps=None):
+    """The `roofline` block of a configs[3] line.  Per GPU: the keyframes one rank renders per step x SURVEY 8(d)'s algorithmic bytes of a
+    forward + backward frame (N b_g + D b_i + px b_p: the metric's figure -- the loss kernels' and the depth/silhouette channels' extra
+    traffic is NOT counted, so the fraction is a lower bound) over the WHOLE step time (render + loss + backward + exchange + Adam) against
+    8 TB/s.  The exchange: bytes a rank puts on its links (reduce-scatter + all-gather: 2 S (ranks - 1) / ranks) over the event-timed
+    exchange (pack -> reduce-scatter -> Adam on the row block -> all-gather -> unpack) against 7 x 153 GB/s."""
+    G = 59 if sh else 14
+    B = frame_bytes(n_gauss, D, npix, sh=sh)
+    per_gpu = KF * B / max(world, 1) / step_s
+    r = {"bound": "hbm", "kernel": "whole keyframe (forward + loss + backward), per GPU", "achieved": round(per_gpu / 1e9, 2), "peak": HBM_PEAK / 1e9,
+         "unit": "GB/s", "frac": round(per_gpu / HBM_PEAK, 5), "frame_frac": round(per_gpu / HBM_PEAK, 5), "traffic": None,
+         "alg_bytes_per_keyframe": int(B), "tile_instances_D_per_keyframe": int(D), "gaussians": int(n_gauss), "keyframes_per_gpu_per_step": KF / max(world, 1),
+         "frame_frac_note": "keyframes x SURVEY 8(d) B_alg(keyframe) / (n_gpus x step time x 8 TB/s); the step time includes loss, exchange and Adam, "
+                            "whose own bytes are not in B_alg"}
+    if exchange_ms and exchange_bytes and world > 1:
+        wire = 2.0 * exchange_bytes * (world - 1) / world
+        hbm = exchange_bytes * 4 + 28.0 * G * n_gauss / world      # pack (read + write), unpack (read + write); Adam on 1/world of the rows
+        r.update(exchange_floats_per_gaussian=G, exchange_buffer_bytes=int(exchange_bytes), exchange_wire_bytes_per_rank=int(wire),
+                 exchange_ms=round(exchange_ms, 4), exchange_frac_xgmi=round(wire / (exchange_ms * 1e-3) / XGMI_PEAK, 4), xgmi_peak_gbs=XGMI_PEAK / 1e9,
+                 exchange_hbm_alg_bytes=int(hbm), exchange_frac_hbm=round(hbm / (exchange_ms * 1e-3) / HBM_PEAK, 4),
+                 exchange_share_of_step=round(exchange_ms * 1e-3 / step_s, 4),
+                 exchange_note="wire bytes a rank sends (reduce-scatter + all-gather) / the event-timed exchange INCLUDING pack, the sharded Adam and unpack "
+                               "/ (7 links x 153 GB/s); gloo on one device (development knob) moves these bytes through host memory, not xGMI")
+    if single_fps:
+        r["single_gpu_frame_frac"] = round(single_fps * B / HBM_PEAK, 5)
+        r["single_gpu_note"] = "the same batch on rank 0's GPU alone (no collective): keyframes/s x B_alg(keyframe) / 8 TB/s"
+    return r
 
 
 class RenderWorkload:
@@ -240,8 +271,13 @@ def suite_tally():
             "rate": round((fired) / max(n, 1), 4), "source": os.path.basename(f)}
 
 
-def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
-    """BASELINE configs[3]: 64 keyframes sharded over the ranks, RCCL gradient exchange, sharded fused Adam."""
+def run_c4(args, dev, rank, world, ranks_info=None, sh_degree=None, light=False):
+    """BASELINE configs[3]: 64 keyframes sharded over the ranks, RCCL gradient exchange, sharded fused Adam.
+    sh_degree: overrides --c4-sh-degree (-1: `rgb_colors`, G = 14; 0..3: `shs` rows, G = 59); light: skip the non-uniform-scene leg of the
+    one-GPU prediction.  The caller emits the line and tears the process group down."""
+    import types
+    if sh_degree is not None:
+        args = types.SimpleNamespace(**dict(vars(args), c4_sh_degree=int(sh_degree)))
     import torch.distributed as dist
     from activesplat_amd import mapping as M, optim as O, parallel as PL, setup_camera
     from activesplat_amd import rasterizer as R
@@ -386,6 +422,9 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
         dist.all_gather(all_ms, mine_ms)
         per_rank = [round(float(t[0]), 3) for t in all_ms]
         per_rank_ex = [round(float(t[1]), 3) for t in all_ms]
+        dd = torch.tensor([float(D)], device=dev, dtype=torch.float64)       # tile instances of every rank's last keyframe -> their mean
+        dist.all_reduce(dd, op=dist.ReduceOp.SUM)
+        D_mean = float(dd.item()) / world
         out = {
             "metric": METRIC + " (configs[3]: keyframes/s of the 64-keyframe optimiser step incl. loss, gradient exchange and Adam)",
             "value": round(KF * args.steps / dt, 2), "unit": "frames/s",
@@ -411,6 +450,8 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
                                       "note": "a rank's own keyframes of one step (render + loss + backward, before the exchange), hipEvents, mean over the timed steps"},
             "per_rank_exchange_plus_adam_ms": per_rank_ex,
         }
+        out["roofline"] = c4_roofline(int(params["means3D"].shape[0]), D_mean, W * H, sh, world, KF, dt / args.steps,
+                                      float(np.mean(ex)) if ex else None, exch.get("bytes"))
     else:
         out = {}
     # the same batch on ONE GPU (rank 0 alone, no collectives, its own parameters and optimiser): the reference point of the
@@ -443,9 +484,13 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
         if world > 1:
             out["single_gpu_same_workload_fps"] = round(ref, 2)
             out["speedup_vs_single_gpu_same_workload"] = round(out["value"] / ref, 3)
+            out["roofline"]["single_gpu_frame_frac"] = round(ref * out["roofline"]["alg_bytes_per_keyframe"] / HBM_PEAK, 5)
+            out["roofline"]["single_gpu_note"] = "the same batch on rank 0's GPU alone (no collective): keyframes/s x B_alg(keyframe) / 8 TB/s"
         else:
-            out = {"workload": f"BASELINE configs[3] on ONE GPU: {N} Gaussians, {KF} keyframes per optimiser step (activations inside the per-Gaussian kernels of the RGB-D render -> "
+            out = {"workload": f"BASELINE configs[3] on ONE GPU: {N} Gaussians{' as 16-coefficient SH rows' if sh else ''}, {KF} keyframes per optimiser step (activations inside the per-Gaussian kernels of the RGB-D render -> "
                                "fused loss -> backward per keyframe, fused Adam), no collective", "keyframes_per_s": round(ref, 2),
+                   "exchange_floats_per_gaussian": 59 if sh else 14,
+                   "roofline": c4_roofline(int(p1["means3D"].shape[0]), int(R.last_stats["num_rendered"]), W * H, sh, 1, KF, KF / ref, None, None),
                    "ms_per_optimiser_step": round(KF / ref * 1e3, 3), "streams": args.streams,
                    "densify_every": every, "densify_event": None if ev1 is None else dict(n_before=ev1[0], n_after=ev1[1], grad_thresh=ev1[2], ms=round(t_event * 1e3, 3))}
             # ---- what ONE device can say about the 8-GPU run: every rank's shard of the batch timed alone (load balance: D differs per
@@ -479,7 +524,7 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
                         ex1 = float(np.mean(xs))
                         S = float(PL.last_exchange["bytes"])
                         wire = 2.0 * (S / R8) / 153e9 * 1e3           # direct reduce-scatter + all-gather: S/ranks per peer and direction, one xGMI link each
-                        pred.update(exchange_1rank_rccl_ms=round(ex1, 4), exchange_collectives=[PL.last_exchange.get("reduce"), PL.last_exchange.get("gather")],
+                        pred.update(exchange_floats_per_gaussian=59 if sh else 14, exchange_1rank_rccl_ms=round(ex1, 4), exchange_collectives=[PL.last_exchange.get("reduce"), PL.last_exchange.get("gather")],
                                     exchange_bytes=int(S), wire_model_ms=round(wire, 4),
                                     predicted_keyframes_per_s=round(KF / ((max(per) + ex1 + wire) * 1e-3), 1),
                                     predicted_speedup_vs_this_gpu=round(KF / ((max(per) + ex1 + wire) * 1e-3) / ref, 3),
@@ -492,6 +537,8 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
                 # ---- the same on a NON-uniform scene (three quarters of the Gaussians in half of the azimuth range: half the views see 3x the
                 # tile instances): contiguous keyframe blocks against the LPT assignment on each keyframe's measured instance count ----
                 try:
+                    if light or sh:
+                        raise RuntimeError("skipped on this leg (the uniform-scene figures above are the G = 59 column; the non-uniform scene runs on the G = 14 map)")
                     raw_u = syn.uneven_shell_scene(N, seed=0, W=W, H=H)
                     pu = {k: torch.nn.Parameter(v.to(dev)) for k, v in raw_u.items()}
                     pu["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([1.0, 0, 0, 0], device=dev).reshape(1, 4, 1))
@@ -525,9 +572,6 @@ def run_c4(args, dev, rank, world, print_line=True, ranks_info=None):
                 out["eight_gpu_prediction"] = {"error": str(e)}
     if world > 1:
         barrier()
-        if rank == 0 and print_line:
-            emit(out)
-        dist.destroy_process_group()
     return out
 
 
@@ -550,6 +594,8 @@ def main():
     ap.add_argument("--keyframes", type=int, default=64, help="configs[3]: keyframes per optimiser step, sharded over the ranks")
     ap.add_argument("--c4-sh-degree", type=int, default=-1, help="configs[3]: -1 = `rgb_colors` (the reference mapper's map, G = 14 floats per Gaussian "
                                                                  "in the exchange); 0..3 = 16-coefficient SH rows (`shs`, G = 59)")
+    ap.add_argument("--c4-one-map", action="store_true", help="configs[3]: time only the map --c4-sh-degree names (default: the rgb_colors map is `value` and the "
+                                                             "same steps are timed again on the SH-3 map, reported as `sh3_map_G59`)")
     ap.add_argument("--predict-ranks", type=int, default=8, help="configs[3] on one GPU: ranks of the load-balance / exchange prediction leg")
     ap.add_argument("--c4-coherent", action="store_true", help="configs[3]: the map's rows ordered by azimuth (a map grown frame by frame) instead of randomly")
     ap.add_argument("--c4-partition", choices=("lpt", "contiguous"), default="lpt", help="configs[3]: keyframes to ranks by longest-processing-time "
@@ -605,7 +651,23 @@ def main():
     lib = _lib.get()                                        # fail loudly if the HIP library is missing
     if dist_on or args.workload == "c4":
         out = run_c4(args, dev, rank, world, ranks_info=ranks_info)
-        if not dist_on:
+        if args.c4_sh_degree < 0 and not args.c4_one_map:
+            # the second exchange SURVEY 8(d)/(e) names for configs[3]: the map's colour as 16-coefficient SH rows (configs[2]'s map), G = 59 floats
+            # per Gaussian, 472 MB at 2 M -- the same timed region (same steps, same barriers) on that map, reported inside the one line
+            o2 = run_c4(args, dev, rank, world, ranks_info=ranks_info, sh_degree=3, light=True)
+            if dist_on and rank == 0:
+                out["sh3_map_G59"] = {k: o2.get(k) for k in ("value", "unit", "ms_per_step", "exchange_plus_adam_ms", "per_rank_keyframes_ms", "per_rank_exchange_plus_adam_ms",
+                                                             "single_gpu_same_workload_fps", "speedup_vs_single_gpu_same_workload", "roofline")}
+                out["sh3_map_G59"]["config"] = {k: o2["config"].get(k) for k in ("workload", "exchange_floats_per_gaussian", "grad_exchange", "gaussians_at_end",
+                                                                                 "densify_events_in_timed_region", "tile_instances_D_last_keyframe")}
+            elif not dist_on:
+                out["sh3_map_G59"] = o2
+        if dist_on:
+            import torch.distributed as dist
+            if rank == 0:
+                emit(out)
+            dist.destroy_process_group()
+        else:
             emit(out)
         return
 
@@ -926,6 +988,10 @@ def main():
             note("configs[3] on one GPU")
             out["configs3_single_gpu"] = run_c4(args, dev, 0, 1)
             torch.cuda.empty_cache()
+            if args.c4_sh_degree < 0:
+                note("configs[3] on one GPU, SH-3 map (G = 59)")
+                out["configs3_single_gpu"]["sh3_map_G59"] = run_c4(args, dev, 0, 1, sh_degree=3, light=True)
+                torch.cuda.empty_cache()
         except Exception as e:
             out["configs3_single_gpu"] = {"error": str(e)}
         note("mapping-iteration leg")

@@ -75,9 +75,10 @@ def _worker(rank, world, port, emu_path, q, device="cpu", raw=False, lpt=False):
             for k in PL.GRAD_KEYS:
                 seq[k] += params[k].grad
         opt = O.initialize_optimizer(params, lrs)
-        assert list(PL.shard_keyframes(len(kfs), rank, world)) == [2 * rank, 2 * rank + 1]
+        assert sorted(i for r in range(world) for i in PL.shard_keyframes(len(kfs), r, world)) == list(range(len(kfs)))
         part = None
         if lpt:
+            assert world == 2
             # every rank records what ITS keyframes cost; one all-reduce later every rank holds all costs and computes the same assignment
             costs = PL.KeyframeCosts(len(kfs), gaussian_weight=0.0)
             assert costs.partition(world) == [[0, 1], [2, 3]]                  # nothing known yet: contiguous blocks
@@ -150,41 +151,28 @@ def test_two_rank_step_on_a_cost_balanced_partition(emu_lib_path):
         assert err < 1e-5 and same, (rank, err, same)
 
 
-def test_two_rank_gradient_allreduce_equals_sequential_sum(emu_lib_path):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu_lib_path, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=240) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    for rank, err, same, mx, den in res:
+@pytest.mark.parametrize("world", [2, 3])
+def test_gradient_allreduce_equals_sequential_sum(emu_lib_path, world):
+    """Four keyframes on 2 ranks (2 + 2) and on 3 ranks (2 + 1 + 1): the all-reduced flat gradient is the sequential sum over ALL keyframes, every
+    rank steps to the same parameters, the statistics combine as (sum, max)."""
+    for r in sorted(_spawn(_worker, world, (emu_lib_path,), timeout=300)):
+        rank, err, same, mx, den = r
         assert err < 1e-5, (rank, err)          # fp32 sum order differs (local accumulate + ring) but only at rounding level
-        assert same and mx == 2.0 and den == 2.0
+        assert same and mx == float(world) and den == float(world)
 
 
-def test_two_rank_step_with_in_kernel_accumulation_equals_sequential_sum(emu_lib_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_step_with_in_kernel_accumulation_equals_sequential_sum(emu_lib_path, world):
     """The same with the keyframe loss of bench.py's configs[3] step (raw-parameter rasteriser, fused loss, the backward adds into .grad in its
-    kernel): the all-reduced gradient equals the sequential sum of the reference-pattern gradients up to the fused paths' rounding."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu_lib_path, q, "cpu", True)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=240) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    for rank, err, same, mx, den in res:
+    kernel): the all-reduced gradient equals the sequential sum of the reference-pattern gradients up to the fused paths' rounding.  At world 8
+    the four keyframes leave ranks 4-7 without work: they pack zeros (no .grad at all on those ranks) and still end on the common parameters."""
+    for r in sorted(_spawn(_worker, world, (emu_lib_path, "cpu", True), timeout=300)):
+        rank, err, same, mx, den = r
         assert err < 1e-3, (rank, err)
-        assert same and mx == 2.0 and den == 2.0
+        assert same and mx == float(world) and den == float(world)
 
 
-def _worker_sharded_adam(rank, world, port, emu_path, q, sh=False):
+def _worker_sharded_adam(rank, world, port, emu_path, q, sh=False, n=601):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -192,7 +180,6 @@ def _worker_sharded_adam(rank, world, port, emu_path, q, sh=False):
         from activesplat_amd import optim as O, parallel as PL
         from tests import util
         util.use_emulated_kernels(emu_path)
-        n = 601                                                    # not a multiple of the world size
         widths = dict(means3D=(3,), rgb_colors=(3,), unnorm_rotations=(4,), logit_opacities=(1,), log_scales=(3,))
         lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3)
         if sh:                                                     # configs[2]'s map: 16-coefficient SH rows instead of rgb_colors, G = 59
@@ -214,30 +201,74 @@ def _worker_sharded_adam(rank, world, port, emu_path, q, sh=False):
                 else:
                     PL.reduce_scatter_adam_step(params, opt)
             if mode == "reduce_scatter":
+                rows, lo, hi = PL._row_block(n, rank, world)
+                own = (lo, hi)
+                # before the moments are gathered a rank has only advanced its own row block: the other rows still hold their initial zeros
+                stale = all(bool((opt.state[params[k]]["exp_avg"][:lo] == 0).all()) and bool((opt.state[params[k]]["exp_avg"][hi:] == 0).all())
+                            for k in widths)
                 PL.gather_moments(params, opt)
             runs.append({k: (params[k].detach().clone(), opt.state[params[k]]["exp_avg"].clone(),
                              opt.state[params[k]]["exp_avg_sq"].clone(), float(opt.state[params[k]]["step"])) for k in widths})
-        same = all(torch.equal(a, b) for k in widths for a, b in zip(runs[0][k][:3], runs[1][k][:3]))
+        # (1) the sharded step leaves IDENTICAL parameters and moments on every rank, to the bit, at any world size
+        flat = torch.cat([t.reshape(-1) for k in widths for t in runs[1][k][:3]])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        cross_rank = all(torch.equal(gathered[0], t) for t in gathered)
+        # (2) against all-reduce + full Adam: the same sums in another order (the padded flat buffer changes the ring's chunking, and with >= 3
+        # addends the order matters) -> closeness; bit-equality only where it is a theorem (see the test)
+        bit_equal = all(torch.equal(a, b) for k in widths for a, b in zip(runs[0][k][:3], runs[1][k][:3]))
+        rel = max(float((a - b).norm() / (a.norm() + 1e-30)) for k in widths for a, b in zip(runs[0][k][:3], runs[1][k][:3]))
         steps = all(runs[0][k][3] == runs[1][k][3] == 3.0 for k in widths)
-        G = int(PL.last_exchange["bytes"]) // 4 // (2 * ((n + 1) // 2))
-        q.put((rank, same, steps and G == (59 if sh else 14)))
+        G = int(PL.last_exchange["bytes"]) // 4 // (world * ((n + world - 1) // world))
+        q.put(dict(rank=rank, cross_rank=cross_rank, bit_equal=bit_equal, rel=rel, steps=steps, G=G, own=own, stale=stale))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sh", [False, True], ids=["rgb-G14", "shs-G59"])
-def test_reduce_scatter_sharded_adam_equals_allreduce_adam(emu_lib_path, sh):
+def _spawn(target, world, args, timeout=400):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_sharded_adam, args=(r, 2, port, emu_lib_path, q, sh)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args[:1]) + (q,) + tuple(args[1:])) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=240) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert all(same and steps for _, same, steps in res), res
+    try:
+        res = [q.get(timeout=timeout) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return res
+
+
+#: (world, n, SH rows?): 601 = not a multiple of any world size here; 8 = one row per rank at world 8; 5 and 1 leave ranks with EMPTY row
+#: blocks.  G = 59 (configs[2]'s [N,16,3] rows) at n = 601 for each world size and with empty row blocks at world 8
+_SHARDED_ADAM_CASES = [(2, 601, False), (2, 8, False), (2, 1, False), (3, 601, False), (3, 100, False), (3, 1, False),
+                       (8, 601, False), (8, 8, False), (8, 5, False), (8, 1, False),
+                       (2, 601, True), (3, 601, True), (8, 601, True), (8, 5, True)]
+
+
+@pytest.mark.parametrize("world,n,sh", _SHARDED_ADAM_CASES, ids=[f"w{w}-n{n}-{'shs-G59' if sh else 'rgb-G14'}" for w, n, sh in _SHARDED_ADAM_CASES])
+def test_reduce_scatter_sharded_adam_equals_allreduce_adam(emu_lib_path, world, n, sh):
+    """reduce-scatter -> Adam on the rank's row block -> all-gather against all-reduce -> full Adam, three steps, at the world sizes the north
+    star names (2 ... 8) and with row blocks that are ragged or empty.  Proven at every size: all ranks hold bit-identical parameters and
+    moments.  Against the unsharded step the result is CLOSE (<= 1e-6 rel: fp32 sums of `world` addends in another order), and bit-equal only
+    where that is a theorem: two addends commute (world 2), or the padded buffer is the unpadded one (n a multiple of world), so both paths
+    run the identical all-reduce on gloo."""
+    res = sorted(_spawn(_worker_sharded_adam, world, (emu_lib_path, sh, n)), key=lambda r: r["rank"])
+    rows = (n + world - 1) // world
+    assert [r["own"] for r in res] == [(min(r * rows, n), min((r + 1) * rows, n)) for r in range(world)]
+    if n < world:
+        assert sum(1 for r in res if r["own"][0] == r["own"][1]) == world - n          # ranks that own no row at all
+    for r in res:
+        assert r["cross_rank"], r
+        assert r["steps"] and r["G"] == (59 if sh else 14), r
+        assert r["stale"], r
+        assert r["rel"] <= 1e-6, r
+        if world == 2 or n % world == 0:
+            assert r["bit_equal"], r
 
 
 @pytest.mark.gpu
@@ -312,7 +343,8 @@ def test_bench_configs3_workload_two_ranks_on_one_device(hip, n_gauss, kf):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    BENCH_SAME_DEVICE="1", BENCH_BACKEND="gloo")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                                       "--c4-gaussians", str(n_gauss), "--keyframes", str(kf), "--c4-densify-every", "2"], env=env, stdout=subprocess.PIPE,
+                                       "--c4-gaussians", str(n_gauss), "--keyframes", str(kf), "--c4-densify-every", "2"] +
+                                      (["--c4-one-map"] if n_gauss > 1_000_000 else []), env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
@@ -330,6 +362,21 @@ def test_bench_configs3_workload_two_ranks_on_one_device(hip, n_gauss, kf):
     assert d["config"]["gaussians_at_end"] == ev[0]["n_after"] and abs(ev[0]["n_after"] - n_gauss) < 0.05 * n_gauss
     assert d["config"]["grad_exchange"]["bytes"] // (14 * 4) in (ev[0]["n_after"], ev[0]["n_after"] + 1)
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]          # only rank 0 prints
+    # the N > 1 line's roofline block: per-GPU fraction of the HBM roofline, the exchange against the xGMI links, the one-GPU reference beside it
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] == rf["frame_frac"] < 1 and rf["keyframes_per_gpu_per_step"] == kf / 2
+    assert abs(rf["frame_frac"] - kf * rf["alg_bytes_per_keyframe"] / (2 * d["ms_per_step"] * 1e-3 * 8e12)) < 1e-3 * rf["frame_frac"] + 1e-5
+    assert rf["exchange_floats_per_gaussian"] == 14 and rf["exchange_wire_bytes_per_rank"] == rf["exchange_buffer_bytes"]     # 2 S (2 - 1) / 2
+    assert rf["exchange_frac_xgmi"] > 0 and rf["xgmi_peak_gbs"] == 1071.0 and 0 < rf["single_gpu_frame_frac"] < 1
+    if n_gauss > 1_000_000:
+        assert "sh3_map_G59" not in d                                                # (--c4-one-map)
+    else:
+        # the same steps on the SH-3 map: G = 59 floats per Gaussian in the exchange, its own value / roofline inside the ONE line
+        s3 = d["sh3_map_G59"]
+        assert s3["value"] > 0 and s3["config"]["exchange_floats_per_gaussian"] == 59 and s3["roofline"]["exchange_floats_per_gaussian"] == 59
+        n3 = s3["config"]["gaussians_at_end"]
+        assert s3["config"]["grad_exchange"]["bytes"] // (59 * 4) in (n3, n3 + 1)
+        assert s3["roofline"]["alg_bytes_per_keyframe"] > rf["alg_bytes_per_keyframe"] and s3["single_gpu_same_workload_fps"] > 0
 
 
 def test_bench_gpus_n_without_enough_devices_refuses():
@@ -357,7 +404,7 @@ def test_bench_gpus_2_launches_its_own_ranks(hip):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(BENCH_SAME_DEVICE="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--c4-gaussians", "200000",
-                        "--keyframes", "8", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+                        "--keyframes", "8", "--no-extras", "--c4-one-map"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -536,40 +583,112 @@ def _worker_surgery(rank, world, port, emu_path, q, device="cpu", n=900, W=64, H
         dist.destroy_process_group()
 
 
-def _check_surgery(res):
+def _check_surgery(res, world=2, keyframes=4):
     res = sorted(res, key=lambda r: r["rank"])
+    assert [r["rank"] for r in res] == list(range(world))
     for r in res:
-        assert r["same_n"] and r["same"], r                        # identical N, parameters AND moments on both ranks, to the bit
+        assert r["same_n"] and r["same"], r                        # identical N, parameters AND moments on every rank, to the bit
         assert r["steps"] == [6] and r["ts_ok"], r
     t = res[0]["trace"]
-    assert [x[:4] for x in t] == [x[:4] for x in res[1]["trace"]]
+    for r in res[1:]:
+        assert [x[:4] for x in t] == [x[:4] for x in r["trace"]]
     kinds = [x[0] for x in t]
     assert kinds == ["densify", "prune", "densify"], kinds        # iterations 3 (densify), 4 (prune), 6 (densify)
     d = t[0]
     assert d[3] != d[2], d                                         # the event changed N
-    # the ranks' accumulators were PARTIAL sums before the event: each holds only its own keyframes' visibility counts
-    assert res[0]["trace"][0][4] + res[1]["trace"][0][4] == res[0]["single_trace"][0][4] > 0, (res[0]["trace"], res[0]["single_trace"])
+    # the ranks' accumulators were PARTIAL sums before the event: each holds only its own keyframes' visibility counts -- a rank that owns no
+    # keyframe (world > number of keyframes) holds zeros and still takes every decision the others take
+    partial = [r["trace"][0][4] for r in res]
+    assert sum(partial) == res[0]["single_trace"][0][4] > 0, (partial, res[0]["single_trace"])
+    assert [p_ > 0 for p_ in partial] == [r < keyframes for r in range(world)], partial
     assert t[1][3] < t[1][2], t                                    # the prune removed rows
     # against the loop run by one rank alone: the same N after every event, the same state up to fp32 summation order
     assert [x[:4] for x in res[0]["single_trace"]] == [x[:4] for x in t], (res[0]["single_trace"], t)
     assert res[0]["single_same_n"] and res[0]["single_rel"] < 1e-5, res[0]
 
 
-def test_two_rank_sharded_steps_densify_prune_sharded_steps(emu_lib_path):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_steps_densify_prune_sharded_steps(emu_lib_path, world):
     """Sharded Adam steps -> all-reduced statistics -> gathered moments -> fused densify (split offsets drawn in the kernel from a seed that is a
-    function of replicated state) -> prune -> sharded steps again, on two gloo ranks (emulated kernels): identical N / parameters / moments on
-    both ranks, a rebuilt shard plan, and agreement with the same loop run by one rank alone (slam_external.py:143-247 under SURVEY 8e)."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_surgery, args=(r, 2, port, emu_lib_path, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=400) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    _check_surgery(res)
+    function of replicated state) -> prune -> sharded steps again, on 2, 4 and 8 gloo ranks (emulated kernels; the batch has FOUR keyframes, so at
+    world 8 ranks 4-7 own none and contribute zero gradients and zero statistics): identical N / parameters / moments on every rank, a rebuilt
+    shard plan, and agreement with the same loop run by one rank alone (slam_external.py:143-247 under SURVEY 8e)."""
+    _check_surgery(_spawn(_worker_surgery, world, (emu_lib_path,), timeout=600), world=world)
+
+
+def _worker_reset_only(rank, world, port, emu_path, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from activesplat_amd import optim as O, parallel as PL
+        n = 50
+        g = torch.Generator().manual_seed(1)
+        params = {k: torch.nn.Parameter(torch.randn(n, w, generator=g)) for k, w in
+                  dict(means3D=3, rgb_colors=3, unnorm_rotations=4, logit_opacities=1, log_scales=3).items()}
+        opt = O.initialize_optimizer(params, {k: 1e-3 for k in params})
+        variables = dict(means2D_gradient_accum=torch.full((n,), float(rank + 1)), denom=torch.full((n,), float(rank + 1)),
+                         max_2D_radius=torch.full((n,), float(rank + 1)), timestep=torch.zeros(n))
+        dd = dict(start_after=500, remove_big_after=0, stop_after=5000, densify_every=100, grad_thresh=2e-4, num_to_split_into=2,
+                  removal_opacity_threshold=0.005, final_removal_opacity_threshold=0.005, reset_opacities=True, reset_opacities_every=30)
+        assert O.densify_event(30, dd) and not O.densify_restructures(30, dd)
+        params, variables = PL.sharded_densify(params, variables, opt, 30, dd, accumulate=False)
+        q.put(dict(rank=rank, accum=float(variables["means2D_gradient_accum"][0]), denom=float(variables["denom"][0]),
+                   reset=bool(torch.allclose(torch.sigmoid(params["logit_opacities"]), torch.full((n, 1), 0.01), atol=1e-6))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_opacity_reset_only_iteration_leaves_the_partial_statistics_rank_local():
+    """An iteration on which densify only resets the opacities (slam_external.py:243-246; reset_opacities_every hit before start_after) must not
+    all-reduce the accumulators: they are not zeroed there, and the next real event would reduce the already-reduced sums again (x world)."""
+    for r in _spawn(_worker_reset_only, 2, (None,), timeout=120):
+        assert r["reset"] and r["accum"] == r["denom"] == float(r["rank"] + 1), r
+
+
+def _worker_lpt_64(rank, world, port, emu_path, q):
+    """configs[3]'s shape on the host: 64 keyframes on `world` ranks, each rank records the cost of the keyframes IT rendered, one all-reduce makes
+    the costs common, every rank computes the LPT assignment."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from activesplat_amd import parallel as PL
+        K = 64
+        rng = np.random.RandomState(7)
+        true = (rng.lognormal(0.0, 0.6, size=K) * 4_000_000).astype(np.int64)          # tile instances per keyframe: a wall at 1 m ... a corridor
+        kc = PL.KeyframeCosts(K)
+        first = kc.partition(world)
+        assert first == [list(PL.shard_keyframes(K, r, world)) for r in range(world)]
+        for i in first[rank]:
+            kc.record(i, int(true[i]), 2_000_000)
+        part = kc.sync("cpu").partition(world)
+        enc = torch.tensor([len(p_) for p_ in part] + [i for p_ in part for i in p_])
+        got = [torch.zeros_like(enc) for _ in range(world)]
+        dist.all_gather(got, enc)
+        # second round on the new assignment: the owners changed, the recorded costs still cover every keyframe exactly once
+        for i in part[rank]:
+            kc.record(i, int(true[i]) + 1, 2_000_000)
+        part2 = kc.sync("cpu").partition(world)
+        q.put(dict(rank=rank, part=part, part2=part2, same=all(torch.equal(got[0], g_) for g_ in got), cost=list(kc.cost), true=true.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_lpt_partition_of_64_keyframes_on_8_ranks():
+    """BASELINE configs[3]: 64 keyframes, 8 ranks.  Costs recorded by the owners and all-reduced give every rank the same LPT assignment; it is
+    a partition of the 64 keyframes, every rank gets work, and the slowest rank is within LPT's bound of the mean (contiguous blocks are not)."""
+    from activesplat_amd import parallel as PL
+    res = sorted(_spawn(_worker_lpt_64, 8, (None,), timeout=120), key=lambda r: r["rank"])
+    part, true = res[0]["part"], np.asarray(res[0]["true"], dtype=np.float64)
+    cost = true + 1.6 * 2_000_000
+    for r in res:
+        assert r["same"] and r["part"] == part and r["part2"] == res[0]["part2"]
+        assert np.allclose(r["cost"], cost + 1.0)                  # after the second sync: every keyframe recorded by exactly one (new) owner
+    assert sorted(i for p_ in part for i in p_) == list(range(64)) and all(len(p_) > 0 for p_ in part)
+    load = lambda pp: np.array([cost[p_].sum() for p_ in pp])  # noqa: E731
+    contiguous = [list(PL.shard_keyframes(64, r, 8)) for r in range(8)]
+    mean = cost.sum() / 8
+    assert load(part).max() / mean < 1.03 < load(contiguous).max() / mean, (load(part).max() / mean, load(contiguous).max() / mean)
+    assert load(part).max() <= (4 / 3 - 1 / 24) * max(mean, cost.max())
 
 
 @pytest.mark.gpu
