@@ -306,8 +306,10 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
 
 # ------------------------------------------------------------------------------------------------------------
 # SURVEY 8(e) "preferred refinement": reduce-scatter -> Adam on this rank's 1/world row block -> all-gather of
-# the updated rows.  Same bytes on the wire as the all-reduce, 1/world of the Adam HBM traffic per GPU, and the
-# result is identical because Adam is element-wise.  Moments are only kept current for the owned rows;
+# the updated rows.  Same bytes on the wire as the all-reduce, 1/world of the Adam HBM traffic per GPU.  Adam is
+# element-wise, so every row is stepped by exactly one rank and copied: all ranks end bit-identical at ANY world size.
+# Against all-reduce + full Adam the result is equal up to the order in which the collective adds the `world` partial
+# gradients (<= 1e-6 rel; to the bit only for two ranks or unpadded buffers).  Moments are only kept current for the owned rows;
 # `gather_moments` refreshes the full tensors before row surgery (densify / prune, every ~100 iterations).
 # ------------------------------------------------------------------------------------------------------------
 def _row_block(n: int, rank: int, world: int):

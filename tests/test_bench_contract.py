@@ -24,3 +24,24 @@ def test_emit_without_a_claim_still_prints_the_line():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert [json.loads(ln) for ln in r.stdout.splitlines()] == [{"k": [1, 2]}]
+
+
+def test_configs3_roofline_block_arithmetic():
+    """The N > 1 line's `roofline` block (bench.c4_roofline): per-GPU fraction of the HBM roofline from SURVEY 8(d)'s bytes per frame, the
+    exchange against 7 xGMI links, for both exchanges SURVEY 8(e) names (G = 14 -> 112 MB, G = 59 -> 472 MB at 2 M Gaussians)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    N, D, px = 2_000_000, 4_500_000, 640 * 480
+    assert bench.frame_bytes(N, D, px, sh=True) == N * 832 + D * 160 + px * 48        # SURVEY 8(d): C3 render, 2.40 GB
+    for sh, G in ((False, 14), (True, 59)):
+        S = N * G * 4
+        r = bench.c4_roofline(N, D, px, sh, 8, 64, 6e-3, 1.0, S, single_fps=1000.0)
+        B = bench.frame_bytes(N, D, px, sh=sh)
+        assert r["alg_bytes_per_keyframe"] == B and r["keyframes_per_gpu_per_step"] == 8
+        assert abs(r["frame_frac"] - 8 * B / 6e-3 / 8e12) < 1e-5 and r["frac"] == r["frame_frac"] and r["bound"] == "hbm"
+        assert r["exchange_buffer_bytes"] == S == {14: 112_000_000, 59: 472_000_000}[G]
+        assert r["exchange_wire_bytes_per_rank"] == int(2 * S * 7 / 8)
+        assert abs(r["exchange_frac_xgmi"] - (2 * S * 7 / 8) / 1e-3 / (7 * 153e9)) < 1e-4
+        assert abs(r["single_gpu_frame_frac"] - 1000.0 * B / 8e12) < 1e-5
+    one = bench.c4_roofline(N, D, px, False, 1, 64, 32e-3, None, None)
+    assert "exchange_frac_xgmi" not in one and one["keyframes_per_gpu_per_step"] == 64
