@@ -54,10 +54,10 @@ SORT_AUTO, SORT_TILE_LDS, SORT_RADIX = 0, 1, 2
 
 # every symbol include/gsplat_hip.h declares (tests check the library exports all of them)
 #: the GS_ABI_VERSION of include/gsplat_hip.h this binding was written against (checked when a library is bound)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 SYMBOLS = ("gs_abi_version", "gs_geom_layout", "gs_image_layout", "gs_bin_layout", "gs_backward_scratch_bytes", "gs_last_error",
-           "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_set_half_quadrants", "gs_set_backward_chain", "gs_set_backward_chain_tickets", "gs_set_backward_chain_polls", "gs_async_status_word", "gs_recorded_cut", "gs_set_backward_segments", "gs_preprocess_forward", "gs_preprocess_forward_raw", "gs_render_forward", "gs_render_backward", "gs_render_backward_raw", "gs_render_backward_raw_adam", "gs_adam_step", "gs_adam_step_multi",
+           "gs_version", "gs_set_sort_path", "gs_set_forward_segments", "gs_set_half_quadrants", "gs_set_backward_chain", "gs_set_backward_chain_tickets", "gs_set_backward_chain_polls", "gs_async_status_word", "gs_async_status_clear", "gs_recorded_cut", "gs_set_backward_segments", "gs_preprocess_forward", "gs_preprocess_forward_raw", "gs_render_forward", "gs_render_backward", "gs_render_backward_raw", "gs_render_backward_raw_adam", "gs_adam_step", "gs_adam_step_multi",
            "gs_profile_enable", "gs_profile_stage_count", "gs_profile_stage_name", "gs_profile_collect",
            "gs_compact_scratch_bytes", "gs_compact_index", "gs_gather_rows", "gs_mapping_loss_scratch_bytes", "gs_mapping_loss", "gs_activate_forward", "gs_activate_backward", "gs_activate_backward_accumulate",
            "gs_grow_scratch_bytes", "gs_grow_gaussians", "gs_keyframe_overlap", "gs_visibility_stats", "gs_accumulate_grad2d",
@@ -217,10 +217,12 @@ def poll_async_status():
         check(get().gs_async_status_word(C.byref(w)))
         _status = w
     if _status[0]:
-        _status[0] = 0
         check(get().gs_set_backward_chain(1, -1))
+        check(get().gs_async_status_clear())      # (synchronises the device, then clears the sticky device word: optimiser steps run again)
+        _status[0] = 0
         raise RuntimeError("activesplat_amd: a chained backward walk timed out waiting for the piece in front of it -- the gradients of the previous "
-                           "backward on this process are invalid (NaN).  Chained walks are now off (gs_set_backward_chain(1, -1)); render that frame again.")
+                           "backward on this process are invalid (NaN); optimiser steps enqueued behind it were SKIPPED by their kernels (parameters and "
+                           "moments untouched, step counters one ahead).  Chained walks are now off (gs_set_backward_chain(1, -1)); render that frame again.")
 
 
 def emulated() -> bool:

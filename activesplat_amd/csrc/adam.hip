@@ -12,8 +12,10 @@ namespace gs {
 
 __global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v, float one_m_b1,
-                                                       float b2, float one_m_b2, float step_size, float inv_bc2s, float eps)
+                                                       float b2, float one_m_b2, float step_size, float inv_bc2s, float eps,
+                                                       const uint32_t* __restrict__ fail)
 {
+    if (chain_failed(fail)) return;            // a backward in front of this step timed out (NaN gradients): leave parameters and moments alone
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     float4* p4 = reinterpret_cast<float4*>(p);
@@ -46,7 +48,7 @@ hipError_t launch_adam(int64_t n, float* p, const float* g, float* m, float* v, 
     if (nb < 1) nb = 1;
     if (nb > 256 * 8) nb = 256 * 8;          // grid-stride: 8 workgroups per CU
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, n, p, g, m, v, (float)(1.0 - b1), (float)b2,
-                       (float)(1.0 - b2), step_size, inv_bc2s, (float)eps);
+                       (float)(1.0 - b2), step_size, inv_bc2s, (float)eps, (const uint32_t*)g_chain_fail_dev);
     return hipGetLastError();
 }
 
@@ -62,10 +64,11 @@ struct AdamSlot {
     int stream;                      // tensor larger than the last-level cache: non-temporal loads / stores
 };
 constexpr int64_t kAdamStreamBytes = 256ll << 20;     // 256 MiB last-level (Infinity) cache: beyond it, re-use is impossible anyway
-struct AdamBatch { AdamSlot s[kAdamMaxTensors]; int count; };
+struct AdamBatch { AdamSlot s[kAdamMaxTensors]; int count; const uint32_t* fail; };
 
 __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamBatch b)
 {
+    if (chain_failed(b.fail)) return;          // (see adam_kernel)
     int t = 0;
 #pragma unroll
     for (int i = 1; i < kAdamMaxTensors; ++i)
@@ -125,6 +128,7 @@ hipError_t launch_adam_multi(int count, const GsAdamTensor* t, hipStream_t st)
 {
     for (int base = 0; base < count; base += kAdamMaxTensors) {
         AdamBatch b{};
+        b.fail = g_chain_fail_dev;
         unsigned next = 0;
         for (int i = base; i < count && i < base + kAdamMaxTensors; ++i) {
             if (t[i].n <= 0) continue;

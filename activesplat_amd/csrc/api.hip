@@ -190,10 +190,24 @@ int gs_async_status_word(uint32_t** host_word)
         memset(h, 0, 64);
         void* d = nullptr;
         if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); return fail(GS_ELAUNCH, "gs_async_status_word: no device view of the host word"); }
+        // the sticky device-memory twin the optimiser kernels read (Cam::chain_fail).  Without it the library still works -- the step is then not
+        // protected against a timed-out walk, as before round 6
+        void* f = nullptr;
+        if (hipMalloc(&f, 64) == hipSuccess && hipMemset(f, 0, 64) == hipSuccess) gs::g_chain_fail_dev = (uint32_t*)f;
+        else (void)hipGetLastError();
         word = (uint32_t*)h;
         gs::g_async_status_dev = (uint32_t*)d;
     }
     if (host_word) *host_word = word;
+    return GS_OK;
+}
+
+int gs_async_status_clear(void)
+{
+    // the host has seen and reported the event: optimiser steps run again.  Synchronous (the rare path): every launch enqueued so far has ended
+    // when this returns, so no walker of an old launch can raise the word again behind the clear
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return fail(GS_ELAUNCH, "gs_async_status_clear: device synchronisation failed"); }
+    if (gs::g_chain_fail_dev && hipMemset(gs::g_chain_fail_dev, 0, 4) != hipSuccess) { (void)hipGetLastError(); return fail(GS_ELAUNCH, "gs_async_status_clear: hipMemset failed"); }
     return GS_OK;
 }
 
@@ -494,6 +508,7 @@ static int render_backward_impl(const GsCamera* cam, int32_t P, int64_t D, const
             fa.p[t] = a.param; fa.m[t] = a.exp_avg; fa.v[t] = a.exp_avg_sq;
             fa.c[t] = gs::adam_coef(a.lr, a.beta1, a.beta2, a.eps, a.step);
         }
+        fa.fail = gs::g_chain_fail_dev;
     } else {
         if (!means3D || !radii || !dL_dmeans2D || !dL_dmeans3D || !dL_dopacities)
             return fail(GS_EINVAL, "gs_render_backward: null input/output pointer");

@@ -809,8 +809,13 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(3, 3
             __builtin_amdgcn_s_sleep(16);
             if (++polls > cam.chain_polls) handed = false;
         }
-        if (!handed && lane == 0 && cam.async_status)       // (host-mapped word: rasterizer.py reads it before the next launch and stops chaining)
-            __hip_atomic_fetch_or(cam.async_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!handed && lane == 0) {
+            // host-mapped word: rasterizer.py reads it before the next launch and stops chaining.  A plain system-scope STORE: every writer writes
+            // the same 1, and a read-modify-write on host memory would need PCIe atomics, which not every platform routes
+            if (cam.async_status) __hip_atomic_store(cam.async_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // device word: the optimiser kernels behind this backward on the stream read it and skip their step (Cam::chain_fail)
+            if (cam.chain_fail) __hip_atomic_store(cam.chain_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         GS_WAIT_VMEM();
         const float* in = chain_st + (piece - 1) * 2 * kWave;
         T = __hip_atomic_load(in + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1059,6 +1064,7 @@ std::atomic<int> g_chain_min_tiles{kChainMinTiles};
 std::atomic<int> g_chain_tickets{0};
 std::atomic<int> g_chain_polls{kChainPollsDefault};      // bound of a piece's wait for the piece in front (gs_set_backward_chain_polls: tests)
 uint32_t* g_async_status_dev = nullptr;      // device view of the host-mapped status word (api.hip: gs_async_status_word)
+uint32_t* g_chain_fail_dev = nullptr;        // its sticky device-memory twin (Cam::chain_fail)
 // list segments (walkers) per quadrant in the few-tile backward: 3 x 256 tiles x 4 quadrants = the chip's 3072 walker slots (gs_set_backward_segments)
 std::atomic<int> g_few_segments{kFewSegmentsMax};
 
@@ -1141,6 +1147,7 @@ hipError_t launch_blend_backward(const Cam& cam_in, const uint2* ranges, const u
     do { cam.chain_epoch = ++epoch; } while (cam.chain_epoch == 0u);          // (the forward leaves zero in the hand-over flags)
     cam.chain_ticket = g_chain_tickets.load(std::memory_order_relaxed); cam.chain_polls = g_chain_polls.load(std::memory_order_relaxed);
     cam.async_status = g_async_status_dev;
+    cam.chain_fail = g_chain_fail_dev;
     const int per = ((cam.gx * cam.gy + 7) >> 3) * (cam.split ? cam.split : cam.chain > 1 ? cam.chain : 1);
 #define GS_BWD(DG, FEW)                                                                                                          \
     hipLaunchKernelGGL((blend_backward_kernel<DG, 1, FEW>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom, final_T, \

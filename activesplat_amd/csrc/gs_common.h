@@ -50,6 +50,11 @@ struct Cam {
     // (host-mapped, gs_async_status) and goes on with NaN state
     int chain_ticket, chain_polls;
     uint32_t* async_status;
+    // the same event for the DEVICE: a sticky word in device memory that the timed-out walker sets next to the host-visible one.  Every kernel that
+    // applies an optimiser step (adam.hip, rows.hip, the Adam inside the per-Gaussian backward) reads it first and leaves parameters and moments
+    // untouched while it is set -- the backward is asynchronous, the host learns of the timeout a render later, and by then a step on NaN gradients
+    // would have destroyed the map in place.  Cleared by the host when it has reported the event (gs_async_status_clear)
+    uint32_t* chain_fail;
     // raw-parameter mode of the per-Gaussian kernels (gs_preprocess_forward_raw / gs_render_backward_raw): the inputs are the mapper's
     // PARAMETERS -- world-frame means, unnormalised quaternions, logit opacities, log scales ([P,1] when act_iso) -- and the frame transform
     // + activations of slam_helpers.py:252-304,124-139 (activate.hip) happen inside the kernels; act_accumulate: the backward ADDS its
@@ -125,6 +130,7 @@ struct FusedAdam {
     float* m[5];
     float* v[5];
     AdamCoef c[5];
+    const uint32_t* fail;      // Cam::chain_fail: set -> the step is skipped
 };
 
 // Per-Gaussian screen-space record, 3 x float4 = 48 B, one gather per tile instance in the blend.
@@ -398,6 +404,12 @@ __device__ __forceinline__ void sh_direction_jacobian(int deg, float x, float y,
 }
 #undef GS_SHJ
 
+// Has a chained backward walk of this process timed out since the host last cleared the word (Cam::chain_fail)?  One cached 4-byte load per workgroup.
+__device__ __forceinline__ bool chain_failed(const uint32_t* w)
+{
+    return w != nullptr && __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+
 // One Adam update (torch's single-tensor arithmetic; adam.hip and rows.hip share it so that the keyframe-sharded step is the full step to the bit)
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float one_m_b1, float b2, float one_m_b2,
                                           float step_size, float inv_bc2s, float eps)
@@ -540,6 +552,7 @@ extern std::atomic<int> g_chain_min_tiles;
 extern std::atomic<int> g_chain_tickets;
 extern std::atomic<int> g_chain_polls;
 extern uint32_t* g_async_status_dev;
+extern uint32_t* g_chain_fail_dev;      // device-memory twin of the status word (Cam::chain_fail); null until gs_async_status_word has been called
 extern std::atomic<int> g_few_segments;
 // images of few tiles (at most kFewTiles; the knob above can only lower the limit): the forward records every pixel's running state
 // at the recorded list positions (cut_level below: every 256th up to 4096, then powers of two) for the segmented backward.  Planes of H*W floats: [level][T, C0, C1, C2, D], then the

@@ -47,6 +47,12 @@ __global__ __launch_bounds__(kBlock, (ACT && SH == 3) ? GS_PBWD_RAW_SH_WGS : 4) 
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kBlock + tid;
     const bool in_range = i < P;
+    if (ADAM && chain_failed(ad.fail)) {
+        // this backward's blend timed out in a chained walk (NaN in the gradient records): no step -- parameters and moments stay as they are, the
+        // screen-space gradient leaves as zeros; the host reports the event in front of the next render (Cam::chain_fail)
+        if (in_range) { dmeans2D[3 * i] = 0.f; dmeans2D[3 * i + 1] = 0.f; dmeans2D[3 * i + 2] = 0.f; }
+        return;
+    }
     if (!HAS_SH && !in_range) return;
     const int ic = in_range ? i : P - 1;                       // clamped index: out-of-range lanes only help with the SH slabs
     const bool live = in_range && radii[ic] > 0;
@@ -59,7 +65,12 @@ __global__ __launch_bounds__(kBlock, (ACT && SH == 3) ? GS_PBWD_RAW_SH_WGS : 4) 
     const bool gate = ACT && !ADAM && !SLAB && cam.act_accumulate;
     float4 ga, gb, gc;
     if (gate) {
-        if (!__any(live)) return;
+        if (!__any(live)) {
+            // dL/dmeans2D is NOT accumulated: the header promises that every row is written, and the host hands the buffer out uninitialised
+            // (torch.empty).  12 B per row against the 64-byte record read the gate saves.
+            if (in_range) { dmeans2D[3 * i] = 0.f; dmeans2D[3 * i + 1] = 0.f; dmeans2D[3 * i + 2] = 0.f; }
+            return;
+        }
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         ga = z4; gb = z4; gc = z4;
         if (live) { ga = gr4[0]; gb = gr4[1]; gc = gr4[2]; }

@@ -28,6 +28,7 @@ struct RowBatch {
     float one_m_b1[kAdamMaxTensors], b2[kAdamMaxTensors], one_m_b2[kAdamMaxTensors], step_size[kAdamMaxTensors],
         inv_bc2s[kAdamMaxTensors], eps[kAdamMaxTensors];
     int count, G;
+    const uint32_t* fail;      // Cam::chain_fail (MODE 2): set -> rows pass through unstepped
 };
 
 // MODE 0: pack, 1: unpack, 2: adam.  ROWS x GMAX floats of LDS hold the block's tile of the flat buffer: BOTH sides of every copy are contiguous runs in
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(RowBatch b, int64_t row0, 
     __shared__ float tile[ROWS * GMAX];
     const int tid = threadIdx.x;
     const int G = b.G;
+    const bool step_ok = MODE != 2 || !chain_failed(b.fail);   // (a backward in front of this step timed out: the rows pass through unstepped)
     const int64_t nblocks = (n_rows + ROWS - 1) / ROWS;
     for (int64_t rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
         const int64_t r0 = rb * ROWS;
@@ -70,9 +72,11 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(RowBatch b, int64_t row0, 
                     float pv = 0.0f;
                     if (j < n) {
                         pv = b.p[t][k];
-                        float mv = b.m[t][k], vv = b.v[t][k];
-                        adam_elem(pv, *cell, mv, vv, b.one_m_b1[t], b.b2[t], b.one_m_b2[t], b.step_size[t], b.inv_bc2s[t], b.eps[t]);
-                        b.p[t][k] = pv; b.m[t][k] = mv; b.v[t][k] = vv;
+                        if (step_ok) {
+                            float mv = b.m[t][k], vv = b.v[t][k];
+                            adam_elem(pv, *cell, mv, vv, b.one_m_b1[t], b.b2[t], b.one_m_b2[t], b.step_size[t], b.inv_bc2s[t], b.eps[t]);
+                            b.p[t][k] = pv; b.m[t][k] = mv; b.v[t][k] = vv;
+                        }
                     }
                     *cell = pv;                                    // (each cell is read and rewritten by the one thread that owns it)
                 }
@@ -103,7 +107,7 @@ hipError_t launch_rows(int mode, int count, const GsRowTensor* t, int64_t row0, 
         }
         G += t[i].width;
     }
-    b.count = count; b.G = G;
+    b.count = count; b.G = G; b.fail = mode == 2 ? g_chain_fail_dev : nullptr;
     if (n_rows <= 0 || G <= 0) return hipSuccess;
     const bool wide = G > 16;
     if (G > 64) return hipErrorInvalidValue;                        // (gs_pack_columns refuses more than 64 floats per Gaussian before it gets here)

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <tuple>
 #include <unordered_map>
@@ -73,6 +74,9 @@ PerStream& per_stream(int device, hipStream_t st)
     if (it != tl_streams.end()) return it->second;
     if (tl_streams.size() >= 64) {                                        // short-lived streams: do not grow without bound
         auto v = tl_streams.begin();
+        // a forward still in flight on the evicted stream writes these pinned counters from its counting kernels: wait for the event recorded
+        // behind them before the memory goes back
+        if (v->second.ev) (void)hipEventSynchronize(v->second.ev);
         if (v->second.h_counts) (void)hipHostFree(v->second.h_counts);
         if (v->second.ev) (void)hipEventDestroy(v->second.ev);
         tl_streams.erase(v);
@@ -84,19 +88,26 @@ PerStream& per_stream(int device, hipStream_t st)
     return tl_streams[key] = ps;
 }
 
-uint32_t* g_status = nullptr;
+std::atomic<uint32_t*> g_status{nullptr};      // (double-checked under g_mu: the pointer itself is published with release / read with acquire)
 
 void poll_async_status()
 {
-    if (!g_status) {
+    uint32_t* w = g_status.load(std::memory_order_acquire);
+    if (!w) {
         std::lock_guard<std::mutex> lk(g_mu);
-        if (!g_status) check(gs_async_status_word(&g_status));
+        w = g_status.load(std::memory_order_relaxed);
+        if (!w) {
+            check(gs_async_status_word(&w));
+            g_status.store(w, std::memory_order_release);
+        }
     }
-    if (*reinterpret_cast<volatile uint32_t*>(g_status)) {
-        *g_status = 0;
+    if (*reinterpret_cast<volatile uint32_t*>(w)) {
         check(gs_set_backward_chain(1, -1));
+        check(gs_async_status_clear());           // (synchronises: no walker of an old launch can raise the words again behind the clear)
+        *reinterpret_cast<volatile uint32_t*>(w) = 0;
         throw std::runtime_error("activesplat_amd: a chained backward walk timed out waiting for the piece in front of it -- the gradients of the previous "
-                                 "backward on this process are invalid (NaN).  Chained walks are now off (gs_set_backward_chain(1, -1)); render that frame again.");
+                                 "backward on this process are invalid (NaN); optimiser steps enqueued behind it were SKIPPED by their kernels (parameters and "
+                                 "moments untouched, step counters one ahead).  Chained walks are now off (gs_set_backward_chain(1, -1)); render that frame again.");
     }
 }
 

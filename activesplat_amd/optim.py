@@ -140,12 +140,14 @@ class GaussianAdam:
                 entries.append((g, st, p))
             cache = self._backward_cache = (ident, arr, entries, tuple((st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for _, st, _ in entries))
         _, arr, entries, moments = cache
+        # validate EVERY entry before any counter moves: a refusal at entry i must not leave the counters of the entries before it advanced
         for i, (g, st, p) in enumerate(entries):
             if p.grad is not None:
                 raise RuntimeError("fused Adam: a parameter already holds a gradient (accumulated keyframes?) -- step() it or zero_grad() first")
             if (st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) != moments[i]:      # (row surgery replaced the moments: rebuild)
                 self._backward_cache = None
                 return self.backward_step_descriptors(tensors)
+        for i, (g, st, p) in enumerate(entries):
             st["step"] = int(st["step"]) + 1
             b1, b2 = g["betas"]
             t = arr[i]

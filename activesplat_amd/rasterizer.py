@@ -303,8 +303,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             pose, iso, _acc, logit = ctx.raw
             d_m2d = torch.empty(P, 3, dtype=torch.float32, device=device)
             opt, tensors = ctx.adam
-            ctx.adam = "stepped"
-            desc = opt.backward_step_descriptors(tensors)                 # (advances the step counters ...)
+            desc = opt.backward_step_descriptors(tensors)                 # (validates, then advances the step counters ...; a refusal here
+            ctx.adam = "stepped"                                          # leaves counters AND this graph as they were: the caller may retry)
             try:
                 _lib.check(lib.gs_render_backward_raw_adam(
                     C.byref(cam), P, ctx.D, _ptr(means3D), _ptr(shs if has_sh else None), _ptr(colors if has_col else None), _ptr(logit),
@@ -312,6 +312,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     _ptr(grad_depth), _ptr(d_m2d), _ptr(scratch), 1 if clean else 0, int(ctx.sh_jac), desc, _stream(device)))
             except Exception:
                 opt.rollback_backward_step(tensors)                       # (... which a launch that did not happen must not keep)
+                ctx.adam = (opt, tensors)
                 raise
             # the parameters changed in place behind autograd's back: bump their version counters, so that any other graph that saved them
             # (a regulariser on the same parameters, a second keyframe rendered before this backward) fails loudly in ITS backward instead of
@@ -377,7 +378,10 @@ def _frontend_apply(means3D, means2D, shs, colors_precomp, opacities, scales, ro
         return None
     caps = getattr(_tls, "captures", None)
     from . import _frontend
-    ext = _frontend.get()                               # (raises when it has not been built: no silent slow path on a GPU box)
+    _lib.get()                                          # (the HIP library itself missing: raises -- there is no CPU path)
+    ext = _frontend.get_or_none()                       # (no g++ / torch headers on this box: ONE warning, then the Python twin -- the same library calls)
+    if ext is None:
+        return None
     device = means3D.device
     P, W, H = int(means3D.shape[0]), int(rs.image_width), int(rs.image_height)
     key = (P, W, H, device.index)

@@ -726,7 +726,13 @@ def main():
                     vi = float(pm[kern]["SQ_INSTS_VALU"])
                     valu = {"wave_insts_per_launch": int(vi), "achieved_ginst_s": round(vi / (stages[dom]["avg_us"] * 1e-6) / 1e9, 1),
                             "peak_ginst_s": VALU_ISSUE_PEAK / 1e9, "frac": round(vi / (stages[dom]["avg_us"] * 1e-6) / VALU_ISSUE_PEAK, 4),
-                            "source": os.path.basename(f2)}
+                            "source": os.path.basename(f2),
+                            # the denominator is this build's own micro-benchmark; the same instructions against the other candidates, so that the
+                            # reader can re-derive `frac`: v_fma_f32 measured 651 Ginst/s, the guide's 2-cycle wave64 issue at 2.4 GHz 1228.8
+                            "valu_peak_source": "measured v_mul_f32 / v_add_f32 issue rate, 890 Ginst/s (scripts/exp/valu_issue.hip, profiles/r02_valu_issue.txt); "
+                                                "v_fma_f32 measured 651; MI355X_MICROARCH.md 2-cycle issue x 1024 SIMDs x 2.4 GHz = 1228.8",
+                            "frac_vs_measured_v_fma_651": round(vi / (stages[dom]["avg_us"] * 1e-6) / 651e9, 4),
+                            "frac_vs_guide_issue_1228_8": round(vi / (stages[dom]["avg_us"] * 1e-6) / 1228.8e9, 4)}
                 all_traffic = {k: int(v["traffic_bytes"]) for k, v in pm.items() if "traffic_bytes" in v}
             # counter bytes next to the model's bytes, per stage (the binning stages share one kernel name in the counter tables: one figure for all)
             if all_traffic:
@@ -758,7 +764,8 @@ def main():
                 valu["valu_busy_frac"] = round(busy, 4)
                 if 0.85 <= traffic / sb[dom] <= 1.15 and busy > 0.6:
                     roof = {"bound": "valu", "kernel": dom, "achieved": valu["achieved_ginst_s"], "peak": valu["peak_ginst_s"], "unit": "Ginst/s (wave64 VALU instructions)",
-                            "frac": valu["frac"], "valu_busy_frac": valu["valu_busy_frac"],
+                            "frac": valu["frac"], "valu_busy_frac": valu["valu_busy_frac"], "valu_peak_source": valu["valu_peak_source"],
+                            "frac_vs_measured_v_fma_651": valu["frac_vs_measured_v_fma_651"], "frac_vs_guide_issue_1228_8": valu["frac_vs_guide_issue_1228_8"],
                             "why": f"counter traffic {traffic / sb[dom]:.2f} x the algorithmic bytes and the vector ALUs busy in {busy:.0%} of the kernel's cycles: "
                                    "not an HBM-bound kernel; instructions per launch from the PMC pass, duration live",
                             "frac_hbm": round(ach / HBM_PEAK, 5), "achieved_hbm_gbs": round(ach / 1e9, 2), "peak_hbm_gbs": HBM_PEAK / 1e9}
@@ -803,6 +810,12 @@ def main():
             out["blend_flops"] = {"evaluations_E": E, "forward_frac_fp32_peak": round(E * 12 / tf / FP32_PEAK, 4),
                                   "backward_frac_fp32_peak": round(E * 40 / tb / FP32_PEAK, 4), "peak_tflops": FP32_PEAK / 1e12,
                                   "note": "SURVEY 8(d): F_alg = E*(12 fwd + 40 bwd) flop, E = sum of n_contrib"}
+            # the dominant kernel against the fp32 vector peak, inside `roofline` (SURVEY 8(d)'s secondary figure for the blend)
+            if dom in ("blend_backward", "blend_forward"):
+                fl = E * (40 if dom == "blend_backward" else 12)
+                out["roofline"]["alg_flops_per_launch"] = int(fl)
+                out["roofline"]["frac_flops"] = round(fl / (stages[dom]["avg_us"] * 1e-6) / FP32_PEAK, 4)
+                out["roofline"]["flops_peak_tflops"] = FP32_PEAK / 1e12
             del rv_ng, m2d0
         except Exception as e:
             out["secondary_error"] = str(e)
@@ -889,6 +902,12 @@ def main():
                                "cpu_path": "oracle/dense_torch.render_dense(tiled=True): plain PyTorch CPU ops, tile by tile",
                                "hip_forward_frames_per_s": round(1.0 / t_gpu, 1),
                                "psnr_hip_vs_cpu_pytorch_db": round(10 * np.log10(1.0 / max(mse0, 1e-30)), 1)}
+            if isinstance(out.get("cpu_baseline"), dict):
+                # "the reference's CPU PyTorch path" of the north star, next to the C port: SURVEY 8(d) -- the reference has no CPU render path, so this
+                # is the build's dense PyTorch restatement on configs[0] (10 k Gaussians, forward only), the one size it finishes in seconds
+                out["cpu_baseline"]["cpu_pytorch_configs0"] = {"value": round(1.0 / t_cpu, 3), "unit": "frames/s (forward only, 10k Gaussians, 640x480)",
+                                                               "cores": torch.get_num_threads(), "kind": "port (oracle/dense_torch.py, plain PyTorch CPU ops)",
+                                                               "hip_forward_same_scene_frames_per_s": round(1.0 / t_gpu, 1)}
         except Exception as e:
             out["configs0"] = {"error": str(e)}
         torch.set_num_threads(th0)

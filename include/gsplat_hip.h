@@ -154,10 +154,17 @@ int gs_set_backward_chain(int32_t pieces, int32_t min_tiles);
  * A wait that runs out sets bit 0 of the process' host-mapped status word and the walk continues with NaN state (NaN gradients for that
  * quadrant's Gaussians).  gs_async_status_word returns the word's HOST address (created on first call; call it once before the first
  * backward): the caller reads it -- a plain load -- before its next launch; non-zero = the previous chained backward's gradients are invalid:
- * clear the word, gs_set_backward_chain(1, -1), and render again (activesplat_amd/rasterizer.py does exactly that). */
+ * gs_set_backward_chain(1, -1), gs_async_status_clear(), clear the word, and render again (activesplat_amd/rasterizer.py does exactly that).
+ * The backward is asynchronous: the host learns of the event a render later, by which time an optimiser step on the NaN gradients would have
+ * been enqueued (optimizer.step(), gs_adam_rows, or the Adam inside gs_render_backward_raw_adam -- the same launch).  The timed-out walker
+ * therefore also sets a sticky word in DEVICE memory (created together with the host word) that every optimiser kernel of this library reads
+ * first: while it is set gs_adam_step / gs_adam_step_multi / gs_adam_rows / gs_render_backward_raw_adam leave parameters and moments
+ * untouched (gs_adam_rows still forwards the unstepped rows; the raw_adam backward writes zeros to dL_dmeans2D).  gs_async_status_clear
+ * synchronises the device and clears that word: steps run again.  Step counters the host advanced for skipped steps stay advanced. */
 int gs_set_backward_chain_tickets(int32_t on);
 int gs_set_backward_chain_polls(int32_t polls);
 int gs_async_status_word(uint32_t** host_word);
+int gs_async_status_clear(void);
 /* Introspection of the few-tile backward's cuts: the recorded list position nearest to `target` (0: none below it) and its level (-1: none) --
  * every 256th position up to 4096, then the powers of two up to 131072, nearest in ratio above 4096. */
 int gs_recorded_cut(uint32_t target, uint32_t* nearest, int32_t* level);
@@ -174,7 +181,7 @@ const char* gs_version(void);
 /* Integer version of THIS binary interface: bumped whenever an entry point's argument list or a published record layout changes (e.g.
  * the seed argument of gs_densify_children, the 40-byte SH Jacobian record).  A host binding compares it with the GS_ABI_VERSION it was
  * written against before the first call, so that a stale prebuilt library fails at load time instead of misreading its arguments. */
-#define GS_ABI_VERSION 9
+#define GS_ABI_VERSION 10
 int32_t gs_abi_version(void);
 
 /* Optional per-stage timing (hipEvents recorded on the caller's stream around each stage's launches).

@@ -574,6 +574,80 @@ def check_adam_backward_guards(device, n=400, W=64, H=48):
     im = render()[0]
     im.sum().backward()
     assert set(int(opt.state[v]["step"]) for v in prm.values()) == {2}
+    # a refusal BEFORE the launch (entry 1 of the five already holds a gradient): no counter moves -- not even entry 0's -- and the SAME graph can
+    # be retried once the cause is gone
+    im = render()[0]
+    prm["logit_opacities"].grad = torch.zeros_like(prm["logit_opacities"])
+    try:
+        im.sum().backward(retain_graph=True)
+        raise AssertionError("a parameter that already holds a gradient must be refused")
+    except RuntimeError as e:
+        assert "already holds a gradient" in str(e), e
+    assert set(int(opt.state[v]["step"]) for v in prm.values()) == {2}
+    prm["logit_opacities"].grad = None
+    im.sum().backward()
+    assert set(int(opt.state[v]["step"]) for v in prm.values()) == {3}
+
+
+class poisoned_empty:
+    """Every float tensor torch.empty / empty_like hands out inside the block is filled with NaN: a row the product path allocates uninitialised
+    and then does not write shows up as NaN instead of as whatever the allocator's block held before."""
+
+    def __enter__(self):
+        self.real = (torch.empty, torch.empty_like)
+
+        def poison(fn):
+            def f(*a, **k):
+                t = fn(*a, **k)
+                if t.is_floating_point() and t.numel():
+                    t.detach().fill_(float("nan"))
+                return t
+            return f
+        torch.empty, torch.empty_like = poison(self.real[0]), poison(self.real[1])
+        return self
+
+    def __exit__(self, *exc):
+        torch.empty, torch.empty_like = self.real
+        return False
+
+
+def check_unrendered_rows_are_written(device, n=512, W=64, H=48):
+    """Keyframe batches (raw parameters, gradients added into .grad in the kernel): a wavefront none of whose Gaussians was rendered leaves the
+    per-Gaussian backward early -- and must still write its rows of dL/dmeans2D, which is not accumulated and which the host allocates
+    uninitialised (ADVICE r5: 256 / 256 unseen rows were NaN in a NaN-prefilled buffer).  Rows n/2.. lie behind the camera; colours and SH rows;
+    every float allocation of the call is poisoned with NaN."""
+    from activesplat_amd import mapping as M
+    from activesplat_amd import synthetic as syn
+    from activesplat_amd.camera import setup_camera
+    for sh in (False, True):
+        p0 = syn.make_params(n, W, H, seed=4)
+        p0["means3D"][n // 2:, 2] = -p0["means3D"][n // 2:, 2]                   # whole wavefronts of unseen Gaussians
+        if sh:
+            g = torch.Generator().manual_seed(8)
+            shs = 0.2 * torch.randn(n, 16, 3, generator=g)
+            shs[:, 0, :] = (p0.pop("rgb_colors") - 0.5) / 0.28209479177387814
+            p0["shs"] = shs
+        cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=device, sh_degree=3 if sh else 0)
+        prm = {k: torch.nn.Parameter(v.clone().to(device)) for k, v in p0.items()}
+        prm["cam_unnorm_rots"] = torch.nn.Parameter(torch.tensor([1.0, 0, 0, 0], device=device).reshape(1, 4, 1))
+        prm["cam_trans"] = torch.nn.Parameter(torch.zeros(1, 3, 1, device=device))
+        var = {k: torch.zeros(n, device=device) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+        tim, tdepth = syn.make_targets(W, H)
+        kf = dict(cam=cam, im=tim.to(device), depth=tdepth.to(device), id=0, w2c=torch.eye(4, device=device))
+        for step in range(2):                                   # step 0 creates the .grad tensors, step 1 accumulates into them (acc = 1: the gated path)
+            with poisoned_empty():
+                loss, var, _ = M.get_loss(prm, kf, var, 0, dict(im=0.5, depth=1.0), fused=True, fused_loss=True, fused_inputs=True, fused_preprocess=True,
+                                          pose7=[1.0, 0, 0, 0, 0, 0, 0], accumulate_grads=True)
+                loss.backward()
+            g2 = var["means2D"].grad
+            assert g2 is not None and bool(torch.isfinite(g2).all()), (sh, step, int((~torch.isfinite(g2)).any(dim=1).sum()))
+            seen = var["seen"]
+            assert int(seen[n // 2:].sum()) == 0 and int(seen[:n // 2].sum()) > 0
+            assert float(g2[n // 2:].abs().max()) == 0.0 and float(g2[:n // 2].abs().max()) > 0.0
+            for k, v in prm.items():
+                if not k.startswith("cam_"):
+                    assert v.grad is not None and bool(torch.isfinite(v.grad).all()), (k, sh, step)
+                    assert float(v.grad[n // 2:].abs().max()) == 0.0, (k, sh, step)
 
 
 def check_mapping_iteration_without_autograd(device, n=500, exact=True):
@@ -727,11 +801,38 @@ def check_chained_backward_fails_safe(device, N=5000, W=288, H=272, seed=33):
         bad = util.run_product(rs, rv, dL)
         sync()
         assert not all(np.isfinite(g).all() for g in bad["grads"].values())      # NaN state went through the pieces behind the first
+        # (c) the host has not looked yet (the backward is asynchronous: it learns of the event in front of the NEXT render) -- optimiser steps
+        # enqueued behind the failed backward must leave parameters and moments alone: the separate step ...
+        from activesplat_amd import optim as O, rasterizer as R
+        from activesplat_amd import synthetic as syn
+        w = torch.nn.Parameter(torch.randn(1001, 3, generator=torch.Generator().manual_seed(1)).to(device))
+        o1 = O.initialize_optimizer({"means3D": w}, {"means3D": 1e-2})
+        w.grad = torch.full_like(w, float("nan"))
+        w0 = w.detach().clone()
+        o1.step(); sync()
+        assert torch.equal(w0, w.detach()) and float(o1.state[w]["exp_avg"].abs().max()) == 0.0, "Adam stepped on the gradients of a timed-out backward"
+        # ... and the step INSIDE a backward whose own blend times out (same launch sequence: nobody could have intervened)
+        p0 = syn.make_params(N, W, H, seed=seed)
+        prm = {k: torch.nn.Parameter(v.clone().to(device)) for k, v in p0.items()}
+        o2 = O.initialize_optimizer(prm, {k: 1e-2 for k in prm})
+        m2d = torch.empty_like(prm["means3D"], requires_grad=True)
+        _lib._status[0] = 0                                      # (this render's poll must pass: the event under test is the one its OWN backward raises)
+        im = R.render_rgbd_raw(rs, prm["means3D"], m2d, prm["logit_opacities"], prm["log_scales"], prm["unnorm_rotations"],
+                               [1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], adam=o2, colors_precomp=prm["rgb_colors"])[0]
+        im.backward(dL.to(device)); sync()
+        for k, v in prm.items():
+            assert torch.equal(v.detach().cpu(), p0[k]), k
+            assert float(o2.state[v]["exp_avg"].abs().max()) == 0.0 and float(o2.state[v]["exp_avg_sq"].abs().max()) == 0.0, k
+        assert float(m2d.grad.abs().max()) == 0.0
         try:
             util.run_product(rs, rv, dL)
             raise AssertionError("the render after a timed-out chained backward must raise")
         except RuntimeError as e:
-            assert "timed out" in str(e), e
+            assert "timed out" in str(e) and "SKIPPED" in str(e), e
+        # reported and cleared: steps run again
+        w.grad = torch.ones_like(w)
+        o1.step(); sync()
+        assert not torch.equal(w0, w.detach())
         _lib.check(lib.gs_set_backward_chain_polls(-1))
         again = util.run_product(rs, rv, dL)                       # chaining is off now (one walker per quadrant): finite and equal
         sync()

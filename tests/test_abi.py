@@ -120,3 +120,39 @@ def test_frontend_builds_loads_and_refuses_host_tensors():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ext.rasterize(z, None, None, z, torch.zeros(4, 1), z, torch.zeros(4, 4), None, torch.zeros(3), torch.eye(4), torch.eye(4), torch.zeros(3),
                       32, 32, 1.0, 1.0, 1.0, 0, False, 0, 0, False)
+
+
+def test_frontend_first_use_from_several_processes_and_the_fallback():
+    """concurrent first use (the ranks of a torchrun launch) must never load a half-written module -- builders queue on a file lock, the
+    compiler writes a private temporary file and the library appears atomically; a process that arrives while another builds waits and finds it
+    up to date.  Where the build is impossible (no g++ on the box) the drop-in call falls back to the Python twin after ONE warning."""
+    import subprocess
+    import sys
+    import warnings
+    from activesplat_amd import _frontend
+    _frontend.build()
+    assert not _frontend._stale()
+    # three processes, all told the module is stale at the same moment: one compiles, the others find it fresh once they hold the lock
+    code = ("import os, sys, time; sys.path.insert(0, %r); from activesplat_amd import _frontend as F; "
+            "os.utime(F.SO, (1, 1)) if sys.argv[1] == '0' else time.sleep(1.0); t = time.time(); F.build(); "
+            "print('built' if os.path.getmtime(F.SO) > 1 else 'stale', round(time.time() - t, 1)); F.get()") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(i)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for i in range(3)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    assert all(o[0].startswith("built") for o in outs), outs
+    assert not _frontend._stale() and not [f for f in os.listdir(os.path.dirname(_frontend.SO)) if f.endswith(".tmp")]
+    # the fallback: a box where the build fails
+    real = (_frontend.build, _frontend._stale, _frontend._mod, _frontend.unavailable)
+    try:
+        _frontend._mod, _frontend.unavailable = None, None
+        _frontend._stale = lambda: True
+
+        def no_compiler(force=False):
+            raise FileNotFoundError("g++")
+        _frontend.build = no_compiler
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert _frontend.get_or_none() is None and _frontend.get_or_none() is None
+        assert len([x for x in w if "Python twin" in str(x.message)]) == 1
+    finally:
+        _frontend.build, _frontend._stale, _frontend._mod, _frontend.unavailable = real

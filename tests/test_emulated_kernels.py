@@ -146,6 +146,10 @@ def test_emulated_adam_inside_the_backward_is_applied_once_and_never_silently(em
     pc.check_adam_backward_guards(emu)
 
 
+def test_emulated_unrendered_rows_of_a_keyframe_batch_are_written(emu):
+    pc.check_unrendered_rows_are_written(emu)
+
+
 def test_emulated_mapping_iteration_without_autograd_equals_the_autograd_path(emu):
     import ctypes
     omp = ctypes.CDLL("libgomp.so.1")

@@ -625,6 +625,12 @@ def test_adam_inside_the_backward_is_applied_once_and_never_silently(hip):
     pc.check_adam_backward_guards(hip, n=5000, W=96, H=64)
 
 
+@pytest.mark.gpu
+def test_unrendered_rows_of_a_keyframe_batch_are_written(hip):
+    """the keyframe-batch gate of the per-Gaussian backward must still write dL/dmeans2D for wavefronts it skips."""
+    pc.check_unrendered_rows_are_written(hip, n=8192, W=96, H=64)
+
+
 def test_mapping_iteration_without_autograd_equals_the_autograd_path(hip):
     pc.check_mapping_iteration_without_autograd(hip, n=20000, exact=False)
 
