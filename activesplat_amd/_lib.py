@@ -92,6 +92,8 @@ def _bind(lib):
     lib.gs_set_backward_chain_tickets.restype = C.c_int
     lib.gs_set_backward_chain_polls.argtypes = [i32]
     lib.gs_set_backward_chain_polls.restype = C.c_int
+    lib.gs_async_status_clear.argtypes = []
+    lib.gs_async_status_clear.restype = C.c_int
     lib.gs_async_status_word.argtypes = [C.POINTER(C.POINTER(C.c_uint32))]
     lib.gs_async_status_word.restype = C.c_int
     lib.gs_recorded_cut.argtypes = [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(i32)]

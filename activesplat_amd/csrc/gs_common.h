@@ -15,7 +15,10 @@ constexpr int kTile = GS_TILE;      // 16x16 pixel tile = one 256-thread workgro
 constexpr int kBlock = 256;
 constexpr int kWave = 64;           // CDNA wavefront
 constexpr int kQuad = 8;            // each wavefront owns one 8x8 pixel quadrant of the tile
-constexpr int kBinChunk = 2048;     // Gaussians per tile-binning workgroup (LDS-private histogram)
+#ifndef GS_BIN_CHUNK
+#define GS_BIN_CHUNK 2048           // (A/B knob: scripts/exp/build_variant.sh c4096 -DGS_BIN_CHUNK=4096)
+#endif
+constexpr int kBinChunk = GS_BIN_CHUNK;     // Gaussians per tile-binning workgroup (LDS-private histogram)
 constexpr int kMaxLdsTiles = 8192;  // tile-binning path needs the tile histogram in LDS (32 KiB)
 constexpr int kSortChunk = 2048;    // keys one workgroup bitonic-sorts in LDS
 constexpr int kSortCapMax = 16384;  // largest per-tile list whose sorted chunks are rank-merged in LDS (128 KiB); beyond -> pairwise merge passes

@@ -130,17 +130,23 @@ __device__ __forceinline__ uint32_t project_gaussian(const Cam& cam, int P, int 
                 const float pxx = cam.V > 1 ? pxv + (float)(xs * kTile) : pxv;
                 const int y0 = clamp_tile((pyy - rf) / 16.0f, cam.gy), y1 = clamp_tile(((pyy + rf) + 15.0f) / 16.0f, cam.gy);
                 const int area = (x1 - x0) * (y1 - y0);
-                if (area > 0) {
+                float cr, cg, cb;
+                if (HAS_SH) { cr = sh_rgb[0]; cg = sh_rgb[1]; cb = sh_rgb[2]; }
+                else { cr = s_col[tid * 3]; cg = s_col[tid * 3 + 1]; cb = s_col[tid * 3 + 2]; }
+                const float con_a = k11 * det_inv, con_b = -k01 * det_inv, con_c = k00 * det_inv;
+                // NON-FINITE RULE: a Gaussian whose screen-space record -- pixel mean, conic, opacity, colour, depth -- holds a
+                // NaN or an infinity is CULLED like one behind the camera (radius 0, no tile instance, zero gradients).  Whatever made it so (a NaN /
+                // inf mean, scale, quaternion, opacity, colour or SH coefficient of an active degree: a diverged optimiser step) then cannot reach
+                // a pixel -- the blend kernels weight a skipped record's colour with 0 instead of branching, and NaN x 0 would poison every pixel
+                // of the tiles the record is staged for.  Finite but out-of-range values (opacity 2, negative scales) are taken as they are.
+                const bool finite = __builtin_isfinite(pxx) && __builtin_isfinite(pyy) && __builtin_isfinite(con_a) && __builtin_isfinite(con_b) &&
+                                    __builtin_isfinite(con_c) && __builtin_isfinite(o) && __builtin_isfinite(cr) && __builtin_isfinite(cg) &&
+                                    __builtin_isfinite(cb) && __builtin_isfinite(tz);
+                if (area > 0 && finite) {
                     radius = (int)rf;
                     ntiles = (uint32_t)area;
                     rc = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
-                    float cr, cg, cb;
-                    if (HAS_SH) {
-                        clampbits = sh_clamp;
-                        cr = sh_rgb[0]; cg = sh_rgb[1]; cb = sh_rgb[2];
-                    } else {
-                        cr = s_col[tid * 3]; cg = s_col[tid * 3 + 1]; cb = s_col[tid * 3 + 2];
-                    }
+                    if (HAS_SH) clampbits = sh_clamp;
                     // work-skipping extents: alpha >= 1/255 needs power >= -ln(255 o); the ellipse
                     // {d : d^T conic d <= 2 tau} has half-extents sqrt(2 tau cov_xx), sqrt(2 tau cov_yy).
                     // tau carries a 0.02 slack (>> any fp32 rounding of conic / exp); o*255 <= 1 -> never visible.
@@ -151,8 +157,8 @@ __device__ __forceinline__ uint32_t project_gaussian(const Cam& cam, int P, int 
                         ex = sqrtf(tau2 * k00) + 0.01f;
                         ey = sqrtf(tau2 * k11) + 0.01f;
                     }
-                    g0 = make_float4(pxx, pyy, k11 * det_inv, -k01 * det_inv);
-                    g1 = make_float4(k00 * det_inv, o, cr, cg);
+                    g0 = make_float4(pxx, pyy, con_a, con_b);
+                    g1 = make_float4(con_c, o, cr, cg);
                     g2 = make_float4(cb, tz, ex, ey);
                 }
             }
@@ -285,7 +291,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
                 if (gp.sh_jac) sh_direction_jacobian(cam.sh_degree, dx * inv, dy * inv, dz * inv, sh, J);   // for the backward: it need not read the coefficient rows again
                 acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
                 sh_clamp = (acc[0] < 0.f ? 1u : 0u) | (acc[1] < 0.f ? 0x100u : 0u) | (acc[2] < 0.f ? 0x10000u : 0u);
-                sh_rgb[0] = fmaxf(acc[0], 0.f); sh_rgb[1] = fmaxf(acc[1], 0.f); sh_rgb[2] = fmaxf(acc[2], 0.f);
+                // (a select, not fmaxf: a NaN colour must stay NaN -- the non-finite rule of project_gaussian culls it -- where maxNum would turn it into 0)
+                sh_rgb[0] = acc[0] < 0.f ? 0.f : acc[0]; sh_rgb[1] = acc[1] < 0.f ? 0.f : acc[1]; sh_rgb[2] = acc[2] < 0.f ? 0.f : acc[2];
                 if (gp.sh_jac) store_sh_jac(gp.sh_jac, (size_t)io, J, sh_clamp);
             }
         }
@@ -376,7 +383,8 @@ __global__ __launch_bounds__(kBlock, 4) void preprocess_forward_sh48_kernel(
             acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
             sh_clamp = (acc[0] < 0.f ? 1u : 0u) | (acc[1] < 0.f ? 0x100u : 0u) | (acc[2] < 0.f ? 0x10000u : 0u);
             if (gp.sh_jac) store_sh_jac(gp.sh_jac, (size_t)io, J, sh_clamp);
-            sh_rgb[0] = fmaxf(acc[0], 0.f); sh_rgb[1] = fmaxf(acc[1], 0.f); sh_rgb[2] = fmaxf(acc[2], 0.f);
+            // (a select, not fmaxf: a NaN colour must stay NaN -- the non-finite rule of project_gaussian culls it -- where maxNum would turn it into 0)
+                sh_rgb[0] = acc[0] < 0.f ? 0.f : acc[0]; sh_rgb[1] = acc[1] < 0.f ? 0.f : acc[1]; sh_rgb[2] = acc[2] < 0.f ? 0.f : acc[2];
         }
     }
     int radius = 0;

@@ -108,11 +108,20 @@ __global__ __launch_bounds__(kBlock, (ACT && SH == 3) ? GS_PBWD_RAW_SH_WGS : 4) 
         if (cam.act_iso) { sc_in[0] = sc_in[1] = sc_in[2] = __expf(scales[ic]); }
         else { sc_in[0] = __expf(scales[3 * ic]); sc_in[1] = __expf(scales[3 * ic + 1]); sc_in[2] = __expf(scales[3 * ic + 2]); }
         rq_raw = reinterpret_cast<const float4*>(rots)[ic];
+        lg_in = logit[ic];
+        if (!live) {
+            // A Gaussian that was not rendered leaves with ZERO parameter gradients.  The chain below multiplies its zero 2-D gradients with the
+            // activations' derivatives -- which are NaN / inf for the very parameters the non-finite rule may have culled it for (0 x NaN): such a
+            // row runs the chain on harmless stand-ins instead.  The Adam operands of the ADAM instantiation are loaded
+            // separately from ad.p: the parameters themselves are stepped as they are.
+            sc_in[0] = sc_in[1] = sc_in[2] = 0.f;
+            rq_raw = make_float4(1.f, 0.f, 0.f, 0.f);
+            lg_in = 0.f;
+        }
         const float qr[4] = {rq_raw.x, rq_raw.y, rq_raw.z, rq_raw.w};
         float qa[4];
         activate_rotation(cam.act_q, cam.act_iso, qr, qa);
         rq_in = make_float4(qa[0], qa[1], qa[2], qa[3]);
-        lg_in = logit[ic];
     } else {
         sc_in[0] = scales[3 * ic]; sc_in[1] = scales[3 * ic + 1]; sc_in[2] = scales[3 * ic + 2];
         rq_in = reinterpret_cast<const float4*>(rots)[ic];

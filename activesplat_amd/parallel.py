@@ -220,7 +220,9 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
     densifier's accumulators right after its backward (optim.accumulate_mean2d_gradient) -- the batch's statistic is then the sum over all of its
     keyframes whatever the number of ranks; the accumulators are rank-local partial sums until parallel.sharded_densify all-reduces them.
     partition: list of this step's keyframe indices per rank (parallel.balanced_partition); default: contiguous blocks (shard_keyframes).
-    costs: a KeyframeCosts that the serial walk feeds with every rendered keyframe's tile-instance count (sync + partition are the caller's)."""
+    costs: a KeyframeCosts that the serial walk feeds with every rendered keyframe's tile-instance count (sync + partition are the caller's).
+    (Round 6 built and removed a PIPELINED two-stream walk with in-kernel accumulation -- only the accumulating kernels ordered across the streams:
+    -5 ... +4 % against this serial walk at 2 M Gaussians / 64 keyframes, kill criterion + 6 %: profiles/r06_ab_pipelined.txt.)"""
     on = dist.is_available() and dist.is_initialized()
     rank = (dist.get_rank() if on else 0) if rank is None else rank
     world = (dist.get_world_size() if on else 1) if world is None else world

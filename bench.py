@@ -256,6 +256,52 @@ def pmc_file(pattern):
     return files[-1] if files else None
 
 
+def profiled_kernels(leg):
+    """What rocprofv3 says about a non-headline leg (scripts/gpu_round_end.sh -> scripts/prof_legs.py): the newest profiles/rNN_<leg>_kernel_stats.csv
+    (kernel-trace averages) merged with profiles/rNN_<leg>_pmc_summary.json (FETCH_SIZE / WRITE_SIZE from their own passes, FETCH doubled per the
+    guide's gfx950 correction; SQ counters) -> {kernel<template args>: {calls, avg_us, pmc_bytes, frac_hbm_pmc, valu_busy}} for the library's and RCCL's
+    kernels, or None when this tree holds no such profile.  PMC counters cannot be collected inside this process: the figures are from a separate
+    pass of the same workload and say so (`source`)."""
+    import csv
+    import re
+    fk, fp = pmc_file(f"r[0-9][0-9]_{leg}_kernel_stats.csv"), pmc_file(f"r[0-9][0-9]_{leg}_pmc_summary.json")
+    if not fk:
+        return None
+    norm = lambda n: re.sub(r"\s+", "", re.sub(r"\(.*", "", re.sub(r"^void ", "", n)).replace("gs::", ""))  # noqa: E731
+    pm = {}
+    if fp:
+        pm = {norm(k): v for k, v in json.load(open(fp)).items()}
+    out = {}
+    with open(fk) as fh:
+        for row in csv.DictReader(fh):
+            name = row["Name"]
+            if "gs::" not in name and "nccl" not in name.lower() and "rccl" not in name.lower():
+                continue
+            k = norm(name)
+            us = float(row["AverageNs"]) / 1e3
+            e = {"calls": int(row["Calls"]), "avg_us": round(us, 2)}
+            c = pm.get(k) or pm.get(re.sub(r"<.*", "", k))
+            if c and "traffic_bytes" in c:
+                e["pmc_bytes"] = int(c["traffic_bytes"])
+                e["frac_hbm_pmc"] = round(c["traffic_bytes"] / (us * 1e-6) / HBM_PEAK, 4)
+            if c and "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"]:
+                e["valu_busy"] = round(float(c["SQ_ACTIVE_INST_VALU"]) * 4.0 / (1024.0 * float(c["GRBM_GUI_ACTIVE"]) / 8.0), 4)
+            out[k] = e
+    return {"kernels": out, "source": [os.path.basename(fk)] + ([os.path.basename(fp)] if fp else []),
+            "note": "rocprofv3 --kernel-trace --stats averages; pmc_bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes) from separate --pmc passes of the same "
+                    "workload (scripts/prof_legs.py); frac_hbm_pmc = pmc_bytes / avg duration / 8 TB/s; valu_busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles)"}
+
+
+def counters_for(prof, *patterns):
+    """-> (pmc_bytes, avg_us) of the first profiled kernel whose normalised name contains every pattern (spaces removed), else (None, None)"""
+    if not prof:
+        return None, None
+    for k, e in prof["kernels"].items():
+        if all(p.replace(" ", "") in k for p in patterns):
+            return e.get("pmc_bytes"), e.get("avg_us")
+    return None, None
+
+
 def suite_tally():
     """The tiered gradient rule's tally of the most recent `-m gpu` suite log kept under profiles/ (tests/conftest.py prints it): how many gradient
     tensors were compared with the fp64 oracle, how often the fp32-oracle rule and the decision-matched comparison decided instead of the stated bar."""
@@ -649,6 +695,8 @@ def main():
     from activesplat_amd import rasterizer as R
     from activesplat_amd import synthetic as syn
     lib = _lib.get()                                        # fail loudly if the HIP library is missing
+    if os.environ.get("GS_CHAIN_OFF"):                      # development knob (A/B): one backward walker per quadrant, no chained pieces
+        _lib.check(lib.gs_set_backward_chain(1, -1))
     if dist_on or args.workload == "c4":
         out = run_c4(args, dev, rank, world, ranks_info=ranks_info)
         if args.c4_sh_degree < 0 and not args.c4_one_map:
@@ -932,6 +980,15 @@ def main():
                               "stages": {k: {"avg_us": v["avg_us"], "frac_hbm": v["frac_hbm"]} for k, v in st1.items()}}
                 if n_ == 500_000:
                     params1 = w1.params
+                    pr1 = profiled_kernels("c1")
+                    if pr1:
+                        for st_name, pat in (("preprocess_forward+scan", "preprocess_forward_kernel"), ("blend_forward", "blend_forward_streams_kernel"),
+                                             ("blend_backward", "blend_backward_kernel"), ("preprocess_backward", "preprocess_backward_kernel")):
+                            by, _ = counters_for(pr1, pat)
+                            if by is not None and st_name in side[name]["stages"]:
+                                side[name]["stages"][st_name]["pmc_bytes"] = by
+                                side[name]["stages"][st_name]["frac_hbm_pmc"] = round(by / (side[name]["stages"][st_name]["avg_us"] * 1e-6) / HBM_PEAK, 4)
+                        side[name]["rocprof"] = pr1
                 del w1
                 torch.cuda.empty_cache()
             out["side_legs"] = side
@@ -999,6 +1056,30 @@ def main():
                 "densify_event": {"ms": dens_ms, "alg_bytes": int(dens_bytes),
                                   "frac_hbm": round(dens_bytes / (dens_ms[0] * 1e-3) / HBM_PEAK, 4) if dens_ms else None,
                                   "note": "one classification launch, one index, one gather per tensor: 2 x (59 parameter + 118 moment floats) x N bytes"}}
+            pr2 = profiled_kernels("c2loop")
+            if pr2:
+                c2 = out["configs2_loop"]
+                by, _ = counters_for(pr2, "preprocess_backward_kernel<3,true,true>")
+                if by is not None and c2["backward_with_adam"]["avg_us"]:
+                    c2["backward_with_adam"]["pmc_bytes"] = by
+                    c2["backward_with_adam"]["frac_hbm_pmc"] = round(by / (c2["backward_with_adam"]["avg_us"] * 1e-6) / HBM_PEAK, 4)
+                npx = W * H
+                for key, pat, alg in (("loss_stats", "loss_stats_kernel", npx * 36), ("loss_grad", "loss_grad_kernel", npx * 52)):
+                    by, us = counters_for(pr2, pat)
+                    if us:
+                        c2[key] = {"kernel": pat, "avg_us": us, "alg_bytes": int(alg), "frac_hbm": round(alg / (us * 1e-6) / HBM_PEAK, 4), "pmc_bytes": by,
+                                   "frac_hbm_pmc": round(by / (us * 1e-6) / HBM_PEAK, 4) if by else None,
+                                   "note": "per pixel: colour 12 + target 12 + depth 4 + target depth 4 + depth^2 4 B read" + ("" if key == "loss_stats" else "; dL/dcolour 12 + dL/ddepth 4 B written")
+                                           + "; duration from the rocprofv3 kernel table of the same loop"}
+                ev = {}
+                for pat in ("densify_classify_kernel", "compact3_count_kernel", "compact3_write_kernel", "gather_rows_vec4_kernel", "gather_rows_kernel",
+                            "densify_children_kernel", "adam_multi_kernel"):
+                    by, us = counters_for(pr2, pat)
+                    if us:
+                        ev[pat] = {"avg_us": us, "pmc_bytes": by, "frac_hbm_pmc": round(by / (us * 1e-6) / HBM_PEAK, 4) if by else None,
+                                   "calls": next(e["calls"] for k, e in pr2["kernels"].items() if pat in k)}
+                c2["densify_event"]["kernels"] = ev
+                c2["rocprof"] = pr2
             torch.cuda.empty_cache()
         except Exception as e:
             out["configs2_loop"] = {"error": str(e)}
@@ -1007,6 +1088,22 @@ def main():
             note("configs[3] on one GPU")
             out["configs3_single_gpu"] = run_c4(args, dev, 0, 1)
             torch.cuda.empty_cache()
+            pr3 = profiled_kernels("c3step")
+            if pr3:
+                n3 = args.c4_gaussians
+                rows = {}
+                for k, e in pr3["kernels"].items():
+                    if k.startswith("rows_kernel<"):
+                        wide = "64,64" in k
+                        G = 59 if wide else 14
+                        mode = k.split("<")[1].split(",")[0]
+                        # pack: gradients in, flat out; adam (one rank: ALL rows): flat in, p / m / v in and out, flat out; unpack: flat in, parameters out
+                        alg = n3 * G * 4 * {"0": 2, "1": 2, "2": 8}.get(mode, 2)
+                        rows[k] = dict(e, exchange_floats_per_gaussian=G, role={"0": "pack", "1": "unpack", "2": "adam on the row block"}.get(mode),
+                                       alg_bytes=int(alg), frac_hbm=round(alg / (e["avg_us"] * 1e-6) / HBM_PEAK, 4))
+                out["configs3_single_gpu"]["exchange_kernels"] = rows
+                out["configs3_single_gpu"]["rccl_kernels"] = {k: e for k, e in pr3["kernels"].items() if "nccl" in k.lower() or "rccl" in k.lower()}
+                out["configs3_single_gpu"]["rocprof"] = pr3
             if args.c4_sh_degree < 0:
                 note("configs[3] on one GPU, SH-3 map (G = 59)")
                 out["configs3_single_gpu"]["sh3_map_G59"] = run_c4(args, dev, 0, 1, sh_degree=3, light=True)

@@ -124,6 +124,11 @@ def render_dense(cam: dict, means3D, opacities, colors=None, shs=None, scales=No
     else:
         rgb = colors
     op = opacities.reshape(-1)
+    # the non-finite rule (gs_oracle.c): a Gaussian whose screen-space record holds a NaN or an infinity is culled
+    fin = torch.isfinite(pix.detach()).all(1) & torch.isfinite(ca.detach()) & torch.isfinite(cb.detach()) & torch.isfinite(cc.detach()) \
+        & torch.isfinite(op.detach()) & torch.isfinite(rgb.detach()).all(1) & torch.isfinite(tz.detach())
+    vis = vis & fin
+    radii = torch.where(vis, rf, torch.zeros_like(rf)).to(torch.int32)
     # global (depth as float32 bits, index) order
     key = tz.detach().to(torch.float32)
     key = torch.where(vis, key, torch.full_like(key, float("inf")))

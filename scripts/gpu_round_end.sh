@@ -1,8 +1,8 @@
 # End-of-round evidence run: parity tests, bench line, rocprof kernel summaries, PMC passes.  Run via gpurun from the repo root:
-#   gpurun --timeout 1800 -- 'bash scripts/gpu_round_end.sh r05'
+#   gpurun --timeout 2400 -- 'bash scripts/gpu_round_end.sh r06'
 # Every step is bounded by its own timeout; outputs land in gpurun_out/final (copy what is to be judged into profiles/).
 # The headline workload (bench.py, N = 1) is BASELINE configs[2]'s render: 2 M Gaussians, SH degree 3, 640x480, forward + backward.
-R=$PWD; TAG=${1:-r05}
+R=$PWD; TAG=${1:-r06}
 mkdir -p gpurun_out/final
 timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/final/build_smoke.log 2>&1; echo build+smoke rc=$?
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -40 > gpurun_out/final/${TAG}_pytest_gpu.log; tail -4 gpurun_out/final/${TAG}_pytest_gpu.log
@@ -17,11 +17,19 @@ pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
 pmc sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
-# configs[1] (500 k, SH-0): kernel table
-N=500000 STEPS=40 WARMUP=10 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final -o ${TAG}_c1 -- python $R/scripts/stage_times.py > $R/gpurun_out/final/${TAG}_c1_prof.log 2>&1; echo prof c1 rc=$?
+# the legs that rounds 1-5 supported with hipEvent stage times only: kernel table + counters (FETCH / WRITE in their own passes, one SQ group)
+# for configs[1]'s frames, 20 iterations of configs[2]'s loop incl. one densify event, and configs[3]'s step on one GPU incl. the 1-rank RCCL exchange (G = 14 and 59)
+leg() { name=$1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final -o ${TAG}_${name} -- python $R/scripts/prof_legs.py $name > $R/gpurun_out/final/${TAG}_${name}_prof.log 2>&1; echo prof $name rc=$?
+  for grp in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
+    set -- $grp; g=$1; shift
+    STEPS=4 ITERS=12 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/final -o ${TAG}_${name}_pmc_$g -- python $R/scripts/prof_legs.py $name > $R/gpurun_out/final/${TAG}_${name}_pmc_$g.log 2>&1; echo pmc $name $g rc=$?
+  done; }
+leg c1; leg c2loop; leg c3step
 cd $R
 python scripts/pmc_summarise.py gpurun_out/final ${TAG}_2m > gpurun_out/final/${TAG}_2m_pmc_summary.txt 2>&1
-cp profiles/${TAG}_2m_pmc_summary.json gpurun_out/final/ 2>/dev/null
+for name in c1 c2loop c3step; do python scripts/pmc_summarise.py gpurun_out/final ${TAG}_${name} > gpurun_out/final/${TAG}_${name}_pmc_summary.txt 2>&1; done
+cp profiles/${TAG}_*_pmc_summary.json gpurun_out/final/ 2>/dev/null
 # the bench line once more, now that this round's PMC summary exists (roofline.traffic reads it)
 timeout 400 python bench.py > gpurun_out/final/${TAG}_bench.json 2> gpurun_out/final/bench.err; echo bench rc=$?
 # BASELINE configs[2]'s loop and the configs[4] substitute (256 x 256 and 512 x 512, PSNR + SSIM, HIP loop vs oracle-backed loop); the planner's top-down camera

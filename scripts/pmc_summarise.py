@@ -15,13 +15,19 @@ src, tag = sys.argv[1], sys.argv[2]
 out = {}
 for f in sorted(glob.glob(os.path.join(src, f"{tag}_pmc_*_counter_collection.csv"))):
     d = pd.read_csv(f)
-    d = d[d["Kernel_Name"].str.contains("gs::")]
+    d = d[d["Kernel_Name"].str.contains("gs::|nccl|rccl", regex=True)]      # this library's kernels and RCCL's (configs[3]'s exchange)
     d["k"] = d["Kernel_Name"].map(lambda n: re.sub(r"<.*", "", re.sub(r"^void ", "", n)).split("(")[0].replace("gs::", ""))
+    # the same with the template arguments kept ("preprocess_backward_kernel<3, true, true>"): one loop can run several instantiations of a kernel
+    d["kfull"] = d["Kernel_Name"].map(lambda n: re.sub(r"\(.*", "", re.sub(r"^void ", "", n)).replace("gs::", "").strip())
     # a dispatch appears once per counter (values already summed over the device's XCDs / SEs); skip each kernel's warm-up launches
-    for (k, c), g in d.groupby(["k", "Counter_Name"]):
-        vals = g.sort_values("Dispatch_Id")["Counter_Value"].tolist()
-        vals = vals[len(vals) // 4:] or vals
-        out.setdefault(k, {})[c] = sum(vals) / len(vals)
+    for col in ("k", "kfull"):
+        for (k, c), g in d.groupby([col, "Counter_Name"]):
+            if col == "kfull" and "<" not in k:
+                continue
+            vals = g.sort_values("Dispatch_Id")["Counter_Value"].tolist()
+            vals = vals[len(vals) // 4:] or vals
+            out.setdefault(k, {})[c] = sum(vals) / len(vals)
+            out[k]["launches_averaged"] = len(vals)
 for k, v in out.items():
     if "FETCH_SIZE" in v:
         v["hbm_read_bytes_raw"] = v["FETCH_SIZE"] * 1024

@@ -109,6 +109,40 @@ def build_case(name, device):
         N, kw = 1003, dict(sh_degree=2, w2c=util.pose(0.1, (0.0, 0.05, 0.1)))
     elif name == "cov3d_precomp":
         pass
+    elif name in ("nonfinite_geometry", "nonfinite_appearance", "nonfinite_sh"):
+        # Parameters a diverged Adam step can produce (the reference guards poses only: src/mapper/splatam/__init__.py:514-515; NaN depth pixels are
+        # masked in the loss, splatam.py:221-231 -- nothing guards the Gaussians).  Geometry: NaN / inf means, inf / zero / NaN / negative scales,
+        # zero and NaN quaternions, view depth exactly at the 0.2 near cull, a scale of 1e4 (radius ~ 1e6 px).  Appearance: NaN opacity, NaN colour
+        # (one channel), opacity above 1 and below 0.  Rule: a Gaussian whose screen-space record holds a NaN or an infinity is
+        # culled (radius 0, zero gradients); finite out-of-range values are taken as they are.
+        W, H, N = 160, 120, 3000
+        if name == "nonfinite_sh":
+            kw = dict(sh_degree=3)
+
+        def mutate(rv, name=name):
+            nan, inf = float("nan"), float("inf")
+            m, sc, q = rv["means3D"].clone(), rv["scales"].clone(), rv["rotations"].clone()
+            m[0, 0] = nan; m[1, 1] = nan; m[2, 2] = nan; m[3] = nan
+            m[10, 0] = inf; m[11, 1] = -inf; m[12, 2] = inf; m[13, 2] = -inf; m[14] = inf
+            sc[20, 0] = inf; sc[21] = inf; sc[30, 1] = 0.0; sc[31] = 0.0; sc[40, 2] = nan; sc[41] = nan; sc[50, 0] = -sc[50, 0]; sc[51] = -sc[51]
+            q[60] = 0.0; q[61] = 0.0; q[70, 0] = nan; q[71] = nan
+            m[80:90, 2] = 0.2                                 # exactly the near-cull depth (culled: p_view.z <= 0.2)
+            m[90:92, 2] = 0.20000002                          # the next float above it (kept)
+            sc[95:98] = 1.0e4
+            upd = dict(means3D=m, scales=sc, rotations=q)
+            if name != "nonfinite_geometry":
+                o = rv["opacities"].clone()
+                o[100] = nan; o[101] = nan; o[102] = 2.0; o[103] = -0.5
+                upd["opacities"] = o
+                if "colors_precomp" in rv:
+                    c = rv["colors_precomp"].clone()
+                    c[110, 1] = nan; c[111] = nan
+                    upd["colors_precomp"] = c
+                else:
+                    sh = rv["shs"].clone()
+                    sh[110, 0, 1] = nan; sh[111, 5, :] = nan      # a DC coefficient, a degree-2 coefficient of all channels
+                    upd["shs"] = sh
+            rv.update(upd)
     else:
         raise KeyError(name)
     rs, rv = util.scene(N, W, H, seed=abs(hash(name)) % 1000 if False else sum(map(ord, name)), device=device, **kw)
@@ -155,6 +189,9 @@ CASES = ["basic", "ragged_image", "tiny_lookaround", "lookaround_intrinsics", "p
          "topdown_1000m_white", "behind_camera", "all_culled",
          "huge_gaussians", "dense_overdraw", "mixed_sizes", "low_opacity", "one_gaussian", "not_multiple_of_block", "sh0", "sh1", "sh2",
          "sh3", "sh2_ragged", "sh3_half_culled", "cov3d_precomp"]
+#: inputs with NaN / inf / out-of-range parameters (culled; images and gradients stay finite -- the ordinary checks apply)
+NONFINITE_CASES = ["nonfinite_geometry", "nonfinite_appearance", "nonfinite_sh"]
+CASES += NONFINITE_CASES
 
 
 def set_sort_path(path):
@@ -222,6 +259,100 @@ def check_raw_parameter_mode(device, n=500):
                     assert float((a - b).norm()) < 1e-5 * float(out[0][1]["means3D"].norm()), (k, float((a - b).norm()))
                     continue
                 assert float((a - b).norm() / a.norm()) < 3e-4, (iso, k, float((a - b).norm() / a.norm()))
+
+
+def check_raw_parameter_mode_nonfinite(device, n=600):
+    """The non-finite rule in the mapper's own call (get_loss from the PARAMETERS: the frame transform and the activations run inside the per-Gaussian
+    kernels): NaN / inf means, log scales of +inf (exp -> inf) and -inf (exp -> 0: finite, kept), NaN and +inf logits (sigmoid(+inf) = 1: finite, kept),
+    a zero quaternion (F.normalize's eps keeps it zero: finite, kept) and a NaN quaternion, a NaN colour.  Every path -- activation kernels + plain rasteriser, raw-parameter rasteriser, the
+    same with in-kernel accumulation, the Adam step inside the backward -- culls the same rows: finite loss, finite gradients, zero gradient and
+    `seen` = False for the culled rows, and the parameters of every OTHER row step as they do without the bad rows' presence being felt."""
+    from activesplat_amd import mapping as M, optim as O
+    from tests.test_parallel import _scene
+    nan, inf = float("nan"), float("inf")
+    bad = [3, 4, 5, 10, 20, 21, 31, 40]
+    kept = [11, 22, 30]
+    lrs = dict(means3D=1e-4, rgb_colors=2.5e-3, unnorm_rotations=1e-3, logit_opacities=0.05, log_scales=1e-3, cam_unnorm_rots=0.0, cam_trans=0.0)
+
+    def scene():
+        params, kfs = _scene(n=n, device=device)
+        with torch.no_grad():
+            params["means3D"][3, 0] = nan; params["means3D"][4, 2] = inf; params["means3D"][5] = -inf
+            params["log_scales"][10, 1] = inf; params["log_scales"][11, 1] = -inf
+            params["logit_opacities"][20] = nan; params["logit_opacities"][21] = -nan; params["logit_opacities"][22] = inf
+            params["unnorm_rotations"][30] = 0.0; params["unnorm_rotations"][31, 2] = nan
+            params["rgb_colors"][40, 1] = nan
+        return params, kfs
+    outs = {}
+    for mode in ("kernels", "raw", "raw_acc", "raw_adam"):
+        params, kfs = scene()
+        variables = {k: torch.zeros(n, device=device) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+        opt = O.initialize_optimizer(params, lrs)
+        flags = dict(kernels=dict(fused=True, fused_loss=True, fused_inputs=True), raw=dict(fused=True, fused_loss=True, fused_preprocess=True),
+                     raw_acc=dict(fused=True, fused_loss=True, fused_preprocess=True, accumulate_grads=True),
+                     raw_adam=dict(fused=True, fused_loss=True, fused_preprocess=True, fused_adam=opt))[mode]
+        before = {k: v.detach().clone() for k, v in params.items()}
+        loss, variables, _ = M.get_loss(params, kfs[1], variables, 1, dict(im=0.5, depth=1.0), **flags)
+        loss.backward()
+        assert bool(torch.isfinite(loss)), (mode, float(loss))
+        seen = variables["seen"]
+        assert not bool(seen[bad].any()), (mode, seen[bad].tolist())
+        assert bool(torch.isfinite(variables["means2D"].grad).all()) and float(variables["means2D"].grad[bad].abs().max()) == 0.0, mode
+        if mode == "raw_adam":
+            for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
+                rows = [i for i in range(n) if i not in bad and i not in kept]
+                assert bool(torch.isfinite(params[k].detach()[rows]).all()), (mode, k)
+                # a culled row is stepped with a zero gradient: first step, zero moments -> the parameter does not move (a NaN stays the NaN it was)
+                a, b = params[k].detach()[bad], before[k][bad]
+                assert bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all()), (mode, k)
+        else:
+            good = torch.ones(n, dtype=torch.bool, device=params["means3D"].device)
+            good[bad] = False
+            for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
+                g = params[k].grad
+                assert g is not None and bool(torch.isfinite(g[good]).all()), (mode, k)
+                if mode != "kernels":
+                    # (the separate activation kernels -- like the reference's torch activations -- chain the rasteriser's ZERO gradient of a culled
+                    # row through the derivative of a NaN activation: 0 x NaN.  The raw-parameter kernels write the culled row's zero directly)
+                    assert bool(torch.isfinite(g).all()) and float(g[bad].abs().max()) == 0.0, (mode, k, g[bad])
+            outs[mode] = (float(loss.detach()), {k: params[k].grad[good].clone() for k in lrs if params[k].grad is not None})
+    for mode in ("raw", "raw_acc"):
+        assert abs(outs["kernels"][0] - outs[mode][0]) < 4e-6 * abs(outs["kernels"][0]), (mode, outs["kernels"][0], outs[mode][0])
+        for k in ("means3D", "rgb_colors", "logit_opacities", "log_scales"):
+            a, b = outs["kernels"][1][k], outs[mode][1][k]
+            assert float((a - b).norm() / a.norm()) < 3e-4, (mode, k, float((a - b).norm() / a.norm()))
+
+
+def check_loss_masks_nonfinite_depth(device, n=500):
+    """The mapping loss masks pixels without a valid depth measurement (splatam.py:221-231: `depth > 0` and the rendered values not NaN).  A NaN / inf /
+    negative / zero ground-truth depth pixel must count exactly like a missing one (0) in the fused loss (csrc/loss.hip) -- value and every
+    gradient identical to the bit of the same call with those pixels zeroed, everything finite.  (The reference's torch ops give the masked pixels
+    a 0 x sign(NaN) = NaN gradient there; the fused kernels select.)"""
+    from activesplat_amd import mapping as M
+    from tests.test_parallel import _scene
+    out = []
+    for variant in ("zeroed", "nonfinite"):
+        params, kfs = _scene(n=n, device=device)
+        kf = dict(kfs[1])
+        d = kf["depth"].clone()
+        H, W = d.shape[-2:]
+        d[0, 0:3, :] = 0.0 if variant == "zeroed" else float("nan")
+        d[0, 5, : W // 2] = 0.0 if variant == "zeroed" else float("-inf")
+        d[0, 7, 1::2] = 0.0 if variant == "zeroed" else -1.5
+        d[0, H - 1, :] = 0.0
+        kf["depth"] = d
+        nn_ = params["means3D"].shape[0]
+        variables = {k: torch.zeros(nn_, device=device) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
+        loss, variables, _ = M.get_loss(params, kf, variables, 1, dict(im=0.5, depth=1.0), fused=True, fused_loss=True, fused_inputs=True)
+        loss.backward()
+        assert bool(torch.isfinite(loss)), (variant, float(loss))
+        grads = {k: v.grad.clone() for k, v in params.items() if v.grad is not None}
+        assert all(bool(torch.isfinite(g).all()) for g in grads.values()), variant
+        out.append((float(loss.detach()), grads))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
+        a, b = out[0][1][k], out[1][1][k]
+        assert float((a - b).norm()) <= 2e-5 * float(a.norm()), k          # (device: the atomic sums' order; emulated kernels: equal)
 
 
 def check_raw_parameter_mode_sh(device, n=400, W=64, H=48):
@@ -968,6 +1099,7 @@ def check_forward(rs, rv, oracle32, exact_float=False, oracle64=None):
     # ---- images ----
     for k_got, k_ref in (("color", "color"), ("depth", "out_depth"), ("opacity", "opacity")):
         a, b = got[k_got], ref[k_ref]
+        assert np.isfinite(a).all() and np.isfinite(b).all(), k_got        # (non-finite inputs are culled: DESIGN.md section 2)
         if exact_float:
             assert np.array_equal(a, b), k_got
         else:

@@ -45,3 +45,17 @@ def test_configs3_roofline_block_arithmetic():
         assert abs(r["single_gpu_frame_frac"] - 1000.0 * B / 8e12) < 1e-5
     one = bench.c4_roofline(N, D, px, False, 1, 64, 32e-3, None, None)
     assert "exchange_frac_xgmi" not in one and one["keyframes_per_gpu_per_step"] == 64
+
+
+def test_profiled_kernels_merges_the_rocprof_table_with_the_counter_summary():
+    """bench.profiled_kernels: the committed rocprofv3 kernel table of a leg + its PMC summary -> per-kernel duration, counter bytes (FETCH doubled
+    + WRITE), fraction of 8 TB/s.  Checked on the committed 2 M profile (any round's: the newest is taken)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    pr = bench.profiled_kernels("2m")
+    assert pr and any(s.endswith("_2m_kernel_stats.csv") for s in pr["source"]) and any(s.endswith("_2m_pmc_summary.json") for s in pr["source"])
+    by, us = bench.counters_for(pr, "blend_backward_kernel<false,1,false>")
+    assert by and us and 100 < us < 400 and 2e8 < by < 6e8                      # ~180 us, ~367 MB at 2 M Gaussians / 4.84 M instances
+    e = next(v for k, v in pr["kernels"].items() if k.startswith("blend_backward_kernel<"))
+    assert abs(e["frac_hbm_pmc"] - by / (us * 1e-6) / 8e12) < 1e-3 and 0.3 < e["valu_busy"] < 1.0
+    assert bench.profiled_kernels("no_such_leg") is None and bench.counters_for(None, "x") == (None, None)

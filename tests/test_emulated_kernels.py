@@ -41,7 +41,7 @@ def test_emulated_forward_radix_path_matches_oracle(emu, oracle32, case):
 
 @pytest.mark.parametrize("case", ["basic", "ragged_image", "posed_white_bg", "scale_modifier", "dense_overdraw", "mixed_sizes",
                                   "huge_gaussians", "all_culled", "sh3", "sh2_ragged", "sh3_half_culled", "cov3d_precomp", "lookaround_intrinsics",
-                                  "scale_modifier_001", "topdown_1000m", "topdown_1000m_white"])
+                                  "scale_modifier_001", "topdown_1000m", "topdown_1000m_white"] + pc.NONFINITE_CASES)
 def test_emulated_backward_matches_fp64_oracle(emu, oracle64, case):
     rs, rv = pc.build_case(case, emu)
     pc.check_backward(rs, rv, oracle64)
@@ -115,9 +115,14 @@ def test_emulated_fused_loss_equals_two_pass_loss(emu):
             assert float((a - b).norm() / a.norm()) < 2e-4, k
 
 
+def test_emulated_fused_loss_masks_nonfinite_depth_pixels(emu):
+    pc.check_loss_masks_nonfinite_depth("cpu")
+
+
 def test_emulated_raw_parameter_rasteriser_equals_the_activation_kernels(emu):
     pc.check_raw_parameter_mode("cpu")
     pc.check_raw_parameter_mode_sh("cpu")
+    pc.check_raw_parameter_mode_nonfinite("cpu")
     assert pc.check_raw_entry_random_draw(1, "cpu") == "ok"                 # one draw of the device sweep (1111 Gaussians, 96 x 157): the same checker code
 
 

@@ -635,9 +635,14 @@ def test_mapping_iteration_without_autograd_equals_the_autograd_path(hip):
     pc.check_mapping_iteration_without_autograd(hip, n=20000, exact=False)
 
 
+def test_fused_loss_masks_nonfinite_depth_pixels(hip):
+    pc.check_loss_masks_nonfinite_depth(hip, n=20000)
+
+
 def test_raw_parameter_rasteriser_equals_the_activation_kernels(hip):
     pc.check_raw_parameter_mode(hip, n=20000)
     pc.check_raw_parameter_mode_sh(hip, n=20000, W=160, H=128)
+    pc.check_raw_parameter_mode_nonfinite(hip, n=20000)
 
 
 @pytest.mark.parametrize("seed", list(range(12)) + [135, 444, 604, 630, 812])
