@@ -75,11 +75,38 @@ __device__ __forceinline__ uint32_t project_gaussian(const Cam& cam, int P, int 
             const float hw = ((q[3] * px + q[7] * py) + q[11] * pz) + q[15];
             const float pw = 1.0f / (hw + 1e-7f);
             const float ndcx = hx * pw, ndcy = hy * pw;
-            float c0, c1, c2, c3, c4, c5;             // 3-D covariance (upper triangle)
+            // EWA projection of the covariance: cov2D = T Sigma T^T + 0.3 I with T = J W (2 x 3)
+            const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+            const float txtz = tx / tz, tytz = ty / tz;
+            const float cx_ = fminf(limx, fmaxf(-limx, txtz)) * tz;
+            const float cy_ = fminf(limy, fmaxf(-limy, tytz)) * tz;
+            const float J00 = cam.fx / tz, J02 = -(cam.fx * cx_) / (tz * tz);
+            const float J11 = cam.fy / tz, J12 = -(cam.fy * cy_) / (tz * tz);
+            const float T00 = J00 * m[0] + J02 * m[2], T01 = J00 * m[4] + J02 * m[6], T02 = J00 * m[8] + J02 * m[10];
+            const float T10 = J11 * m[1] + J12 * m[2], T11 = J11 * m[5] + J12 * m[6], T12 = J11 * m[9] + J12 * m[10];
+            float k00, k01, k11, det;
             if (has_cov) {
-                c0 = s_cov[tid * 6]; c1 = s_cov[tid * 6 + 1]; c2 = s_cov[tid * 6 + 2];
-                c3 = s_cov[tid * 6 + 3]; c4 = s_cov[tid * 6 + 4]; c5 = s_cov[tid * 6 + 5];
+                // a covariance handed in as six numbers: the quadratic form as it stands, det = k00 k11 - k01^2
+                const float c0 = s_cov[tid * 6], c1 = s_cov[tid * 6 + 1], c2 = s_cov[tid * 6 + 2];
+                const float c3 = s_cov[tid * 6 + 3], c4 = s_cov[tid * 6 + 4], c5 = s_cov[tid * 6 + 5];
+                const float v00 = (c0 * T00 + c1 * T01) + c2 * T02;
+                const float v01 = (c1 * T00 + c3 * T01) + c4 * T02;
+                const float v02 = (c2 * T00 + c4 * T01) + c5 * T02;
+                const float v10 = (c0 * T10 + c1 * T11) + c2 * T12;
+                const float v11 = (c1 * T10 + c3 * T11) + c4 * T12;
+                const float v12 = (c2 * T10 + c4 * T11) + c5 * T12;
+                k00 = ((T00 * v00 + T01 * v01) + T02 * v02) + 0.3f;
+                k01 = (T10 * v00 + T11 * v01) + T12 * v02;
+                k11 = ((T10 * v10 + T11 * v11) + T12 * v12) + 0.3f;
+                det = k00 * k11 - k01 * k01;
             } else {
+                // Scale + rotation: Sigma = M M^T with M = R diag(s), so cov2D = A A^T + 0.3 I with A = T M (rows a1, a2), and (Lagrange)
+                //   det = |a1 x a2|^2 + 0.3 (|a1|^2 + |a2|^2) + 0.09 :
+                // a sum of non-negative terms.  (Rounds 1-5 formed Sigma, then T Sigma T^T, then k00 k11 - k01^2: for an elongated splat -- a 240 : 1
+                // needle of radius 3973 px in front of the near plane, seed 180021 of the s = 1.2 sweep -- that determinant is 3e-5 of either
+                // product, and the fp32 rounding of the ENTRIES alone put 2e-3 of relative error on the conic: forward images 1e-3 off, dL/dmeans2D
+                // 1.1e-3 -- in the fp32 oracle just as in the kernels.  The cross product's error is eps / sin(theta) instead of eps / sin^2:
+                // 1e-5 on that splat.  Same mathematics as the published T Sigma T^T; profiles/README.md, "The determinant without its cancellation".)
                 const float sx = cam.mod * s_scale[tid * 3], sy = cam.mod * s_scale[tid * 3 + 1], sz = cam.mod * s_scale[tid * 3 + 2];
                 const float4 rq = reinterpret_cast<const float4*>(s_rot)[tid];
                 const float r = rq.x, x = rq.y, y = rq.z, z = rq.w;
@@ -89,32 +116,15 @@ __device__ __forceinline__ uint32_t project_gaussian(const Cam& cam, int P, int 
                 const float M00 = R00 * sx, M01 = R01 * sy, M02 = R02 * sz;
                 const float M10 = R10 * sx, M11 = R11 * sy, M12 = R12 * sz;
                 const float M20 = R20 * sx, M21 = R21 * sy, M22 = R22 * sz;
-                c0 = (M00 * M00 + M01 * M01) + M02 * M02;
-                c1 = (M00 * M10 + M01 * M11) + M02 * M12;
-                c2 = (M00 * M20 + M01 * M21) + M02 * M22;
-                c3 = (M10 * M10 + M11 * M11) + M12 * M12;
-                c4 = (M10 * M20 + M11 * M21) + M12 * M22;
-                c5 = (M20 * M20 + M21 * M21) + M22 * M22;
+                const float a10 = (T00 * M00 + T01 * M10) + T02 * M20, a11 = (T00 * M01 + T01 * M11) + T02 * M21, a12 = (T00 * M02 + T01 * M12) + T02 * M22;
+                const float a20 = (T10 * M00 + T11 * M10) + T12 * M20, a21 = (T10 * M01 + T11 * M11) + T12 * M21, a22 = (T10 * M02 + T11 * M12) + T12 * M22;
+                const float n1 = (a10 * a10 + a11 * a11) + a12 * a12, n2 = (a20 * a20 + a21 * a21) + a22 * a22;
+                const float xc = a11 * a22 - a12 * a21, yc = a12 * a20 - a10 * a22, zc = a10 * a21 - a11 * a20;
+                k00 = n1 + 0.3f;
+                k01 = (a10 * a20 + a11 * a21) + a12 * a22;
+                k11 = n2 + 0.3f;
+                det = (((xc * xc + yc * yc) + zc * zc) + 0.3f * (n1 + n2)) + 0.09f;
             }
-            // EWA projection of the covariance
-            const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
-            const float txtz = tx / tz, tytz = ty / tz;
-            const float cx_ = fminf(limx, fmaxf(-limx, txtz)) * tz;
-            const float cy_ = fminf(limy, fmaxf(-limy, tytz)) * tz;
-            const float J00 = cam.fx / tz, J02 = -(cam.fx * cx_) / (tz * tz);
-            const float J11 = cam.fy / tz, J12 = -(cam.fy * cy_) / (tz * tz);
-            const float T00 = J00 * m[0] + J02 * m[2], T01 = J00 * m[4] + J02 * m[6], T02 = J00 * m[8] + J02 * m[10];
-            const float T10 = J11 * m[1] + J12 * m[2], T11 = J11 * m[5] + J12 * m[6], T12 = J11 * m[9] + J12 * m[10];
-            const float v00 = (c0 * T00 + c1 * T01) + c2 * T02;
-            const float v01 = (c1 * T00 + c3 * T01) + c4 * T02;
-            const float v02 = (c2 * T00 + c4 * T01) + c5 * T02;
-            const float v10 = (c0 * T10 + c1 * T11) + c2 * T12;
-            const float v11 = (c1 * T10 + c3 * T11) + c4 * T12;
-            const float v12 = (c2 * T10 + c4 * T11) + c5 * T12;
-            const float k00 = ((T00 * v00 + T01 * v01) + T02 * v02) + 0.3f;
-            const float k01 = (T10 * v00 + T11 * v01) + T12 * v02;
-            const float k11 = ((T10 * v10 + T11 * v11) + T12 * v12) + 0.3f;
-            const float det = k00 * k11 - k01 * k01;
             if (det > 0.0f) {
                 const float det_inv = 1.0f / det;
                 const float mid = 0.5f * (k00 + k11);

@@ -224,43 +224,55 @@ __global__ __launch_bounds__(kBlock, (ACT && SH == 3) ? GS_PBWD_RAW_SH_WGS : 4) 
         const float W0[3] = {m[0], m[4], m[8]}, W1[3] = {m[1], m[5], m[9]}, W2[3] = {m[2], m[6], m[10]};
         float T0[3], T1[3];
         for (int c = 0; c < 3; c++) { T0[c] = J00 * W0[c] + J02 * W2[c]; T1[c] = J11 * W1[c] + J12 * W2[c]; }
-        // 3-D covariance
-        float S[3][3];
+        // 2-D covariance (with the 0.3 low-pass) p, q, r, its determinant, and Sigma T0^T, Sigma T1^T for the chain to T
+        float ST0[3], ST1[3];
         float Rm[3][3], s3[3] = {0.f, 0.f, 0.f};
         float r = 0.f, x = 0.f, y = 0.f, z = 0.f;
+        double p_d, q_d, r_d, det_d;
+        // The ONE ill-conditioned block of the chain, in fp64: for an elongated splat the determinant of the 2-D covariance lies orders of magnitude
+        // below its entries (seed 160050 of the round-5 sweep: p, q, r = 74, -208, 590, det = 396), and the conic-to-covariance gradient divides
+        // by its square -- in fp32 this block alone put 3.5e-3 of relative error on that Gaussian's rotation gradient (the fp32 oracle: 3.4e-4); with
+        // the block in fp64 the row is at 2.8e-5.  ~25 double-precision operations per Gaussian in an HBM-bound kernel: no measurable time
+        // (profiles/README.md).
         if (cov3Dp) {
             const float* c = cov_in;
-            S[0][0] = c[0]; S[0][1] = c[1]; S[0][2] = c[2]; S[1][0] = c[1]; S[1][1] = c[3]; S[1][2] = c[4];
-            S[2][0] = c[2]; S[2][1] = c[4]; S[2][2] = c[5];
+            const float S[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
+            for (int a = 0; a < 3; a++) {
+                ST0[a] = S[a][0] * T0[0] + S[a][1] * T0[1] + S[a][2] * T0[2];
+                ST1[a] = S[a][0] * T1[0] + S[a][1] * T1[1] + S[a][2] * T1[2];
+            }
+            p_d = (double)T0[0] * ST0[0] + (double)T0[1] * ST0[1] + (double)T0[2] * ST0[2] + 0.3;
+            q_d = (double)T1[0] * ST0[0] + (double)T1[1] * ST0[1] + (double)T1[2] * ST0[2];
+            r_d = (double)T1[0] * ST1[0] + (double)T1[1] * ST1[1] + (double)T1[2] * ST1[2] + 0.3;
+            det_d = p_d * r_d - q_d * q_d;
         } else {
+            // scale + rotation: the forward's factorised form (preprocess.hip): A = T M with M = R diag(s), cov2D = A A^T + 0.3 I,
+            // det = |a1 x a2|^2 + 0.3 (|a1|^2 + |a2|^2) + 0.09 -- round 6: with p r - q^2 even fp64 arithmetic inherits eps32 / sin^2(theta) from
+            // the fp32 rounding of p, q, r themselves (2e-3 on the 240 : 1 needle of seed 180021); the cross product of the fp32 rows: 1e-5
             s3[0] = cam.mod * sc_in[0]; s3[1] = cam.mod * sc_in[1]; s3[2] = cam.mod * sc_in[2];
             const float4 rq = rq_in;
             r = rq.x; x = rq.y; y = rq.z; z = rq.w;
             Rm[0][0] = 1.f - 2.f * (y * y + z * z); Rm[0][1] = 2.f * (x * y - r * z); Rm[0][2] = 2.f * (x * z + r * y);
             Rm[1][0] = 2.f * (x * y + r * z); Rm[1][1] = 1.f - 2.f * (x * x + z * z); Rm[1][2] = 2.f * (y * z - r * x);
             Rm[2][0] = 2.f * (x * z - r * y); Rm[2][1] = 2.f * (y * z + r * x); Rm[2][2] = 1.f - 2.f * (x * x + y * y);
-            for (int a = 0; a < 3; a++)
-                for (int b2 = 0; b2 < 3; b2++) {
-                    float acc = 0.f;
-                    for (int j = 0; j < 3; j++) acc += (Rm[a][j] * s3[j]) * (Rm[b2][j] * s3[j]);
-                    S[a][b2] = acc;
-                }
+            float a1[3], a2[3];
+            for (int j = 0; j < 3; j++) {
+                a1[j] = (T0[0] * Rm[0][j] + T0[1] * Rm[1][j] + T0[2] * Rm[2][j]) * s3[j];
+                a2[j] = (T1[0] * Rm[0][j] + T1[1] * Rm[1][j] + T1[2] * Rm[2][j]) * s3[j];
+            }
+            for (int a = 0; a < 3; a++) {                       // Sigma T^T = M (M^T T^T) = M a^T
+                ST0[a] = Rm[a][0] * s3[0] * a1[0] + Rm[a][1] * s3[1] * a1[1] + Rm[a][2] * s3[2] * a1[2];
+                ST1[a] = Rm[a][0] * s3[0] * a2[0] + Rm[a][1] * s3[1] * a2[1] + Rm[a][2] * s3[2] * a2[2];
+            }
+            const double n1 = (double)a1[0] * a1[0] + (double)a1[1] * a1[1] + (double)a1[2] * a1[2];
+            const double n2 = (double)a2[0] * a2[0] + (double)a2[1] * a2[1] + (double)a2[2] * a2[2];
+            const double xc = (double)a1[1] * a2[2] - (double)a1[2] * a2[1], yc = (double)a1[2] * a2[0] - (double)a1[0] * a2[2],
+                         zc = (double)a1[0] * a2[1] - (double)a1[1] * a2[0];
+            p_d = n1 + 0.3;
+            q_d = (double)a1[0] * a2[0] + (double)a1[1] * a2[1] + (double)a1[2] * a2[2];
+            r_d = n2 + 0.3;
+            det_d = (xc * xc + yc * yc + zc * zc) + 0.3 * (n1 + n2) + 0.09;
         }
-        // 2-D covariance (with the 0.3 low-pass) and conic -> cov2D gradient
-        float ST0[3], ST1[3];                                   // Sigma T0^T, Sigma T1^T
-        for (int a = 0; a < 3; a++) {
-            ST0[a] = S[a][0] * T0[0] + S[a][1] * T0[1] + S[a][2] * T0[2];
-            ST1[a] = S[a][0] * T1[0] + S[a][1] * T1[1] + S[a][2] * T1[2];
-        }
-        // The ONE ill-conditioned block of the chain, in fp64: for an elongated splat the determinant of the 2-D covariance lies orders of magnitude
-        // below its entries (seed 160050 of the round-5 sweep: p, q, r = 74, -208, 590, det = 396), and the conic-to-covariance gradient divides
-        // by its square -- in fp32 this block alone put 3.5e-3 of relative error on that Gaussian's rotation gradient (the fp32 oracle: 3.4e-4); with
-        // the block in fp64 the row is at 2.8e-5.  ~25 double-precision operations per Gaussian in an HBM-bound kernel: no measurable time
-        // (profiles/README.md).
-        const double p_d = (double)T0[0] * ST0[0] + (double)T0[1] * ST0[1] + (double)T0[2] * ST0[2] + 0.3;
-        const double q_d = (double)T1[0] * ST0[0] + (double)T1[1] * ST0[1] + (double)T1[2] * ST0[2];
-        const double r_d = (double)T1[0] * ST1[0] + (double)T1[1] * ST1[1] + (double)T1[2] * ST1[2] + 0.3;
-        const double det_d = p_d * r_d - q_d * q_d;
         const double d2_d = 1.0 / (det_d * det_d);
         const double dA = -0.5 * ga.z, dB = -(double)ga.w, dC = -0.5 * gb.x;      // true partials w.r.t. conic (a, b, c)
         const float dp = (float)((-r_d * r_d * dA + q_d * r_d * dB - q_d * q_d * dC) * d2_d);

@@ -173,6 +173,22 @@ static void cov3d_from_scale_rot(const real *s, real mod, const real *q, real *c
     c[5] = (M20 * M20 + M21 * M21) + M22 * M22;
 }
 
+/* rows of A = T M, M = R diag(mod s): A1 = T0 M, A2 = T1 M (the factorised 2-D covariance: cov2D = A A^T + 0.3 I) */
+static void scaled_rotation_rows(const real *s, real mod, const real *q, real T00, real T01, real T02, real T10, real T11, real T12,
+                                 real *A1, real *A2)
+{
+    real sx = mod * s[0], sy = mod * s[1], sz = mod * s[2];
+    real r = q[0], x = q[1], y = q[2], z = q[3];
+    real R00 = R(1) - R(2) * (y * y + z * z), R01 = R(2) * (x * y - r * z), R02 = R(2) * (x * z + r * y);
+    real R10 = R(2) * (x * y + r * z), R11 = R(1) - R(2) * (x * x + z * z), R12 = R(2) * (y * z - r * x);
+    real R20 = R(2) * (x * z - r * y), R21 = R(2) * (y * z + r * x), R22 = R(1) - R(2) * (x * x + y * y);
+    real M00 = R00 * sx, M01 = R01 * sy, M02 = R02 * sz;
+    real M10 = R10 * sx, M11 = R11 * sy, M12 = R12 * sz;
+    real M20 = R20 * sx, M21 = R21 * sy, M22 = R22 * sz;
+    A1[0] = (T00 * M00 + T01 * M10) + T02 * M20; A1[1] = (T00 * M01 + T01 * M11) + T02 * M21; A1[2] = (T00 * M02 + T01 * M12) + T02 * M22;
+    A2[0] = (T10 * M00 + T11 * M10) + T12 * M20; A2[1] = (T10 * M01 + T11 * M11) + T12 * M21; A2[2] = (T10 * M02 + T11 * M12) + T12 * M22;
+}
+
 static int clamp_tile(real v, int hi)
 {
     /* float -> int with an explicit, platform-independent saturation first */
@@ -213,7 +229,7 @@ int64_t gso_preprocess(const GsoCam *cam, const real *means3D, const real *shs, 
         if (cov3D_precomp) for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * i + k];
         else cov3d_from_scale_rot(scales + 3 * i, cam->scale_modifier, rots + 4 * i, c3);
         for (int k = 0; k < 6; k++) cov3d[6 * i + k] = c3[k];
-        /* EWA projection */
+        /* EWA projection: cov2D = T Sigma T^T + 0.3 I, T = J W (2 x 3) */
         const real limx = R(1.3) * cam->tanfovx, limy = R(1.3) * cam->tanfovy;
         const real txtz = tx / tz, tytz = ty / tz;
         const real cx_ = r_min(limx, r_max(-limx, txtz)) * tz;
@@ -223,16 +239,33 @@ int64_t gso_preprocess(const GsoCam *cam, const real *means3D, const real *shs, 
         /* W_rc = m[4*c + r] */
         const real T00 = J00 * m[0] + J02 * m[2], T01 = J00 * m[4] + J02 * m[6], T02 = J00 * m[8] + J02 * m[10];
         const real T10 = J11 * m[1] + J12 * m[2], T11 = J11 * m[5] + J12 * m[6], T12 = J11 * m[9] + J12 * m[10];
-        const real v00 = (c3[0] * T00 + c3[1] * T01) + c3[2] * T02;
-        const real v01 = (c3[1] * T00 + c3[3] * T01) + c3[4] * T02;
-        const real v02 = (c3[2] * T00 + c3[4] * T01) + c3[5] * T02;
-        const real v10 = (c3[0] * T10 + c3[1] * T11) + c3[2] * T12;
-        const real v11 = (c3[1] * T10 + c3[3] * T11) + c3[4] * T12;
-        const real v12 = (c3[2] * T10 + c3[4] * T11) + c3[5] * T12;
-        const real c00 = ((T00 * v00 + T01 * v01) + T02 * v02) + R(0.3);
-        const real c01 = (T10 * v00 + T11 * v01) + T12 * v02;
-        const real c11 = ((T10 * v10 + T11 * v11) + T12 * v12) + R(0.3);
-        const real det = c00 * c11 - c01 * c01;
+        real c00, c01, c11, det;
+        if (cov3D_precomp) {
+            /* a covariance handed in as six numbers: the quadratic form as it stands */
+            const real v00 = (c3[0] * T00 + c3[1] * T01) + c3[2] * T02;
+            const real v01 = (c3[1] * T00 + c3[3] * T01) + c3[4] * T02;
+            const real v02 = (c3[2] * T00 + c3[4] * T01) + c3[5] * T02;
+            const real v10 = (c3[0] * T10 + c3[1] * T11) + c3[2] * T12;
+            const real v11 = (c3[1] * T10 + c3[3] * T11) + c3[4] * T12;
+            const real v12 = (c3[2] * T10 + c3[4] * T11) + c3[5] * T12;
+            c00 = ((T00 * v00 + T01 * v01) + T02 * v02) + R(0.3);
+            c01 = (T10 * v00 + T11 * v01) + T12 * v02;
+            c11 = ((T10 * v10 + T11 * v11) + T12 * v12) + R(0.3);
+            det = c00 * c11 - c01 * c01;
+        } else {
+            /* scale + rotation: Sigma = M M^T, M = R diag(s); cov2D = A A^T + 0.3 I with A = T M (rows a1, a2), and by Lagrange's identity
+             *   det = |a1 x a2|^2 + 0.3 (|a1|^2 + |a2|^2) + 0.09
+             * -- no difference of large products (the published family's k00 k11 - k01^2 loses eps / sin^2(theta) on an elongated splat, the cross
+             * product eps / sin(theta)); same mathematics.  The kernels (csrc/preprocess.hip) evaluate exactly this, operation for operation. */
+            real A1[3], A2[3];
+            scaled_rotation_rows(scales + 3 * i, cam->scale_modifier, rots + 4 * i, T00, T01, T02, T10, T11, T12, A1, A2);
+            const real n1 = (A1[0] * A1[0] + A1[1] * A1[1]) + A1[2] * A1[2], n2 = (A2[0] * A2[0] + A2[1] * A2[1]) + A2[2] * A2[2];
+            const real xc = A1[1] * A2[2] - A1[2] * A2[1], yc = A1[2] * A2[0] - A1[0] * A2[2], zc = A1[0] * A2[1] - A1[1] * A2[0];
+            c00 = n1 + R(0.3);
+            c01 = (A1[0] * A2[0] + A1[1] * A2[1]) + A1[2] * A2[2];
+            c11 = n2 + R(0.3);
+            det = (((xc * xc + yc * yc) + zc * zc) + R(0.3) * (n1 + n2)) + R(0.09);
+        }
         if (!(det > R(0))) { offsets[i] = run; continue; }
         const real det_inv = R(1) / det;
         const real mid = R(0.5) * (c00 + c11);
@@ -512,11 +545,22 @@ void gso_preprocess_backward(const GsoCam *cam, const real *means3D, const real 
         for (int c = 0; c < 3; c++) { T[0][c] = J00 * Wm[0][c] + J02 * Wm[2][c]; T[1][c] = J11 * Wm[1][c] + J12 * Wm[2][c]; }
         const real *c3 = cov3d + 6 * i;
         const real S[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
-        real p_ = 0.3, q_ = 0, r_ = 0.3;
-        for (int a = 0; a < 3; a++) for (int b2 = 0; b2 < 3; b2++) {
-            p_ += T[0][a] * S[a][b2] * T[0][b2]; q_ += T[0][a] * S[a][b2] * T[1][b2]; r_ += T[1][a] * S[a][b2] * T[1][b2];
+        real p_ = 0.3, q_ = 0, r_ = 0.3, det;
+        if (scales && rots) {
+            /* the factorised form of the forward (see gso_preprocess) */
+            real A1[3], A2[3];
+            scaled_rotation_rows(scales + 3 * i, cam->scale_modifier, rots + 4 * i, T[0][0], T[0][1], T[0][2], T[1][0], T[1][1], T[1][2], A1, A2);
+            const real n1 = (A1[0] * A1[0] + A1[1] * A1[1]) + A1[2] * A1[2], n2 = (A2[0] * A2[0] + A2[1] * A2[1]) + A2[2] * A2[2];
+            const real xc = A1[1] * A2[2] - A1[2] * A2[1], yc = A1[2] * A2[0] - A1[0] * A2[2], zc = A1[0] * A2[1] - A1[1] * A2[0];
+            p_ = n1 + R(0.3); q_ = (A1[0] * A2[0] + A1[1] * A2[1]) + A1[2] * A2[2]; r_ = n2 + R(0.3);
+            det = (((xc * xc + yc * yc) + zc * zc) + R(0.3) * (n1 + n2)) + R(0.09);
+        } else {
+            for (int a = 0; a < 3; a++) for (int b2 = 0; b2 < 3; b2++) {
+                p_ += T[0][a] * S[a][b2] * T[0][b2]; q_ += T[0][a] * S[a][b2] * T[1][b2]; r_ += T[1][a] * S[a][b2] * T[1][b2];
+            }
+            det = p_ * r_ - q_ * q_;
         }
-        const real det = p_ * r_ - q_ * q_, d2 = R(1) / (det * det);
+        const real d2 = R(1) / (det * det);
         const real dA = dL_dconic[3 * i], dB = dL_dconic[3 * i + 1], dC = dL_dconic[3 * i + 2];
         const real dp = (-r_ * r_ * dA + q_ * r_ * dB - q_ * q_ * dC) * d2;
         const real dq = (R(2) * q_ * r_ * dA - (p_ * r_ + q_ * q_) * dB + R(2) * p_ * q_ * dC) * d2;

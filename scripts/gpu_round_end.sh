@@ -30,6 +30,8 @@ cd $R
 python scripts/pmc_summarise.py gpurun_out/final ${TAG}_2m > gpurun_out/final/${TAG}_2m_pmc_summary.txt 2>&1
 for name in c1 c2loop c3step; do python scripts/pmc_summarise.py gpurun_out/final ${TAG}_${name} > gpurun_out/final/${TAG}_${name}_pmc_summary.txt 2>&1; done
 cp profiles/${TAG}_*_pmc_summary.json gpurun_out/final/ 2>/dev/null
+# bench.py's legs read the kernel tables next to the counter summaries (bench.profiled_kernels): both under profiles/ for the second bench run below
+cp gpurun_out/final/${TAG}_2m_kernel_stats.csv gpurun_out/final/${TAG}_c1_kernel_stats.csv gpurun_out/final/${TAG}_c2loop_kernel_stats.csv gpurun_out/final/${TAG}_c3step_kernel_stats.csv profiles/ 2>/dev/null
 # the bench line once more, now that this round's PMC summary exists (roofline.traffic reads it)
 timeout 400 python bench.py > gpurun_out/final/${TAG}_bench.json 2> gpurun_out/final/bench.err; echo bench rc=$?
 # BASELINE configs[2]'s loop and the configs[4] substitute (256 x 256 and 512 x 512, PSNR + SSIM, HIP loop vs oracle-backed loop); the planner's top-down camera
