@@ -33,6 +33,25 @@ def sweep_scene(seed, device, plain=None):
     return rs, rv
 
 
+def hard_scene(seed, device, s=1.2, plain=None):
+    """The `HARD=s` variant of the sweeps (scripts/exp/fuzz_gpu.py): every axis of every splat scaled by an independent exp(N(0, s)) -- at s = 1.2 a median
+    anisotropy of 8, a maximum above 2 000 -- and every odd seed's scene moved right in front of the near plane."""
+    import torch
+    rs, rv = sweep_scene(seed, device, plain)
+    if "scales" in rv:
+        gen = torch.Generator().manual_seed(seed)
+        rv["scales"] = rv["scales"] * torch.exp(float(s) * torch.randn(rv["scales"].shape, generator=gen)).to(rv["scales"].device)
+        if seed % 2:
+            rv["means3D"] = rv["means3D"] * torch.tensor([1.0, 1.0, 0.35], device=rv["means3D"].device)
+    return rs, rv
+
+
+#: scenes the round-5 sweep with strongly anisotropic splats (s = 1.2, profiles/r05_fuzz_hard.txt) flagged for gradients 2.4-2.8 x the fp32 oracle's error, located in
+#: round 6: the determinant of the 2-D covariance as k00 k11 - k01^2 -- 3e-5 of either product for the 240 : 1 needle of seed 180021 (radius 3973 px in front of
+#: the near plane), so that the fp32 rounding of the ENTRIES alone put 2e-3 on the conic, in the fp32 oracle as in the kernels.  Since the factorised form
+#: (cov2D = A A^T + 0.3 I, det = |a1 x a2|^2 + ..., csrc/preprocess.hip) they pass: (seed, s)
+FLAGGED_R06_HARD = [(180021, 1.2), (180459, 1.2), (180489, 1.2)]
+
 #: scenes the round-4 sweeps flagged (profiles/r04_fuzz5.txt): (seed, plain).  Ten pass under the operative gradient rule of DESIGN section 6
 #: (the fp64 bar, or at most 1.5 x the fp32 oracle's own error); 120013 is the alpha = 1/255 threshold scene analysed in
 #: profiles/README.md ("seed 120013"): it passes through the decision-matched third tier of parity_cases.check_fused_rgbd.

@@ -42,17 +42,18 @@ def test_threshold_factor_of_the_oracle_flips_exactly_one_decision(oracle64):
 
 
 def test_decision_matched_tier_end_to_end_on_the_emulated_kernels(emu, oracle32, oracle64):
-    """Seed 140658 (round-5 sweep, 256 Gaussians on 44 x 65 pixels): Gaussian 112 -- radius 50, faint -- owns pixel (0,39) at 255 alpha - 1 = -5.9e-7.
-    Both oracles skip it; the kernel's FMA / exp2 form (device AND emulated build) blends it, which moves Gaussian 112's row by a whole pixel's
-    contribution and every Gaussian that blends at that pixel by alpha = 1/255 of theirs: 10 of 1024 rotation elements outside the element-wise
-    tolerance at a relative L2 of 4.7e-5.  Tiers 1 and 2 fail; the oracles re-run with the other decision at that one pixel agree with the kernel."""
-    rs, rv = sweep_scene(140658, emu)
+    """Seed 142083 of the sweep generator (a `cov3D_precomp` draw): Gaussian 8 owns pixel (44,52) at 255 alpha - 1 = +2.2e-7.  Both oracles blend it;
+    the kernel's FMA / exp2 form skips it, which moves Gaussian 8's row by a whole pixel's contribution and every Gaussian that blends at that pixel
+    by alpha = 1/255 of theirs.  Tiers 1 and 2 fail; the oracles re-run with the other decision at that one pixel agree with the kernel.
+    (Rounds 4-5 pinned seed 140658 -- Gaussian 112, pixel (0,39), -5.9e-7 -- here: with round 6's factorised 2-D covariance that alpha moved off the
+    threshold and the scene passes at the stated tolerance; 142083 is what a 2 400-scene search on the emulated kernels found under the new arithmetic.)"""
+    rs, rv = sweep_scene(142083, emu)
     before = (pc.HATCH["fired"], pc.HATCH["decisions"])
     pc.check_backward(rs, rv, oracle64, oracle32=oracle32)
     assert pc.HATCH["decisions"] > before[1]
     where = pc.HATCH["decision_where"][before[1]:]
-    assert all([(i, x, y) for i, x, y, _ in combo] == [(112, 0, 39)] for _, combo, _, _ in where), where
-    assert all(rel < 1e-5 for _, _, rel, _ in where)                          # with the decision matched: 6e-7, the fp32 oracle's own level
+    assert all([(i, x, y) for i, x, y, _ in combo] == [(8, 44, 52)] for _, combo, _, _ in where), where
+    assert all(rel < 1e-5 for _, _, rel, _ in where)                          # with the decision matched: the fp32 oracle's own level
 
 
 def test_decision_matched_tier_does_not_rescue_a_defect(emu, oracle32, oracle64, monkeypatch):
@@ -101,3 +102,22 @@ def test_depth_tie_rule_covers_only_the_pair_s_footprints():
         d[30, 50] = 0.1                                     # inside the third splat only: never excused
         ok, covered, total = pc._depth_ties_cover(means, pose, means, radius, d, W, H, 1e-3)
         assert not ok and total == 2 and covered == (1 if expect else 0)
+
+
+def test_needle_splat_conic_is_well_conditioned(emu, oracle32, oracle64):
+    """Seed 180021 of the s = 1.2 sweep holds a 240 : 1 needle (scales 0.015 / 3.73 / 0.026 at depth 0.205: radius 3973 px) whose 2-D covariance has
+    k00 k11 and k01^2 of 7.29e11 each and a determinant of 2.4e7.  With the determinant as their difference the fp32 conic carried 2e-3 of relative error
+    (oracle AND kernels: the spec was shared), the rendered image 1e-3; the factorised form (det = |a1 x a2|^2 + 0.3 (|a1|^2 + |a2|^2) + 0.09) holds 1e-5:
+    here the fp32 oracle's conic of that Gaussian against the fp64 oracle's, the images, and the emulated kernels under the ordinary checks."""
+    from tests.fuzz_scenes import hard_scene
+    rs, rv = hard_scene(180021, emu, 1.2)
+    f32, f64 = util.run_oracle(oracle32, rs, rv), util.run_oracle(oracle64, rs, rv)
+    assert np.array_equal(f32["radii"], f64["radii"]) and int(f64["radii"][14164]) > 3000
+    c32, c64 = np.asarray(f32["conic_opacity"], np.float64)[14164, :3], np.asarray(f64["conic_opacity"], np.float64)[14164, :3]
+    assert np.abs(c32 - c64).max() <= 5e-5 * np.abs(c64).max(), (c32, c64)             # (rounds 1-5: 2e-3)
+    live = np.asarray(f64["radii"]) > 0
+    rel = np.abs(np.asarray(f32["conic_opacity"], np.float64)[live, :3] - np.asarray(f64["conic_opacity"], np.float64)[live, :3]).max(1) / \
+        np.abs(np.asarray(f64["conic_opacity"], np.float64)[live, :3]).max(1)
+    assert rel.max() <= 2e-4, float(rel.max())                                          # every splat of the scene
+    assert np.abs(np.asarray(f32["color"], np.float64) - np.asarray(f64["color"], np.float64)).max() < 3e-4
+    pc.check_forward(rs, rv, oracle32, oracle64=oracle64)
