@@ -118,7 +118,8 @@ def c4_roofline(n_gauss, D, npix, sh, world, KF, step_s, exchange_ms, exchange_b
                             "whose own bytes are not in B_alg"}
     if exchange_ms and exchange_bytes and world > 1:
         wire = 2.0 * exchange_bytes * (world - 1) / world
-        hbm = exchange_bytes * 4 + 28.0 * G * n_gauss / world      # pack (read + write), unpack (read + write); Adam on 1/world of the rows
+        # pack (gradients in, flat buffer out), unpack (flat in, parameters out): 4 S; Adam on 1/world of the rows: reduced shard in, p / m / v in and out, updated shard out
+        hbm = exchange_bytes * 4 + 32.0 * G * n_gauss / world
         r.update(exchange_floats_per_gaussian=G, exchange_buffer_bytes=int(exchange_bytes), exchange_wire_bytes_per_rank=int(wire),
                  exchange_ms=round(exchange_ms, 4), exchange_frac_xgmi=round(wire / (exchange_ms * 1e-3) / XGMI_PEAK, 4), xgmi_peak_gbs=XGMI_PEAK / 1e9,
                  exchange_hbm_alg_bytes=int(hbm), exchange_frac_hbm=round(hbm / (exchange_ms * 1e-3) / HBM_PEAK, 4),
@@ -576,6 +577,20 @@ def run_c4(args, dev, rank, world, ranks_info=None, sh_degree=None, light=False)
                                     predicted_speedup_vs_this_gpu=round(KF / ((max(per) + ex1 + wire) * 1e-3) / ref, 3),
                                     prediction="keyframes / (slowest rank's shard + the measured 1-rank RCCL exchange incl. Adam on ALL rows + the modelled xGMI "
                                                "time of the 8-rank collectives): a model from one device, not a measurement of 8")
+                        # the same with the Adam launch at 1/ranks of the rows, as the 8-rank step runs it: pack + unpack as measured (they cover all rows on every
+                        # rank), the Adam kernel's share from the rocprofv3 kernel table of this very exchange (profiles/rNN_c3step_kernel_stats.csv) divided by ranks
+                        prk = profiled_kernels("c3step")
+                        if prk:
+                            tag = "64,64" if sh else "256,16"
+                            us = {m: next((e["avg_us"] for k, e in prk["kernels"].items() if k.startswith(f"rows_kernel<{m},{tag}")), None) for m in (0, 1, 2)}
+                            if all(us.values()):
+                                ex8 = (us[0] + us[1] + us[2] / R8) * 1e-3 + wire
+                                pred.update(exchange_kernels_us={"pack": us[0], "unpack": us[1], "adam_all_rows": us[2]},
+                                            exchange_model_sharded_adam_ms=round(ex8, 4),
+                                            predicted_keyframes_per_s_sharded_adam=round(KF / ((max(per) + ex8) * 1e-3), 1),
+                                            predicted_speedup_sharded_adam=round(KF / ((max(per) + ex8) * 1e-3) / ref, 3),
+                                            sharded_adam_note=f"pack + unpack (all rows, profiled) + Adam kernel / {R8} (each rank steps its row block) + the modelled wire time; "
+                                                              "the figure above charges the Adam of ALL rows, which a one-rank group runs")
                     finally:
                         dist.destroy_process_group()
                 except Exception as e:

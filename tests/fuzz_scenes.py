@@ -65,3 +65,6 @@ FLAGGED_RGBD = [(122026, "2"), (122050, "2"), (122083, "2"), (122086, "2"), (122
 #: 2-D covariance has a determinant two orders below its entries: the fp32 conic-gradient block lost 3.5e-3 of that row -- it is evaluated in fp64 since) through check_backward
 FLAGGED_R05_RGBD = [(130045, None), (130237, None), (130378, None), (142132, "2"), (150586, None)]
 FLAGGED_R05_BACKWARD = [(140658, None), (160050, None)]
+#: round-6 sweep (profiles/r06_fuzz.txt): 142045 -- Gaussian 15776 (radius 61) owns pixel (223,106) at 255 alpha - 1 = +1.06e-5 where the exponent's terms are 22 + 36 + 55: the
+#: kernel skips it, both oracles blend it (94-97 % of three tensors' error in that row); the decision-matched tier's window now follows the terms' magnitude
+FLAGGED_R06_RGBD = [(142045, "2")]

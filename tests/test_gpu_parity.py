@@ -417,7 +417,8 @@ def test_flagged_sweep_scene_fused_rgbd(hip, oracle32, oracle64, seed, plain):
         _lib.check(lib.gs_set_half_quadrants(256)); _lib.check(lib.gs_set_backward_chain(3, -1))
 
 
-@pytest.mark.parametrize("seed,plain", __import__("tests.fuzz_scenes", fromlist=["FLAGGED_R05_RGBD"]).FLAGGED_R05_RGBD)
+@pytest.mark.parametrize("seed,plain", __import__("tests.fuzz_scenes", fromlist=["FLAGGED_R05_RGBD"]).FLAGGED_R05_RGBD +
+                         __import__("tests.fuzz_scenes", fromlist=["FLAGGED_R06_RGBD"]).FLAGGED_R06_RGBD)
 def test_flagged_round5_sweep_scene_fused_rgbd(hip, oracle32, oracle64, seed, plain):
     from activesplat_amd import _lib
     from tests.fuzz_scenes import sweep_scene

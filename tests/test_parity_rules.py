@@ -121,3 +121,22 @@ def test_needle_splat_conic_is_well_conditioned(emu, oracle32, oracle64):
     assert rel.max() <= 2e-4, float(rel.max())                                          # every splat of the scene
     assert np.abs(np.asarray(f32["color"], np.float64) - np.asarray(f64["color"], np.float64)).max() < 3e-4
     pc.check_forward(rs, rv, oracle32, oracle64=oracle64)
+
+
+def test_threshold_window_follows_the_size_of_the_exponents_terms():
+    """threshold_gaussians: a pixel is a legitimate place for two fp32 evaluations of alpha to decide differently when 255 alpha - 1 lies within 1e-5 --
+    or within what an fp32 evaluation of the exponent can be off by at THAT pixel, 4 (eps / 2) x (|a| dx^2 / 2 + |c| dy^2 / 2 + |b dx dy|).  A splat whose
+    threshold pixel sits 31 / 23 pixels off its centre with terms of 22 + 36 + 55 (seed 142045's Gaussian 15776) is proven at +1.06e-5; the same alpha
+    distance next to the centre of a round splat (terms of ~3) is not."""
+    def record(conic, dx, dy, a255):
+        a, b, c = conic
+        power = -0.5 * (a * dx * dx + c * dy * dy) - b * dx * dy
+        opacity = (1.0 + a255) / 255.0 / np.exp(power)
+        return dict(xy=np.array([[100.0 + dx, 100.0 + dy]]), conic_opacity=np.array([[a, b, c, opacity]]), radii=np.array([64]))
+    elongated = record((0.04700032, 0.07774512, 0.13831199), 31.0, -23.0, 1.06e-5)
+    got = pc.threshold_gaussians(elongated, [0], 200, 200)
+    assert got and got[0][:3] in ((0, 100, 100), (0, 162, 54)) and abs(got[0][3] - 1.06e-5) < 1e-7, got      # (the pixel or its mirror image through the centre)
+    assert not pc.threshold_gaussians(record((0.04700032, 0.07774512, 0.13831199), 31.0, -23.0, 4.0e-5), [0], 200, 200)        # beyond what fp32 can move it
+    round_splat = record((0.05, 0.0, 0.05), 8.0, 7.0, 1.06e-5)                 # terms of 1.6 + 1.2: the plain 1e-5 window applies
+    assert not pc.threshold_gaussians(round_splat, [0], 200, 200)
+    assert pc.threshold_gaussians(record((0.05, 0.0, 0.05), 8.0, 7.0, 0.9e-5), [0], 200, 200)
