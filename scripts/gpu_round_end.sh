@@ -6,6 +6,7 @@ R=$PWD; TAG=${1:-r06}
 mkdir -p gpurun_out/final
 timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/final/build_smoke.log 2>&1; echo build+smoke rc=$?
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -40 > gpurun_out/final/${TAG}_pytest_gpu.log; tail -4 gpurun_out/final/${TAG}_pytest_gpu.log
+cp gpurun_out/final/${TAG}_pytest_gpu.log profiles/ 2>/dev/null      # (bench.py carries the suite's tier tally: parity_vs_oracle.gpu_suite_tally)
 timeout 400 python bench.py > gpurun_out/final/${TAG}_bench.json 2> gpurun_out/final/bench.err; echo bench rc=$?; head -c 400 gpurun_out/final/${TAG}_bench.json; echo
 timeout 100 python bench.py --gpus 1 --steps 20 --warmup 5 --no-extras > gpurun_out/final/${TAG}_bench_driver_flags.json 2>/dev/null; head -c 300 gpurun_out/final/${TAG}_bench_driver_flags.json; echo
 export TMPDIR=/tmp; cd /tmp
