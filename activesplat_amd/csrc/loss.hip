@@ -75,13 +75,24 @@ __global__ __launch_bounds__(kBlock) void loss_stats_kernel(int W, int H, const 
     float sum_ssim = 0.f, sum_l1 = 0.f;
     const int ch = blockIdx.z;                  // one colour channel per workgroup: 3x the workgroups, a third of the serial chain
     {
-        for (int e = tid; e < kLP * kLP; e += kBlock) {
+        // the tile + halo: 676 values of each image, three per thread.  ALL loads are issued before the first LDS store: as a loop with a store
+        // behind each load the staging was three dependent memory round trips -- 5 of a wavefront's 6.8 us (round 6, rocprofv3 SQ_WAVE_CYCLES)
+        constexpr int kStage = (kLP * kLP + kBlock - 1) / kBlock;
+        float vx[kStage], vy[kStage];
+#pragma unroll
+        for (int it = 0; it < kStage; it++) {
+            const int e = tid + it * kBlock;
             const int r = e / kLP, c = e - r * kLP;
             const int gx = x0 + c - kLH, gy = y0 + r - kLH;
-            const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
-            const size_t o = ch * HW + (size_t)gy * W + gx;
-            s_x[r][c] = in ? im[o] : 0.f;
-            s_y[r][c] = in ? gt[o] : 0.f;
+            const bool in = e < kLP * kLP && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const size_t o = ch * HW + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+            vx[it] = im[o]; vy[it] = gt[o];
+            if (!in) { vx[it] = 0.f; vy[it] = 0.f; }
+        }
+#pragma unroll
+        for (int it = 0; it < kStage; it++) {
+            const int e = tid + it * kBlock;
+            if (e < kLP * kLP) { const int r = e / kLP, c = e - r * kLP; s_x[r][c] = vx[it]; s_y[r][c] = vy[it]; }
         }
         __syncthreads();
         for (int e = tid; e < kLP * kLT; e += kBlock) {       // horizontal pass: 26 rows x 16 columns
@@ -158,14 +169,23 @@ __global__ __launch_bounds__(kBlock) void loss_grad_kernel(int W, int H, const f
     const float k_ssim = -0.2f * w_im / n3, k_l1 = 0.8f * w_im / n3;
     const int ch = blockIdx.z;
     {
-        for (int e = tid; e < kLP * kLP; e += kBlock) {
+        // (all nine loads of a thread -- and the centre pixel's im / gt of the combine below -- in flight before the first LDS store: see loss_stats_kernel)
+        constexpr int kStage = (kLP * kLP + kBlock - 1) / kBlock;
+        float v0[kStage], v1[kStage], v2[kStage];
+#pragma unroll
+        for (int it = 0; it < kStage; it++) {
+            const int e = tid + it * kBlock;
             const int r = e / kLP, c = e - r * kLP;
             const int gx = x0 + c - kLH, gy = y0 + r - kLH;
-            const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
-            const size_t o = ch * HW + (size_t)gy * W + gx;
-            s_p[0][r][c] = in ? partials[o] : 0.f;
-            s_p[1][r][c] = in ? partials[3 * HW + o] : 0.f;
-            s_p[2][r][c] = in ? partials[6 * HW + o] : 0.f;
+            const bool in = e < kLP * kLP && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const size_t o = ch * HW + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+            v0[it] = partials[o]; v1[it] = partials[3 * HW + o]; v2[it] = partials[6 * HW + o];
+            if (!in) { v0[it] = 0.f; v1[it] = 0.f; v2[it] = 0.f; }
+        }
+#pragma unroll
+        for (int it = 0; it < kStage; it++) {
+            const int e = tid + it * kBlock;
+            if (e < kLP * kLP) { const int r = e / kLP, c = e - r * kLP; s_p[0][r][c] = v0[it]; s_p[1][r][c] = v1[it]; s_p[2][r][c] = v2[it]; }
         }
         __syncthreads();
         for (int e = tid; e < kLP * kLT; e += kBlock) {

@@ -221,7 +221,8 @@ class SplatMapper:
                                                       mc["ignore_outlier_depth_loss"], fused=cfg["fused_render"], fused_loss=cfg["fused_loss"],
                                                       fused_inputs=cfg["fused_inputs"], fused_preprocess=cfg.get("fused_preprocess", False),
                                                       fused_adam=self.optimizer if in_backward else None)
-            loss.backward(gradient=self._one)           # cached dL/dloss = 1: saves autograd's ones_like launch per iteration
+            with M.backward_on_calling_thread():        # (no hand-over to autograd's device thread: mapping.backward_on_calling_thread)
+                loss.backward(gradient=self._one)       # cached dL/dloss = 1: saves autograd's ones_like launch per iteration
             with torch.no_grad():
                 if mc["prune_gaussians"]:
                     self.params, self.variables = O.prune_gaussians(self.params, self.variables, self.optimizer, it, mc["pruning_dict"])

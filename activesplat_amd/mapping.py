@@ -239,6 +239,16 @@ def fused_rendervar(params, time_idx, pose7=None, accumulate_grads=False):
 _UNIT_GRADS = {}
 
 
+def backward_on_calling_thread():
+    """Context manager for `loss.backward()` in a mapping loop: autograd runs the backward of CUDA tensors on a per-device worker thread and the calling
+    thread waits for it -- two thread hand-overs per iteration, which on a many-core host cost nothing or ~100-190 us depending on where the scheduler
+    has put the two threads (measured at the reference's 256 x 256 / 200 k frame: 315-390 us per mapping iteration in the slow placement, 199-223 us in
+    the fast one, bimodal from run to run; `scripts/exp/ab_host_mt.sh`).  With multithreading off the backward runs on the calling thread: 199-223 us,
+    median = best.  One device per process (this package's layout), so nothing is lost.  A reference checkout gets the same with ONE line around
+    its loop."""
+    return torch.autograd.set_multithreading_enabled(False)
+
+
 def unit_gradient(like: torch.Tensor) -> torch.Tensor:
     """A cached scalar 1 of `like`'s device and dtype for `loss.backward(unit_gradient(loss))`."""
     key = (str(like.device), like.dtype)

@@ -278,7 +278,7 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
             params[k].grad = g
         total = float(torch.stack(losses).sum())
     else:
-        from .mapping import unit_gradient
+        from .mapping import backward_on_calling_thread, unit_gradient
         losses = []
         for i in mine:
             loss, variables = loss_fn(params, keyframes[i], variables)
@@ -287,7 +287,8 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
                 costs.record(i, _R.last_stats.get("num_rendered", 0), _R.last_stats.get("P", 0))
             # dL/dloss = 1 from the cache (autograd would fill a fresh one per keyframe: a launch each; the fused loss skips its scaling
             # launch for this very tensor); autograd accumulates into .grad across this rank's keyframes
-            loss.backward(unit_gradient(loss) if loss.dim() == 0 else None)
+            with backward_on_calling_thread():
+                loss.backward(unit_gradient(loss) if loss.dim() == 0 else None)
             losses.append(loss.detach())          # (read after the loop: a float() here would stall the host once per keyframe)
             if accumulate_statistics:
                 from .optim import accumulate_mean2d_gradient

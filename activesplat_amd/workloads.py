@@ -51,7 +51,8 @@ def configs2_optimise_loop(N, iters, device, densify_fn=None, densify_every=50, 
             rv.pop("colors_precomp")
             im, radius, depth, sil, dsq = R.render_rgbd(cam, shs=params["shs"], **rv)
         loss, _ = M.fused_mapping_loss(im, depth, dsq, gt_im, gt_depth, dict(im=0.5, depth=1.0))
-        loss.backward(M.unit_gradient(loss))             # (cached dL/dloss = 1: no fill launch, and the fused loss skips its scaling launch)
+        with M.backward_on_calling_thread():
+            loss.backward(M.unit_gradient(loss))         # (cached dL/dloss = 1: no fill launch, and the fused loss skips its scaling launch)
         variables["means2D"] = rv["means2D"]
         variables["seen"] = O.visibility_stats(radius, variables["max_2D_radius"])      # one launch: seen + running max radius in place
         with torch.no_grad():

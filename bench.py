@@ -152,7 +152,10 @@ class RenderWorkload:
     def step(self):
         from activesplat_amd import GaussianRasterizer
         color = GaussianRasterizer(raster_settings=self.cam)(means2D=self.m2d, **self.rv)[0]
-        return torch.autograd.grad(color, [self.rv[k] for k in self.keys] + [self.m2d], self.dL)
+        # (the backward on the calling thread instead of autograd's device thread: no thread hand-over per frame -- at 2 M Gaussians the frame is GPU-bound
+        # either way; at the reference's 256 x 256 frames the hand-over is what made the host the bound in the slow thread placement: INTEGRATION.md 3b)
+        with torch.autograd.set_multithreading_enabled(False):
+            return torch.autograd.grad(color, [self.rv[k] for k in self.keys] + [self.m2d], self.dL)
 
     def sequential(self, steps, warmup):
         for _ in range(warmup):
@@ -239,7 +242,8 @@ def mapping_iteration_ms(dev, params_cpu, W, H, flags, iters=20, warm=5):
             return
         loss, _, _ = M.get_loss(prm, data, var, 0, dict(im=0.5, depth=1.0), pose7=[1.0, 0, 0, 0, 0, 0, 0] if flags else None,
                                 fused_adam=opt if in_bwd else None, **flags)
-        loss.backward(M.unit_gradient(loss) if flags else None)
+        with M.backward_on_calling_thread():             # (the backward on the calling thread: 315-390 -> 199-223 us at 256 x 256 / 200 k, profiles/README.md)
+            loss.backward(M.unit_gradient(loss) if flags else None)
         with torch.no_grad():
             opt.step(); opt.zero_grad(set_to_none=True)
     for _ in range(warm):

@@ -33,6 +33,8 @@ def it():
         opt.step(); opt.zero_grad(set_to_none=True)
 
 
+if os.environ.get("MT") == "0":                             # the backward on the calling thread instead of autograd's device thread (no hand-over per iteration)
+    torch.autograd.set_multithreading_enabled(False)
 for _ in range(30):
     it()
 K = int(os.environ.get("K", 300))
