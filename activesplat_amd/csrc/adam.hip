@@ -48,7 +48,7 @@ hipError_t launch_adam(int64_t n, float* p, const float* g, float* m, float* v, 
     if (nb < 1) nb = 1;
     if (nb > 256 * 8) nb = 256 * 8;          // grid-stride: 8 workgroups per CU
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, n, p, g, m, v, (float)(1.0 - b1), (float)b2,
-                       (float)(1.0 - b2), step_size, inv_bc2s, (float)eps, (const uint32_t*)g_chain_fail_dev);
+                       (float)(1.0 - b2), step_size, inv_bc2s, (float)eps, (const uint32_t*)chain_fail_word());
     return hipGetLastError();
 }
 
@@ -128,7 +128,7 @@ hipError_t launch_adam_multi(int count, const GsAdamTensor* t, hipStream_t st)
 {
     for (int base = 0; base < count; base += kAdamMaxTensors) {
         AdamBatch b{};
-        b.fail = g_chain_fail_dev;
+        b.fail = chain_fail_word();
         unsigned next = 0;
         for (int i = base; i < count && i < base + kAdamMaxTensors; ++i) {
             if (t[i].n <= 0) continue;

@@ -193,7 +193,7 @@ int gs_async_status_word(uint32_t** host_word)
         // the sticky device-memory twin the optimiser kernels read (Cam::chain_fail).  Without it the library still works -- the step is then not
         // protected against a timed-out walk, as before round 6
         void* f = nullptr;
-        if (hipMalloc(&f, 64) == hipSuccess && hipMemset(f, 0, 64) == hipSuccess) gs::g_chain_fail_dev = (uint32_t*)f;
+        if (hipMalloc(&f, 64) == hipSuccess && hipMemset(f, 0, 64) == hipSuccess && hipGetDevice(&gs::g_chain_fail_device) == hipSuccess) gs::g_chain_fail_dev = (uint32_t*)f;
         else (void)hipGetLastError();
         word = (uint32_t*)h;
         gs::g_async_status_dev = (uint32_t*)d;
@@ -508,7 +508,7 @@ static int render_backward_impl(const GsCamera* cam, int32_t P, int64_t D, const
             fa.p[t] = a.param; fa.m[t] = a.exp_avg; fa.v[t] = a.exp_avg_sq;
             fa.c[t] = gs::adam_coef(a.lr, a.beta1, a.beta2, a.eps, a.step);
         }
-        fa.fail = gs::g_chain_fail_dev;
+        fa.fail = gs::chain_fail_word();
     } else {
         if (!means3D || !radii || !dL_dmeans2D || !dL_dmeans3D || !dL_dopacities)
             return fail(GS_EINVAL, "gs_render_backward: null input/output pointer");

@@ -1065,6 +1065,7 @@ std::atomic<int> g_chain_tickets{0};
 std::atomic<int> g_chain_polls{kChainPollsDefault};      // bound of a piece's wait for the piece in front (gs_set_backward_chain_polls: tests)
 uint32_t* g_async_status_dev = nullptr;      // device view of the host-mapped status word (api.hip: gs_async_status_word)
 uint32_t* g_chain_fail_dev = nullptr;        // its sticky device-memory twin (Cam::chain_fail)
+int g_chain_fail_device = -1;
 // list segments (walkers) per quadrant in the few-tile backward: 3 x 256 tiles x 4 quadrants = the chip's 3072 walker slots (gs_set_backward_segments)
 std::atomic<int> g_few_segments{kFewSegmentsMax};
 
@@ -1147,7 +1148,7 @@ hipError_t launch_blend_backward(const Cam& cam_in, const uint2* ranges, const u
     do { cam.chain_epoch = ++epoch; } while (cam.chain_epoch == 0u);          // (the forward leaves zero in the hand-over flags)
     cam.chain_ticket = g_chain_tickets.load(std::memory_order_relaxed); cam.chain_polls = g_chain_polls.load(std::memory_order_relaxed);
     cam.async_status = g_async_status_dev;
-    cam.chain_fail = g_chain_fail_dev;
+    cam.chain_fail = chain_fail_word();
     const int per = ((cam.gx * cam.gy + 7) >> 3) * (cam.split ? cam.split : cam.chain > 1 ? cam.chain : 1);
 #define GS_BWD(DG, FEW)                                                                                                          \
     hipLaunchKernelGGL((blend_backward_kernel<DG, 1, FEW>), dim3(per * 8 * 4), dim3(kWave), 0, st, cam, ranges, point_list, geom, final_T, \

@@ -556,6 +556,16 @@ extern std::atomic<int> g_chain_tickets;
 extern std::atomic<int> g_chain_polls;
 extern uint32_t* g_async_status_dev;
 extern uint32_t* g_chain_fail_dev;      // device-memory twin of the status word (Cam::chain_fail); null until gs_async_status_word has been called
+extern int g_chain_fail_device;         // the device it lives on
+// the word for a launch on the CURRENT device: one process per GPU is this library's layout, but a launch on another device of the same process must
+// not be handed a pointer into the first one's memory (it then runs unprotected, as before round 6)
+inline uint32_t* chain_fail_word()
+{
+    if (!g_chain_fail_dev) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return dev == g_chain_fail_device ? g_chain_fail_dev : nullptr;
+}
 extern std::atomic<int> g_few_segments;
 // images of few tiles (at most kFewTiles; the knob above can only lower the limit): the forward records every pixel's running state
 // at the recorded list positions (cut_level below: every 256th up to 4096, then powers of two) for the segmented backward.  Planes of H*W floats: [level][T, C0, C1, C2, D], then the

@@ -107,7 +107,7 @@ hipError_t launch_rows(int mode, int count, const GsRowTensor* t, int64_t row0, 
         }
         G += t[i].width;
     }
-    b.count = count; b.G = G; b.fail = mode == 2 ? g_chain_fail_dev : nullptr;
+    b.count = count; b.G = G; b.fail = mode == 2 ? chain_fail_word() : nullptr;
     if (n_rows <= 0 || G <= 0) return hipSuccess;
     const bool wide = G > 16;
     if (G > 64) return hipErrorInvalidValue;                        // (gs_pack_columns refuses more than 64 floats per Gaussian before it gets here)

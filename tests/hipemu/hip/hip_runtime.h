@@ -333,6 +333,7 @@ static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std:
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p ? 0 : 2; }
 static inline hipError_t hipMemset(void* p, int v, size_t n) { std::memset(p, v, n); return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 typedef void* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
