@@ -40,6 +40,8 @@ timeout 600 python scripts/configs_report.py > gpurun_out/final/${TAG}_configs.j
 timeout 200 python scripts/topdown_time.py > gpurun_out/final/${TAG}_topdown.json 2> gpurun_out/final/topdown.err; echo topdown rc=$?
 # `bench.py --gpus 2` with no launcher environment (both ranks on this one device: gloo): the self-launch path's line
 BENCH_SAME_DEVICE=1 timeout 300 python bench.py --gpus 2 --steps 3 --warmup 1 --no-extras > gpurun_out/final/${TAG}_bench_gpus2_same_device.json 2> gpurun_out/final/bench2.err; echo bench2 rc=$?
+# the same with EIGHT ranks on the one device (the north star's rank count: partition, exchange at row blocks of N / 8, densify cadence, both maps; gloo through host memory)
+BENCH_SAME_DEVICE=1 timeout 600 python bench.py --gpus 8 --steps 3 --warmup 1 --no-extras > gpurun_out/final/${TAG}_bench_gpus8_same_device.json 2> gpurun_out/final/bench8.err; echo bench8 rc=$?
 # the stand-alone multi-tensor Adam (keyframe batches, event iterations) on configs[2]'s 118 M elements; the mapping iteration at the reference's frames
 ELEMS=118000000 timeout 100 python scripts/adam_bench.py > gpurun_out/final/${TAG}_adam.txt 2>&1; tail -1 gpurun_out/final/${TAG}_adam.txt
 for mode in "ADAM=0 DIRECT=0" "ADAM=1 DIRECT=0" "ADAM=1 DIRECT=1"; do env $mode PROFILE=0 BATCHES=5 N=200000 W=256 H=256 timeout 120 taskset -c 4 python scripts/exp/map_iter.py 2>&1 | tail -1 | sed "s/^/$mode /"; done > gpurun_out/final/${TAG}_map_iter_256.txt; cat gpurun_out/final/${TAG}_map_iter_256.txt

@@ -417,6 +417,31 @@ def test_bench_gpus_2_launches_its_own_ranks(hip):
 
 
 @pytest.mark.gpu
+def test_bench_gpus_8_on_one_device(hip):
+    """`bench.py --gpus 8` as the driver's 8-GPU run launches it -- eight ranks, LPT partition of 16 keyframes, one densify event in the timed region, both
+    maps (G = 14 and the SH-3 leg, G = 59) -- with the development knob that puts all ranks on the one GPU of the test box (gloo)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_SAME_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--c4-gaussians", "100000",
+                        "--keyframes", "16", "--no-extras", "--c4-densify-every", "2"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["keyframes_per_rank_per_step"] == 2 and [x["rank"] for x in d["ranks"]] == list(range(8))
+    assert len({x["pid"] for x in d["ranks"]}) == 8 and d["config"]["partition"] == "lpt" and sum(d["config"]["keyframes_per_rank_last_step"]) == 16
+    assert len(d["per_rank_keyframes_ms"]["values"]) == 8 and min(d["per_rank_keyframes_ms"]["values"]) > 0
+    assert len(d["config"]["densify_events_in_timed_region"]) == 1 and d["config"]["gaussians_at_end"] != 100000
+    rf = d["roofline"]
+    assert rf["keyframes_per_gpu_per_step"] == 2 and rf["exchange_wire_bytes_per_rank"] == int(2 * rf["exchange_buffer_bytes"] * 7 / 8)
+    s3 = d["sh3_map_G59"]
+    assert s3["value"] > 0 and s3["roofline"]["exchange_floats_per_gaussian"] == 59 and len(s3["per_rank_keyframes_ms"]["values"]) == 8
+
+
+@pytest.mark.gpu
 def test_bench_configs3_with_sh_rows_exchanges_59_floats(hip):
     """configs[3] with configs[2]'s map (16-coefficient SH rows): the exchange carries G = 59 floats per Gaussian."""
     import json
@@ -689,6 +714,23 @@ def test_lpt_partition_of_64_keyframes_on_8_ranks():
     mean = cost.sum() / 8
     assert load(part).max() / mean < 1.03 < load(contiguous).max() / mean, (load(part).max() / mean, load(contiguous).max() / mean)
     assert load(part).max() <= (4 / 3 - 1 / 24) * max(mean, cost.max())
+
+
+@pytest.mark.gpu
+def test_eight_rank_row_surgery_on_the_device(hip):
+    """The north star's rank count on the real kernels: EIGHT processes share the one GPU of the test box (gloo for the exchange), four keyframes -- so
+    ranks 4-7 own none --, sharded Adam steps -> densify -> prune -> sharded steps: N, parameters and both moments identical on all eight ranks to
+    the bit, the same events everywhere, the shard plan rebuilt for row blocks of N / 8."""
+    res = sorted(_spawn(_worker_surgery, 8, (None, "cuda", 30000, 160, 128), timeout=900), key=lambda r: r["rank"])
+    assert [r["rank"] for r in res] == list(range(8))
+    for r in res:
+        assert r["same_n"] and r["same"] and r["steps"] == [6] and r["ts_ok"], r
+        assert [x[:4] for x in r["trace"]] == [x[:4] for x in res[0]["trace"]]
+    assert [x[0] for x in res[0]["trace"]] == ["densify", "prune", "densify"] and res[0]["trace"][0][3] != res[0]["trace"][0][2]
+    partial = [r["trace"][0][4] for r in res]
+    assert [p_ > 0 for p_ in partial] == [True] * 4 + [False] * 4, partial                  # the ranks without a keyframe hold zero statistics
+    n8, n1 = res[0]["trace"][-1][3], res[0]["single_trace"][-1][3]
+    assert abs(n8 - n1) <= max(2, 0.002 * n1), (n8, n1)                                       # (one rank alone: atomics order -> threshold neighbours)
 
 
 @pytest.mark.gpu
