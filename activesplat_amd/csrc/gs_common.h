@@ -661,7 +661,7 @@ uint64_t compact3_scratch_bytes(int64_t n);
 hipError_t launch_compact_index3(int64_t n, const uint8_t* ka, const uint8_t* kb, const uint8_t* kc, int n_rep, uint32_t* src_index,
                                  uint32_t* d_counts, void* scratch, hipStream_t st);
 
-// sort backend (sort_rocprim.hip): stable ascending radix sort of (key64, val32) pairs on bits [0,end_bit)
+// sort backend (sort_radix.hip: hand-written LSD radix sort, 8 bits per pass): stable ascending sort of (key64, val32) pairs on bits [0,end_bit)
 size_t sort_temp_bytes(int64_t D, int end_bit);
 hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
                       const uint32_t* vals_in, uint32_t* vals_out, int64_t D, int end_bit, hipStream_t st);

@@ -203,6 +203,20 @@ def test_more_tiles_than_the_lds_histogram_holds(hip, oracle32, oracle64):
     pc.check_backward(rs, rv, oracle64, oracle32=oracle32)
 
 
+@pytest.mark.parametrize("case", ["equal_depth", "crowded_depth_big", "merge_passes_even"])
+def test_radix_path_is_stable_on_long_tile_lists(hip, oracle32, case):
+    """The radix binning path (csrc/sort_radix.hip: hand-written LSD sort, round 6) on the scenes built for the per-tile sorts: every key of
+    `equal_depth` differs from its tile neighbours in nothing -- the order inside a tile is the sort's stability through its passes --, the others
+    hold tile lists of 10 k / 75 k keys with clustered depths.  keys, ids and ranges bit-exact against the oracle's stable sort."""
+    rs, rv = pc.build_case(case, hip)
+    pc.set_sort_path("radix")
+    try:
+        pc.check_forward(rs, rv, oracle32)
+        assert util.artefacts()["path"] == 2
+    finally:
+        pc.set_sort_path("auto")
+
+
 def test_zero_gaussians(hip):
     from activesplat_amd import GaussianRasterizer
     rs, _ = util.scene(4, 70, 50, device=hip, bg=(0.2, 0.4, 0.6))
