@@ -28,7 +28,7 @@ def test_emulated_big_tile_lists(emu, oracle32, case, path):
     assert util.artefacts()["path"] == path
 
 
-@pytest.mark.parametrize("case", ["basic", "ragged_image", "all_culled", "huge_gaussians", "dense_overdraw", "one_gaussian", "equal_depth"])   # (equal_depth: 9000 keys that differ in the
+@pytest.mark.parametrize("case", ["basic", "ragged_image", "all_culled", "huge_gaussians", "dense_overdraw", "one_gaussian", "equal_depth", "merge_tiles"])   # (merge_tiles: 22 run blocks of the sort in six workgroups; equal_depth: 9000 keys that differ in the
 # tile bits only inside a tile -- the order inside a tile is the STABILITY of sort_radix.hip, pass after pass)
 def test_emulated_forward_radix_path_matches_oracle(emu, oracle32, case):
     rs, rv = pc.build_case(case, emu)
