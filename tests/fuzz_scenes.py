@@ -67,4 +67,6 @@ FLAGGED_R05_RGBD = [(130045, None), (130237, None), (130378, None), (142132, "2"
 FLAGGED_R05_BACKWARD = [(140658, None), (160050, None)]
 #: round-6 sweep (profiles/r06_fuzz.txt): 142045 -- Gaussian 15776 (radius 61) owns pixel (223,106) at 255 alpha - 1 = +1.06e-5 where the exponent's terms are 22 + 36 + 55: the
 #: kernel skips it, both oracles blend it (94-97 % of three tensors' error in that row); the decision-matched tier's window now follows the terms' magnitude
-FLAGGED_R06_RGBD = [(142045, "2")]
+#: round-6 soak (profiles/r06_soak.txt): 210541 -- Gaussian 23255 at pixel (179,9): the fp32 record both fp32 evaluations share puts alpha within 3e-7 of 1/255 (the fp32 oracle skips,
+#: the kernel blends) while the fp64 record's pixel mean, 3.5e-5 px away, puts it at -3.04e-5: the tier now also proves a threshold pixel from the fp32 oracle's record
+FLAGGED_R06_RGBD = [(142045, "2"), (210541, "2")]
