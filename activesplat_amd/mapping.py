@@ -493,41 +493,6 @@ def mapping_iteration(params, curr_data, variables, iter_time_idx, loss_weights,
     return loss, variables, {"im": parts[1], "depth": parts[2], "loss": loss}
 
 
-def keyframe_gradients(params, curr_data, variables, iter_time_idx, loss_weights, pose7=None):
-    """One keyframe of a BATCH without autograd: the library calls of get_loss(fused=True, fused_loss=True, fused_preprocess=True, accumulate_grads=True) +
-    loss.backward(), issued directly -- the parameter gradients are ADDED into the parameters' .grad inside the per-Gaussian backward kernel (created
-    on the first keyframe), nothing is stepped.  What mapping_iteration is to the single-keyframe step, for parallel.sharded_keyframe_step(grad_fn=...).
-    Maps with `rgb_colors` (SH rows hand their gradient to the caller instead of accumulating in the kernel).
-    -> (loss, variables): variables['means2D'].grad, ['seen'], ['max_2D_radius'] as get_loss + backward leave them."""
-    from . import rasterizer as R
-    if pose7 is None:
-        q = F.normalize(params["cam_unnorm_rots"][..., iter_time_idx].detach()).reshape(4)
-        pose7 = torch.cat([q, params["cam_trans"][..., iter_time_idx].detach().reshape(3)]).cpu().tolist()
-    if "shs" in params:
-        raise Exception("keyframe_gradients: maps with `rgb_colors` only")
-    mx = variables["max_2D_radius"]
-    means = params["means3D"]
-    if not (mx.dtype == torch.float32 and mx.is_contiguous() and mx.device == means.device and mx.numel() == means.shape[0]):
-        raise RuntimeError("keyframe_gradients: variables['max_2D_radius'] must be a contiguous float32 [N] tensor on the parameters' device")
-    seen = torch.empty(mx.numel(), dtype=torch.bool, device=mx.device)
-    m2d = torch.empty_like(means, requires_grad=True)
-    iso = int(params["log_scales"].shape[1]) == 1
-    rctx = _DirectCtx()
-    im, radius, depth, _sil, depth_sq = R._RasterizeGaussians.forward(
-        rctx, means, m2d, None, params["rgb_colors"], params["logit_opacities"], params["log_scales"], params["unnorm_rotations"], None, curr_data["cam"], True,
-        (pose7, iso, True, (mx, seen), None))
-    lctx = _DirectCtx()
-    loss, parts = _FusedMappingLoss.forward(lctx, im, depth, depth_sq, curr_data["im"], curr_data["depth"], loss_weights["im"], loss_weights["depth"])
-    grads = lctx.saved_tensors[0]
-    out = R._RasterizeGaussians.backward(rctx, grads[:3], None, grads[3:], None, None)
-    if any(o is not None for i, o in enumerate(out) if i != 1):
-        raise RuntimeError("keyframe_gradients: the backward did not accumulate in the kernel (parameters must be contiguous fp32 leaves whose .grad tensors all exist or all do not)")
-    m2d.grad = out[1]
-    variables["means2D"] = m2d
-    variables["seen"] = seen
-    return loss, variables
-
-
 # ---------------------------------------------------------------------------------------------------
 # map initialisation / growth (splatam.py:25-115,304-379)
 # ---------------------------------------------------------------------------------------------------

@@ -204,7 +204,7 @@ def all_reduce_statistics(variables, group=None):
 
 def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank=None, world=None, buf=None,
                           sharded_adam=False, streams=1, densify_statistics=False, timing=False, accumulate_statistics=False, partition=None,
-                          costs=None, grad_fn=None):
+                          costs=None):
     """One optimiser step over a batch of keyframes sharded across ranks.
     loss_fn(params, keyframe, variables) -> (loss, variables).  Returns the local loss sum.
 
@@ -220,8 +220,6 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
     densifier's accumulators right after its backward (optim.accumulate_mean2d_gradient) -- the batch's statistic is then the sum over all of its
     keyframes whatever the number of ranks; the accumulators are rank-local partial sums until parallel.sharded_densify all-reduces them.
     partition: list of this step's keyframe indices per rank (parallel.balanced_partition); default: contiguous blocks (shard_keyframes).
-    grad_fn(params, keyframe, variables) -> (loss, variables) (serial walk only): in place of loss_fn + loss.backward() -- a call that has ALREADY added the
-    keyframe's gradients into .grad (mapping.keyframe_gradients: the same library calls without autograd).
     costs: a KeyframeCosts that the serial walk feeds with every rendered keyframe's tile-instance count (sync + partition are the caller's).
     (Round 6 built and removed a PIPELINED two-stream walk with in-kernel accumulation -- only the accumulating kernels ordered across the streams:
     -5 ... +4 % against this serial walk at 2 M Gaussians / 64 keyframes, kill criterion + 6 %: profiles/r06_ab_pipelined.txt.)"""
@@ -283,15 +281,14 @@ def sharded_keyframe_step(params, variables, keyframes, optimizer, loss_fn, rank
         from .mapping import backward_on_calling_thread, unit_gradient
         losses = []
         for i in mine:
-            loss, variables = (grad_fn or loss_fn)(params, keyframes[i], variables)
+            loss, variables = loss_fn(params, keyframes[i], variables)
             if costs is not None:                 # (the forward has read its counters back already: a host number, no sync)
                 from . import rasterizer as _R
                 costs.record(i, _R.last_stats.get("num_rendered", 0), _R.last_stats.get("P", 0))
             # dL/dloss = 1 from the cache (autograd would fill a fresh one per keyframe: a launch each; the fused loss skips its scaling
             # launch for this very tensor); autograd accumulates into .grad across this rank's keyframes
-            if grad_fn is None:
-                with backward_on_calling_thread():
-                    loss.backward(unit_gradient(loss) if loss.dim() == 0 else None)
+            with backward_on_calling_thread():
+                loss.backward(unit_gradient(loss) if loss.dim() == 0 else None)
             losses.append(loss.detach())          # (read after the loop: a float() here would stall the host once per keyframe)
             if accumulate_statistics:
                 from .optim import accumulate_mean2d_gradient

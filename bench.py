@@ -379,10 +379,6 @@ def run_c4(args, dev, rank, world, ranks_info=None, sh_degree=None, light=False)
                                 accumulate_grads=args.streams <= 1)
         return loss, v
 
-    def grad_fn(p, kf, v):
-        return M.keyframe_gradients(p, kf, v, 0, weights, pose7=kf["pose7"])
-    direct = grad_fn if (args.c4_direct and not sh and args.streams <= 1) else None
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -442,7 +438,7 @@ def run_c4(args, dev, rank, world, ranks_info=None, sh_degree=None, light=False)
 
     def step():
         _, state["v"], _ = PL.sharded_keyframe_step(params, state["v"], keyframes, opt, loss_fn, rank=rank, world=world,
-                                                    sharded_adam=True, streams=args.streams, grad_fn=direct, timing=True, accumulate_statistics=bool(every),
+                                                    sharded_adam=True, streams=args.streams, timing=True, accumulate_statistics=bool(every),
                                                     partition=state["part"], costs=costs)
         state["it"] += 1
         if lpt and (state["it"] == 1 or state["it"] % max(args.c4_rebalance_every, 1) == 0):
@@ -516,7 +512,7 @@ def run_c4(args, dev, rank, world, ranks_info=None, sh_degree=None, light=False)
         s1 = dict(v=v1)
 
         def step1():
-            _, s1["v"], _ = PL.sharded_keyframe_step(p1, s1["v"], keyframes, o1, loss_fn, rank=0, world=1, sharded_adam=True, streams=args.streams, grad_fn=direct)
+            _, s1["v"], _ = PL.sharded_keyframe_step(p1, s1["v"], keyframes, o1, loss_fn, rank=0, world=1, sharded_adam=True, streams=args.streams)
         n_ref = max(1, min(3, args.steps))
         step1()
         torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -663,8 +659,6 @@ def main():
     ap.add_argument("--keyframes", type=int, default=64, help="configs[3]: keyframes per optimiser step, sharded over the ranks")
     ap.add_argument("--c4-sh-degree", type=int, default=-1, help="configs[3]: -1 = `rgb_colors` (the reference mapper's map, G = 14 floats per Gaussian "
                                                                  "in the exchange); 0..3 = 16-coefficient SH rows (`shs`, G = 59)")
-    ap.add_argument("--c4-direct", action="store_true", help="configs[3], rgb_colors map: a keyframe's forward + loss + backward as direct library calls "
-                                                            "(mapping.keyframe_gradients) instead of get_loss + loss.backward() through autograd")
     ap.add_argument("--c4-one-map", action="store_true", help="configs[3]: time only the map --c4-sh-degree names (default: the rgb_colors map is `value` and the "
                                                              "same steps are timed again on the SH-3 map, reported as `sh3_map_G59`)")
     ap.add_argument("--predict-ranks", type=int, default=8, help="configs[3] on one GPU: ranks of the load-balance / exchange prediction leg")

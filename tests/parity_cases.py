@@ -828,35 +828,6 @@ def check_mapping_iteration_without_autograd(device, n=500, exact=True):
                 assert rel(a[1][k][0], b[1][k][0]) < 5e-5, (k, rel(a[1][k][0], b[1][k][0]))
 
 
-def check_keyframe_gradients(device, n=500):
-    """mapping.keyframe_gradients (a batch keyframe's forward + loss + backward as direct library calls, gradients added into .grad in the kernel) against
-    get_loss(fused ..., accumulate_grads=True) + loss.backward() through autograd: three keyframes accumulated -- losses equal, every .grad, means2D.grad,
-    seen and the running max radius equal to the order of the atomic sums."""
-    from activesplat_amd import mapping as M
-    from tests.test_parallel import _scene
-    outs = []
-    for direct in (False, True):
-        params, kfs = _scene(n=n, device=device)
-        nn_ = params["means3D"].shape[0]
-        var = {k: torch.zeros(nn_, device=device) for k in ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")}
-        tot = []
-        for t in (1, 2, 3):
-            if direct:
-                loss, var = M.keyframe_gradients(params, kfs[t], var, t, dict(im=0.5, depth=1.0))
-            else:
-                loss, var, _ = M.get_loss(params, kfs[t], var, t, dict(im=0.5, depth=1.0), fused=True, fused_loss=True, fused_preprocess=True, accumulate_grads=True)
-                loss.backward()
-            tot.append(float(loss.detach()))
-        outs.append((tot, {k: v.grad.clone() for k, v in params.items() if v.grad is not None}, var["max_2D_radius"].clone(), var["seen"].clone(),
-                     var["means2D"].grad.clone()))
-    a, b = outs
-    assert all(abs(x - y) <= 1e-6 * abs(x) for x, y in zip(a[0], b[0])), (a[0], b[0])
-    assert sorted(a[1]) == sorted(b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
-    for k in a[1]:
-        assert float((a[1][k] - b[1][k]).norm()) <= 2e-5 * float(a[1][k].norm()), k
-    assert float((a[4] - b[4]).norm()) <= 2e-5 * float(a[4].norm())
-
-
 def check_few_tile_backward_segments(device, oracle64, oracle32=None, N=20000, W=64, H=48, seed=41):
     """Images of at most 256 tiles: the backward walks every quadrant's list in 3 (default), 2 or 1 segments on as many wavefronts, the
     front ones resuming from the per-pixel state the forward recorded (every 256th list position up to 4096, powers of two beyond).  A scene

@@ -658,10 +658,6 @@ def test_unrendered_rows_of_a_keyframe_batch_are_written(hip):
     pc.check_unrendered_rows_are_written(hip, n=8192, W=96, H=64)
 
 
-def test_keyframe_gradients_without_autograd_equal_the_autograd_path(hip):
-    pc.check_keyframe_gradients(hip, n=20000)
-
-
 def test_mapping_iteration_without_autograd_equals_the_autograd_path(hip):
     pc.check_mapping_iteration_without_autograd(hip, n=20000, exact=False)
 
