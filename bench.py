@@ -997,6 +997,18 @@ def main():
                 side[name] = {"workload": label, "sequential_frames_per_s": round(1.0 / t, 1), "ms_per_frame": round(t * 1e3, 4), "tile_instances_D": D1,
                               "frame_alg_bytes": fb1, "frame_frac_hbm": round(fb1 / t / HBM_PEAK, 4), "two_stream_frames_per_s": round(1.0 / t2, 1),
                               "stages": {k: {"avg_us": v["avg_us"], "frac_hbm": v["frac_hbm"]} for k, v in st1.items()}}
+                try:
+                    # the blend pair against the fp32 vector peak (F_alg = E x (12 fwd + 40 bwd) flop, E = sum of n_contrib): how much of a
+                    # blend's time is WORK -- early termination saturates the evaluations per pixel, so E does not grow with the Gaussian count
+                    with torch.no_grad(), R.capture() as st_c:
+                        GaussianRasterizer(raster_settings=w1.cam)(means2D=torch.zeros(n_, 3, device=dev), **{k: v.detach() for k, v in w1.rv.items()})
+                    il1 = st_c["il"]
+                    E1 = int(st_c["image"][il1.n_contrib:il1.n_contrib + 4 * W * H].view(torch.int32).to(torch.int64).sum().item())
+                    del st_c
+                    side[name]["blend_flops"] = {"evaluations_E": E1, "forward_frac_fp32_peak": round(E1 * 12 / (st1["blend_forward"]["avg_us"] * 1e-6) / FP32_PEAK, 4),
+                                                 "backward_frac_fp32_peak": round(E1 * 40 / (st1["blend_backward"]["avg_us"] * 1e-6) / FP32_PEAK, 4)}
+                except Exception as e:
+                    side[name]["blend_flops"] = {"error": str(e)}
                 if n_ == 500_000:
                     params1 = w1.params
                     pr1 = profiled_kernels("c1")

@@ -7,7 +7,7 @@
 // for tests/ only: nothing in activesplat_amd/ includes, links or falls back to it, and the product
 // loader (activesplat_amd/_lib.py) only ever opens the hipcc-built libgsplat_hip.so.
 //
-// Model: one workgroup = one OS thread running blockDim fibers (ucontext).  A fiber runs until it
+// Model: one workgroup = one OS thread running blockDim fibers (a register-only context switch on x86-64, ucontext elsewhere).  A fiber runs until it
 // reaches __syncthreads(), a wave collective, or the end of the kernel.  Wave collectives
 // (__shfl*, __ballot, ...) rendezvous the live lanes of a 64-lane wavefront.  Workgroups run in
 // parallel over OpenMP threads.  Not modelled: memory-ordering subtleties, LDS bank conflicts,
@@ -64,7 +64,11 @@ static inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; 
 namespace hipemu {
 enum St { READY, AT_BARRIER, AT_WAVE, DONE };
 struct Fiber {
+#if defined(__x86_64__)
+    void* sp;                        // saved stack pointer (hipemu.cpp's register-only switch: no signal-mask system call per yield)
+#else
     ucontext_t ctx;
+#endif
     St st;
     dim3 tid;
     unsigned long long wave_in;      // payload deposited for a wave collective
@@ -73,7 +77,11 @@ struct Fiber {
 };
 struct Block {
     std::vector<Fiber> fibers;
+#if defined(__x86_64__)
+    void* sched_sp;
+#else
     ucontext_t sched;
+#endif
     int cur = -1;
     dim3 bid, bdim, gdim;
     unsigned long long wave_out[16][64];    // snapshot per wave (<=1024 threads)

@@ -7,6 +7,58 @@ thread_local Block* g_blk = nullptr;
 
 static constexpr size_t STACK = 96 * 1024;
 
+#if defined(__x86_64__)
+// swapcontext() saves and restores the signal mask: two system calls per yield, and a barrier of a 256-thread workgroup is 512 yields.  The
+// fibers here never touch signals, so the switch is the callee-saved registers and the stack pointer (System V x86-64 ABI).
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch,.-hipemu_switch
+)");
+
+void yield_to_sched()
+{
+    Block* b = g_blk;
+    hipemu_switch(&b->fibers[b->cur].sp, b->sched_sp);
+}
+
+static void fiber_entry()
+{
+    Block* b = g_blk;
+    (*b->body)();
+    b->fibers[b->cur].st = DONE;
+    for (;;) yield_to_sched();          // a finished fiber is never resumed; it must not return (there is no frame below it)
+}
+
+static void fiber_init(Block& b, Fiber& f)
+{
+    // the first switch pops six registers and `ret`s into fiber_entry with the stack as after a call (rsp = 8 mod 16)
+    uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
+    void** sp = (void**)(top - 64);
+    for (int i = 0; i < 8; i++) sp[i] = nullptr;
+    sp[6] = (void*)fiber_entry;
+    f.sp = sp;
+}
+static inline void resume(Block& b, Fiber& f) { hipemu_switch(&b.sched_sp, f.sp); }
+#else
 void yield_to_sched()
 {
     Block* b = g_blk;
@@ -22,6 +74,17 @@ static void fiber_entry()
     // returning switches to uc_link (= scheduler)
 }
 
+static void fiber_init(Block& b, Fiber& f)
+{
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = STACK;
+    f.ctx.uc_link = &b.sched;
+    makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+}
+static inline void resume(Block& b, Fiber& f) { swapcontext(&b.sched, &f.ctx); }
+#endif
+
 static void run_block(Block& b, int nthreads)
 {
     g_blk = &b;
@@ -29,11 +92,7 @@ static void run_block(Block& b, int nthreads)
         Fiber& f = b.fibers[t];
         f.st = READY;
         f.tid = dim3(t % b.bdim.x, (t / b.bdim.x) % b.bdim.y, t / (b.bdim.x * b.bdim.y));
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = STACK;
-        f.ctx.uc_link = &b.sched;
-        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+        fiber_init(b, f);
     }
     b.barrier_acc = 0; b.barrier_count = 0;
     const int nwaves = (nthreads + 63) / 64;
@@ -43,7 +102,7 @@ static void run_block(Block& b, int nthreads)
             if (b.fibers[t].st != READY) continue;
             ran = true;
             b.cur = t;
-            swapcontext(&b.sched, &b.fibers[t].ctx);
+            resume(b, b.fibers[t]);
         }
         // release wave collectives: after a full pass no fiber is READY, so the lanes waiting at a
         // collective are exactly the active lanes of it.
@@ -90,8 +149,17 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& body)
     {
         Block b;
         b.fibers.resize(nthreads);
-        std::vector<char> stacks((size_t)nthreads * STACK);
-        for (int t = 0; t < nthreads; t++) b.fibers[t].stack = stacks.data() + (size_t)t * STACK;
+        // the fiber stacks of an OS thread live as long as the thread (OpenMP keeps its pool): a fresh zero-filled 24 MB vector per thread and
+        // launch was most of the emulated suite's system time (page faults)
+        static thread_local char* stacks = nullptr;
+        static thread_local int stacks_for = 0;
+        if (stacks_for < nthreads) {
+            std::free(stacks);
+            stacks = (char*)std::malloc((size_t)nthreads * STACK + 64);
+            if (!stacks) { std::fprintf(stderr, "hipemu: out of memory for the fiber stacks\n"); std::abort(); }
+            stacks_for = nthreads;
+        }
+        for (int t = 0; t < nthreads; t++) b.fibers[t].stack = stacks + (size_t)t * STACK;
         b.bdim = block; b.gdim = grid; b.body = &body;
 #pragma omp for schedule(dynamic, 1)
         for (long long i = 0; i < nblocks; i++) {
