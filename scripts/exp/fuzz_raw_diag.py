@@ -70,3 +70,17 @@ for seed in [int(s) for s in os.environ["SEEDS"].split(",")]:
             print(f"   depth order not decided in fp32, both footprints reach the box: Gaussians {i0} / {i1}: z {float(z32c[i0]):.9g} / {float(z32c[i1]):.9g} (fp64 {float(z64[i0]):.12g} / {float(z64[i1]):.12g}); "
                   f"centres ({px[i0]:.1f},{py[i0]:.1f}) r {ra[i0]} / ({px[i1]:.1f},{py[i1]:.1f}) r {ra[i1]}; opacities {float(torch.sigmoid(p['logit_opacities'][i0])):.3f} / {float(torch.sigmoid(p['logit_opacities'][i1])):.3f}")
     print(f"   {len(inv)} adjacent pairs in the fp32 depth order are within four ulps in fp32 or inverted in fp64; {int((ra != rb).sum())} radii differ")
+    # the pixels no undecided pair covers (tests/parity_cases._depth_ties_cover's criterion), with their differences
+    rad = out[0][1].cpu().float()
+    cov = torch.zeros(len(ys), dtype=torch.bool)
+    xs_c, ys_c = xs.cpu(), ys.cpu()
+    pxt, pyt = torch.from_numpy(px), torch.from_numpy(py)
+    for j in inv.tolist():
+        i0, i1 = int(order[j]), int(order[j + 1])
+        if rad[i0] > 0 and rad[i1] > 0:
+            both = torch.ones(len(ys), dtype=torch.bool)
+            for i in (i0, i1):
+                both &= ((xs_c - pxt[i]).abs() <= rad[i] + 1) & ((ys_c - pyt[i]).abs() <= rad[i] + 1)
+            cov |= both
+    unc = torch.nonzero(~cov)[:, 0].tolist()
+    print(f"   {len(unc)} differing pixels outside every undecided pair's footprints:", [(int(xs_c[k]), int(ys_c[k]), "%.2e" % float(d[ys[k], xs[k]])) for k in unc[:12]])

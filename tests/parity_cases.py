@@ -395,7 +395,7 @@ def check_raw_parameter_mode_sh(device, n=400, W=64, H=48):
 def _depth_ties_cover(prm_means, pose, rv_means, radius, d, W, H, tol):
     """True when every pixel of `d` above `tol` lies in the footprints of a pair of Gaussians whose view depths are within four ulps in fp32 (or ordered the other
     way in fp64): the depth order of such a pair is not decided in fp32, the two entries evaluate the frame transform with different roundings, and either order is a
-    valid rendering (scripts/exp/fuzz_raw_diag.py prints the pairs)."""
+    valid rendering (scripts/exp/fuzz_raw_diag.py prints the pairs).  -> (all covered, covered pixels, differing pixels, largest difference OUTSIDE the pairs' footprints)."""
     from activesplat_amd import synthetic as syn
     K = syn.intrinsics(W, H)
     z32 = rv_means[:, 2].cpu()
@@ -417,7 +417,8 @@ def _depth_ties_cover(prm_means, pose, rv_means, radius, d, W, H, tol):
             for i in (i0, i1):
                 both &= ((xs - px[i]).abs() <= ra[i] + 1) & ((ys - py[i]).abs() <= ra[i] + 1)
             covered |= both
-    return bool(covered.all()), int(covered.sum()), len(ys)
+    rest = d.cpu()[ys[~covered], xs[~covered]]
+    return bool(covered.all()), int(covered.sum()), len(ys), (float(rest.max()) if len(rest) else 0.0)
 
 
 def check_raw_entry_random_draw(seed, device, rows_detail=False):
@@ -467,8 +468,11 @@ def check_raw_entry_random_draw(seed, device, rows_detail=False):
     for u, v, tol, nm in ((x[0], y[0], 5e-5, "colour"), (x[1], y[1], 5e-4, "depth")):
         d = (u - v).abs()
         if not (float((d > tol).float().mean()) < 2e-3 and float(d.max()) < 0.03 * max(1.0, float(v.abs().max()))):
-            ok, c, m = _depth_ties_cover(p["means3D"], pose, tm, x[2], d.amax(0), W, H, tol)
-            assert ok, (nm, float(d.max()), int((d > tol).sum()), "pixels in depth-tie footprints: %d of %d" % (c, m))
+            # a depth tie may come with the ordinary alpha = 1/255 threshold flips elsewhere in the image (seeds 4385 / 4668 of the round-6 soak: one and two
+            # pixels of 4e-4 .. 2.4e-3 next to 60 / 63 tie pixels): what the pairs' footprints do not cover must meet the bound a scene without a tie meets
+            ok, c, m, rest = _depth_ties_cover(p["means3D"], pose, tm, x[2], d.amax(0), W, H, tol)
+            assert c > 0 and (m - c) / float(H * W) < 2e-3 and rest < 0.03 * max(1.0, float(v.abs().max())), \
+                (nm, float(d.max()), int((d > tol).sum()), "pixels in depth-tie footprints: %d of %d, largest difference outside them %.2e" % (c, m, rest))
             return "depth tie"
     verdict = "ok"
     for k in x[3]:
@@ -522,7 +526,7 @@ def _classify_loss_call_difference(p, q, t, kf, cam, W, H, dev):
         return "depth L1 kink", flips
     d = (a[0] - b[0]).abs().amax(0)
     if int((d > 5e-5).sum()):
-        ok, c, m = _depth_ties_cover(p["means3D"], pose7, rv0["means3D"].detach(), a[1], d, W, H, 5e-5)
+        ok, c, m, _ = _depth_ties_cover(p["means3D"], pose7, rv0["means3D"].detach(), a[1], d, W, H, 5e-5)
         if ok:
             return "depth tie", "%d pixels differ by more than 5e-5 (max %.1e), all in the footprints of depth-tied pairs" % (m, float(d.max()))
         return None, "%d pixels differ by more than 5e-5 (max %.1e), %d of them in depth-tie footprints" % (m, float(d.max()), c)

@@ -100,8 +100,8 @@ def test_depth_tie_rule_covers_only_the_pair_s_footprints():
         d[21, 21] = 0.1                                     # inside both footprints
         assert pc._depth_ties_cover(means, pose, means, radius, d, W, H, 1e-3)[0] is expect
         d[30, 50] = 0.1                                     # inside the third splat only: never excused
-        ok, covered, total = pc._depth_ties_cover(means, pose, means, radius, d, W, H, 1e-3)
-        assert not ok and total == 2 and covered == (1 if expect else 0)
+        ok, covered, total, rest = pc._depth_ties_cover(means, pose, means, radius, d, W, H, 1e-3)
+        assert not ok and total == 2 and covered == (1 if expect else 0) and abs(rest - 0.1) < 1e-7     # (the residue is what the caller bounds like a scene without a tie)
 
 
 def test_needle_splat_conic_is_well_conditioned(emu, oracle32, oracle64):

@@ -29,9 +29,30 @@ def _draw(seed, device):
     return rs, rv
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(120))
 def test_random_scene_matches_oracle(emu, oracle32, oracle64, seed):
     rs, rv = _draw(1000 + seed, emu)
     pc.check_forward(rs, rv, oracle32)
-    if seed % 2 == 0:
-        pc.check_backward(rs, rv, oracle64, oracle32=oracle32)
+    pc.check_backward(rs, rv, oracle64, oracle32=oracle32)
+    if seed % 3 == 0 and "colors_precomp" in rv and "cov3D_precomp" not in rv:
+        pc.check_fused_rgbd(rs, rv, oracle64, seed=seed, oracle32=oracle32)   # the single-pass RGB-D render and its depth-gradient backward (as the GPU sweep does)
+
+
+@pytest.mark.parametrize("seed", [4 * k + 1 for k in range(75_000, 75_008)])
+def test_larger_sweep_scene_matches_oracle(emu, oracle32, oracle64, seed):
+    """The sweeps' larger draw (tests/fuzz_scenes.py, seed % 4 == 1): 3 000..30 000 Gaussians on up to 200 x 160 pixels -- several binning chunks and tile
+    lists of thousands on the emulated kernels."""
+    from tests.fuzz_scenes import sweep_scene
+    rs, rv = sweep_scene(seed, emu)
+    pc.check_forward(rs, rv, oracle32)
+    pc.check_backward(rs, rv, oracle64, oracle32=oracle32)
+
+
+@pytest.mark.parametrize("seed", range(330_000, 330_024))
+def test_anisotropic_scene_matches_oracle(emu, oracle32, oracle64, seed):
+    """The sweeps' HARD = 1.2 variant: every axis of every splat scaled by an independent exp(N(0, 1.2)) (median anisotropy 8, maximum above 2 000), every odd
+    seed's scene right in front of the near plane -- the scenes whose needle splats the factorised 2-D covariance was introduced for."""
+    from tests.fuzz_scenes import hard_scene
+    rs, rv = hard_scene(seed, emu, 1.2)
+    pc.check_forward(rs, rv, oracle32, oracle64=oracle64)
+    pc.check_backward(rs, rv, oracle64, oracle32=oracle32)
