@@ -16,13 +16,19 @@ def run(N=500_000, W=640, H=480, steps=int(os.environ.get("STEPS", 30)), warmup=
     dev = torch.device("cuda")
     sh = os.environ.get("SH")
     cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=dev, sh_degree=int(sh) if sh else 0)
-    rv = {k: v.to(dev).requires_grad_(True) for k, v in syn.activate(syn.make_params(N, W, H, seed=0, sh_degree=int(sh) if sh else None)).items()}
+    prm = syn.make_params(N, W, H, seed=0, sh_degree=int(sh) if sh else None)
+    if os.environ.get("CULL"):                              # this fraction of the Gaussians, picked at random, lies behind the camera (the bench scene is 100 % visible)
+        hide = torch.rand(N, generator=torch.Generator().manual_seed(3)) < float(os.environ["CULL"])
+        prm["means3D"][hide, 2] = -prm["means3D"][hide, 2]
+    rv = {k: v.to(dev).requires_grad_(True) for k, v in syn.activate(prm).items()}
     dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
     lib = _lib.get()
     if os.environ.get("CHAIN"):                             # gs_set_backward_chain: pieces of a chained backward walk (1 = one walker per quadrant)
         lib.gs_set_backward_chain(int(os.environ["CHAIN"]), int(os.environ.get("CHAIN_MIN_TILES", -1)))
     if os.environ.get("TICKETS"):                           # gs_set_backward_chain_tickets: ordered tickets of the chained walks (A/B)
         lib.gs_set_backward_chain_tickets(int(os.environ["TICKETS"]))
+    if os.environ.get("CULLED_FILL"):                       # gs_set_culled_fill: 0 = the per-Gaussian backward writes the zero rows of unrendered Gaussians itself
+        lib.gs_set_culled_fill(int(os.environ["CULLED_FILL"]))
     if os.environ.get("SEGS"):                              # gs_set_backward_segments: list segments per quadrant in the few-tile backward
         lib.gs_set_backward_segments(int(os.environ["SEGS"]))
     if os.environ.get("HALF"):                              # gs_set_half_quadrants: images of at most this many tiles use half-quadrant wavefronts

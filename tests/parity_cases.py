@@ -481,7 +481,14 @@ def check_raw_entry_random_draw(seed, device, rows_detail=False):
         e2 = ((x[3][k] - y[3][k]).reshape(n, -1) ** 2).sum(1)
         nr = float(x[3][k].norm().clamp_min(1e-30))
         rest = float((e2.sum() - e2.sort().values[-2:].sum()).clamp_min(0).sqrt()) if n > 8 else 0.0
-        assert rest < 3e-4 * nr, (k, rest / nr, float(e2.sum().sqrt()) / nr)
+        if not rest < 3e-4 * nr:
+            # a depth tie SMALL enough for the images to pass the bound above (seeds 8395 / 8572 of the round-6 soak: 15 / 11 pixels, at most 1.8e-3 / 5.6e-3)
+            # still reorders the pair for every Gaussian blended behind it there -- more than two rows move (3.4e-4 / 4.5e-4 of the norm without the two
+            # worst): the same verdict as above when the pairs' footprints cover every differing pixel
+            d = (x[0] - y[0]).abs().amax(0)
+            ok, c, m, _ = _depth_ties_cover(p["means3D"], pose, tm, x[2], d, W, H, 5e-5)
+            assert ok and c > 0 and rest < 3e-3 * nr, (k, rest / nr, float(e2.sum().sqrt()) / nr, "pixels in depth-tie footprints: %d of %d" % (c, m))
+            return "depth tie"
         if not float(e2.sum().sqrt()) < 3e-3 * nr and verdict == "ok":
             w = int(e2.argmax())
             verdict = ("rows", k, w, round(float(e2.sum().sqrt()) / nr, 5))
@@ -783,6 +790,58 @@ def check_unrendered_rows_are_written(device, n=512, W=64, H=48):
                 if not k.startswith("cam_"):
                     assert v.grad is not None and bool(torch.isfinite(v.grad).all()), (k, sh, step)
                     assert float(v.grad[n // 2:].abs().max()) == 0.0, (k, sh, step)
+
+
+def check_unrendered_rows_of_dense_gradients(device):
+    """The dense gradient outputs of the drop-in call and of the raw-parameter entry (nothing accumulated): with every float allocation of the call
+    poisoned with NaN (the Python twin of the front-end allocates through torch.empty) every gradient is finite and the row of a Gaussian the frame did
+    not render is exactly zero in every output.  Colours, 16- and 9-coefficient SH rows, a precomputed covariance, ragged Gaussian counts, a scene none
+    of whose Gaussians is rendered, whole wavefronts of unrendered rows as well as scattered ones, images on both sides of the few-tile threshold."""
+    from activesplat_amd import rasterizer as R
+    from activesplat_amd import synthetic as syn
+    from activesplat_amd.camera import setup_camera
+    was = R.use_frontend
+    R.use_frontend = False
+    try:
+        for name, n_over in (("basic", None), ("sh3", None), ("sh2_ragged", None), ("cov3d_precomp", None), ("all_culled", None), ("one_gaussian", None),
+                             ("basic", 511), ("basic", 513), ("sh3", 1025), ("mixed_sizes", None)):
+            rs, rv = build_case(name, device)
+            if n_over:
+                rv = {k: v[:n_over].contiguous() for k, v in rv.items()}
+            n = rv["means3D"].shape[0]
+            if name != "all_culled" and n > 8:
+                rv = {k: v.clone() for k, v in rv.items()}
+                rv["means3D"][n // 3:n // 3 + min(200, n // 4), 2] = -1.0
+            H, W = int(rs.image_height), int(rs.image_width)
+            dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(11))
+            with poisoned_empty():
+                res = util.run_product(rs, rv, dL)
+            dead = res["radii"] <= 0
+            assert name == "all_culled" or dead.any() or n <= 8, (name, "no unrendered row in the case")
+            for k, g in res["grads"].items():
+                assert np.isfinite(g).all(), (name, n_over, k, int((~np.isfinite(g)).sum()))
+                assert not dead.any() or float(np.abs(g[dead]).max()) == 0.0, (name, n_over, k)
+        for iso, (W, H), n in ((False, (64, 48), 700), (True, (64, 48), 700), (False, (288, 272), 3000)):
+            p = syn.make_params(n, W, H, seed=21)
+            if iso:
+                p["log_scales"] = p["log_scales"][:, :1].contiguous()
+            p["means3D"][n // 2:n // 2 + 150, 2] = -p["means3D"][n // 2:n // 2 + 150, 2]
+            cam = setup_camera(W, H, syn.intrinsics(W, H), np.eye(4), device=device)
+            g = torch.Generator().manual_seed(5)
+            dLc, dLd = torch.randn(3, H, W, generator=g).to(device), torch.randn(1, H, W, generator=g).to(device)
+            prm = {k: torch.nn.Parameter(v.clone().to(device)) for k, v in p.items()}
+            with poisoned_empty():
+                m2d = torch.empty_like(prm["means3D"], requires_grad=True)
+                im, radius, depth, sil, dsq = R.render_rgbd_raw(cam, prm["means3D"], m2d, prm["logit_opacities"], prm["log_scales"], prm["unnorm_rotations"],
+                                                                [1.0, 0, 0, 0, 0, 0, 0], colors_precomp=prm["rgb_colors"])
+                ((im * dLc).sum() + (depth * dLd).sum()).backward()
+            dead = radius.cpu() <= 0
+            assert bool(dead.any()) and not bool(dead.all())
+            for k, gk in dict({k: v.grad.cpu() for k, v in prm.items()}, means2D=m2d.grad.cpu()).items():
+                assert bool(torch.isfinite(gk).all()), (iso, W, k)
+                assert float(gk[dead].abs().max()) == 0.0, (iso, W, k)
+    finally:
+        R.use_frontend = was
 
 
 def check_mapping_iteration_without_autograd(device, n=500, exact=True):

@@ -156,6 +156,10 @@ def test_emulated_unrendered_rows_of_a_keyframe_batch_are_written(emu):
     pc.check_unrendered_rows_are_written(emu)
 
 
+def test_emulated_unrendered_rows_of_dense_gradients_are_zero(emu):
+    pc.check_unrendered_rows_of_dense_gradients(emu)
+
+
 def test_emulated_mapping_iteration_without_autograd_equals_the_autograd_path(emu):
     import ctypes
     omp = ctypes.CDLL("libgomp.so.1")

@@ -653,6 +653,11 @@ def test_adam_inside_the_backward_is_applied_once_and_never_silently(hip):
 
 
 @pytest.mark.gpu
+def test_unrendered_rows_of_dense_gradients_are_zero(hip):
+    pc.check_unrendered_rows_of_dense_gradients(hip)
+
+
+@pytest.mark.gpu
 def test_unrendered_rows_of_a_keyframe_batch_are_written(hip):
     """the keyframe-batch gate of the per-Gaussian backward must still write dL/dmeans2D for wavefronts it skips."""
     pc.check_unrendered_rows_are_written(hip, n=8192, W=96, H=64)
@@ -682,11 +687,12 @@ def test_loss_call_fully_fused_equals_the_reference_call_pattern_on_random_draws
     assert v == "ok" or v[0] in ("L1 kink", "depth L1 kink", "depth tie", "rows")
 
 
-@pytest.mark.parametrize("seed", list(range(24)) + [1782, 3452, 3570, 3988, 4385, 4668])
+@pytest.mark.parametrize("seed", list(range(24)) + [1782, 3452, 3570, 3988, 4385, 4668, 8395, 8572])
 def test_raw_parameter_rasteriser_on_random_draws(hip, seed):
     """Two dozen draws of the 4000-scene sweep of profiles/r05_fuzz_raw.txt (scripts/exp/fuzz_raw.py), plus four it flagged: 1782 / 3452 (two overlapping splats
     one / two fp32 ulps apart in view depth, blended in either order by the two entries: 0.15 / 0.065 on their footprints) and 3570 / 3988 (one alpha = 1/255
     decision at one pixel moves one Gaussian's gradient row by 2-5 %) and two the round-6 soak flagged: 4385 / 4668 (a depth tie on 60 / 63 pixels AND one / two ordinary
-    threshold flips of 4e-4 .. 2.4e-3 elsewhere: the residue outside the pair's footprints is held to the bound of a scene without a tie).  The draw itself asserts; the classes are what the sweep recorded, not asserted here (they
+    threshold flips of 4e-4 .. 2.4e-3 elsewhere: the residue outside the pair's footprints is held to the bound of a scene without a tie) and 8395 / 8572 (a tie on
+    15 / 11 pixels -- inside the image bound -- that moves more than two gradient rows: 3.4e-4 / 4.5e-4 without the two worst).  The draw itself asserts; the classes are what the sweep recorded, not asserted here (they
     hang on the last bit of the device's arithmetic)."""
     assert pc.check_raw_entry_random_draw(seed, hip) in ("ok", "depth tie") or seed in (3570, 3988)
