@@ -56,6 +56,21 @@ def test_decision_matched_tier_end_to_end_on_the_emulated_kernels(emu, oracle32,
     assert all(rel < 1e-5 for _, _, rel, _ in where)                          # with the decision matched: the fp32 oracle's own level
 
 
+def test_decision_matched_tier_with_two_threshold_pixels_of_one_gaussian(emu, oracle32, oracle64):
+    """Seed 400746 of the emulated sweep (scripts/exp/fuzz_emu.py; 257 Gaussians with SH rows and a precomputed covariance): Gaussian 67 owns pixel
+    (7, 31) at 255 alpha - 1 = -8.5e-7, where the kernel blends it and both oracles skip it, AND pixel (33, 29) inside the default 5e-6 move of the
+    threshold, where all three skip it.  dL/dopacity fails tiers 1 and 2 through the five Gaussians blended BEHIND 67 at (7, 31) -- 67's own row is not
+    among the three that carry most of the error -- so the tier reuses the decision means3D was matched with, and needs a move of the threshold narrow
+    enough to stop between the two pixels."""
+    rs, rv = sweep_scene(400746, emu)
+    before = pc.HATCH["decisions"]
+    pc.check_forward(rs, rv, oracle32)
+    pc.check_backward(rs, rv, oracle64, oracle32=oracle32)
+    where = pc.HATCH["decision_where"][before:]
+    assert any(k == "opacities" for k, _, _, _ in where), where
+    assert all([(i, x, y) for i, x, y, _ in combo] == [(67, 7, 31)] for _, combo, _, _ in where), where
+
+
 def test_decision_matched_tier_does_not_rescue_a_defect(emu, oracle32, oracle64, monkeypatch):
     """The same scene with a DEFECT injected into the kernel's result (a Gaussian without any threshold pixel gets a wrong gradient row; and,
     separately, an error spread over all rows): no subset of flipped decisions explains either, the check fails."""
