@@ -1,3 +1,5 @@
+# RECORD of how profiles/r06_ab_culled_fill.txt was measured: the code it drove (gs_set_culled_fill, the CULLED_FILL knob of scripts/stage_times.py, the lazy / trail /
+# lead variants) lost and is in no commit -- the script does not run against this tree.
 # round 6: A/B of the culled-row fill (gs_set_culled_fill): the zero rows of unrendered Gaussians stored by filler workgroups inside the backward blend
 # (1, the default) against the per-Gaussian backward writing every row itself (0, rounds 1-5); one process per scene, alternating, hipEvent stage times
 mkdir -p gpurun_out/abcf

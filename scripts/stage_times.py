@@ -27,8 +27,6 @@ def run(N=500_000, W=640, H=480, steps=int(os.environ.get("STEPS", 30)), warmup=
         lib.gs_set_backward_chain(int(os.environ["CHAIN"]), int(os.environ.get("CHAIN_MIN_TILES", -1)))
     if os.environ.get("TICKETS"):                           # gs_set_backward_chain_tickets: ordered tickets of the chained walks (A/B)
         lib.gs_set_backward_chain_tickets(int(os.environ["TICKETS"]))
-    if os.environ.get("CULLED_FILL"):                       # gs_set_culled_fill: 0 = the per-Gaussian backward writes the zero rows of unrendered Gaussians itself
-        lib.gs_set_culled_fill(int(os.environ["CULLED_FILL"]))
     if os.environ.get("SEGS"):                              # gs_set_backward_segments: list segments per quadrant in the few-tile backward
         lib.gs_set_backward_segments(int(os.environ["SEGS"]))
     if os.environ.get("HALF"):                              # gs_set_half_quadrants: images of at most this many tiles use half-quadrant wavefronts
