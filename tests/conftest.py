@@ -29,6 +29,8 @@ def emu_lib_path():
     """Host-emulated build of the kernel sources (tests/hipemu) -- a debugging aid, CPU only."""
     import subprocess
     d = os.path.join(ROOT, "tests", "hipemu")
+    if os.environ.get("GS_EMU_LIB"):          # another build of the same sources (scripts/exp/emu_asan.sh: AddressSanitizer + UBSan)
+        return os.path.abspath(os.environ["GS_EMU_LIB"])
     subprocess.check_call(["make", "-C", d, "-j8"], stdout=subprocess.DEVNULL)
     return os.path.join(d, "libgsplat_emu.so")
 

@@ -64,7 +64,7 @@ static inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; 
 namespace hipemu {
 enum St { READY, AT_BARRIER, AT_WAVE, DONE };
 struct Fiber {
-#if defined(__x86_64__)
+#if defined(__x86_64__) && !defined(HIPEMU_UCONTEXT)
     void* sp;                        // saved stack pointer (hipemu.cpp's register-only switch: no signal-mask system call per yield)
 #else
     ucontext_t ctx;
@@ -77,7 +77,7 @@ struct Fiber {
 };
 struct Block {
     std::vector<Fiber> fibers;
-#if defined(__x86_64__)
+#if defined(__x86_64__) && !defined(HIPEMU_UCONTEXT)
     void* sched_sp;
 #else
     ucontext_t sched;

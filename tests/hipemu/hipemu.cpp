@@ -7,7 +7,7 @@ thread_local Block* g_blk = nullptr;
 
 static constexpr size_t STACK = 96 * 1024;
 
-#if defined(__x86_64__)
+#if defined(__x86_64__) && !defined(HIPEMU_UCONTEXT)
 // swapcontext() saves and restores the signal mask: two system calls per yield, and a barrier of a 256-thread workgroup is 512 yields.  The
 // fibers here never touch signals, so the switch is the callee-saved registers and the stack pointer (System V x86-64 ABI).
 extern "C" void hipemu_switch(void** save_sp, void* load_sp);
