@@ -96,9 +96,21 @@ static void run_block(Block& b, int nthreads)
     }
     b.barrier_acc = 0; b.barrier_count = 0;
     const int nwaves = (nthreads + 63) / 64;
-    for (;;) {
+    // The order in which READY fibres run between two rendezvous is not part of the programming model: a kernel whose result depends on it is
+    // missing a barrier (or leans on lockstep execution the source does not ask for).  HIPEMU_ORDER=reverse | random[:seed] runs them in another
+    // order than 0, 1, 2, ... -- a poor man's race detector for the tests (scripts/exp/emu_orders.sh).
+    static const int order_mode = [] { const char* e = std::getenv("HIPEMU_ORDER"); return !e ? 0 : e[0] == 'r' && e[1] == 'e' ? 1 : e[0] == 'r' ? 2 : 0; }();
+    static const unsigned order_seed = [] { const char* e = std::getenv("HIPEMU_ORDER"); const char* c = e ? std::strchr(e, ':') : nullptr; return c ? (unsigned)std::atoi(c + 1) : 1u; }();
+    static thread_local std::vector<int> order;
+    order.resize(nthreads);
+    for (int t = 0; t < nthreads; t++) order[t] = order_mode == 1 ? nthreads - 1 - t : t;
+    unsigned rng = order_seed * 2654435761u + b.bid.x * 40503u + b.bid.y * 9973u + 12345u;
+    for (unsigned pass = 0;; pass++) {
         bool ran = false;
-        for (int t = 0; t < nthreads; t++) {
+        if (order_mode == 2)                                       // a fresh permutation for every pass (Fisher-Yates, xorshift)
+            for (int t = nthreads - 1; t > 0; t--) { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; std::swap(order[t], order[rng % (unsigned)(t + 1)]); }
+        for (int oi = 0; oi < nthreads; oi++) {
+            const int t = order[oi];
             if (b.fibers[t].st != READY) continue;
             ran = true;
             b.cur = t;
